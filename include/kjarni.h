@@ -1,0 +1,190 @@
+/*
+ * kjarni.h -- the kjarni-ffi C ABI, served by the MI355X encoder core.
+ *
+ * Drop-in surface for the reference's `libkjarni_ffi.so`
+ * (crates/kjarni-ffi/Cargo.toml:7-8).  Every declaration below names the Rust
+ * `extern "C"` item it replaces; struct layouts are the reference's
+ * `#[repr(C)]` layouts byte for byte.  Authoritative source is the Rust code,
+ * not the stale cbindgen header (crates/kjarni-ffi/include/kjarni.h): in
+ * particular every `*_free` takes a POINTER to the struct, as the Rust source
+ * (kjarni-ffi/src/lib.rs:131-174, reranker.rs:51-57, classifier.rs:55-67) and
+ * the Go binding (bindings/go/embedder.go:227-234) do.
+ *
+ * Behavioural differences from the reference, by design:
+ *   - inference always runs on an AMD GPU through hand-written HIP kernels;
+ *     `device` (Cpu/Gpu) is accepted for layout compatibility and both values
+ *     select the GPU.  Without a usable HIP device `*_new` returns
+ *     KJARNI_ERROR_GPU_UNAVAILABLE -- there is no CPU fallback.
+ *   - models are never downloaded (no network): a registry name must already
+ *     be present under <cache>/<org>_<repo>/, otherwise
+ *     KJARNI_ERROR_MODEL_NOT_FOUND.  `model_path` is honoured by all three
+ *     components (the reference's Embedder ignores it, kjarni/src/embedder/
+ *     model.rs:51-116).
+ */
+#ifndef KJARNI_H
+#define KJARNI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- errors: kjarni-ffi/src/error.rs:7-100 ---------------------------------- */
+typedef enum KjarniErrorCode {
+    KJARNI_OK = 0,
+    KJARNI_ERROR_NULL_POINTER = 1,
+    KJARNI_ERROR_INVALID_UTF8 = 2,
+    KJARNI_ERROR_MODEL_NOT_FOUND = 3,
+    KJARNI_ERROR_LOAD_FAILED = 4,
+    KJARNI_ERROR_INFERENCE_FAILED = 5,
+    KJARNI_ERROR_GPU_UNAVAILABLE = 6,
+    KJARNI_ERROR_INVALID_CONFIG = 7,
+    KJARNI_ERROR_CANCELLED = 8,
+    KJARNI_ERROR_TIMEOUT = 9,
+    KJARNI_ERROR_STREAM_ENDED = 10,
+    KJARNI_ERROR_UNKNOWN = 255,
+} KjarniErrorCode;
+
+/* error.rs:63-85: static "KJARNI_OK" / "KJARNI_ERROR_*" names. */
+const char* kjarni_error_name(KjarniErrorCode err);
+const char* kjarni_error_code_to_string(KjarniErrorCode err); /* error.rs:56-61 */
+/* error.rs:87-100: thread-local; valid until the next failing call or clear on
+ * this thread; NULL when none. */
+const char* kjarni_last_error_message(void);
+void kjarni_clear_error(void);
+
+/* ---- runtime: kjarni-ffi/src/lib.rs:35-57 ----------------------------------- */
+KjarniErrorCode kjarni_init(void);   /* optional, idempotent */
+void kjarni_shutdown(void);          /* no-op, as in the reference */
+const char* kjarni_version(void);    /* static "0.1.0" */
+
+/* ---- arrays: kjarni-ffi/src/lib.rs:59-174 -----------------------------------
+ * The library allocates, the caller frees exactly once with the matching free.
+ * Empty = {NULL, 0[, 0]}. */
+typedef struct KjarniFloatArray {
+    float* data;
+    size_t len;
+} KjarniFloatArray;
+
+typedef struct KjarniFloat2DArray {
+    float* data; /* row-major */
+    size_t rows;
+    size_t cols;
+} KjarniFloat2DArray;
+
+typedef struct KjarniStringArray {
+    char** strings;
+    size_t len;
+} KjarniStringArray;
+
+void kjarni_float_array_free(const KjarniFloatArray* arr);       /* lib.rs:131-138 */
+void kjarni_float_2d_array_free(const KjarniFloat2DArray* arr);  /* lib.rs:141-149 */
+void kjarni_string_free(char* s);                                /* lib.rs:152-159 */
+void kjarni_string_array_free(const KjarniStringArray* arr);     /* lib.rs:162-174 */
+
+/* lib.rs:176-188 -> kjarni/src/embedder/model.rs:247-257; 0.0 on NULL / len 0. */
+float kjarni_cosine_similarity(const float* a, const float* b, size_t len);
+
+/* ---- device: kjarni-ffi/src/embedder.rs:13-18 ------------------------------- */
+typedef enum KjarniDevice {
+    KJARNI_DEVICE_CPU = 0,
+    KJARNI_DEVICE_GPU = 1,
+} KjarniDevice;
+
+/* ---- Embedder: kjarni-ffi/src/embedder.rs:20-275 ---------------------------- */
+typedef struct KjarniEmbedderConfig {
+    KjarniDevice device;
+    const char* cache_dir;  /* NULL = default cache */
+    const char* model_name; /* NULL = "minilm-l6-v2" */
+    const char* model_path; /* NULL = registry */
+    int32_t normalize;      /* honoured by encode / similarity, not by encode_batch */
+    int32_t quiet;
+} KjarniEmbedderConfig;
+
+typedef struct KjarniEmbedder KjarniEmbedder;
+
+KjarniEmbedderConfig kjarni_embedder_config_default(void);                          /* :39-48 */
+KjarniErrorCode kjarni_embedder_new(const KjarniEmbedderConfig* config, KjarniEmbedder** out); /* :56-127 */
+void kjarni_embedder_free(KjarniEmbedder* embedder);                                /* :130-135 */
+KjarniErrorCode kjarni_embedder_encode(KjarniEmbedder* embedder, const char* text,
+                                       KjarniFloatArray* out);                      /* :138-171 */
+KjarniErrorCode kjarni_embedder_encode_batch(KjarniEmbedder* embedder, const char* const* texts,
+                                             size_t num_texts, KjarniFloat2DArray* out); /* :174-224 */
+KjarniErrorCode kjarni_embedder_similarity(KjarniEmbedder* embedder, const char* text1,
+                                           const char* text2, float* out);          /* :227-262 */
+size_t kjarni_embedder_dim(const KjarniEmbedder* embedder);                         /* :265-275 */
+
+/* ---- Classifier: kjarni-ffi/src/classifier.rs:10-297 ------------------------ */
+typedef struct KjarniClassResult {
+    char* label;
+    float score;
+} KjarniClassResult;
+
+typedef struct KjarniClassResults {
+    KjarniClassResult* results;
+    size_t len;
+} KjarniClassResults;
+
+typedef struct KjarniClassifierConfig {
+    KjarniDevice device;
+    const char* cache_dir;
+    const char* model_name; /* NULL = "sentiment" */
+    const char* model_path;
+    const char* const* labels; /* NULL = model labels */
+    size_t num_labels;
+    int32_t multi_label;
+    int32_t quiet;
+} KjarniClassifierConfig;
+
+typedef struct KjarniClassifier KjarniClassifier;
+
+void kjarni_class_results_free(const KjarniClassResults* results);                  /* :55-67 */
+KjarniClassifierConfig kjarni_classifier_config_default(void);                      /* :91-103 */
+KjarniErrorCode kjarni_classifier_new(const KjarniClassifierConfig* config, KjarniClassifier** out);
+void kjarni_classifier_free(KjarniClassifier* classifier);
+KjarniErrorCode kjarni_classifier_classify(KjarniClassifier* classifier, const char* text,
+                                           KjarniClassResults* out);               /* :226-256 */
+KjarniErrorCode kjarni_classifier_labels(const KjarniClassifier* classifier, KjarniStringArray* out);
+size_t kjarni_classifier_num_labels(const KjarniClassifier* classifier);
+
+/* ---- Reranker: kjarni-ffi/src/reranker.rs:10-322 ---------------------------- */
+typedef struct KjarniRerankResult {
+    size_t index; /* position in the input array */
+    float score;
+} KjarniRerankResult;
+
+typedef struct KjarniRerankResults {
+    KjarniRerankResult* results;
+    size_t len;
+} KjarniRerankResults;
+
+typedef struct KjarniRerankerConfig {
+    KjarniDevice device;
+    const char* cache_dir;
+    const char* model_name; /* NULL = "minilm-l6-v2-cross-encoder" */
+    const char* model_path;
+    int32_t quiet;
+} KjarniRerankerConfig;
+
+typedef struct KjarniReranker KjarniReranker;
+
+void kjarni_rerank_results_free(const KjarniRerankResults* results);                /* :51-57 */
+KjarniRerankerConfig kjarni_reranker_config_default(void);                          /* :70-79 */
+KjarniErrorCode kjarni_reranker_new(const KjarniRerankerConfig* config, KjarniReranker** out); /* :88-163 */
+void kjarni_reranker_free(KjarniReranker* reranker);                                /* :166-171 */
+KjarniErrorCode kjarni_reranker_score(KjarniReranker* reranker, const char* query,
+                                      const char* document, float* out);            /* :174-212 */
+KjarniErrorCode kjarni_reranker_rerank(KjarniReranker* reranker, const char* query,
+                                       const char* const* documents, size_t num_docs,
+                                       KjarniRerankResults* out);                   /* :215-269 */
+KjarniErrorCode kjarni_reranker_rerank_top_k(KjarniReranker* reranker, const char* query,
+                                             const char* const* documents, size_t num_docs,
+                                             size_t top_k, KjarniRerankResults* out); /* :272-322 */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* KJARNI_H */

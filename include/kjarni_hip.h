@@ -1,0 +1,180 @@
+/*
+ * kjarni_hip.h -- token-level C ABI of the MI355X encoder core.
+ *
+ * These entry points sit at the reference's token-level boundary
+ *   EncoderLanguageModel::get_hidden_states_batch_from_ids
+ *     (crates/kjarni-transformers/src/cpu/encoder/traits.rs:66-139)
+ *   CpuEncoderOps::forward_tokens (traits.rs:295-313)
+ *   SentenceEncoder::encode_batch_flat
+ *     (crates/kjarni-models/src/models/sentence_encoder/model.rs:201-218)
+ *   CrossEncoder::predict_pairs / SequenceClassifier::predict_logits
+ *     (models/cross_encoder/model.rs:170-240, models/sequence_classifier/mod.rs:265-346)
+ *   VectorStore::search / Segment::search_vectors
+ *     (crates/kjarni-search/src/vector.rs:150-166, crates/kjarni-rag/src/segment.rs:307-337)
+ * i.e. the place where the reference's wgpu backend plugs in
+ * (GpuEncoderOps, traits.rs:443-527).  The string-level kjarni-ffi surface
+ * (kjarni.h) is built on top of them.
+ *
+ * Plain C: pointers and sizes only.  "_dev" arguments are device pointers on
+ * the encoder's HIP device; work is enqueued on `stream` (a hipStream_t passed
+ * as void*, NULL = the default stream) and NOT synchronised unless stated.
+ * ids / attention mask / token type ids are uint32 [batch, seq] row-major, as
+ * in the reference (Array2<u32>).
+ */
+#ifndef KJARNI_HIP_H
+#define KJARNI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "kjarni.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct KjarniHipEncoder KjarniHipEncoder;
+
+/* Pooling strategies: crates/kjarni-transformers/src/cpu/encoder/config.rs (PoolingStrategy). */
+typedef enum KjarniHipPooling {
+    KJARNI_HIP_POOL_MEAN = 0,
+    KJARNI_HIP_POOL_CLS = 1,
+    KJARNI_HIP_POOL_MAX = 2,
+    KJARNI_HIP_POOL_LAST_TOKEN = 3,
+} KjarniHipPooling;
+
+/* Padding-mask fill value.  The reference overwrites masked scores with -1e9 on
+ * its alloc path (utils/masks.rs:4-36) and with -inf on its no-alloc path
+ * (cpu/encoder/encoder_self_attention.rs:311-325); AUTO applies its selection
+ * rule (cpu/strategy.rs:43-44: no-alloc iff tokens <= 1 or tokens >= 1000) for
+ * embed/hidden_states and the alloc value for logits (forward_tokens always
+ * takes the alloc path). */
+typedef enum KjarniHipMaskFill {
+    KJARNI_HIP_MASK_AUTO = 0,
+    KJARNI_HIP_MASK_NEG_1E9 = 1,
+    KJARNI_HIP_MASK_NEG_INF = 2,
+} KjarniHipMaskFill;
+
+/* Number of visible HIP devices (0 when none / no runtime). */
+int32_t kjarni_hip_device_count(void);
+
+/* Load <model_dir>/{config.json, model.safetensors} onto HIP device `device`.
+ * Errors: KJARNI_ERROR_GPU_UNAVAILABLE (no device), KJARNI_ERROR_MODEL_NOT_FOUND
+ * (files missing), KJARNI_ERROR_LOAD_FAILED (bad files). */
+KjarniErrorCode kjarni_hip_encoder_load(const char* model_dir, int32_t device, KjarniHipEncoder** out);
+void kjarni_hip_encoder_free(KjarniHipEncoder* enc);
+
+int32_t kjarni_hip_encoder_hidden_size(const KjarniHipEncoder* enc);
+int32_t kjarni_hip_encoder_num_layers(const KjarniHipEncoder* enc);
+int32_t kjarni_hip_encoder_max_seq_len(const KjarniHipEncoder* enc);
+int32_t kjarni_hip_encoder_vocab_size(const KjarniHipEncoder* enc);
+int32_t kjarni_hip_encoder_num_labels(const KjarniHipEncoder* enc); /* 0: no classification head */
+int32_t kjarni_hip_encoder_device(const KjarniHipEncoder* enc);
+/* Tokens processed per internal chunk (workspace size); 0 keeps the default. */
+KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64_t tokens);
+
+/* hidden_out_dev: f32 [batch, seq, hidden].  type_ids_dev may be NULL (token
+ * type row 0 is added to every token, cpu/embeddings/mod.rs:216-223). */
+KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
+                                                 const uint32_t* mask_dev, const uint32_t* type_ids_dev,
+                                                 int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                                 float* hidden_out_dev, void* stream);
+
+/* out_dev: f32 [batch, hidden].  mean-pool + normalize = encode_batch_flat. */
+KjarniErrorCode kjarni_hip_encoder_embed(KjarniHipEncoder* enc, const uint32_t* ids_dev,
+                                         const uint32_t* mask_dev, const uint32_t* type_ids_dev,
+                                         int64_t batch, int32_t seq, KjarniHipPooling pooling,
+                                         int32_t normalize, KjarniHipMaskFill fill, float* out_dev,
+                                         void* stream);
+
+/* logits_out_dev: f32 [batch, num_labels] (rerank score = column 0). */
+KjarniErrorCode kjarni_hip_encoder_logits(KjarniHipEncoder* enc, const uint32_t* ids_dev,
+                                          const uint32_t* mask_dev, const uint32_t* type_ids_dev,
+                                          int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                          float* logits_out_dev, void* stream);
+
+/* Host-pointer variants: copy in, run, copy out, synchronise. */
+KjarniErrorCode kjarni_hip_encoder_hidden_states_host(KjarniHipEncoder* enc, const uint32_t* ids,
+                                                      const uint32_t* mask, const uint32_t* type_ids,
+                                                      int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                                      float* hidden_out);
+KjarniErrorCode kjarni_hip_encoder_embed_host(KjarniHipEncoder* enc, const uint32_t* ids,
+                                              const uint32_t* mask, const uint32_t* type_ids,
+                                              int64_t batch, int32_t seq, KjarniHipPooling pooling,
+                                              int32_t normalize, KjarniHipMaskFill fill, float* out);
+KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* enc, const uint32_t* ids,
+                                               const uint32_t* mask, const uint32_t* type_ids,
+                                               int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                               float* logits_out);
+
+/* ---- cosine scan ------------------------------------------------------------
+ * corpus: f32 [n_docs, dim] row-major (the layout of vectors.bin,
+ * crates/kjarni-rag/src/segment.rs:240-262).  queries: f32 [n_queries, dim].
+ * mode 0 = VectorStore semantics (vector.rs:131-148: dot / max(|q||d|, 1e-9)),
+ * mode 1 = Segment semantics (segment.rs:355-371: 0 when |d| < 1e-9). */
+typedef enum KjarniHipCosineMode {
+    KJARNI_HIP_COSINE_VECTOR_STORE = 0,
+    KJARNI_HIP_COSINE_SEGMENT = 1,
+} KjarniHipCosineMode;
+
+/* scores_out_dev: f32 [n_queries, n_docs]. */
+KjarniErrorCode kjarni_hip_cosine_scores(int32_t device, const float* queries_dev, int32_t n_queries,
+                                         const float* corpus_dev, int64_t n_docs, int32_t dim,
+                                         KjarniHipCosineMode mode, float* scores_out_dev, void* stream);
+
+/* Top-k of a score matrix [n_queries, n_docs]: score descending, equal scores by
+ * ascending document index (stable sort of an index-ordered list, vector.rs:162).
+ * idx_out_dev: int64 [n_queries, k], score_out_dev: f32 [n_queries, k]; entries
+ * past n_docs are (-1, -inf).  workspace_dev must hold
+ * kjarni_hip_cosine_topk_workspace_bytes(n_queries, n_docs, k) bytes. */
+size_t kjarni_hip_cosine_topk_workspace_bytes(int32_t n_queries, int64_t n_docs, int32_t k);
+KjarniErrorCode kjarni_hip_cosine_topk(int32_t device, const float* scores_dev, int32_t n_queries,
+                                       int64_t n_docs, int32_t k, void* workspace_dev,
+                                       int64_t* idx_out_dev, float* score_out_dev, void* stream);
+
+/* Whole search with host buffers (scan + top-k + copies + synchronise):
+ * idx_out int64 [n_queries, k], score_out f32 [n_queries, k]; *n_hits_out =
+ * min(k, n_docs) (0 for a Segment-mode query whose norm is < 1e-9 is reported
+ * per query through idx -1). */
+KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, const float* queries, int32_t n_queries,
+                                              const float* corpus, int64_t n_docs, int32_t dim,
+                                              KjarniHipCosineMode mode, int32_t k, int64_t* idx_out,
+                                              float* score_out, int64_t* n_hits_out);
+
+/* ---- tokenizer -----------------------------------------------------------------
+ * The reference tokenises on the host with the HF `tokenizers` crate configured at
+ * load time (crates/kjarni-transformers/src/pipeline/encoder/loader.rs:98-115:
+ * truncation max_length = max_seq_len, padding BatchLongest, pad id 0).  This handle
+ * exposes the same step (BERT WordPiece pipelines) so callers can pre-tokenise and
+ * use the token-level entry points above.  Token ids are bit-exact with that crate. */
+typedef struct KjarniTokenizer KjarniTokenizer;
+
+typedef struct KjarniTokenBatch {
+    uint32_t* ids;            /* [batch, seq] */
+    uint32_t* attention_mask; /* [batch, seq] */
+    uint32_t* type_ids;       /* [batch, seq] */
+    size_t batch;
+    size_t seq; /* longest sequence in the batch */
+} KjarniTokenBatch;
+
+/* max_length 0 keeps the default (512). */
+KjarniErrorCode kjarni_tokenizer_load(const char* tokenizer_json_path, size_t max_length, KjarniTokenizer** out);
+void kjarni_tokenizer_free(KjarniTokenizer* tok);
+/* texts_b NULL: single sequences ([CLS] a [SEP]); otherwise pairs ([CLS] a [SEP] b [SEP], type ids 0/1).
+ * The library allocates *out; free with kjarni_token_batch_free. */
+KjarniErrorCode kjarni_tokenizer_encode_batch(const KjarniTokenizer* tok, const char* const* texts_a,
+                                              const char* const* texts_b, size_t n, KjarniTokenBatch* out);
+void kjarni_token_batch_free(const KjarniTokenBatch* batch);
+
+/* ---- device memory helpers for callers without a HIP runtime binding --------- */
+KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev);
+KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev);
+KjarniErrorCode kjarni_hip_memcpy_h2d(int32_t device, void* dst_dev, const void* src, size_t bytes);
+KjarniErrorCode kjarni_hip_memcpy_d2h(int32_t device, void* dst, const void* src_dev, size_t bytes);
+KjarniErrorCode kjarni_hip_synchronize(int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* KJARNI_HIP_H */

@@ -1,0 +1,240 @@
+"""ctypes binding of libkjarni_ffi.so (include/kjarni.h + include/kjarni_hip.h).
+
+Mirrors the reference's Python binding (crates/kjarni-ffi/bindings/python/
+kjarni/_ffi.py): same struct mirrors, same check_error contract.  The library
+is the product; if it is missing this module raises -- there is no Python or
+CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkjarni_ffi.so")
+
+
+class KjarniError:
+    OK = 0
+    NULL_POINTER = 1
+    INVALID_UTF8 = 2
+    MODEL_NOT_FOUND = 3
+    LOAD_FAILED = 4
+    INFERENCE_FAILED = 5
+    GPU_UNAVAILABLE = 6
+    INVALID_CONFIG = 7
+    CANCELLED = 8
+    TIMEOUT = 9
+    STREAM_ENDED = 10
+    UNKNOWN = 255
+
+
+class KjarniDevice:
+    CPU = 0
+    GPU = 1
+
+
+class KjarniException(Exception):
+    def __init__(self, code: int, message: str):
+        self.code = code
+        self.message = message
+        super().__init__(f"{error_name(code)}: {message}")
+
+
+class KjarniFloatArray(Structure):
+    _fields_ = [("data", POINTER(c_float)), ("len", c_size_t)]
+
+    def to_numpy(self) -> np.ndarray:
+        if not self.data or self.len == 0:
+            return np.zeros(0, np.float32)
+        return np.ctypeslib.as_array(self.data, shape=(self.len,)).copy()
+
+    def free(self):
+        lib().kjarni_float_array_free(byref(self))
+
+
+class KjarniFloat2DArray(Structure):
+    _fields_ = [("data", POINTER(c_float)), ("rows", c_size_t), ("cols", c_size_t)]
+
+    def to_numpy(self) -> np.ndarray:
+        if not self.data or self.rows == 0 or self.cols == 0:
+            return np.zeros((0, 0), np.float32)
+        return np.ctypeslib.as_array(self.data, shape=(self.rows, self.cols)).copy()
+
+    def free(self):
+        lib().kjarni_float_2d_array_free(byref(self))
+
+
+class KjarniStringArray(Structure):
+    _fields_ = [("strings", POINTER(c_char_p)), ("len", c_size_t)]
+
+    def to_list(self):
+        return [self.strings[i].decode("utf-8") for i in range(self.len)]
+
+    def free(self):
+        lib().kjarni_string_array_free(byref(self))
+
+
+class KjarniEmbedderConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
+                ("model_path", c_char_p), ("normalize", c_int32), ("quiet", c_int32)]
+
+
+class KjarniClassResult(Structure):
+    _fields_ = [("label", c_char_p), ("score", c_float)]
+
+
+class KjarniClassResults(Structure):
+    _fields_ = [("results", POINTER(KjarniClassResult)), ("len", c_size_t)]
+
+    def to_list(self):
+        return [(self.results[i].label.decode("utf-8"), float(self.results[i].score))
+                for i in range(self.len)]
+
+    def free(self):
+        lib().kjarni_class_results_free(byref(self))
+
+
+class KjarniClassifierConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
+                ("model_path", c_char_p), ("labels", POINTER(c_char_p)), ("num_labels", c_size_t),
+                ("multi_label", c_int32), ("quiet", c_int32)]
+
+
+class KjarniRerankResult(Structure):
+    _fields_ = [("index", c_size_t), ("score", c_float)]
+
+
+class KjarniRerankResults(Structure):
+    _fields_ = [("results", POINTER(KjarniRerankResult)), ("len", c_size_t)]
+
+    def to_list(self):
+        return [(int(self.results[i].index), float(self.results[i].score)) for i in range(self.len)]
+
+    def free(self):
+        lib().kjarni_rerank_results_free(byref(self))
+
+
+class KjarniRerankerConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
+                ("model_path", c_char_p), ("quiet", c_int32)]
+
+
+_u32p = POINTER(C.c_uint32)
+_f32p = POINTER(c_float)
+_i64p = POINTER(c_int64)
+
+# name -> (restype, argtypes).  Everything include/*.h declares is listed here;
+# tests/test_abi.py checks the two stay in sync.
+SIGNATURES = {
+    # kjarni.h
+    "kjarni_error_name": (c_char_p, [c_int32]),
+    "kjarni_error_code_to_string": (c_char_p, [c_int32]),
+    "kjarni_last_error_message": (c_char_p, []),
+    "kjarni_clear_error": (None, []),
+    "kjarni_init": (c_int32, []),
+    "kjarni_shutdown": (None, []),
+    "kjarni_version": (c_char_p, []),
+    "kjarni_float_array_free": (None, [POINTER(KjarniFloatArray)]),
+    "kjarni_float_2d_array_free": (None, [POINTER(KjarniFloat2DArray)]),
+    "kjarni_string_free": (None, [c_void_p]),
+    "kjarni_string_array_free": (None, [POINTER(KjarniStringArray)]),
+    "kjarni_cosine_similarity": (c_float, [_f32p, _f32p, c_size_t]),
+    "kjarni_embedder_config_default": (KjarniEmbedderConfig, []),
+    "kjarni_embedder_new": (c_int32, [POINTER(KjarniEmbedderConfig), POINTER(c_void_p)]),
+    "kjarni_embedder_free": (None, [c_void_p]),
+    "kjarni_embedder_encode": (c_int32, [c_void_p, c_char_p, POINTER(KjarniFloatArray)]),
+    "kjarni_embedder_encode_batch": (c_int32, [c_void_p, POINTER(c_char_p), c_size_t,
+                                               POINTER(KjarniFloat2DArray)]),
+    "kjarni_embedder_similarity": (c_int32, [c_void_p, c_char_p, c_char_p, POINTER(c_float)]),
+    "kjarni_embedder_dim": (c_size_t, [c_void_p]),
+    "kjarni_class_results_free": (None, [POINTER(KjarniClassResults)]),
+    "kjarni_classifier_config_default": (KjarniClassifierConfig, []),
+    "kjarni_classifier_new": (c_int32, [POINTER(KjarniClassifierConfig), POINTER(c_void_p)]),
+    "kjarni_classifier_free": (None, [c_void_p]),
+    "kjarni_classifier_classify": (c_int32, [c_void_p, c_char_p, POINTER(KjarniClassResults)]),
+    "kjarni_classifier_labels": (c_int32, [c_void_p, POINTER(KjarniStringArray)]),
+    "kjarni_classifier_num_labels": (c_size_t, [c_void_p]),
+    "kjarni_rerank_results_free": (None, [POINTER(KjarniRerankResults)]),
+    "kjarni_reranker_config_default": (KjarniRerankerConfig, []),
+    "kjarni_reranker_new": (c_int32, [POINTER(KjarniRerankerConfig), POINTER(c_void_p)]),
+    "kjarni_reranker_free": (None, [c_void_p]),
+    "kjarni_reranker_score": (c_int32, [c_void_p, c_char_p, c_char_p, POINTER(c_float)]),
+    "kjarni_reranker_rerank": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t,
+                                         POINTER(KjarniRerankResults)]),
+    "kjarni_reranker_rerank_top_k": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t, c_size_t,
+                                               POINTER(KjarniRerankResults)]),
+    # kjarni_hip.h
+    "kjarni_hip_device_count": (c_int32, []),
+    "kjarni_hip_encoder_load": (c_int32, [c_char_p, c_int32, POINTER(c_void_p)]),
+    "kjarni_hip_encoder_free": (None, [c_void_p]),
+    "kjarni_hip_encoder_hidden_size": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_num_layers": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_max_seq_len": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_vocab_size": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_num_labels": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_device": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_set_chunk_tokens": (c_int32, [c_void_p, c_int64]),
+    "kjarni_hip_encoder_hidden_states": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                                   c_int32, c_void_p, c_void_p]),
+    "kjarni_hip_encoder_embed": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                           c_int32, c_int32, c_void_p, c_void_p]),
+    "kjarni_hip_encoder_logits": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                            c_void_p, c_void_p]),
+    "kjarni_hip_encoder_hidden_states_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32,
+                                                        c_int32, _f32p]),
+    "kjarni_hip_encoder_embed_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32,
+                                                c_int32, c_int32, _f32p]),
+    "kjarni_hip_encoder_logits_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32,
+                                                 _f32p]),
+    "kjarni_hip_cosine_scores": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32,
+                                           c_void_p, c_void_p]),
+    "kjarni_hip_cosine_topk_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32]),
+    "kjarni_hip_cosine_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
+    "kjarni_hip_cosine_search_host": (c_int32, [c_int32, _f32p, c_int32, _f32p, c_int64, c_int32, c_int32,
+                                                c_int32, _i64p, _f32p, _i64p]),
+    "kjarni_hip_malloc": (c_int32, [c_int32, c_size_t, POINTER(c_void_p)]),
+    "kjarni_hip_free": (c_int32, [c_int32, c_void_p]),
+    "kjarni_hip_memcpy_h2d": (c_int32, [c_int32, c_void_p, c_void_p, c_size_t]),
+    "kjarni_hip_memcpy_d2h": (c_int32, [c_int32, c_void_p, c_void_p, c_size_t]),
+    "kjarni_hip_synchronize": (c_int32, [c_int32]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the native library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C kjarni_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no fallback implementation.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if not hasattr(L, name):
+                continue  # reported by tests/test_abi.py; partial builds stay importable
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def error_name(code: int) -> str:
+    return lib().kjarni_error_name(int(code)).decode()
+
+
+def last_error() -> str:
+    msg = lib().kjarni_last_error_message()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check_error(code: int):
+    if code != KjarniError.OK:
+        raise KjarniException(int(code), last_error())

@@ -1,0 +1,459 @@
+#include "encoder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "json.h"
+#include "safetensors.h"
+
+namespace kjarni {
+
+void hip_check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        (void)hipGetLastError();
+        throw HipError(msg);
+    }
+}
+
+int visible_device_count()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static std::string read_file(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+EncoderModel::~EncoderModel()
+{
+    (void)hipSetDevice(device_);
+    for (void* p : allocs_) (void)hipFree(p);
+    for (void* p : {(void*)ws_hidden_, (void*)ws_qkv_, (void*)ws_ctx_, (void*)ws_mid_, (void*)ws_feat_,
+                    scratch_, scratch2_})
+        if (p) (void)hipFree(p);
+}
+
+float* EncoderModel::upload(const std::vector<float>& host)
+{
+    float* d = nullptr;
+    const size_t bytes = host.size() * sizeof(float);
+    hip_check(hipMalloc((void**)&d, bytes ? bytes : 4), "hipMalloc(weights)");
+    allocs_.push_back(d);
+    if (bytes) hip_check(hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    weight_bytes_ += bytes;
+    return d;
+}
+
+namespace {
+
+struct Names {
+    std::string emb, q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b, ln1_g, ln1_b, w1, b1, w2, b2, ln2_g, ln2_b;
+};
+
+std::string fmt_layer(const std::string& pattern, int i)
+{
+    std::string s = pattern;
+    const size_t p = s.find("{}");
+    if (p != std::string::npos) s.replace(p, 2, std::to_string(i));
+    return s;
+}
+
+// Tensor-name layouts: crates/kjarni-models/src/models/sentence_encoder/configs.rs
+// :218-366 (BERT, plain and "bert."-prefixed) and :638-687 (DistilBERT).
+Names bert_names(const std::string& pre)
+{
+    Names n;
+    n.emb = pre + "embeddings.";
+    const std::string l = pre + "encoder.layer.{}.";
+    n.q_w = l + "attention.self.query.weight";
+    n.q_b = l + "attention.self.query.bias";
+    n.k_w = l + "attention.self.key.weight";
+    n.k_b = l + "attention.self.key.bias";
+    n.v_w = l + "attention.self.value.weight";
+    n.v_b = l + "attention.self.value.bias";
+    n.o_w = l + "attention.output.dense.weight";
+    n.o_b = l + "attention.output.dense.bias";
+    n.ln1_g = l + "attention.output.LayerNorm.weight";
+    n.ln1_b = l + "attention.output.LayerNorm.bias";
+    n.w1 = l + "intermediate.dense.weight";
+    n.b1 = l + "intermediate.dense.bias";
+    n.w2 = l + "output.dense.weight";
+    n.b2 = l + "output.dense.bias";
+    n.ln2_g = l + "output.LayerNorm.weight";
+    n.ln2_b = l + "output.LayerNorm.bias";
+    return n;
+}
+
+Names distilbert_names(const std::string& pre)
+{
+    Names n;
+    n.emb = pre + "embeddings.";
+    const std::string l = pre + "transformer.layer.{}.";
+    n.q_w = l + "attention.q_lin.weight";
+    n.q_b = l + "attention.q_lin.bias";
+    n.k_w = l + "attention.k_lin.weight";
+    n.k_b = l + "attention.k_lin.bias";
+    n.v_w = l + "attention.v_lin.weight";
+    n.v_b = l + "attention.v_lin.bias";
+    n.o_w = l + "attention.out_lin.weight";
+    n.o_b = l + "attention.out_lin.bias";
+    n.ln1_g = l + "sa_layer_norm.weight";
+    n.ln1_b = l + "sa_layer_norm.bias";
+    n.w1 = l + "ffn.lin1.weight";
+    n.b1 = l + "ffn.lin1.bias";
+    n.w2 = l + "ffn.lin2.weight";
+    n.b2 = l + "ffn.lin2.bias";
+    n.ln2_g = l + "output_layer_norm.weight";
+    n.ln2_b = l + "output_layer_norm.bias";
+    return n;
+}
+
+void expect_shape(const std::vector<int64_t>& got, std::initializer_list<int64_t> want,
+                  const std::string& name)
+{
+    std::vector<int64_t> w(want);
+    if (got != w) {
+        std::string m = "tensor " + name + " has unexpected shape [";
+        for (size_t i = 0; i < got.size(); ++i) m += (i ? "," : "") + std::to_string(got[i]);
+        m += "], expected [";
+        for (size_t i = 0; i < w.size(); ++i) m += (i ? "," : "") + std::to_string(w[i]);
+        throw std::runtime_error(m + "]");
+    }
+}
+
+}  // namespace
+
+std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int device)
+{
+    const int ndev = visible_device_count();
+    if (ndev <= 0)
+        throw GpuUnavailable("no HIP device is visible: this library runs the encoder on an AMD GPU only");
+    if (device < 0 || device >= ndev)
+        throw GpuUnavailable("HIP device " + std::to_string(device) + " requested but only " +
+                             std::to_string(ndev) + " visible");
+
+    std::unique_ptr<EncoderModel> m(new EncoderModel());
+    m->device_ = device;
+    EncoderConfig& c = m->cfg_;
+    c.config_json = read_file(dir + "/config.json");
+    Json cfg = Json::parse(c.config_json);
+    SafeTensors st;
+    st.open(dir + "/model.safetensors");
+
+    c.model_type = cfg.get_string("model_type", "bert");
+    Names names;
+    if (c.model_type == "distilbert") {
+        const std::string pre = st.contains("distilbert.embeddings.word_embeddings.weight") ? "distilbert." : "";
+        names = distilbert_names(pre);
+        c.hidden = (int)cfg.get_int("dim", 768);
+        c.layers = (int)cfg.get_int("n_layers", 6);
+        c.heads = (int)cfg.get_int("n_heads", 12);
+        c.inter = (int)cfg.get_int("hidden_dim", 4 * c.hidden);
+        c.eps = 1e-12f;                // configs.rs:620 (DistilBERT norm_eps is fixed)
+        c.ffn_act = EPI_BIAS_GELU;     // configs.rs:621
+    } else if (c.model_type == "bert") {
+        const std::string pre = st.contains("bert.embeddings.word_embeddings.weight") ? "bert." : "";
+        names = bert_names(pre);
+        c.hidden = (int)cfg.get_int("hidden_size", 0);
+        c.layers = (int)cfg.get_int("num_hidden_layers", 0);
+        c.heads = (int)cfg.get_int("num_attention_heads", 0);
+        c.inter = (int)cfg.get_int("intermediate_size", 0);
+        if (c.inter <= 0) c.inter = 4 * c.hidden;  // configs.rs:160-167
+        c.eps = (float)cfg.get_double("layer_norm_eps", 1e-12);
+        // configs.rs:194-200: "gelu" -> erf GELU, "gelu_new" -> tanh GELU, "relu"; anything else erf GELU
+        std::string act = cfg.get_string("hidden_act", cfg.get_string("activation_function", "gelu"));
+        if (act == "gelu_new") c.ffn_act = EPI_BIAS_GELU_NEW;
+        else if (act == "relu") c.ffn_act = EPI_BIAS_RELU;
+        else if (act == "swiglu") throw std::runtime_error("SwiGLU (Nomic) encoders are not supported by the HIP encoder");
+        else c.ffn_act = EPI_BIAS_GELU;
+    } else {
+        throw std::runtime_error("unsupported model_type '" + c.model_type +
+                                 "' (the HIP encoder covers bert and distilbert)");
+    }
+    if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads != 0)
+        throw std::runtime_error("invalid encoder dimensions in config.json");
+
+    hip_check(hipSetDevice(device), "hipSetDevice");
+
+    std::vector<float> buf, buf2, buf3;
+    const int H = c.hidden, I = c.inter;
+    auto shape = st.read_f32(names.emb + "word_embeddings.weight", buf);
+    if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("word_embeddings has wrong shape");
+    c.vocab = (int)shape[0];
+    m->word_ = m->upload(buf);
+    shape = st.read_f32(names.emb + "position_embeddings.weight", buf);
+    if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("position_embeddings has wrong shape");
+    c.max_pos = (int)shape[0];
+    m->pos_ = m->upload(buf);
+    if (c.model_type == "bert" && st.contains(names.emb + "token_type_embeddings.weight")) {
+        shape = st.read_f32(names.emb + "token_type_embeddings.weight", buf);
+        if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("token_type_embeddings has wrong shape");
+        c.type_vocab = (int)shape[0];
+        m->type_ = m->upload(buf);
+    }
+    expect_shape(st.read_f32(names.emb + "LayerNorm.weight", buf), {H}, "embeddings.LayerNorm.weight");
+    m->emb_ln_g_ = m->upload(buf);
+    expect_shape(st.read_f32(names.emb + "LayerNorm.bias", buf), {H}, "embeddings.LayerNorm.bias");
+    m->emb_ln_b_ = m->upload(buf);
+
+    m->layers_.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        DeviceLayer& L = m->layers_[i];
+        // Fused [3H,H] QKV weight (cpu/encoder/qkv_projection.rs:30-41).
+        std::vector<float> wqkv((size_t)3 * H * H), bqkv((size_t)3 * H);
+        const std::string* wn[3] = {&names.q_w, &names.k_w, &names.v_w};
+        const std::string* bn[3] = {&names.q_b, &names.k_b, &names.v_b};
+        for (int p = 0; p < 3; ++p) {
+            const std::string w_name = fmt_layer(*wn[p], i), b_name = fmt_layer(*bn[p], i);
+            expect_shape(st.read_f32(w_name, buf), {H, H}, w_name);
+            std::memcpy(wqkv.data() + (size_t)p * H * H, buf.data(), sizeof(float) * H * H);
+            if (st.contains(b_name)) {
+                expect_shape(st.read_f32(b_name, buf), {H}, b_name);
+                std::memcpy(bqkv.data() + (size_t)p * H, buf.data(), sizeof(float) * H);
+            } else {
+                std::fill(bqkv.begin() + (size_t)p * H, bqkv.begin() + (size_t)(p + 1) * H, 0.0f);
+            }
+        }
+        L.wqkv = m->upload(wqkv);
+        L.bqkv = m->upload(bqkv);
+        auto up = [&](const std::string& pattern, std::initializer_list<int64_t> want) {
+            const std::string name = fmt_layer(pattern, i);
+            expect_shape(st.read_f32(name, buf), want, name);
+            return m->upload(buf);
+        };
+        auto up_bias = [&](const std::string& pattern, int n) {
+            const std::string name = fmt_layer(pattern, i);
+            if (!st.contains(name)) {
+                buf.assign((size_t)n, 0.0f);
+                return m->upload(buf);
+            }
+            expect_shape(st.read_f32(name, buf), {n}, name);
+            return m->upload(buf);
+        };
+        L.wo = up(names.o_w, {H, H});
+        L.bo = up_bias(names.o_b, H);
+        L.ln1_g = up(names.ln1_g, {H});
+        L.ln1_b = up(names.ln1_b, {H});
+        L.w1 = up(names.w1, {I, H});
+        L.b1 = up_bias(names.b1, I);
+        L.w2 = up(names.w2, {H, I});
+        L.b2 = up_bias(names.b2, H);
+        L.ln2_g = up(names.ln2_g, {H});
+        L.ln2_b = up(names.ln2_b, {H});
+    }
+
+    // Classification head auto-detection: cpu/encoder/classifier.rs:103-202.
+    std::string dense_w, dense_b, cls_w, cls_b;
+    if (st.contains("classification_head.dense.weight")) {
+        dense_w = "classification_head.dense.weight"; dense_b = "classification_head.dense.bias";
+        cls_w = "classification_head.out_proj.weight"; cls_b = "classification_head.out_proj.bias";
+        c.head_kind = 1;
+    } else if (st.contains("classifier.dense.weight")) {
+        dense_w = "classifier.dense.weight"; dense_b = "classifier.dense.bias";
+        cls_w = "classifier.out_proj.weight"; cls_b = "classifier.out_proj.bias";
+        c.head_kind = 1;
+    } else if (st.contains("pre_classifier.weight")) {
+        dense_w = "pre_classifier.weight"; dense_b = "pre_classifier.bias";
+        cls_w = "classifier.weight"; cls_b = "classifier.bias";
+        c.head_kind = 2;
+    } else if (st.contains("bert.pooler.dense.weight") && st.contains("classifier.weight")) {
+        dense_w = "bert.pooler.dense.weight"; dense_b = "bert.pooler.dense.bias";
+        cls_w = "classifier.weight"; cls_b = "classifier.bias";
+        c.head_kind = 1;
+    } else if (st.contains("classifier.weight")) {
+        cls_w = "classifier.weight"; cls_b = "classifier.bias";
+        c.head_kind = 3;
+    }
+    if (c.head_kind != 0) {
+        if (!dense_w.empty()) {
+            expect_shape(st.read_f32(dense_w, buf), {H, H}, dense_w);
+            m->head_dense_w_ = m->upload(buf);
+            if (st.contains(dense_b)) st.read_f32(dense_b, buf); else buf.assign((size_t)H, 0.0f);
+            m->head_dense_b_ = m->upload(buf);
+        }
+        shape = st.read_f32(cls_w, buf);
+        if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("classifier weight has wrong shape");
+        c.num_labels = (int)shape[0];
+        m->head_cls_w_ = m->upload(buf);
+        if (st.contains(cls_b)) st.read_f32(cls_b, buf); else buf.assign((size_t)c.num_labels, 0.0f);
+        m->head_cls_b_ = m->upload(buf);
+        // id2label in id order
+        if (const Json* id2 = cfg.find("id2label")) {
+            if (id2->is_object()) {
+                c.labels.assign((size_t)c.num_labels, std::string());
+                for (const auto& kv : id2->obj) {
+                    const long id = std::strtol(kv.first.c_str(), nullptr, 10);
+                    if (id >= 0 && id < c.num_labels && kv.second.is_string()) c.labels[(size_t)id] = kv.second.str;
+                }
+            }
+        }
+    }
+    return m;
+}
+
+int64_t EncoderModel::sentences_per_chunk(int seq) const
+{
+    int64_t n = chunk_tokens_ / std::max(seq, 1);
+    return n < 1 ? 1 : n;
+}
+
+void EncoderModel::ensure_workspace(int64_t tokens, int64_t sentences)
+{
+    if (tokens <= ws_tokens_ && sentences <= ws_sentences_) return;
+    tokens = std::max(tokens, ws_tokens_);
+    sentences = std::max(sentences, ws_sentences_);
+    // The workspace may still be in use by earlier launches.
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(workspace)");
+    for (float** p : {&ws_hidden_, &ws_qkv_, &ws_ctx_, &ws_mid_, &ws_feat_})
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    const size_t H = (size_t)cfg_.hidden, I = (size_t)cfg_.inter, T = (size_t)tokens;
+    hip_check(hipMalloc((void**)&ws_hidden_, T * H * 4), "hipMalloc(ws_hidden)");
+    hip_check(hipMalloc((void**)&ws_qkv_, T * 3 * H * 4), "hipMalloc(ws_qkv)");
+    hip_check(hipMalloc((void**)&ws_ctx_, T * H * 4), "hipMalloc(ws_ctx)");
+    hip_check(hipMalloc((void**)&ws_mid_, T * I * 4), "hipMalloc(ws_mid)");
+    hip_check(hipMalloc((void**)&ws_feat_, (size_t)sentences * H * 4), "hipMalloc(ws_feat)");
+    ws_tokens_ = tokens;
+    ws_sentences_ = sentences;
+}
+
+static void* grow(void*& p, size_t& have, size_t want)
+{
+    if (want > have) {
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(scratch)");
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        hip_check(hipMalloc(&p, want), "hipMalloc(scratch)");
+        have = want;
+    }
+    return p;
+}
+
+void* EncoderModel::scratch(size_t bytes)
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    return grow(scratch_, scratch_bytes_, bytes);
+}
+
+void* EncoderModel::scratch2(size_t bytes)
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    return grow(scratch2_, scratch2_bytes_, bytes);
+}
+
+// embed -> embed_norm -> layers (post-norm):
+//   h1 = LN1(x + Attn(x)); y = LN2(h1 + FFN(h1))
+// (cpu/encoder/encoder_layer.rs:113-179 / 216-232, transformer_encoder.rs:335-368;
+// no final norm, :300-302).  `hidden` is both the residual stream and the output.
+void EncoderModel::forward_chunk(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+                                 int64_t batch, int seq, float mask_value, float* hidden,
+                                 hipStream_t stream)
+{
+    const int H = cfg_.hidden, I = cfg_.inter;
+    const int64_t T = batch * seq;
+    hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,
+                                     seq, H, cfg_.vocab, cfg_.max_pos, cfg_.type_vocab, cfg_.pos_offset,
+                                     0, hidden, stream),
+              "embed_layernorm");
+    for (const DeviceLayer& L : layers_) {
+        hip_check(launch_gemm(hidden, H, L.wqkv, L.bqkv, nullptr, 0, ws_qkv_, 3 * H, T, 3 * H, H, EPI_BIAS,
+                              stream),
+                  "gemm(qkv)");
+        hip_check(launch_attention(ws_qkv_, mask, batch, seq, cfg_.heads, H / cfg_.heads, mask_value,
+                                   ws_ctx_, stream),
+                  "attention");
+        // hidden = ctx Wo^T + bo + hidden  (in place: each element is read then written by one thread)
+        hip_check(launch_gemm(ws_ctx_, H, L.wo, L.bo, hidden, H, hidden, H, T, H, H, EPI_BIAS_RESIDUAL,
+                              stream),
+                  "gemm(out_proj)");
+        hip_check(launch_layernorm(hidden, L.ln1_g, L.ln1_b, cfg_.eps, T, H, hidden, stream), "layernorm1");
+        hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws_mid_, I, T, I, H, cfg_.ffn_act, stream),
+                  "gemm(fc1)");
+        hip_check(launch_gemm(ws_mid_, I, L.w2, L.b2, hidden, H, hidden, H, T, H, I, EPI_BIAS_RESIDUAL,
+                              stream),
+                  "gemm(fc2)");
+        hip_check(launch_layernorm(hidden, L.ln2_g, L.ln2_b, cfg_.eps, T, H, hidden, stream), "layernorm2");
+    }
+}
+
+void EncoderModel::hidden_states(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+                                 int64_t batch, int seq, float mask_value, float* out, hipStream_t stream)
+{
+    if (batch <= 0 || seq <= 0) return;
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    const int64_t per = sentences_per_chunk(seq);
+    ensure_workspace(std::min(per, batch) * seq, std::min(per, batch));
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+        const int64_t nb = std::min(per, batch - b0);
+        forward_chunk(ids + b0 * seq, mask ? mask + b0 * seq : nullptr, type_ids ? type_ids + b0 * seq : nullptr,
+                      nb, seq, mask_value, out + b0 * seq * (int64_t)cfg_.hidden, stream);
+    }
+}
+
+void EncoderModel::embed(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                         int seq, PoolMode pool, bool normalize, float mask_value, float* out,
+                         hipStream_t stream)
+{
+    if (batch <= 0 || seq <= 0) return;
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    const int64_t per = sentences_per_chunk(seq);
+    ensure_workspace(std::min(per, batch) * seq, std::min(per, batch));
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+        const int64_t nb = std::min(per, batch - b0);
+        const uint32_t* m = mask ? mask + b0 * seq : nullptr;
+        forward_chunk(ids + b0 * seq, m, type_ids ? type_ids + b0 * seq : nullptr, nb, seq, mask_value,
+                      ws_hidden_, stream);
+        hip_check(launch_pool(ws_hidden_, m, nb, seq, cfg_.hidden, pool, normalize ? 1 : 0,
+                              out + b0 * (int64_t)cfg_.hidden, stream),
+                  "pool");
+    }
+}
+
+void EncoderModel::logits(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                          int seq, float mask_value, float* out, hipStream_t stream)
+{
+    if (batch <= 0 || seq <= 0) return;
+    if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    const int H = cfg_.hidden;
+    const int64_t per = sentences_per_chunk(seq);
+    ensure_workspace(std::min(per, batch) * seq, std::min(per, batch));
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+        const int64_t nb = std::min(per, batch - b0);
+        forward_chunk(ids + b0 * seq, mask ? mask + b0 * seq : nullptr, type_ids ? type_ids + b0 * seq : nullptr,
+                      nb, seq, mask_value, ws_hidden_, stream);
+        // CLS rows are read in place: row stride seq*H (cpu/encoder/classifier.rs:219).
+        const float* feat = ws_hidden_;
+        int64_t ld = (int64_t)seq * H;
+        if (cfg_.head_kind == 1 || cfg_.head_kind == 2) {
+            hip_check(launch_gemm(ws_hidden_, ld, head_dense_w_, head_dense_b_, nullptr, 0, ws_feat_, H, nb, H, H,
+                                  cfg_.head_kind == 1 ? EPI_BIAS_TANH : EPI_BIAS_RELU, stream),
+                      "gemm(head dense)");
+            feat = ws_feat_;
+            ld = H;
+        }
+        hip_check(launch_small_linear(feat, ld, head_cls_w_, head_cls_b_, nb, H, cfg_.num_labels,
+                                      out + b0 * cfg_.num_labels, stream),
+                  "classifier");
+    }
+}
+
+}  // namespace kjarni

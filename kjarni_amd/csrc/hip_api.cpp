@@ -1,0 +1,344 @@
+// Token-level C ABI (include/kjarni_hip.h).
+#include <sys/stat.h>
+
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "../../include/kjarni_hip.h"
+#include "ffi_common.h"
+
+using namespace kjarni;
+
+struct KjarniHipEncoder {
+    std::unique_ptr<EncoderModel> model;
+};
+
+namespace {
+
+bool file_exists(const std::string& p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+// cpu/strategy.rs:43-44 (scratch buffers iff tokens <= 1 or tokens >= 1000) decides
+// between the -inf (no-alloc) and -1e9 (alloc) mask fills on the embed path.
+float resolve_fill(KjarniHipMaskFill fill, int64_t tokens, bool logits_path)
+{
+    const float neg_inf = -std::numeric_limits<float>::infinity();
+    switch (fill) {
+    case KJARNI_HIP_MASK_NEG_1E9: return -1e9f;
+    case KJARNI_HIP_MASK_NEG_INF: return neg_inf;
+    default: break;
+    }
+    if (logits_path) return -1e9f;  // forward_tokens: always encoder.forward (alloc path)
+    return (tokens <= 1 || tokens >= 1000) ? neg_inf : -1e9f;
+}
+
+PoolMode pool_mode(KjarniHipPooling p)
+{
+    switch (p) {
+    case KJARNI_HIP_POOL_MEAN: return POOL_MEAN;
+    case KJARNI_HIP_POOL_CLS: return POOL_CLS;
+    case KJARNI_HIP_POOL_MAX: return POOL_MAX;
+    case KJARNI_HIP_POOL_LAST_TOKEN: return POOL_LAST;
+    }
+    throw InvalidConfig("unknown pooling strategy");
+}
+
+void check_shape(const EncoderModel& m, int64_t batch, int32_t seq)
+{
+    if (batch < 0 || seq < 0) throw InvalidConfig("negative batch or sequence length");
+    if (seq > m.config().max_pos)
+        throw InvalidConfig("sequence length " + std::to_string(seq) + " exceeds max_position_embeddings " +
+                            std::to_string(m.config().max_pos));
+}
+
+struct DeviceBuf {
+    void* p = nullptr;
+    explicit DeviceBuf(size_t bytes) { hip_check(hipMalloc(&p, bytes ? bytes : 4), "hipMalloc"); }
+    ~DeviceBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    DeviceBuf(const DeviceBuf&) = delete;
+    DeviceBuf& operator=(const DeviceBuf&) = delete;
+};
+
+void use_device(int32_t device)
+{
+    const int n = visible_device_count();
+    if (n <= 0) throw GpuUnavailable("no HIP device is visible");
+    if (device < 0 || device >= n) throw GpuUnavailable("HIP device index out of range");
+    hip_check(hipSetDevice(device), "hipSetDevice");
+}
+
+}  // namespace
+
+KJARNI_EXPORT int32_t kjarni_hip_device_count(void) { return visible_device_count(); }
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_load(const char* model_dir, int32_t device,
+                                                      KjarniHipEncoder** out)
+{
+    if (!model_dir || !out) return KJARNI_ERROR_NULL_POINTER;
+    *out = nullptr;
+    return guarded(KJARNI_ERROR_LOAD_FAILED, [&] {
+        const std::string dir(model_dir);
+        if (!file_exists(dir + "/config.json") || !file_exists(dir + "/model.safetensors"))
+            throw ModelNotFound("model files not found in '" + dir +
+                                "' (need config.json and model.safetensors)");
+        auto h = std::make_unique<KjarniHipEncoder>();
+        h->model = EncoderModel::load(dir, device);
+        *out = h.release();
+    });
+}
+
+KJARNI_EXPORT void kjarni_hip_encoder_free(KjarniHipEncoder* enc) { delete enc; }
+
+KJARNI_EXPORT int32_t kjarni_hip_encoder_hidden_size(const KjarniHipEncoder* e) { return e ? e->model->config().hidden : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_encoder_num_layers(const KjarniHipEncoder* e) { return e ? e->model->config().layers : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_encoder_max_seq_len(const KjarniHipEncoder* e) { return e ? e->model->config().max_pos : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_encoder_vocab_size(const KjarniHipEncoder* e) { return e ? e->model->config().vocab : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_encoder_num_labels(const KjarniHipEncoder* e) { return e ? e->model->config().num_labels : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_encoder_device(const KjarniHipEncoder* e) { return e ? e->model->device() : -1; }
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64_t tokens)
+{
+    if (!enc) return KJARNI_ERROR_NULL_POINTER;
+    enc->model->set_chunk_tokens(tokens);
+    return KJARNI_OK;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
+                                                               const uint32_t* mask_dev,
+                                                               const uint32_t* type_ids_dev, int64_t batch,
+                                                               int32_t seq, KjarniHipMaskFill fill,
+                                                               float* hidden_out_dev, void* stream)
+{
+    if (!enc || !ids_dev || !mask_dev || !hidden_out_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(*enc->model, batch, seq);
+        enc->model->hidden_states(ids_dev, mask_dev, type_ids_dev, batch, seq,
+                                  resolve_fill(fill, batch * seq, false), hidden_out_dev,
+                                  static_cast<hipStream_t>(stream));
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_embed(KjarniHipEncoder* enc, const uint32_t* ids_dev,
+                                                       const uint32_t* mask_dev, const uint32_t* type_ids_dev,
+                                                       int64_t batch, int32_t seq, KjarniHipPooling pooling,
+                                                       int32_t normalize, KjarniHipMaskFill fill,
+                                                       float* out_dev, void* stream)
+{
+    if (!enc || !ids_dev || !mask_dev || !out_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(*enc->model, batch, seq);
+        enc->model->embed(ids_dev, mask_dev, type_ids_dev, batch, seq, pool_mode(pooling), normalize != 0,
+                          resolve_fill(fill, batch * seq, false), out_dev, static_cast<hipStream_t>(stream));
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_logits(KjarniHipEncoder* enc, const uint32_t* ids_dev,
+                                                        const uint32_t* mask_dev, const uint32_t* type_ids_dev,
+                                                        int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                                        float* logits_out_dev, void* stream)
+{
+    if (!enc || !ids_dev || !mask_dev || !logits_out_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(*enc->model, batch, seq);
+        enc->model->logits(ids_dev, mask_dev, type_ids_dev, batch, seq, resolve_fill(fill, batch * seq, true),
+                           logits_out_dev, static_cast<hipStream_t>(stream));
+    });
+}
+
+namespace {
+
+// Shared body of the *_host variants: stage ids/mask/type on the device, run
+// `body(ids_dev, mask_dev, type_dev, out_dev)`, copy `out_floats` back.
+template <class F>
+void run_host(EncoderModel& m, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+              int64_t batch, int32_t seq, size_t out_floats, float* out, F&& body)
+{
+    check_shape(m, batch, seq);
+    if (batch == 0 || seq == 0) return;
+    hip_check(hipSetDevice(m.device()), "hipSetDevice");
+    const size_t n = (size_t)batch * (size_t)seq;
+    const size_t tok_bytes = n * sizeof(uint32_t);
+    const size_t in_bytes = tok_bytes * (type_ids ? 3 : 2);
+    const size_t out_off = (in_bytes + 255) & ~(size_t)255;
+    uint8_t* base = static_cast<uint8_t*>(m.scratch(out_off + out_floats * sizeof(float)));
+    uint32_t* ids_d = reinterpret_cast<uint32_t*>(base);
+    uint32_t* mask_d = reinterpret_cast<uint32_t*>(base + tok_bytes);
+    uint32_t* type_d = type_ids ? reinterpret_cast<uint32_t*>(base + 2 * tok_bytes) : nullptr;
+    float* out_d = reinterpret_cast<float*>(base + out_off);
+    hip_check(hipMemcpyAsync(ids_d, ids, tok_bytes, hipMemcpyHostToDevice, nullptr), "H2D ids");
+    hip_check(hipMemcpyAsync(mask_d, mask, tok_bytes, hipMemcpyHostToDevice, nullptr), "H2D mask");
+    if (type_ids) hip_check(hipMemcpyAsync(type_d, type_ids, tok_bytes, hipMemcpyHostToDevice, nullptr), "H2D type ids");
+    body(ids_d, mask_d, type_d, out_d);
+    hip_check(hipMemcpyAsync(out, out_d, out_floats * sizeof(float), hipMemcpyDeviceToHost, nullptr), "D2H output");
+    hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+}
+
+}  // namespace
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states_host(KjarniHipEncoder* enc, const uint32_t* ids,
+                                                                    const uint32_t* mask,
+                                                                    const uint32_t* type_ids, int64_t batch,
+                                                                    int32_t seq, KjarniHipMaskFill fill,
+                                                                    float* hidden_out)
+{
+    if (!enc || !ids || !mask || !hidden_out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        EncoderModel& m = *enc->model;
+        run_host(m, ids, mask, type_ids, batch, seq, (size_t)batch * seq * m.config().hidden, hidden_out,
+                 [&](uint32_t* i, uint32_t* k, uint32_t* t, float* o) {
+                     m.hidden_states(i, k, t, batch, seq, resolve_fill(fill, batch * seq, false), o, nullptr);
+                 });
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_embed_host(KjarniHipEncoder* enc, const uint32_t* ids,
+                                                            const uint32_t* mask, const uint32_t* type_ids,
+                                                            int64_t batch, int32_t seq, KjarniHipPooling pooling,
+                                                            int32_t normalize, KjarniHipMaskFill fill, float* out)
+{
+    if (!enc || !ids || !mask || !out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        EncoderModel& m = *enc->model;
+        const PoolMode pm = pool_mode(pooling);
+        run_host(m, ids, mask, type_ids, batch, seq, (size_t)batch * m.config().hidden, out,
+                 [&](uint32_t* i, uint32_t* k, uint32_t* t, float* o) {
+                     m.embed(i, k, t, batch, seq, pm, normalize != 0, resolve_fill(fill, batch * seq, false), o,
+                             nullptr);
+                 });
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* enc, const uint32_t* ids,
+                                                             const uint32_t* mask, const uint32_t* type_ids,
+                                                             int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                                             float* logits_out)
+{
+    if (!enc || !ids || !mask || !logits_out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        EncoderModel& m = *enc->model;
+        run_host(m, ids, mask, type_ids, batch, seq, (size_t)batch * m.config().num_labels, logits_out,
+                 [&](uint32_t* i, uint32_t* k, uint32_t* t, float* o) {
+                     m.logits(i, k, t, batch, seq, resolve_fill(fill, batch * seq, true), o, nullptr);
+                 });
+    });
+}
+
+// ---- cosine scan ----------------------------------------------------------------
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_scores(int32_t device, const float* queries_dev,
+                                                       int32_t n_queries, const float* corpus_dev,
+                                                       int64_t n_docs, int32_t dim, KjarniHipCosineMode mode,
+                                                       float* scores_out_dev, void* stream)
+{
+    if (!queries_dev || !corpus_dev || !scores_out_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (dim <= 0 || n_queries < 0 || n_docs < 0) throw InvalidConfig("invalid scan dimensions");
+        use_device(device);
+        hip_check(launch_cosine_scores(queries_dev, n_queries, corpus_dev, n_docs, dim, (int)mode,
+                                       scores_out_dev, static_cast<hipStream_t>(stream)),
+                  "cosine_scores");
+    });
+}
+
+KJARNI_EXPORT size_t kjarni_hip_cosine_topk_workspace_bytes(int32_t n_queries, int64_t n_docs, int32_t k)
+{
+    if (n_queries <= 0 || n_docs <= 0 || k <= 0) return 256;
+    return cosine_topk_workspace_bytes(n_queries, n_docs, k);
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_topk(int32_t device, const float* scores_dev, int32_t n_queries,
+                                                     int64_t n_docs, int32_t k, void* workspace_dev,
+                                                     int64_t* idx_out_dev, float* score_out_dev, void* stream)
+{
+    if (!scores_dev || !workspace_dev || !idx_out_dev || !score_out_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        use_device(device);
+        hip_check(launch_cosine_topk(scores_dev, n_queries, n_docs, k, workspace_dev, idx_out_dev,
+                                     score_out_dev, static_cast<hipStream_t>(stream)),
+                  "cosine_topk");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, const float* queries,
+                                                            int32_t n_queries, const float* corpus,
+                                                            int64_t n_docs, int32_t dim, KjarniHipCosineMode mode,
+                                                            int32_t k, int64_t* idx_out, float* score_out,
+                                                            int64_t* n_hits_out)
+{
+    if (!queries || !corpus || !idx_out || !score_out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (dim <= 0 || n_queries < 0 || n_docs < 0 || k < 0) throw InvalidConfig("invalid search dimensions");
+        if (n_hits_out) *n_hits_out = 0;
+        if (n_queries == 0 || n_docs == 0 || k == 0) return;
+        use_device(device);
+        const size_t qb = (size_t)n_queries * dim * 4, cb = (size_t)n_docs * dim * 4;
+        DeviceBuf q_d(qb), c_d(cb), s_d((size_t)n_queries * n_docs * 4);
+        DeviceBuf ws(cosine_topk_workspace_bytes(n_queries, n_docs, k));
+        DeviceBuf i_d((size_t)n_queries * k * 8), o_d((size_t)n_queries * k * 4);
+        hip_check(hipMemcpy(q_d.p, queries, qb, hipMemcpyHostToDevice), "H2D queries");
+        hip_check(hipMemcpy(c_d.p, corpus, cb, hipMemcpyHostToDevice), "H2D corpus");
+        hip_check(launch_cosine_scores((const float*)q_d.p, n_queries, (const float*)c_d.p, n_docs, dim, (int)mode,
+                                       (float*)s_d.p, nullptr),
+                  "cosine_scores");
+        hip_check(launch_cosine_topk((const float*)s_d.p, n_queries, n_docs, k, ws.p, (int64_t*)i_d.p,
+                                     (float*)o_d.p, nullptr),
+                  "cosine_topk");
+        hip_check(hipMemcpy(idx_out, i_d.p, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost), "D2H idx");
+        hip_check(hipMemcpy(score_out, o_d.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost), "D2H scores");
+        if (n_hits_out) *n_hits_out = (k < n_docs) ? k : n_docs;
+    });
+}
+
+// ---- device memory helpers ------------------------------------------------------
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev)
+{
+    if (!out_dev) return KJARNI_ERROR_NULL_POINTER;
+    *out_dev = nullptr;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        use_device(device);
+        hip_check(hipMalloc(out_dev, bytes ? bytes : 4), "hipMalloc");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev)
+{
+    if (!ptr_dev) return KJARNI_OK;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        use_device(device);
+        hip_check(hipFree(ptr_dev), "hipFree");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_memcpy_h2d(int32_t device, void* dst_dev, const void* src, size_t bytes)
+{
+    if (!dst_dev || !src) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        use_device(device);
+        hip_check(hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_memcpy_d2h(int32_t device, void* dst, const void* src_dev, size_t bytes)
+{
+    if (!dst || !src_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        use_device(device);
+        hip_check(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_synchronize(int32_t device)
+{
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        use_device(device);
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    });
+}

@@ -1,0 +1,73 @@
+// Launchers for the hand-written gfx950 kernels of the encoder hot path.
+// Every launcher enqueues on `stream` and returns the launch status; nothing
+// here allocates, synchronises or touches the host (graph-capturable).
+//
+// Reference rows each kernel replaces are cited at the
+// kernel definitions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kjarni {
+
+// Epilogues of the projection GEMM  Y = X * W^T + b  (W is [N,K] row-major).
+enum GemmEpilogue : int {
+    EPI_BIAS = 0,           // y = acc + b
+    EPI_BIAS_GELU = 1,      // erf GELU   (activations.rs:56-59)
+    EPI_BIAS_GELU_NEW = 2,  // tanh GELU  (activations.rs:62-66)
+    EPI_BIAS_RELU = 3,
+    EPI_BIAS_TANH = 4,
+    EPI_BIAS_RESIDUAL = 5,  // y = acc + b + R   (encoder_layer.rs:129-136, 155-163)
+};
+
+enum PoolMode : int { POOL_MEAN = 0, POOL_CLS = 1, POOL_MAX = 2, POOL_LAST = 3 };
+
+// R2 + R3: word/pos/type gather-add fused with the embedding LayerNorm.
+hipError_t launch_embed_layernorm(const uint32_t* ids, const uint32_t* type_ids, const float* word,
+                                  const float* pos, const float* type, const float* gamma,
+                                  const float* beta, float eps, int64_t tokens, int seq, int hidden,
+                                  int vocab, int max_pos, int type_vocab, int pos_offset,
+                                  int scale_embeddings, float* out, hipStream_t stream);
+
+// R3: row LayerNorm, in == out allowed.
+hipError_t launch_layernorm(const float* in, const float* gamma, const float* beta, float eps,
+                            int64_t rows, int hidden, float* out, hipStream_t stream);
+
+// R4/R5/R9: fp32 MFMA GEMM with fused epilogue.  A rows are `lda` floats apart
+// (lets the head GEMM read CLS rows in place), R/Y rows ldr/ldy apart.
+hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float* bias,
+                       const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
+                       GemmEpilogue epi, hipStream_t stream);
+
+// R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.
+// qkv is [tokens, 3*hidden] (Q | K | V), mask is u32 [batch, seq], ctx is
+// [tokens, hidden] with heads merged.
+hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq,
+                            int heads, int head_dim, float mask_value, float* ctx,
+                            hipStream_t stream);
+
+// R11: pooling (+ optional L2 normalisation) of [batch, seq, hidden].
+hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t batch, int seq,
+                       int hidden, PoolMode mode, int normalize, float* out, hipStream_t stream);
+
+// R12 tail: logits[b, n] = feat[b,:] . Wc[n,:] + bc[n]  for small num_labels.
+hipError_t launch_small_linear(const float* feat, int64_t ld, const float* w, const float* bias,
+                               int64_t rows, int k, int n, float* out, hipStream_t stream);
+
+// Row softmax / sigmoid over [rows, n] logits (classifier probabilities).
+hipError_t launch_row_softmax(const float* in, int64_t rows, int n, int sigmoid, float* out,
+                              hipStream_t stream);
+
+// R14: cosine scores of every corpus row against `nq` queries.
+// mode 0 = VectorStore (kjarni-search/src/vector.rs:131-148),
+// mode 1 = Segment (kjarni-rag/src/segment.rs:355-371).
+hipError_t launch_cosine_scores(const float* queries, int nq, const float* corpus, int64_t n_docs,
+                                int dim, int mode, float* scores, hipStream_t stream);
+
+// R14 selection: per-query top-k of scores [nq, n_docs], score descending,
+// ties by ascending index.  workspace must hold cosine_topk_workspace_bytes().
+size_t cosine_topk_workspace_bytes(int nq, int64_t n_docs, int k);
+hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k, void* workspace,
+                              int64_t* out_idx, float* out_score, hipStream_t stream);
+
+}  // namespace kjarni

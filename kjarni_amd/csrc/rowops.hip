@@ -1,0 +1,406 @@
+// HBM-bound row kernels of the encoder path: embedding gather + LayerNorm,
+// LayerNorm, pooling (+L2), the small classifier GEMV and the probability
+// softmax / sigmoid.  One wave64 per row, 16-byte loads, wave-shuffle
+// reductions; rows stay in registers between the statistics and the affine
+// pass so every byte is read once.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace kjarni {
+
+namespace {
+
+constexpr int MAX_V4_PER_LANE = 4;  // hidden <= 1024 on the float4 path
+
+// ---------------------------------------------------------------------------
+// LayerNorm core on a row held as float4 registers.
+// (x-mean)/sqrt(var+eps)*gamma+beta with the population variance and eps inside
+// the sqrt: crates/kjarni-transformers/src/cpu/normalization/layer_norm.rs
+// :96-131 (scalar), :37-93 (AVX2), :203-215 (ndarray alloc path).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void ln_row_v4(f32x4 (&x)[MAX_V4_PER_LANE], int nv4, int lane,
+                                          const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float eps, int hidden,
+                                          float* __restrict__ out_row)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4_PER_LANE; ++i)
+        if (lane + i * 64 < nv4) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    const float mean = wave_sum(s) / (float)hidden;
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAX_V4_PER_LANE; ++i)
+        if (lane + i * 64 < nv4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d = x[i][c] - mean;
+                v = fmaf(d, d, v);
+            }
+        }
+    const float var = wave_sum(v) / (float)hidden;
+    const float inv_std = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < MAX_V4_PER_LANE; ++i) {
+        const int c4 = lane + i * 64;
+        if (c4 < nv4) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4 * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4 * 4);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (x[i][c] - mean) * inv_std * g[c] + b[c];
+            *reinterpret_cast<f32x4*>(out_row + c4 * 4) = o;
+        }
+    }
+}
+
+// Embeddings::forward (cpu/embeddings/mod.rs:181-225) fused with embed_norm
+// (cpu/encoder/transformer_encoder.rs:303-305):
+//   h = W_word[id] (zeros when id >= vocab, mod.rs:232-236) [* sqrt(H)]
+//       + P[offset+s] (when offset+s < max_pos, mod.rs:198-212)
+//       + T[type] (row 0 when type_ids is null, mod.rs:214-223); then LayerNorm.
+// A type id >= type_vocab panics in the reference; here it is clamped (the
+// host validates type ids before launch).
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(
+    const uint32_t* __restrict__ ids, const uint32_t* __restrict__ type_ids,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int64_t tokens,
+    int seq, int hidden, int vocab, int max_pos, int type_vocab, int pos_offset, int scale_embeddings,
+    float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= tokens) return;
+    const int nv4 = hidden >> 2;
+    const int s = (int)(t % seq);
+    const uint32_t id = ids[t];
+    const bool has_word = id < (uint32_t)vocab;
+    const bool has_pos = pos != nullptr && (pos_offset + s) < max_pos;
+    const bool has_type = type != nullptr && type_vocab > 0;
+    uint32_t ty = (has_type && type_ids) ? type_ids[t] : 0u;
+    if (has_type && ty >= (uint32_t)type_vocab) ty = (uint32_t)type_vocab - 1;
+    const float* wrow = word + (int64_t)id * hidden;
+    const float* prow = pos + (int64_t)(pos_offset + s) * hidden;
+    const float* trow = type + (int64_t)ty * hidden;
+    const float sc = sqrtf((float)hidden);
+
+    f32x4 x[MAX_V4_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < MAX_V4_PER_LANE; ++i) {
+        const int c4 = lane + i * 64;
+        x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c4 < nv4) {
+            if (has_word) x[i] = *reinterpret_cast<const f32x4*>(wrow + c4 * 4);
+            if (scale_embeddings) x[i] *= sc;
+            if (has_pos) x[i] += *reinterpret_cast<const f32x4*>(prow + c4 * 4);
+            if (has_type) x[i] += *reinterpret_cast<const f32x4*>(trow + c4 * 4);
+        }
+    }
+    float* orow = out + t * hidden;
+    if (gamma != nullptr) {
+        ln_row_v4(x, nv4, lane, gamma, beta, eps, hidden, orow);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAX_V4_PER_LANE; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv4) *reinterpret_cast<f32x4*>(orow + c4 * 4) = x[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        int64_t rows, int hidden,
+                                                        float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= rows) return;
+    const int nv4 = hidden >> 2;
+    const float* irow = in + t * hidden;
+    f32x4 x[MAX_V4_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < MAX_V4_PER_LANE; ++i) {
+        const int c4 = lane + i * 64;
+        x[i] = (c4 < nv4) ? *reinterpret_cast<const f32x4*>(irow + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_row_v4(x, nv4, lane, gamma, beta, eps, hidden, out + t * hidden);
+}
+
+// Any-width fallback (hidden not a multiple of 4 or > 1024): one wave per row,
+// three passes over global memory.  Not on the BERT-family hot path.
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(
+    const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, int64_t rows, int hidden, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= rows) return;
+    const float* irow = in + t * hidden;
+    float s = 0.f;
+    for (int i = lane; i < hidden; i += 64) s += irow[i];
+    const float mean = wave_sum(s) / (float)hidden;
+    float v = 0.f;
+    for (int i = lane; i < hidden; i += 64) {
+        const float d = irow[i] - mean;
+        v = fmaf(d, d, v);
+    }
+    const float inv_std = 1.0f / sqrtf(wave_sum(v) / (float)hidden + eps);
+    float* orow = out + t * hidden;
+    for (int i = lane; i < hidden; i += 64) {
+        const float xv = irow[i];
+        orow[i] = (xv - mean) * inv_std * gamma[i] + beta[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_generic_kernel(
+    const uint32_t* __restrict__ ids, const uint32_t* __restrict__ type_ids,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+    int64_t tokens, int seq, int hidden, int vocab, int max_pos, int type_vocab, int pos_offset,
+    int scale_embeddings, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= tokens) return;
+    const int s = (int)(t % seq);
+    const uint32_t id = ids[t];
+    const bool has_word = id < (uint32_t)vocab;
+    const bool has_pos = pos != nullptr && (pos_offset + s) < max_pos;
+    const bool has_type = type != nullptr && type_vocab > 0;
+    uint32_t ty = (has_type && type_ids) ? type_ids[t] : 0u;
+    if (has_type && ty >= (uint32_t)type_vocab) ty = (uint32_t)type_vocab - 1;
+    const float sc = sqrtf((float)hidden);
+    for (int i = lane; i < hidden; i += 64) {
+        float x = has_word ? word[(int64_t)id * hidden + i] : 0.0f;
+        if (scale_embeddings) x *= sc;
+        if (has_pos) x += pos[(int64_t)(pos_offset + s) * hidden + i];
+        if (has_type) x += type[(int64_t)ty * hidden + i];
+        out[t * hidden + i] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pooling + L2: pooling/mod.rs:11-68 and cpu/encoder/traits.rs:529-536.
+// One block per sentence; thread t owns columns t, t+256, ... so every load of
+// a hidden row is coalesced.  mask is the u32 attention mask (traits.rs:71
+// converts it with `as f32`).
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
+                                                   const uint32_t* __restrict__ mask, int seq,
+                                                   int hidden, int normalize,
+                                                   float* __restrict__ out)
+{
+    __shared__ float red[4];
+    __shared__ float s_cnt;
+    __shared__ int s_last;
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* base = hs + b * seq * (int64_t)hidden;
+    const uint32_t* mrow = mask ? mask + b * seq : nullptr;
+
+    if (tid == 0) {
+        float cnt = 0.0f;
+        int last = 0;
+        for (int s = 0; s < seq; ++s) {
+            const float mv = mrow ? (float)mrow[s] : 1.0f;
+            cnt += mv;
+            if (mv > 0.0f) last = s;  // pooling/mod.rs:61-62 rposition(x > 0), else 0
+        }
+        s_cnt = cnt;
+        s_last = last;
+    }
+    __syncthreads();
+    const float cnt = s_cnt;
+
+    constexpr int MAXC = 4;  // hidden <= 1024
+    float acc[MAXC];
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = tid + j * 256;
+        acc[j] = 0.0f;
+        if (c >= hidden) continue;
+        if (MODE == POOL_MEAN) {
+            if (cnt == 0.0f) {
+                acc[j] = base[c];  // pooling/mod.rs:25-27: all-masked row -> token 0
+            } else {
+                float a = 0.0f;
+                for (int s = 0; s < seq; ++s) {
+                    const float mv = mrow ? (float)mrow[s] : 1.0f;
+                    a += base[(int64_t)s * hidden + c] * mv;
+                }
+                acc[j] = a / cnt;
+            }
+        } else if (MODE == POOL_CLS) {
+            acc[j] = base[c];
+        } else if (MODE == POOL_MAX) {
+            float a = -1e9f;  // MASK_VALUE, pooling/mod.rs:41-52
+            for (int s = 0; s < seq; ++s) {
+                const bool masked = mrow && mrow[s] == 0u;
+                const float xv = masked ? -1e9f : base[(int64_t)s * hidden + c];
+                a = fmaxf(a, xv);
+            }
+            acc[j] = a;
+        } else {
+            acc[j] = base[(int64_t)s_last * hidden + c];
+        }
+        sq = fmaf(acc[j], acc[j], sq);
+    }
+    float inv = 1.0f;
+    if (normalize) {
+        sq = wave_sum(sq);
+        if ((tid & 63) == 0) red[tid >> 6] = sq;
+        __syncthreads();
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        // traits.rs:529-536: divide only when the norm is > 0
+        if (norm > 0.0f) {
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) acc[j] = acc[j] / norm;
+        }
+    }
+    (void)inv;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = tid + j * 256;
+        if (c < hidden) out[b * hidden + c] = acc[j];
+    }
+}
+
+// logits[r, n] = feat[r,:] . w[n,:] + bias[n]: one wave per output element
+// (num_labels is 1 or 2 for the rerank / sentiment heads:
+// cpu/encoder/classifier.rs:258).
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ feat, int64_t ld,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           int64_t rows, int k, int n,
+                                                           float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= rows * n) return;
+    const int64_t r = o / n;
+    const int j = (int)(o % n);
+    const float* x = feat + r * ld;
+    const float* wr = w + (int64_t)j * k;
+    float s = 0.0f;
+    for (int i = lane; i < k; i += 64) s = fmaf(x[i], wr[i], s);
+    s = wave_sum(s);
+    if (lane == 0) out[o] = s + (bias ? bias[j] : 0.0f);
+}
+
+// Classifier probabilities: softmax_inplace (activations.rs:223-242) per row, or
+// sigmoid for multi-label (crates/kjarni/src/classifier/model.rs:529).
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ in, int64_t rows,
+                                                          int n, int sigmoid,
+                                                          float* __restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* x = in + r * n;
+    float* o = out + r * n;
+    if (sigmoid) {
+        for (int i = 0; i < n; ++i) o[i] = 1.0f / (1.0f + expf(-x[i]));
+        return;
+    }
+    float mx = -INFINITY;
+    for (int i = 0; i < n; ++i) mx = fmaxf(mx, x[i]);
+    float sum = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const float e = expf(x[i] - mx);
+        o[i] = e;
+        sum += e;
+    }
+    if (sum > 0.0f) {
+        const float scale = 1.0f / sum;
+        for (int i = 0; i < n; ++i) o[i] *= scale;
+    }
+}
+
+inline unsigned rows_to_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+
+}  // namespace
+
+hipError_t launch_embed_layernorm(const uint32_t* ids, const uint32_t* type_ids, const float* word,
+                                  const float* pos, const float* type, const float* gamma,
+                                  const float* beta, float eps, int64_t tokens, int seq, int hidden,
+                                  int vocab, int max_pos, int type_vocab, int pos_offset,
+                                  int scale_embeddings, float* out, hipStream_t stream)
+{
+    if (tokens <= 0) return hipSuccess;
+    if (hidden % 4 == 0 && hidden <= 256 * MAX_V4_PER_LANE) {
+        hipLaunchKernelGGL(embed_layernorm_kernel, dim3(rows_to_blocks(tokens)), dim3(256), 0, stream,
+                           ids, type_ids, word, pos, type, gamma, beta, eps, tokens, seq, hidden,
+                           vocab, max_pos, type_vocab, pos_offset, scale_embeddings, out);
+    } else {
+        hipLaunchKernelGGL(embed_generic_kernel, dim3(rows_to_blocks(tokens)), dim3(256), 0, stream,
+                           ids, type_ids, word, pos, type, tokens, seq, hidden, vocab, max_pos,
+                           type_vocab, pos_offset, scale_embeddings, out);
+        if (gamma != nullptr)
+            hipLaunchKernelGGL(layernorm_generic_kernel, dim3(rows_to_blocks(tokens)), dim3(256), 0,
+                               stream, out, gamma, beta, eps, tokens, hidden, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* in, const float* gamma, const float* beta, float eps,
+                            int64_t rows, int hidden, float* out, hipStream_t stream)
+{
+    if (rows <= 0) return hipSuccess;
+    if (hidden % 4 == 0 && hidden <= 256 * MAX_V4_PER_LANE)
+        hipLaunchKernelGGL(layernorm_kernel, dim3(rows_to_blocks(rows)), dim3(256), 0, stream, in,
+                           gamma, beta, eps, rows, hidden, out);
+    else
+        hipLaunchKernelGGL(layernorm_generic_kernel, dim3(rows_to_blocks(rows)), dim3(256), 0, stream,
+                           in, gamma, beta, eps, rows, hidden, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t batch, int seq,
+                       int hidden, PoolMode mode, int normalize, float* out, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    if (hidden > 1024 || seq <= 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)batch), block(256);
+    switch (mode) {
+    case POOL_MEAN:
+        hipLaunchKernelGGL(pool_kernel<POOL_MEAN>, grid, block, 0, stream, hidden_states, mask, seq,
+                           hidden, normalize, out);
+        break;
+    case POOL_CLS:
+        hipLaunchKernelGGL(pool_kernel<POOL_CLS>, grid, block, 0, stream, hidden_states, mask, seq,
+                           hidden, normalize, out);
+        break;
+    case POOL_MAX:
+        hipLaunchKernelGGL(pool_kernel<POOL_MAX>, grid, block, 0, stream, hidden_states, mask, seq,
+                           hidden, normalize, out);
+        break;
+    case POOL_LAST:
+        hipLaunchKernelGGL(pool_kernel<POOL_LAST>, grid, block, 0, stream, hidden_states, mask, seq,
+                           hidden, normalize, out);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_small_linear(const float* feat, int64_t ld, const float* w, const float* bias,
+                               int64_t rows, int k, int n, float* out, hipStream_t stream)
+{
+    if (rows <= 0 || n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(small_linear_kernel, dim3(rows_to_blocks(rows * n)), dim3(256), 0, stream, feat,
+                       ld, w, bias, rows, k, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_softmax(const float* in, int64_t rows, int n, int sigmoid, float* out,
+                              hipStream_t stream)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
+                       in, rows, n, sigmoid, out);
+    return hipGetLastError();
+}
+
+}  // namespace kjarni

@@ -1,0 +1,136 @@
+"""Token-level encoder on one MI355X (include/kjarni_hip.h).
+
+Host-side mirror of the reference's token-level interface
+(EncoderLanguageModel::get_hidden_states_batch_from_ids,
+crates/kjarni-transformers/src/cpu/encoder/traits.rs:66-139;
+SentenceEncoder::encode_batch_flat, kjarni-models/.../sentence_encoder/model.rs:201-218;
+CrossEncoder::predict_pairs, .../cross_encoder/model.rs:170-240)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check_error, lib
+
+POOL_MEAN, POOL_CLS, POOL_MAX, POOL_LAST_TOKEN = 0, 1, 2, 3
+MASK_AUTO, MASK_NEG_1E9, MASK_NEG_INF = 0, 1, 2
+COSINE_VECTOR_STORE, COSINE_SEGMENT = 0, 1
+
+_POOL_NAMES = {"mean": POOL_MEAN, "cls": POOL_CLS, "max": POOL_MAX, "lasttoken": POOL_LAST_TOKEN,
+               "last_token": POOL_LAST_TOKEN}
+
+
+def device_count() -> int:
+    return int(lib().kjarni_hip_device_count())
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _p(a: Optional[np.ndarray], typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class HipEncoder:
+    """A BERT-family encoder resident on one HIP device."""
+
+    def __init__(self, model_dir: str, device: int = 0):
+        self._h = C.c_void_p()
+        check_error(lib().kjarni_hip_encoder_load(str(model_dir).encode(), int(device), C.byref(self._h)))
+        L = lib()
+        self.hidden_size = int(L.kjarni_hip_encoder_hidden_size(self._h))
+        self.num_layers = int(L.kjarni_hip_encoder_num_layers(self._h))
+        self.max_seq_len = int(L.kjarni_hip_encoder_max_seq_len(self._h))
+        self.vocab_size = int(L.kjarni_hip_encoder_vocab_size(self._h))
+        self.num_labels = int(L.kjarni_hip_encoder_num_labels(self._h))
+        self.device = int(L.kjarni_hip_encoder_device(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().kjarni_hip_encoder_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chunk_tokens(self, tokens: int):
+        check_error(lib().kjarni_hip_encoder_set_chunk_tokens(self._h, int(tokens)))
+
+    # ---- host-array entry points (copy in, run, copy out, synchronise) ----
+    def hidden_states(self, ids, mask, type_ids=None, fill: int = MASK_AUTO) -> np.ndarray:
+        ids, mask = _u32(ids), _u32(mask)
+        type_ids = None if type_ids is None else _u32(type_ids)
+        B, S = ids.shape
+        out = np.empty((B, S, self.hidden_size), np.float32)
+        check_error(lib().kjarni_hip_encoder_hidden_states_host(
+            self._h, _p(ids, _ffi._u32p), _p(mask, _ffi._u32p), _p(type_ids, _ffi._u32p), B, S, fill,
+            _p(out, _ffi._f32p)))
+        return out
+
+    def embed(self, ids, mask, type_ids=None, pooling="mean", normalize: bool = True,
+              fill: int = MASK_AUTO) -> np.ndarray:
+        ids, mask = _u32(ids), _u32(mask)
+        type_ids = None if type_ids is None else _u32(type_ids)
+        B, S = ids.shape
+        pool = _POOL_NAMES[pooling.lower()] if isinstance(pooling, str) else int(pooling)
+        out = np.empty((B, self.hidden_size), np.float32)
+        check_error(lib().kjarni_hip_encoder_embed_host(
+            self._h, _p(ids, _ffi._u32p), _p(mask, _ffi._u32p), _p(type_ids, _ffi._u32p), B, S, pool,
+            int(bool(normalize)), fill, _p(out, _ffi._f32p)))
+        return out
+
+    def logits(self, ids, mask, type_ids=None, fill: int = MASK_AUTO) -> np.ndarray:
+        ids, mask = _u32(ids), _u32(mask)
+        type_ids = None if type_ids is None else _u32(type_ids)
+        B, S = ids.shape
+        out = np.empty((B, self.num_labels), np.float32)
+        check_error(lib().kjarni_hip_encoder_logits_host(
+            self._h, _p(ids, _ffi._u32p), _p(mask, _ffi._u32p), _p(type_ids, _ffi._u32p), B, S, fill,
+            _p(out, _ffi._f32p)))
+        return out
+
+    # ---- device-pointer entry points (ints are raw device addresses) ----
+    def embed_dev(self, ids_ptr: int, mask_ptr: int, batch: int, seq: int, out_ptr: int,
+                  type_ptr: int = 0, pooling: int = POOL_MEAN, normalize: bool = True,
+                  fill: int = MASK_AUTO, stream: int = 0):
+        check_error(lib().kjarni_hip_encoder_embed(self._h, ids_ptr, mask_ptr, type_ptr or None, batch, seq,
+                                                   pooling, int(bool(normalize)), fill, out_ptr,
+                                                   stream or None))
+
+    def logits_dev(self, ids_ptr: int, mask_ptr: int, type_ptr: int, batch: int, seq: int, out_ptr: int,
+                   fill: int = MASK_AUTO, stream: int = 0):
+        check_error(lib().kjarni_hip_encoder_logits(self._h, ids_ptr, mask_ptr, type_ptr or None, batch, seq,
+                                                    fill, out_ptr, stream or None))
+
+    def hidden_states_dev(self, ids_ptr: int, mask_ptr: int, type_ptr: int, batch: int, seq: int,
+                          out_ptr: int, fill: int = MASK_AUTO, stream: int = 0):
+        check_error(lib().kjarni_hip_encoder_hidden_states(self._h, ids_ptr, mask_ptr, type_ptr or None, batch,
+                                                           seq, fill, out_ptr, stream or None))
+
+
+def cosine_search(queries, corpus, k: int, mode: int = COSINE_VECTOR_STORE, device: int = 0):
+    """Brute-force cosine top-k on the GPU (VectorStore::search / Segment::search_vectors).
+
+    Returns (idx int64 [nq, k'], score f32 [nq, k']) with k' = min(k, n_docs)."""
+    queries = np.ascontiguousarray(queries, np.float32)
+    corpus = np.ascontiguousarray(corpus, np.float32)
+    if queries.ndim == 1:
+        queries = queries[None, :]
+    nq, dim = queries.shape
+    n = corpus.shape[0]
+    if n == 0 or k <= 0 or corpus.shape[1] != dim:
+        return np.zeros((nq, 0), np.int64), np.zeros((nq, 0), np.float32)
+    idx = np.empty((nq, k), np.int64)
+    sc = np.empty((nq, k), np.float32)
+    hits = C.c_int64(0)
+    check_error(lib().kjarni_hip_cosine_search_host(
+        device, _p(queries, _ffi._f32p), nq, _p(corpus, _ffi._f32p), n, dim, mode, k,
+        _p(idx, _ffi._i64p), _p(sc, _ffi._f32p), C.byref(hits)))
+    return idx[:, :hits.value], sc[:, :hits.value]

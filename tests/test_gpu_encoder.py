@@ -1,0 +1,132 @@
+"""GPU parity: HIP encoder (through the C ABI) vs the CPU oracle on the same
+seeded inputs.  Floats within 1e-4 abs (BASELINE.json north_star tolerance)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def minilm(tmp_path_factory):
+    import kjarni_amd
+    d = str(tmp_path_factory.mktemp("minilm"))
+    cfg, t = synth.minilm_embedder(d, seed=0)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    yield enc, O.OracleModel(t, cfg)
+    enc.close()
+
+
+@pytest.fixture(scope="module")
+def cross(tmp_path_factory):
+    import kjarni_amd
+    d = str(tmp_path_factory.mktemp("cross"))
+    cfg, t = synth.minilm_cross_encoder(d, seed=1)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    yield enc, O.OracleModel(t, cfg)
+    enc.close()
+
+
+def test_model_info(minilm):
+    enc, _ = minilm
+    assert (enc.hidden_size, enc.num_layers, enc.max_seq_len, enc.vocab_size, enc.num_labels) == \
+        (384, 6, 512, 30522, 0)
+
+
+@pytest.mark.parametrize("B,S,ragged", [(1, 8, False), (3, 8, True), (3, 128, True), (16, 128, False),
+                                        (2, 37, True), (5, 200, True)])
+def test_hidden_states_parity(minilm, B, S, ragged):
+    import kjarni_amd
+    enc, orc = minilm
+    ids, mask = synth.synthetic_ids(B, S, seed=B * 1000 + S, ragged=ragged)
+    for fill, mv in ((kjarni_amd.MASK_NEG_1E9, O.MASK_ALLOC), (kjarni_amd.MASK_NEG_INF, O.MASK_NOALLOC)):
+        got = enc.hidden_states(ids, mask, fill=fill)
+        ref = orc.forward(ids, mask, None, mv)
+        assert got.shape == ref.shape
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() < TOL
+
+
+@pytest.mark.parametrize("B,S", [(1, 8), (3, 8), (64, 128), (3, 128), (4, 300)])
+def test_embed_parity(minilm, B, S):
+    enc, orc = minilm
+    ids, mask = synth.synthetic_ids(B, S, seed=7 * B + S, ragged=True)
+    got = enc.embed(ids, mask)  # mean + L2 = encode_batch_flat, AUTO mask fill
+    ref = orc.embed_batch(ids, mask)
+    assert np.abs(got - ref).max() < TOL
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+
+
+def test_pooling_modes(minilm):
+    enc, orc = minilm
+    ids, mask = synth.synthetic_ids(4, 32, seed=11, ragged=True)
+    h = orc.forward(ids, mask, None, O.strategy_mask_value(4 * 32))
+    mf = mask.astype(np.float32)
+    for name, ref in (("mean", O.mean_pool(h, mf)), ("cls", O.cls_pool(h)), ("max", O.max_pool(h, mf)),
+                      ("last_token", O.last_token_pool(h, mf))):
+        got = enc.embed(ids, mask, pooling=name, normalize=False)
+        assert np.abs(got - ref).max() < TOL, name
+        gotn = enc.embed(ids, mask, pooling=name, normalize=True)
+        assert np.abs(gotn - O.l2_normalize(ref)).max() < TOL, name
+
+
+def test_type_ids_and_rerank_logits(cross):
+    enc, orc = cross
+    assert enc.num_labels == 1
+    for B, S in ((1, 16), (3, 64), (8, 128)):
+        ids, mask, types = synth.synthetic_pairs(B, S, seed=B + S)
+        got = enc.logits(ids, mask, types)
+        ref = orc.rerank_scores(ids, mask, types)
+        assert got.shape == (B, 1)
+        assert np.abs(got[:, 0] - ref).max() < TOL
+
+
+def test_chunking_is_invisible(minilm):
+    enc, _ = minilm
+    ids, mask = synth.synthetic_ids(40, 64, seed=5, ragged=True)
+    a = enc.embed(ids, mask)
+    enc.set_chunk_tokens(64 * 7)  # 7 sentences per chunk -> ragged last chunk
+    b = enc.embed(ids, mask)
+    enc.set_chunk_tokens(16384)
+    assert np.array_equal(a, b)
+
+
+def test_all_masked_sentence(minilm):
+    import kjarni_amd
+    enc, orc = minilm
+    ids, mask = synth.synthetic_ids(3, 16, seed=3)
+    mask[1, :] = 0
+    got = enc.embed(ids, mask, fill=kjarni_amd.MASK_NEG_1E9)
+    ref = orc.embed_batch(ids, mask, O.MASK_ALLOC)
+    assert np.abs(got - ref).max() < TOL
+    # no-alloc fill: the reference yields NaN for the fully masked row
+    got = enc.embed(ids, mask, fill=kjarni_amd.MASK_NEG_INF)
+    ref = orc.embed_batch(ids, mask, O.MASK_NOALLOC)
+    assert np.isnan(ref[1]).all() and np.isnan(got[1]).all()
+    assert np.abs(got[[0, 2]] - ref[[0, 2]]).max() < TOL
+
+
+def test_out_of_vocab_ids_leave_zero_rows(minilm):
+    enc, orc = minilm
+    ids, mask = synth.synthetic_ids(2, 8, seed=9)
+    ids[0, 3] = 40000  # >= vocab: embeddings/mod.rs:232-236 leaves zeros
+    got = enc.hidden_states(ids, mask)
+    ref = orc.forward(ids, mask, None, O.strategy_mask_value(16))
+    assert np.abs(got - ref).max() < TOL
+
+
+def test_errors(minilm):
+    import kjarni_amd
+    enc, _ = minilm
+    ids, mask = synth.synthetic_ids(1, 8)
+    with pytest.raises(kjarni_amd.KjarniException) as ei:
+        enc.logits(ids, mask)  # no classification head
+    assert ei.value.code == kjarni_amd.KjarniError.INFERENCE_FAILED
+    big = np.zeros((1, 600), np.uint32)
+    with pytest.raises(kjarni_amd.KjarniException) as ei:
+        enc.embed(big, big)
+    assert ei.value.code == kjarni_amd.KjarniError.INVALID_CONFIG
