@@ -107,6 +107,26 @@ KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* enc, const uint
                                                int64_t batch, int32_t seq, KjarniHipMaskFill fill,
                                                float* logits_out);
 
+/* ---- per-kernel timing (HIP events on the launch stream) -------------------------
+ * profile_begin() switches the encoder into timed mode: every kernel launch of the
+ * forward pass is bracketed by two hipEvents on the stream it is launched on.
+ * profile_end() synchronises, resolves the events and fills up to `capacity`
+ * entries (one per kernel kind of the forward pass); *count_out = entries written.
+ * flops / bytes are ALGORITHMIC (2*M*N*K per GEMM, QK^T + PV for attention; every
+ * operand read once and every output written once), summed over the launches. */
+typedef struct KjarniHipKernelStat {
+    const char* kind;   /* static string, e.g. "gemm_fc1" */
+    const char* symbol; /* static string: the kernel function launched */
+    uint64_t launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} KjarniHipKernelStat;
+
+KjarniErrorCode kjarni_hip_encoder_profile_begin(KjarniHipEncoder* enc);
+KjarniErrorCode kjarni_hip_encoder_profile_end(KjarniHipEncoder* enc, KjarniHipKernelStat* stats_out,
+                                               size_t capacity, size_t* count_out);
+
 /* ---- cosine scan ------------------------------------------------------------
  * corpus: f32 [n_docs, dim] row-major (the layout of vectors.bin,
  * crates/kjarni-rag/src/segment.rs:240-262).  queries: f32 [n_queries, dim].

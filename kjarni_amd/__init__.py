@@ -9,4 +9,9 @@ from .encoder import (COSINE_SEGMENT, COSINE_VECTOR_STORE, MASK_AUTO, MASK_NEG_1
                       POOL_CLS, POOL_LAST_TOKEN, POOL_MAX, POOL_MEAN, HipEncoder, cosine_search,
                       device_count)
 
+from .classifier import Classifier  # noqa: F401,E402
+from .embedder import Embedder  # noqa: F401,E402
+from .reranker import Reranker, RerankResult  # noqa: F401,E402
+from .tokenizer import Tokenizer  # noqa: F401,E402
+
 __version__ = "0.1.0"

@@ -78,6 +78,16 @@ class KjarniStringArray(Structure):
         lib().kjarni_string_array_free(byref(self))
 
 
+class KjarniTokenBatch(Structure):
+    _fields_ = [("ids", POINTER(C.c_uint32)), ("attention_mask", POINTER(C.c_uint32)),
+                ("type_ids", POINTER(C.c_uint32)), ("batch", c_size_t), ("seq", c_size_t)]
+
+
+class KjarniHipKernelStat(Structure):
+    _fields_ = [("kind", c_char_p), ("symbol", c_char_p), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 class KjarniEmbedderConfig(Structure):
     _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
                 ("model_path", c_char_p), ("normalize", c_int32), ("quiet", c_int32)]
@@ -190,6 +200,9 @@ SIGNATURES = {
                                                 c_int32, c_int32, _f32p]),
     "kjarni_hip_encoder_logits_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32,
                                                  _f32p]),
+    "kjarni_hip_encoder_profile_begin": (c_int32, [c_void_p]),
+    "kjarni_hip_encoder_profile_end": (c_int32, [c_void_p, POINTER(KjarniHipKernelStat), c_size_t,
+                                                 POINTER(c_size_t)]),
     "kjarni_hip_cosine_scores": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32,
                                            c_void_p, c_void_p]),
     "kjarni_hip_cosine_topk_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32]),
@@ -197,6 +210,11 @@ SIGNATURES = {
                                          c_void_p, c_void_p]),
     "kjarni_hip_cosine_search_host": (c_int32, [c_int32, _f32p, c_int32, _f32p, c_int64, c_int32, c_int32,
                                                 c_int32, _i64p, _f32p, _i64p]),
+    "kjarni_tokenizer_load": (c_int32, [c_char_p, c_size_t, POINTER(c_void_p)]),
+    "kjarni_tokenizer_free": (None, [c_void_p]),
+    "kjarni_tokenizer_encode_batch": (c_int32, [c_void_p, POINTER(c_char_p), POINTER(c_char_p), c_size_t,
+                                                POINTER(KjarniTokenBatch)]),
+    "kjarni_token_batch_free": (None, [POINTER(KjarniTokenBatch)]),
     "kjarni_hip_malloc": (c_int32, [c_int32, c_size_t, POINTER(c_void_p)]),
     "kjarni_hip_free": (c_int32, [c_int32, c_void_p]),
     "kjarni_hip_memcpy_h2d": (c_int32, [c_int32, c_void_p, c_void_p, c_size_t]),

@@ -44,6 +44,11 @@ EncoderModel::~EncoderModel()
 {
     (void)hipSetDevice(device_);
     for (void* p : allocs_) (void)hipFree(p);
+    for (hipEvent_t e : prof_pool_) (void)hipEventDestroy(e);
+    for (const PendingEvent& pe : prof_pending_) {
+        (void)hipEventDestroy(pe.start);
+        (void)hipEventDestroy(pe.stop);
+    }
     for (void* p : {(void*)ws_hidden_, (void*)ws_qkv_, (void*)ws_ctx_, (void*)ws_mid_, (void*)ws_feat_,
                     scratch_, scratch2_})
         if (p) (void)hipFree(p);
@@ -359,6 +364,78 @@ void* EncoderModel::scratch2(size_t bytes)
     return grow(scratch2_, scratch2_bytes_, bytes);
 }
 
+namespace {
+const char* const kKindNames[KK_COUNT] = {"embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm",
+                                          "gemm_fc1", "gemm_fc2", "pool", "head"};
+}
+
+void EncoderModel::profile_begin()
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    for (const PendingEvent& pe : prof_pending_) {
+        prof_pool_.push_back(pe.start);
+        prof_pool_.push_back(pe.stop);
+    }
+    prof_pending_.clear();
+    const char* act_sym = cfg_.ffn_act == EPI_BIAS_GELU ? "gemm_nt_f32_mfma<EPI_BIAS_GELU>"
+                          : cfg_.ffn_act == EPI_BIAS_GELU_NEW ? "gemm_nt_f32_mfma<EPI_BIAS_GELU_NEW>"
+                                                              : "gemm_nt_f32_mfma<EPI_BIAS_RELU>";
+    const char* syms[KK_COUNT] = {"embed_layernorm_kernel", "gemm_nt_f32_mfma<EPI_BIAS>", "attention_kernel",
+                                  "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "layernorm_kernel", act_sym,
+                                  "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "pool_kernel", "head"};
+    for (int k = 0; k < KK_COUNT; ++k) {
+        prof_stats_[k] = KernelStat();
+        prof_stats_[k].kind = kKindNames[k];
+        prof_stats_[k].symbol = syms[k];
+    }
+    prof_on_ = true;
+}
+
+void EncoderModel::prof_start(int kind, hipStream_t stream, double flops, double bytes)
+{
+    if (!prof_on_) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!prof_pool_.empty()) {
+            e = prof_pool_.back();
+            prof_pool_.pop_back();
+        } else {
+            hip_check(hipEventCreate(&e), "hipEventCreate");
+        }
+        return e;
+    };
+    PendingEvent pe{kind, get(), get()};
+    hip_check(hipEventRecord(pe.start, stream), "hipEventRecord");
+    prof_cur_stop_ = pe.stop;
+    prof_pending_.push_back(pe);
+    prof_stats_[kind].launches += 1;
+    prof_stats_[kind].flops += flops;
+    prof_stats_[kind].bytes += bytes;
+}
+
+void EncoderModel::prof_stop(hipStream_t stream)
+{
+    if (!prof_on_) return;
+    hip_check(hipEventRecord(prof_cur_stop_, stream), "hipEventRecord");
+}
+
+std::vector<KernelStat> EncoderModel::profile_end()
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    for (const PendingEvent& pe : prof_pending_) {
+        float ms = 0.0f;
+        hip_check(hipEventElapsedTime(&ms, pe.start, pe.stop), "hipEventElapsedTime");
+        prof_stats_[pe.kind].total_ms += ms;
+        prof_pool_.push_back(pe.start);
+        prof_pool_.push_back(pe.stop);
+    }
+    prof_pending_.clear();
+    prof_on_ = false;
+    return std::vector<KernelStat>(prof_stats_, prof_stats_ + KK_COUNT);
+}
+
 // embed -> embed_norm -> layers (post-norm):
 //   h1 = LN1(x + Attn(x)); y = LN2(h1 + FFN(h1))
 // (cpu/encoder/encoder_layer.rs:113-179 / 216-232, transformer_encoder.rs:335-368;
@@ -369,28 +446,54 @@ void EncoderModel::forward_chunk(const uint32_t* ids, const uint32_t* mask, cons
 {
     const int H = cfg_.hidden, I = cfg_.inter;
     const int64_t T = batch * seq;
+    const double Td = (double)T, Hd = H, Id = I;
+    // Algorithmic work per launch (2*M*N*K per GEMM; attention = QK^T + PV), and
+    // algorithmic bytes (each operand read once, each output written once).
+    const double f_qkv = 2.0 * Td * 3 * Hd * Hd, b_qkv = 4.0 * (Td * Hd + 3 * Hd * Hd + Td * 3 * Hd);
+    const double f_att = 4.0 * (double)batch * seq * seq * Hd, b_att = 4.0 * (Td * 3 * Hd + Td * Hd);
+    const double f_out = 2.0 * Td * Hd * Hd, b_out = 4.0 * (Td * Hd * 3 + Hd * Hd);
+    const double f_fc1 = 2.0 * Td * Hd * Id, b_fc1 = 4.0 * (Td * Hd + Hd * Id + Td * Id);
+    const double f_fc2 = 2.0 * Td * Hd * Id, b_fc2 = 4.0 * (Td * Id + Hd * Id + 2 * Td * Hd);
+    const double b_ln = 8.0 * Td * Hd;
+
+    prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
     hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,
                                      seq, H, cfg_.vocab, cfg_.max_pos, cfg_.type_vocab, cfg_.pos_offset,
                                      0, hidden, stream),
               "embed_layernorm");
+    prof_stop(stream);
     for (const DeviceLayer& L : layers_) {
+        prof_start(KK_GEMM_QKV, stream, f_qkv, b_qkv);
         hip_check(launch_gemm(hidden, H, L.wqkv, L.bqkv, nullptr, 0, ws_qkv_, 3 * H, T, 3 * H, H, EPI_BIAS,
                               stream),
                   "gemm(qkv)");
+        prof_stop(stream);
+        prof_start(KK_ATTENTION, stream, f_att, b_att);
         hip_check(launch_attention(ws_qkv_, mask, batch, seq, cfg_.heads, H / cfg_.heads, mask_value,
                                    ws_ctx_, stream),
                   "attention");
+        prof_stop(stream);
         // hidden = ctx Wo^T + bo + hidden  (in place: each element is read then written by one thread)
+        prof_start(KK_GEMM_OUT, stream, f_out, b_out);
         hip_check(launch_gemm(ws_ctx_, H, L.wo, L.bo, hidden, H, hidden, H, T, H, H, EPI_BIAS_RESIDUAL,
                               stream),
                   "gemm(out_proj)");
+        prof_stop(stream);
+        prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
         hip_check(launch_layernorm(hidden, L.ln1_g, L.ln1_b, cfg_.eps, T, H, hidden, stream), "layernorm1");
+        prof_stop(stream);
+        prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
         hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws_mid_, I, T, I, H, cfg_.ffn_act, stream),
                   "gemm(fc1)");
+        prof_stop(stream);
+        prof_start(KK_GEMM_FC2, stream, f_fc2, b_fc2);
         hip_check(launch_gemm(ws_mid_, I, L.w2, L.b2, hidden, H, hidden, H, T, H, I, EPI_BIAS_RESIDUAL,
                               stream),
                   "gemm(fc2)");
+        prof_stop(stream);
+        prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
         hip_check(launch_layernorm(hidden, L.ln2_g, L.ln2_b, cfg_.eps, T, H, hidden, stream), "layernorm2");
+        prof_stop(stream);
     }
 }
 
@@ -421,9 +524,11 @@ void EncoderModel::embed(const uint32_t* ids, const uint32_t* mask, const uint32
         const uint32_t* m = mask ? mask + b0 * seq : nullptr;
         forward_chunk(ids + b0 * seq, m, type_ids ? type_ids + b0 * seq : nullptr, nb, seq, mask_value,
                       ws_hidden_, stream);
+        prof_start(KK_POOL, stream, 0.0, 4.0 * ((double)nb * seq * cfg_.hidden + (double)nb * cfg_.hidden));
         hip_check(launch_pool(ws_hidden_, m, nb, seq, cfg_.hidden, pool, normalize ? 1 : 0,
                               out + b0 * (int64_t)cfg_.hidden, stream),
                   "pool");
+        prof_stop(stream);
     }
 }
 

@@ -45,6 +45,23 @@ struct DeviceLayer {
           *ln2_g = nullptr, *ln2_b = nullptr;
 };
 
+// Per-kernel HIP-event timing on the launch stream (bench.py's roofline leg).
+// Off by default; when on, every launch of the forward pass is bracketed by two
+// events that are resolved at profile_end().
+enum KernelKind : int {
+    KK_EMBED_LN = 0, KK_GEMM_QKV, KK_ATTENTION, KK_GEMM_OUT, KK_LAYERNORM, KK_GEMM_FC1, KK_GEMM_FC2,
+    KK_POOL, KK_HEAD, KK_COUNT
+};
+
+struct KernelStat {
+    const char* kind;    // e.g. "gemm_fc1"
+    const char* symbol;  // kernel function the launches ran
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+    double flops = 0.0;  // algorithmic FLOPs summed over the launches
+    double bytes = 0.0;  // algorithmic bytes (operands read once + outputs written once)
+};
+
 class EncoderModel {
 public:
     // Loads <dir>/config.json + <dir>/model.safetensors onto `device`.
@@ -74,6 +91,10 @@ public:
     void logits(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
                 int seq, float mask_value, float* out, hipStream_t stream);
 
+    void profile_begin();
+    // Synchronises the device, resolves the events; returns KK_COUNT entries.
+    std::vector<KernelStat> profile_end();
+
     // Scratch on this model's device (grown on demand, reused between calls).
     void* scratch(size_t bytes);
     void* scratch2(size_t bytes);
@@ -87,10 +108,22 @@ private:
                        int64_t batch, int seq, float mask_value, float* hidden, hipStream_t stream);
     int64_t sentences_per_chunk(int seq) const;
 
+    struct PendingEvent {
+        int kind;
+        hipEvent_t start, stop;
+    };
+    void prof_start(int kind, hipStream_t stream, double flops, double bytes);
+    void prof_stop(hipStream_t stream);
+    bool prof_on_ = false;
+    std::vector<PendingEvent> prof_pending_;
+    std::vector<hipEvent_t> prof_pool_;
+    KernelStat prof_stats_[KK_COUNT];
+    hipEvent_t prof_cur_stop_ = nullptr;
+
     EncoderConfig cfg_;
     int device_ = 0;
     size_t weight_bytes_ = 0;
-    int64_t chunk_tokens_ = 16384;
+    int64_t chunk_tokens_ = 65536;
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,

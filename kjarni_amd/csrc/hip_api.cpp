@@ -230,6 +230,34 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* e
     });
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_profile_begin(KjarniHipEncoder* enc)
+{
+    if (!enc) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] { enc->model->profile_begin(); });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_profile_end(KjarniHipEncoder* enc, KjarniHipKernelStat* stats_out,
+                                                             size_t capacity, size_t* count_out)
+{
+    if (!enc || !stats_out || !count_out) return KJARNI_ERROR_NULL_POINTER;
+    *count_out = 0;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        const std::vector<KernelStat> st = enc->model->profile_end();
+        size_t n = 0;
+        for (const KernelStat& k : st) {
+            if (n >= capacity) break;
+            stats_out[n].kind = k.kind;
+            stats_out[n].symbol = k.symbol;
+            stats_out[n].launches = k.launches;
+            stats_out[n].total_ms = k.total_ms;
+            stats_out[n].flops = k.flops;
+            stats_out[n].bytes = k.bytes;
+            ++n;
+        }
+        *count_out = n;
+    });
+}
+
 // ---- cosine scan ----------------------------------------------------------------
 
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_scores(int32_t device, const float* queries_dev,
@@ -292,6 +320,18 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, cons
                   "cosine_topk");
         hip_check(hipMemcpy(idx_out, i_d.p, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost), "D2H idx");
         hip_check(hipMemcpy(score_out, o_d.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost), "D2H scores");
+        if (mode == KJARNI_HIP_COSINE_SEGMENT) {
+            // segment.rs:313-317: a query whose norm is < 1e-9 has no hits.
+            for (int32_t j = 0; j < n_queries; ++j) {
+                float s2 = 0.0f;
+                for (int32_t i = 0; i < dim; ++i) s2 += queries[(size_t)j * dim + i] * queries[(size_t)j * dim + i];
+                if (std::sqrt(s2) < 1e-9f)
+                    for (int32_t i = 0; i < k; ++i) {
+                        idx_out[(size_t)j * k + i] = -1;
+                        score_out[(size_t)j * k + i] = -std::numeric_limits<float>::infinity();
+                    }
+            }
+        }
         if (n_hits_out) *n_hits_out = (k < n_docs) ? k : n_docs;
     });
 }

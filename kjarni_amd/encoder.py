@@ -63,6 +63,19 @@ class HipEncoder:
     def set_chunk_tokens(self, tokens: int):
         check_error(lib().kjarni_hip_encoder_set_chunk_tokens(self._h, int(tokens)))
 
+    def profile_begin(self):
+        """Bracket every kernel launch with HIP events on its stream until profile_end()."""
+        check_error(lib().kjarni_hip_encoder_profile_begin(self._h))
+
+    def profile_end(self):
+        """Returns [{kind, symbol, launches, total_ms, flops, bytes}] (algorithmic flops/bytes)."""
+        arr = (_ffi.KjarniHipKernelStat * 16)()
+        n = C.c_size_t(0)
+        check_error(lib().kjarni_hip_encoder_profile_end(self._h, arr, 16, C.byref(n)))
+        return [dict(kind=arr[i].kind.decode(), symbol=arr[i].symbol.decode(), launches=int(arr[i].launches),
+                     total_ms=float(arr[i].total_ms), flops=float(arr[i].flops), bytes=float(arr[i].bytes))
+                for i in range(n.value)]
+
     # ---- host-array entry points (copy in, run, copy out, synchronise) ----
     def hidden_states(self, ids, mask, type_ids=None, fill: int = MASK_AUTO) -> np.ndarray:
         ids, mask = _u32(ids), _u32(mask)

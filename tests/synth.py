@@ -167,3 +167,14 @@ def synthetic_pairs(n: int, seq: int, vocab: int = 30522, seed: int = 1, qlen: i
     types[:, q_end + 1:] = 1
     mask = np.ones((n, seq), np.uint32)
     return ids, mask, types
+
+
+GOLDEN_TOKENIZER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_small.json")
+
+
+def add_tokenizer(model_dir: str) -> str:
+    """Drops the golden WordPiece tokenizer.json (tests/golden) into a model directory."""
+    import shutil
+    dst = os.path.join(model_dir, "tokenizer.json")
+    shutil.copyfile(GOLDEN_TOKENIZER, dst)
+    return dst
