@@ -107,6 +107,39 @@ KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* enc, const uint
                                                int64_t batch, int32_t seq, KjarniHipMaskFill fill,
                                                float* logits_out);
 
+/* ---- single operators (host pointers) ---------------------------------------------
+ * The kernels of the forward pass, one at a time, at the granularity of the
+ * reference's own operator types: LinearLayer::matmul (+ fused epilogue),
+ * EncoderSelfAttention after the QKV projection, LayerNorm::forward.  Used by the
+ * single-op parity tests (tolerance 1e-5) and the kernel micro-benchmarks: when
+ * iters > 0 the launch is repeated `iters` times between two HIP events and the
+ * average milliseconds per launch are written to *ms_out (ms_out may be NULL). */
+typedef enum KjarniHipEpilogue {
+    KJARNI_HIP_EPI_BIAS = 0,
+    KJARNI_HIP_EPI_BIAS_GELU = 1,
+    KJARNI_HIP_EPI_BIAS_GELU_NEW = 2,
+    KJARNI_HIP_EPI_BIAS_RELU = 3,
+    KJARNI_HIP_EPI_BIAS_TANH = 4,
+    KJARNI_HIP_EPI_BIAS_RESIDUAL = 5,
+} KjarniHipEpilogue;
+
+/* y[m,n] = epilogue(x[m,k] . w[n,k]^T + bias[n] (+ residual[m,n])); bias / residual may be NULL. */
+KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* x, const float* w, const float* bias,
+                                     const float* residual, int64_t m, int32_t k, int32_t n,
+                                     KjarniHipEpilogue epilogue, float* y, int32_t iters, float* ms_out);
+/* qkv: [batch*seq, 3*heads*head_dim] (Q | K | V); mask: u32 [batch, seq] or NULL; ctx: [batch*seq, heads*head_dim]. */
+KjarniErrorCode kjarni_hip_op_attention(int32_t device, const float* qkv, const uint32_t* mask, int64_t batch,
+                                        int32_t seq, int32_t heads, int32_t head_dim, float mask_value,
+                                        float* ctx, int32_t iters, float* ms_out);
+KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const float* gamma, const float* beta,
+                                         float eps, int64_t rows, int32_t hidden, float* y, int32_t iters,
+                                         float* ms_out);
+/* Tuning hook: selects the projection-GEMM tiling variant for subsequent launches in this
+ * process (0 = default).  Every variant computes the same function. */
+void kjarni_hip_set_gemm_variant(int32_t variant);
+/* Same for the attention kernel (0 = default persistent kernel for seq <= 128, 1 = one workgroup per item). */
+void kjarni_hip_set_attention_variant(int32_t variant);
+
 /* ---- per-kernel timing (HIP events on the launch stream) -------------------------
  * profile_begin() switches the encoder into timed mode: every kernel launch of the
  * forward pass is bracketed by two hipEvents on the stream it is launched on.

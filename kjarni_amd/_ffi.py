@@ -200,6 +200,14 @@ SIGNATURES = {
                                                 c_int32, c_int32, _f32p]),
     "kjarni_hip_encoder_logits_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32,
                                                  _f32p]),
+    "kjarni_hip_op_linear": (c_int32, [c_int32, _f32p, _f32p, _f32p, _f32p, c_int64, c_int32, c_int32, c_int32,
+                                       _f32p, c_int32, _f32p]),
+    "kjarni_hip_op_attention": (c_int32, [c_int32, _f32p, _u32p, c_int64, c_int32, c_int32, c_int32, c_float,
+                                          _f32p, c_int32, _f32p]),
+    "kjarni_hip_op_layer_norm": (c_int32, [c_int32, _f32p, _f32p, _f32p, c_float, c_int64, c_int32, _f32p,
+                                           c_int32, _f32p]),
+    "kjarni_hip_set_gemm_variant": (None, [c_int32]),
+    "kjarni_hip_set_attention_variant": (None, [c_int32]),
     "kjarni_hip_encoder_profile_begin": (c_int32, [c_void_p]),
     "kjarni_hip_encoder_profile_end": (c_int32, [c_void_p, POINTER(KjarniHipKernelStat), c_size_t,
                                                  POINTER(c_size_t)]),

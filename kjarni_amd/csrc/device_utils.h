@@ -30,6 +30,25 @@ __device__ __forceinline__ float gelu_erf(float x)
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865475f));
 }
 
+// erf-GELU for the GEMM epilogue.  erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, the
+// same approximation the reference's own GPU shader uses: gpu_ops/blocks/ffn/fc1.wgsl:57-71):
+// 2 transcendentals + ~12 VALU per element instead of ~34 for the libm-grade erff, which matters
+// because FC1's epilogue runs once per 384 MFMA-flops-deep output element.
+__device__ __forceinline__ float gelu_erf_fast(float x)
+{
+    const float z = fabsf(x) * 0.7071067811865475f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float erf_v = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_v);
+}
+
 // activations.rs:62-66
 __device__ __forceinline__ float gelu_tanh(float x)
 {

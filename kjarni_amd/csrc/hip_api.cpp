@@ -258,6 +258,107 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_profile_end(KjarniHipEncoder* e
     });
 }
 
+// ---- single operators -------------------------------------------------------------
+
+namespace {
+
+template <class F>
+void time_launches(int32_t iters, float* ms_out, F&& launch)
+{
+    launch();  // the run whose result is returned
+    if (iters > 0) {
+        hipEvent_t a, b;
+        hip_check(hipEventCreate(&a), "hipEventCreate");
+        hip_check(hipEventCreate(&b), "hipEventCreate");
+        hip_check(hipEventRecord(a, nullptr), "hipEventRecord");
+        for (int32_t i = 0; i < iters; ++i) launch();
+        hip_check(hipEventRecord(b, nullptr), "hipEventRecord");
+        hip_check(hipEventSynchronize(b), "hipEventSynchronize");
+        float ms = 0.0f;
+        hip_check(hipEventElapsedTime(&ms, a, b), "hipEventElapsedTime");
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        if (ms_out) *ms_out = ms / (float)iters;
+    }
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+}
+
+}  // namespace
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* x, const float* w, const float* bias,
+                                                   const float* residual, int64_t m, int32_t k, int32_t n,
+                                                   KjarniHipEpilogue epilogue, float* y, int32_t iters, float* ms_out)
+{
+    if (!x || !w || !y) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (m < 0 || k <= 0 || n <= 0) throw InvalidConfig("invalid GEMM dimensions");
+        if (epilogue == KJARNI_HIP_EPI_BIAS_RESIDUAL && !residual) throw InvalidConfig("residual epilogue without residual");
+        use_device(device);
+        if (m == 0) return;
+        const size_t xb = (size_t)m * k * 4, wb = (size_t)n * k * 4, yb = (size_t)m * n * 4;
+        DeviceBuf xd(xb), wd(wb), bd((size_t)n * 4), rd(residual ? yb : 4), yd(yb);
+        hip_check(hipMemcpy(xd.p, x, xb, hipMemcpyHostToDevice), "H2D x");
+        hip_check(hipMemcpy(wd.p, w, wb, hipMemcpyHostToDevice), "H2D w");
+        if (bias) hip_check(hipMemcpy(bd.p, bias, (size_t)n * 4, hipMemcpyHostToDevice), "H2D bias");
+        if (residual) hip_check(hipMemcpy(rd.p, residual, yb, hipMemcpyHostToDevice), "H2D residual");
+        time_launches(iters, ms_out, [&] {
+            hip_check(launch_gemm((const float*)xd.p, k, (const float*)wd.p, bias ? (const float*)bd.p : nullptr,
+                                  residual ? (const float*)rd.p : nullptr, n, (float*)yd.p, n, m, n, k,
+                                  (GemmEpilogue)epilogue, nullptr),
+                      "gemm");
+        });
+        hip_check(hipMemcpy(y, yd.p, yb, hipMemcpyDeviceToHost), "D2H y");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_attention(int32_t device, const float* qkv, const uint32_t* mask,
+                                                      int64_t batch, int32_t seq, int32_t heads, int32_t head_dim,
+                                                      float mask_value, float* ctx, int32_t iters, float* ms_out)
+{
+    if (!qkv || !ctx) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (batch < 0 || seq <= 0 || heads <= 0 || head_dim <= 0) throw InvalidConfig("invalid attention dimensions");
+        use_device(device);
+        if (batch == 0) return;
+        const size_t T = (size_t)batch * seq, H = (size_t)heads * head_dim;
+        DeviceBuf qd(T * 3 * H * 4), md(T * 4), cd(T * H * 4);
+        hip_check(hipMemcpy(qd.p, qkv, T * 3 * H * 4, hipMemcpyHostToDevice), "H2D qkv");
+        if (mask) hip_check(hipMemcpy(md.p, mask, T * 4, hipMemcpyHostToDevice), "H2D mask");
+        time_launches(iters, ms_out, [&] {
+            hip_check(launch_attention((const float*)qd.p, mask ? (const uint32_t*)md.p : nullptr, batch, seq, heads,
+                                       head_dim, mask_value, (float*)cd.p, nullptr),
+                      "attention");
+        });
+        hip_check(hipMemcpy(ctx, cd.p, T * H * 4, hipMemcpyDeviceToHost), "D2H ctx");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const float* gamma,
+                                                       const float* beta, float eps, int64_t rows, int32_t hidden,
+                                                       float* y, int32_t iters, float* ms_out)
+{
+    if (!x || !gamma || !beta || !y) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (rows < 0 || hidden <= 0) throw InvalidConfig("invalid LayerNorm dimensions");
+        use_device(device);
+        if (rows == 0) return;
+        const size_t b = (size_t)rows * hidden * 4;
+        DeviceBuf xd(b), gd((size_t)hidden * 4), bd((size_t)hidden * 4), yd(b);
+        hip_check(hipMemcpy(xd.p, x, b, hipMemcpyHostToDevice), "H2D x");
+        hip_check(hipMemcpy(gd.p, gamma, (size_t)hidden * 4, hipMemcpyHostToDevice), "H2D gamma");
+        hip_check(hipMemcpy(bd.p, beta, (size_t)hidden * 4, hipMemcpyHostToDevice), "H2D beta");
+        time_launches(iters, ms_out, [&] {
+            hip_check(launch_layernorm((const float*)xd.p, (const float*)gd.p, (const float*)bd.p, eps, rows, hidden,
+                                       (float*)yd.p, nullptr),
+                      "layernorm");
+        });
+        hip_check(hipMemcpy(y, yd.p, b, hipMemcpyDeviceToHost), "D2H y");
+    });
+}
+
+KJARNI_EXPORT void kjarni_hip_set_gemm_variant(int32_t variant) { set_gemm_variant(variant); }
+KJARNI_EXPORT void kjarni_hip_set_attention_variant(int32_t variant) { set_attention_variant(variant); }
+
 // ---- cosine scan ----------------------------------------------------------------
 
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_scores(int32_t device, const float* queries_dev,

@@ -39,6 +39,11 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
                        const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
                        GemmEpilogue epi, hipStream_t stream);
 
+// Tuning hook: which tiling variant launch_gemm uses (0 = default).
+void set_gemm_variant(int variant);
+int gemm_variant();
+void set_attention_variant(int variant);  // 0 = default, 1 = non-persistent kernel
+
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.
 // qkv is [tokens, 3*hidden] (Q | K | V), mask is u32 [batch, seq], ctx is
 // [tokens, hidden] with heads merged.

@@ -1,0 +1,67 @@
+"""Single operators of the forward pass on host arrays (kjarni_hip.h, "single operators"):
+the reference's LinearLayer::matmul (+ fused epilogue), EncoderSelfAttention core and
+LayerNorm::forward, each as one HIP kernel.  For parity tests and micro-benchmarks."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check_error, lib
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_NEW, EPI_BIAS_RELU, EPI_BIAS_TANH, EPI_BIAS_RESIDUAL = range(6)
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(_ffi._f32p)
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, np.float32)
+
+
+def linear(x, w, bias=None, residual=None, epilogue: int = EPI_BIAS, iters: int = 0, device: int = 0
+           ) -> Tuple[np.ndarray, Optional[float]]:
+    x, w, bias, residual = _c(x), _c(w), _c(bias), _c(residual)
+    m, k = x.shape
+    n = w.shape[0]
+    y = np.empty((m, n), np.float32)
+    ms = C.c_float(0)
+    check_error(lib().kjarni_hip_op_linear(device, _f(x), _f(w), _f(bias), _f(residual), m, k, n, epilogue, _f(y),
+                                           iters, C.byref(ms)))
+    return y, (float(ms.value) if iters > 0 else None)
+
+
+def attention(qkv, mask, heads: int, mask_value: float = -1e9, iters: int = 0, device: int = 0
+              ) -> Tuple[np.ndarray, Optional[float]]:
+    qkv = _c(qkv)
+    b, s, h3 = qkv.shape
+    hidden = h3 // 3
+    mask = None if mask is None else np.ascontiguousarray(mask, np.uint32)
+    ctx = np.empty((b, s, hidden), np.float32)
+    ms = C.c_float(0)
+    check_error(lib().kjarni_hip_op_attention(device, _f(qkv), None if mask is None else mask.ctypes.data_as(_ffi._u32p),
+                                              b, s, heads, hidden // heads, float(mask_value), _f(ctx), iters,
+                                              C.byref(ms)))
+    return ctx, (float(ms.value) if iters > 0 else None)
+
+
+def layer_norm(x, gamma, beta, eps: float, iters: int = 0, device: int = 0) -> Tuple[np.ndarray, Optional[float]]:
+    x, gamma, beta = _c(x), _c(gamma), _c(beta)
+    hidden = x.shape[-1]
+    rows = x.size // hidden
+    y = np.empty_like(x)
+    ms = C.c_float(0)
+    check_error(lib().kjarni_hip_op_layer_norm(device, _f(x), _f(gamma), _f(beta), float(eps), rows, hidden, _f(y),
+                                               iters, C.byref(ms)))
+    return y, (float(ms.value) if iters > 0 else None)
+
+
+def set_gemm_variant(v: int):
+    lib().kjarni_hip_set_gemm_variant(int(v))
+
+
+def set_attention_variant(v: int):
+    lib().kjarni_hip_set_attention_variant(int(v))

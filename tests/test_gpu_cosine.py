@@ -80,7 +80,7 @@ def test_full_size_properties():
     q = rng.standard_normal(d, dtype=np.float32)
     planted = [123, 500_000, 999_999, 42]
     for r, i in enumerate(planted):
-        corpus[i] = q * (1.0 + r) + rng.standard_normal(d, dtype=np.float32) * 0.01 * (r + 1)
+        corpus[i] = q * (1.0 + r) + rng.standard_normal(d, dtype=np.float32) * 0.02 * (r + 1) * (1.0 + r)
     idx, sc = kjarni_amd.cosine_search(q, corpus, 10)
     assert list(idx[0][:4]) == planted
     assert (np.diff(sc[0]) <= 0).all() and sc[0][0] > 0.999

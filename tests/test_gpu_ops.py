@@ -1,0 +1,96 @@
+"""Single-operator parity (tolerance 1e-5) through kjarni_hip_op_*."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("m,k,n", [(1, 384, 384), (127, 384, 1152), (128, 384, 1536), (300, 1536, 384),
+                                   (1000, 768, 768), (77, 100, 7), (5, 17, 4), (257, 64, 128), (130, 32, 128)])
+def test_linear_all_epilogues(m, k, n, variant):
+    # LinearLayer::matmul shapes incl. decode (m=1), odd dims (cpu/ops/tests.rs:78-116) and M tails
+    from kjarni_amd import ops
+    ops.set_gemm_variant(variant)
+    rng = np.random.default_rng(m * 7 + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32)
+    base = O.linear(x, w, b)
+    tol = 1e-5 * max(1.0, float(np.abs(base).max()))
+    cases = [(ops.EPI_BIAS, None, base),
+             (ops.EPI_BIAS_GELU, None, np.vectorize(O.gelu, otypes=[np.float32])(base)),
+             (ops.EPI_BIAS_GELU_NEW, None, np.vectorize(O.gelu_new, otypes=[np.float32])(base)),
+             (ops.EPI_BIAS_RELU, None, np.maximum(base, 0)),
+             (ops.EPI_BIAS_TANH, None, np.tanh(base)),
+             (ops.EPI_BIAS_RESIDUAL, r, base + r)]
+    for epi, res, ref in cases:
+        got, _ = ops.linear(x, w, b, res, epi)
+        assert np.abs(got - ref).max() < tol, (epi, float(np.abs(got - ref).max()))
+    got, _ = ops.linear(x, w, None, None, ops.EPI_BIAS)      # no bias
+    assert np.abs(got - O.linear(x, w)).max() < tol
+    ops.set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("B,S,heads,d", [(2, 128, 12, 32), (3, 37, 12, 32), (2, 200, 12, 32), (1, 512, 4, 32),
+                                         (2, 128, 12, 64), (2, 77, 3, 64), (1, 300, 2, 64), (2, 9, 2, 8),
+                                         (1, 1, 12, 32)])
+def test_attention_parity(B, S, heads, d):
+    from kjarni_amd import ops
+    rng = np.random.default_rng(B * 100 + S)
+    H = heads * d
+    qkv = rng.standard_normal((B, S, 3 * H)).astype(np.float32)
+    mask = np.ones((B, S), np.uint32)
+    for b in range(B):
+        mask[b, rng.integers(max(1, S // 2), S + 1):] = 0
+    q, k, v = (np.ascontiguousarray(qkv[..., i * H:(i + 1) * H]) for i in range(3))
+    for mv in (O.MASK_ALLOC, O.MASK_NOALLOC):
+        ref = O.attention(q, k, v, mask.astype(np.float32), heads, mask_value=mv)
+        got, _ = ops.attention(qkv, mask, heads, mask_value=float(mv))
+        assert np.abs(got - ref).max() < 1e-5
+    got, _ = ops.attention(qkv, None, heads)
+    assert np.abs(got - O.attention(q, k, v, None, heads)).max() < 1e-5
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Forces the multi-chunk rescale (cdna guide rule 26): one key in a LATER 128-key chunk
+    dominates every row, so the running max jumps after the first chunk was accumulated."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(3)
+    B, S, heads, d = 1, 384, 2, 32
+    H = heads * d
+    qkv = (rng.standard_normal((B, S, 3 * H)) * 0.3).astype(np.float32)
+    qkv[0, :, 0:H] += 2.0                 # queries share a direction ...
+    qkv[0, 300, H:2 * H] = 6.0            # ... that key 300 (chunk 2) aligns with strongly
+    qkv[0, 140, H:2 * H] = 3.0            # and key 140 (chunk 1) moderately
+    q, k, v = (np.ascontiguousarray(qkv[..., i * H:(i + 1) * H]) for i in range(3))
+    ref = O.attention(q, k, v, None, heads)
+    got, _ = ops.attention(qkv, None, heads)
+    assert np.abs(got - ref).max() < 1e-5
+    # masking the dominant key changes the answer (the branch mattered) and still matches
+    mask = np.ones((B, S), np.uint32)
+    mask[0, 300] = 0
+    ref2 = O.attention(q, k, v, mask.astype(np.float32), heads)
+    got2, _ = ops.attention(qkv, mask, heads)
+    assert np.abs(ref2 - ref).max() > 1e-2 and np.abs(got2 - ref2).max() < 1e-5
+    # a first chunk that is entirely masked with -inf must not poison later chunks
+    mask = np.ones((B, S), np.uint32)
+    mask[0, :128] = 0
+    ref3 = O.attention(q, k, v, mask.astype(np.float32), heads, mask_value=O.MASK_NOALLOC)
+    got3, _ = ops.attention(qkv, mask, heads, mask_value=float("-inf"))
+    assert np.isfinite(got3).all() and np.abs(got3 - ref3).max() < 1e-5
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 384), (1000, 384), (33, 768), (5, 64), (7, 1024), (9, 100), (3, 2048)])
+def test_layer_norm_parity(rows, hidden):
+    from kjarni_amd import ops
+    rng = np.random.default_rng(hidden)
+    x = (rng.standard_normal((rows, hidden)) * 3 + 1).astype(np.float32)
+    g = rng.standard_normal(hidden).astype(np.float32)
+    b = rng.standard_normal(hidden).astype(np.float32)
+    for eps in (1e-12, 1e-5):
+        got, _ = ops.layer_norm(x, g, b, eps)
+        assert np.abs(got - O.layer_norm(x, g, b, eps)).max() < 1e-5
