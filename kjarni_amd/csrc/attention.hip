@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
                 for (int c = 0; c < 4; ++c)
                     s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[kk][c], s[kt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep fragment live ranges short (register budget)
         }
 
         // Q fragments and mask bits of this item are consumed: fetch the next item's.
@@ -350,13 +351,18 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
         const unsigned long long valid_lo = seq >= 64 ? ~0ull : ((1ull << seq) - 1ull);
         const unsigned long long valid_hi = seq >= 128 ? ~0ull : (seq > 64 ? ((1ull << (seq - 64)) - 1ull) : 0ull);
         const bool no_mask = (cur_lo == ~0ull) && (cur_hi == ~0ull);  // wave-uniform
+        // Softmax in the exp2 domain: t = score * log2(e), p = exp2(t - max t); one v_exp_f32 per
+        // element.  c1 folds the reference's 1/sqrt(d) scaling (applied after the dot product) with
+        // log2(e); a masked key's score is overwritten by mask_value (times log2 e).
+        const float c1 = scale * 1.4426950408889634f;
+        const float masked_t = mask_value * 1.4426950408889634f;  // -1e9 -> -1.44e9, -inf -> -inf
         float cmax = -INFINITY;
         if (no_mask) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[kt][r] *= scale;
+                    s[kt][r] *= c1;
                     cmax = fmaxf(cmax, s[kt][r]);
                 }
         } else {
@@ -371,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
-                    float v = s[kt][r] * scale;
-                    v = (keep_w[kt] & bit) ? v : mask_value;   // masked key: score overwritten
+                    float v = s[kt][r] * c1;
+                    v = (keep_w[kt] & bit) ? v : masked_t;     // masked key: score overwritten
                     v = (val_w[kt] & bit) ? v : -INFINITY;     // key beyond seq: contributes exactly 0
                     s[kt][r] = v;
                     cmax = fmaxf(cmax, v);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(s[kt][r] - cmax);
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - cmax);  // NaN for an all -inf row, as the reference
                 s[kt][r] = e;
                 csum += e;
             }
@@ -411,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kt][g * 4 + c], vf[c], o[dt], 0, 0, 0);
+                    if (g == 1 || g == 3) __builtin_amdgcn_sched_barrier(0);
                 }
         }
 

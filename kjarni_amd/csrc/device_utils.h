@@ -49,6 +49,27 @@ __device__ __forceinline__ float gelu_erf_fast(float x)
     return 0.5f * x * (1.0f + erf_v);
 }
 
+// The same on four elements, with the polynomial on packed pairs (v_pk_fma_f32 / v_pk_mul_f32:
+// two elements per VALU instruction) -- the epilogue has no MFMA to hide behind.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x)
+{
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 z = ax * 0.7071067811865475f;
+    const f32x2 d = __builtin_elementwise_fma(z, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    p = p * t;
+    const f32x2 a = z * z * -1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 erf_abs = __builtin_elementwise_fma(-p, e, f32x2{1.0f, 1.0f});  // erf(|x|/sqrt2) in [0,1]
+    // 0.5*x*(1 + sign(x)*erf_abs) = 0.5*(x + |x|*erf_abs)
+    return __builtin_elementwise_fma(ax, erf_abs, x) * 0.5f;
+}
+
 // activations.rs:62-66
 __device__ __forceinline__ float gelu_tanh(float x)
 {

@@ -13,13 +13,29 @@
 // arithmetic class as the reference's AVX2 FMA accumulation (different
 // summation order only).
 //
-// Tiling: 128x128 block tile, BK = 32, 4 waves in a 2x2 grid, each wave a
-// 64x64 sub-tile = 2x2 MFMA tiles of 32x32.  Operand tiles live in LDS as
-// [128 rows][32 k] with a 36-float row stride, which makes the 16-byte
-// fragment reads (one ds_read_b128 feeds four MFMAs: the k order inside an
-// MFMA is free as long as A and B agree) bank-conflict free.  Global->LDS
-// staging goes through registers, issued one K-step ahead (double-buffered
-// LDS, one barrier per K-step).
+// Tiling: 128x128 block tile, 4 waves in a 2x2 grid, each wave a 64x64 sub-tile
+// = 2x2 MFMA tiles of 32x32.  Operand tiles live in LDS as [128 rows][BK k] with
+// a (BK+4)-float row stride, which makes the 16-byte fragment reads (one
+// ds_read_b128 feeds four MFMAs: the k order inside an MFMA is free as long as A
+// and B agree) bank-conflict free.
+//
+// Software pipeline.  A K-step is BK/8 phases of 16 MFMAs and every memory
+// operation is issued under the MFMAs of an earlier phase (co-resident
+// workgroups run the same program almost in lockstep, so a wave cannot count on
+// its SIMD partner to cover its own bubbles):
+//   phase p < last : read fragments kk = p+1                           | MFMA kk = p
+//   one early phase: + write tile t+1 (registers) to the other LDS buffer
+//                    + issue the global loads of tile t+2, one per MFMA
+//   last phase     : barrier, read fragments kk = 0 of tile t+1        | MFMA (from registers)
+// so the only exposed wait is the barrier skew itself.
+//
+// Epilogue: the wave's tile is transposed through its own LDS region (the operand
+// buffers are free after the last barrier) so that bias / activation / residual /
+// store run on 16 bytes per lane: 1 KiB per memory instruction instead of two
+// 128-byte row segments.
+//
+// Workgroup order: XCD-aware (every XCD walks one contiguous run of tiles, N
+// fastest) so the tiles that share an X row panel hit the same L2.
 #include <type_traits>
 
 #include "device_utils.h"
@@ -29,14 +45,30 @@ namespace kjarni {
 
 namespace {
 
-int g_gemm_variant = 0;  // 0: software-pipelined kernel (default), 1: plain double-buffered loop
+// Tuning hook (kjarni_hip_set_gemm_variant): 0 default, 1 BK=32 (2 workgroups/CU),
+// 2 BK=16 (3 workgroups/CU), 3 default tiling with the libm-grade erff in the GELU
+// epilogue, 9 diagnostic build without an epilogue (micro-benchmark upper bound).
+int g_gemm_variant = 0;
 
-constexpr int EPI_GELU_LIBM = 6;  // tuning variant 3: erf-GELU with the libm-grade erff (A/B against the fast form)
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_STRIDE = BK + 4;               // floats
-constexpr int TILE_FLOATS = BM * LDS_STRIDE;     // one operand tile
-constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;  // 2 operands x 2 stages
-constexpr int EPI_STRIDE = 68;                           // floats; 4 waves x 64 x 68 x 4 B <= GEMM_LDS_BYTES
+constexpr int EPI_GELU_LIBM = 6;
+constexpr int BM = 128, BN = 128;
+constexpr int EPI_STRIDE = 68;  // floats per staged output row (64 + 4: conflict-light b128 reads)
+
+template <int BKT>
+struct Tile {
+    static constexpr int BK = BKT;
+    static constexpr int NKK = BKT / 8;            // phases (groups of 16 MFMAs) per K-step
+    static constexpr int STRIDE = BKT + 4;         // floats
+    static constexpr int TILE_FLOATS = BM * STRIDE;
+    static constexpr int LDS_BYTES = 2 * 2 * TILE_FLOATS * 4;  // 2 operands x 2 stages
+    static constexpr int V4_PER_ROW = BKT / 4;
+    static constexpr int LOADS = BM * V4_PER_ROW / 256;  // float4 per thread per operand
+    static constexpr int ROWS_PER_PASS = 256 / V4_PER_ROW;
+    static constexpr int MEM_PHASE = NKK > 2 ? 1 : 0;
+    // Epilogue staging rows per wave per round: as many as fit in this tile's LDS.
+    static constexpr int EPI_ROWS = (LDS_BYTES >= 4 * 64 * EPI_STRIDE * 4) ? 64 : 32;
+    static constexpr int WAVES_PER_SIMD = BKT == 16 ? 3 : 2;
+};
 
 template <int EPI>
 __device__ __forceinline__ float epilogue(float v)
@@ -49,142 +81,17 @@ __device__ __forceinline__ float epilogue(float v)
     return v;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma(const float* __restrict__ A, int64_t lda,
-                                                           const float* __restrict__ W,
-                                                           const float* __restrict__ bias,
-                                                           const float* __restrict__ R, int64_t ldr,
-                                                           float* __restrict__ Y, int64_t ldy,
-                                                           int64_t M, int N, int K, int n_tiles)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                    // [2][128][36]
-    float* sB = smem + 2 * TILE_FLOATS;  // [2][128][36]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    // Consecutive blocks walk N first so the X row-panel is re-read from L2.
-    const int64_t bid = blockIdx.x;
-    const int64_t m0 = (bid / n_tiles) * BM;
-    const int n0 = (int)(bid % n_tiles) * BN;
-
-    // Global staging: 1024 float4 per operand tile, 4 per thread.
-    f32x4 ga[4], gb[4];
-    const int ld_row = tid >> 3;  // + 32*i
-    const int ld_c4 = tid & 7;
-
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = ld_row + 32 * i;
-            const int64_t m = m0 + row;
-            if (m < M)
-                ga[i] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + ld_c4 * 4);
-            else
-                ga[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gb[i] = *reinterpret_cast<const f32x4*>(W + (int64_t)(n0 + row) * K + k0 + ld_c4 * 4);
-        }
-    };
-    auto store_tiles = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = ld_row + 32 * i;
-            *reinterpret_cast<f32x4*>(sA + stage * TILE_FLOATS + row * LDS_STRIDE + ld_c4 * 4) = ga[i];
-            *reinterpret_cast<f32x4*>(sB + stage * TILE_FLOATS + row * LDS_STRIDE + ld_c4 * 4) = gb[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nk = K / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
-    const int a_off = (wr * 64 + l31) * LDS_STRIDE + half * 4;
-    const int b_off = (wc * 64 + l31) * LDS_STRIDE + half * 4;
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-
-        const float* pa = sA + cur * TILE_FLOATS + a_off;
-        const float* pb = sB + cur * TILE_FLOATS + b_off;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + kk * 8);
-            f32x4 a1 = *reinterpret_cast<const f32x4*>(pa + 32 * LDS_STRIDE + kk * 8);
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + kk * 8);
-            f32x4 b1 = *reinterpret_cast<const f32x4*>(pb + 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
-            }
-        }
-
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
-
-    // Epilogue straight from the accumulators: lanes 0..31 of a register hold
-    // 32 consecutive columns of one row (128-byte segments).
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wc * 64 + j * 32 + l31;
-        const float bv = bias ? bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wr * 64 + i * 32 + acc_row(r, half);
-                if (m < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_BIAS_RESIDUAL) v += R[m * ldr + n];
-                    Y[m * ldy + n] = epilogue<EPI>(v);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Software-pipelined variant (same 128x128x32 tile, same arithmetic).
-//
-// The plain loop above exposes, once per K-step and in every wave at the same
-// time (co-resident blocks run the same program in lockstep), the LDS-write ->
-// barrier -> global-load issue -> first LDS read chain, and once per 16 MFMAs
-// the latency of the fragment reads.  Here a K-step is four phases of 16 MFMAs
-// and every memory operation is issued under the MFMAs of an earlier phase:
-//   phase 0: read fragments kk=1                       | MFMA kk=0
-//   phase 1: read fragments kk=2, write tile t+1 to the
-//            other LDS buffer, issue global loads t+2  | MFMA kk=1
-//   phase 2: read fragments kk=3                       | MFMA kk=2
-//   phase 3: barrier, read fragments kk=0 of tile t+1  | MFMA kk=3 (from registers)
-// so the only exposed wait is the barrier skew itself.
-// ---------------------------------------------------------------------------
 struct Frag {
     f32x4 a0, a1, b0, b1;
 };
 
+template <int STRIDE>
 __device__ __forceinline__ void read_frag(Frag& f, const float* pa, const float* pb, int kk)
 {
     f.a0 = *reinterpret_cast<const f32x4*>(pa + kk * 8);
-    f.a1 = *reinterpret_cast<const f32x4*>(pa + 32 * LDS_STRIDE + kk * 8);
+    f.a1 = *reinterpret_cast<const f32x4*>(pa + 32 * STRIDE + kk * 8);
     f.b0 = *reinterpret_cast<const f32x4*>(pb + kk * 8);
-    f.b1 = *reinterpret_cast<const f32x4*>(pb + 32 * LDS_STRIDE + kk * 8);
+    f.b1 = *reinterpret_cast<const f32x4*>(pb + 32 * STRIDE + kk * 8);
 }
 
 __device__ __forceinline__ void mfma16(f32x16 (&acc)[2][2], const Frag& f)
@@ -198,17 +105,17 @@ __device__ __forceinline__ void mfma16(f32x16 (&acc)[2][2], const Frag& f)
     }
 }
 
-template <int EPI, int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_pipe(const float* __restrict__ A, int64_t lda,
-                                                                const float* __restrict__ W,
-                                                                const float* __restrict__ bias,
-                                                                const float* __restrict__ R, int64_t ldr,
-                                                                float* __restrict__ Y, int64_t ldy,
-                                                                int64_t M, int N, int K, int n_tiles)
+template <int EPI, int BKT, int DIAG>
+__global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mfma(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ R, int64_t ldr, float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K,
+    int n_tiles)
 {
+    using T = Tile<BKT>;
+    constexpr int BK = T::BK, NKK = T::NKK, STRIDE = T::STRIDE, TILE_FLOATS = T::TILE_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;
-    float* sB = smem + 2 * TILE_FLOATS;
+    float* sA = smem;                    // [2][128][STRIDE]
+    float* sB = smem + 2 * TILE_FLOATS;  // [2][128][STRIDE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -217,8 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_pipe(const float* __r
     const int l31 = lane & 31, half = lane >> 5;
 
     // Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  Remap so that every
-    // XCD walks one contiguous run of tiles (N fastest): the tiles that share an X row panel
-    // then hit the same L2 instead of fetching the panel once per XCD.  Bijective for any grid.
+    // XCD walks one contiguous run of tiles (N fastest).  Bijective for any grid size.
     const int64_t nwg = gridDim.x;
     const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int64_t q8 = nwg / 8, r8 = nwg % 8;
@@ -227,30 +133,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_pipe(const float* __r
     const int n0 = (int)(bid % n_tiles) * BN;
 
     // Global staging pointers; rows past M are clamped (their results are never stored).
-    const int ld_row = tid >> 3, ld_c4 = tid & 7;
-    const float* ga_ptr[4];
-    const float* gb_ptr[4];
+    const int ld_row = tid / T::V4_PER_ROW, ld_c4 = tid % T::V4_PER_ROW;
+    const float* ga_ptr[T::LOADS];
+    const float* gb_ptr[T::LOADS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int64_t m = m0 + ld_row + 32 * i;
+    for (int i = 0; i < T::LOADS; ++i) {
+        int64_t m = m0 + ld_row + T::ROWS_PER_PASS * i;
         m = m < M ? m : M - 1;
         ga_ptr[i] = A + m * lda + ld_c4 * 4;
-        gb_ptr[i] = W + (int64_t)(n0 + ld_row + 32 * i) * K + ld_c4 * 4;
+        gb_ptr[i] = W + (int64_t)(n0 + ld_row + T::ROWS_PER_PASS * i) * K + ld_c4 * 4;
     }
-    f32x4 ga[4], gb[4];
+    f32x4 ga[T::LOADS], gb[T::LOADS];
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < T::LOADS; ++i) {
             ga[i] = *reinterpret_cast<const f32x4*>(ga_ptr[i] + k0);
             gb[i] = *reinterpret_cast<const f32x4*>(gb_ptr[i] + k0);
         }
     };
-    const int st_off = ld_row * LDS_STRIDE + ld_c4 * 4;
+    const int st_off = ld_row * STRIDE + ld_c4 * 4;
     auto store_tiles = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(sA + stage * TILE_FLOATS + st_off + 32 * i * LDS_STRIDE) = ga[i];
-            *reinterpret_cast<f32x4*>(sB + stage * TILE_FLOATS + st_off + 32 * i * LDS_STRIDE) = gb[i];
+        for (int i = 0; i < T::LOADS; ++i) {
+            *reinterpret_cast<f32x4*>(sA + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * i * STRIDE) = ga[i];
+            *reinterpret_cast<f32x4*>(sB + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * i * STRIDE) = gb[i];
         }
     };
 
@@ -263,16 +169,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_pipe(const float* __r
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = K / BK;
-    const int a_off = (wr * 64 + l31) * LDS_STRIDE + half * 4;
-    const int b_off = (wc * 64 + l31) * LDS_STRIDE + half * 4;
+    const int a_off = (wr * 64 + l31) * STRIDE + half * 4;
+    const int b_off = (wc * 64 + l31) * STRIDE + half * 4;
 
     // Prologue: tile 0 -> LDS[0], tile 1 in flight in registers, fragments kk=0 of tile 0.
     load_tiles(0);
     store_tiles(0);
     if (nk > 1) load_tiles(BK);
     __syncthreads();
-    Frag f0, f1;
-    read_frag(f0, sA + a_off, sB + b_off, 0);
+    Frag fr[2];
+    read_frag<STRIDE>(fr[0], sA + a_off, sB + b_off, 0);
 
     // One K-step.  STORE: tile kt+1 exists (registers -> other LDS buffer, and its first
     // fragments are fetched after the barrier); LOAD: tile kt+2 exists (global -> registers).
@@ -282,56 +188,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_pipe(const float* __r
         const int cur = kt & 1;
         const float* pa = sA + cur * TILE_FLOATS + a_off;
         const float* pb = sB + cur * TILE_FLOATS + b_off;
-
-        // phase 0
-        read_frag(f1, pa, pb, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(acc, f0);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // phase 1: memory traffic of the next tiles is interleaved one-for-one with the MFMAs.
-        read_frag(f0, pa, pb, 2);
-        if (STORE) store_tiles(cur ^ 1);
-        if (LOAD) load_tiles((kt + 2) * BK);
-        mfma16(acc, f1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 x DS read
-        if (STORE) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+        for (int p = 0; p < NKK; ++p) {
+            Frag& use = fr[p & 1];
+            Frag& nxt = fr[(p + 1) & 1];
+            if (p + 1 < NKK) {
+                read_frag<STRIDE>(nxt, pa, pb, p + 1);
+            } else {
+                // Everyone is done reading LDS[cur] (fragments are in registers) and has written
+                // LDS[cur^1]: cross the barrier, fetch the next tile's first fragments, then run the
+                // last 16 MFMAs of this tile from registers.
+                __syncthreads();
+                if (STORE)
+                    read_frag<STRIDE>(nxt, sA + (cur ^ 1) * TILE_FLOATS + a_off, sB + (cur ^ 1) * TILE_FLOATS + b_off, 0);
+            }
+            if (p == T::MEM_PHASE) {
+                // Memory traffic of the next tiles, interleaved one-for-one with this phase's MFMAs.
+                if (STORE) store_tiles(cur ^ 1);
+                if (LOAD) load_tiles((kt + 2) * BK);
+                mfma16(acc, use);
+                if (p + 1 < NKK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 x DS read first
+                if (STORE) {
+#pragma unroll
+                    for (int i = 0; i < 2 * T::LOADS; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+                    }
+                }
+                if (LOAD) {
+#pragma unroll
+                    for (int i = 0; i < 2 * T::LOADS; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(acc, use);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (LOAD) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-
-        // phase 2
-        read_frag(f1, pa, pb, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(acc, f0);
-        __builtin_amdgcn_sched_barrier(0);
-
-        // phase 3: everyone is done reading LDS[cur] (fragments are in registers) and has
-        // written LDS[cur^1]; cross the barrier, fetch the next tile's first fragments, then
-        // run the last 16 MFMAs of this tile from registers.
-        __syncthreads();
-        if (STORE) read_frag(f0, sA + (cur ^ 1) * TILE_FLOATS + a_off, sB + (cur ^ 1) * TILE_FLOATS + b_off, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(acc, f1);
-        __builtin_amdgcn_sched_barrier(0);
     };
-    using T = std::true_type;
-    using F = std::false_type;
+    static_assert((NKK & 1) == 0, "fragment double-buffer parity must repeat every K-step");
+    using TT = std::true_type;
+    using FF = std::false_type;
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) step(T{}, T{}, kt);
-    if (kt + 1 < nk) step(T{}, F{}, kt++);
-    step(F{}, F{}, kt);
+    for (; kt + 2 < nk; ++kt) step(TT{}, TT{}, kt);
+    if (kt + 1 < nk) step(TT{}, FF{}, kt++);
+    step(FF{}, FF{}, kt);
 
     if (DIAG == 1) {
         // Diagnostic build only (tools/kernel_bench.py): no epilogue; keeps the accumulators live.
@@ -345,34 +250,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_pipe(const float* __r
         if (sacc == 123456.789f) Y[0] = sacc;
         return;
     }
-    // Epilogue through LDS.  Straight from the accumulators a store instruction covers two
-    // 128-byte row segments (64 stores + 64 residual loads per wave); transposing the wave's
-    // 64x64 tile through its own LDS region turns that into 16-byte accesses per lane:
-    // 16 loads + 16 stores of 1 KiB each.  After the last barrier nobody reads the operand
-    // tiles any more, so the staging buffers are free.
-    float* sw = smem + wid * (64 * EPI_STRIDE);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sw[(i * 32 + acc_row(r, half)) * EPI_STRIDE + j * 32 + l31] = acc[i][j][r];
+
+    // Epilogue through LDS (wave-private region, LDS operations of one wave execute in order).
+    constexpr int EROWS = T::EPI_ROWS;  // 64: one round; 32: two rounds
+    float* sw = smem + wid * (EROWS * EPI_STRIDE);
     const int e_row = lane >> 4, e_c4 = lane & 15;
     const int n = n0 + wc * 64 + e_c4 * 4;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
-    const int64_t m_base = m0 + wr * 64 + e_row;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int64_t m = m_base + it * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
-        if (m < M) {
-            v += bv;
-            if (EPI == EPI_BIAS_RESIDUAL) v += *reinterpret_cast<const f32x4*>(R + m * ldr + n);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
-            *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
+    for (int round = 0; round < 64 / EROWS; ++round) {
+#pragma unroll
+        for (int ii = 0; ii < EROWS / 32; ++ii) {
+            const int i = round * (EROWS / 32) + ii;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sw[(ii * 32 + acc_row(r, half)) * EPI_STRIDE + j * 32 + l31] = acc[i][j][r];
+        }
+        const int64_t m_base = m0 + wr * 64 + round * EROWS + e_row;
+        // Fully unrolled: all residual loads of the round are issued back to back (the accumulator
+        // registers are free once the tile sits in LDS), instead of a few exposed round trips.
+        f32x4 res[EROWS / 4];
+        if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+            for (int it = 0; it < EROWS / 4; ++it) {
+                int64_t m = m_base + it * 4;
+                m = m < M ? m : M - 1;
+                res[it] = *reinterpret_cast<const f32x4*>(R + m * ldr + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < EROWS / 4; ++it) {
+            const int64_t m = m_base + it * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
+            v += bv;
+            if (EPI == EPI_BIAS_RESIDUAL) v += res[it];
+            if (EPI == EPI_BIAS_GELU) {
+                const f32x2 lo = gelu_erf_fast2(f32x2{v[0], v[1]}), hi = gelu_erf_fast2(f32x2{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
+            }
+            if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
         }
     }
 }
@@ -425,57 +347,54 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_generic(const float* __restri
     }
 }
 
-template <int EPI>
-hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
-                      int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
-                      hipStream_t stream)
+template <int EPI, int BKT, int DIAG>
+hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
+                        int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
 {
-    const bool aligned = (N % BN == 0) && (K % BK == 0) && (lda % 4 == 0) && (ldy % 4 == 0) &&
-                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
-                         (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
-                         (R == nullptr || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(R) & 15) == 0));
-    if (aligned) {
+    using T = Tile<BKT>;
+    if (T::LDS_BYTES > 64 * 1024) {
         // > 64 KiB of dynamic LDS needs the opt-in once per device.
         static bool attr_set[64] = {};
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         if (!attr_set[dev & 63]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma<EPI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma_pipe<EPI, 0>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma<EPI, BKT, DIAG>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
             if (e != hipSuccess) return e;
             attr_set[dev & 63] = true;
         }
-        const int n_tiles = N / BN;
-        const int64_t m_tiles = (M + BM - 1) / BM;
-        dim3 grid((unsigned)(m_tiles * n_tiles));
-        if (g_gemm_variant == 2) {
-            static bool diag_attr = false;
-            if (!diag_attr) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma_pipe<EPI, 1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-                if (e != hipSuccess) return e;
-                diag_attr = true;
-            }
-            hipLaunchKernelGGL((gemm_nt_f32_mfma_pipe<EPI, 1>), grid, dim3(256), GEMM_LDS_BYTES, stream, A, lda, W,
-                               bias, R, ldr, Y, ldy, M, N, K, n_tiles);
-        } else if (g_gemm_variant == 1) {
-            hipLaunchKernelGGL(gemm_nt_f32_mfma<EPI>, grid, dim3(256), GEMM_LDS_BYTES, stream, A, lda, W, bias, R,
-                               ldr, Y, ldy, M, N, K, n_tiles);
-        } else {
-            hipLaunchKernelGGL((gemm_nt_f32_mfma_pipe<EPI, 0>), grid, dim3(256), GEMM_LDS_BYTES, stream, A, lda, W,
-                               bias, R, ldr, Y, ldy, M, N, K, n_tiles);
-        }
-    } else {
-        dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
-        hipLaunchKernelGGL(gemm_nt_f32_generic<EPI>, grid, dim3(256), 0, stream, A, lda, W, bias, R,
-                           ldr, Y, ldy, M, N, K);
     }
+    const int n_tiles = N / BN;
+    const int64_t m_tiles = (M + BM - 1) / BM;
+    dim3 grid((unsigned)(m_tiles * n_tiles));
+    hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
+                       R, ldr, Y, ldy, M, N, K, n_tiles);
+    return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
+                      int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
+                      hipStream_t stream)
+{
+    const bool aligned = (N % BN == 0) && (K % 32 == 0) && (lda % 4 == 0) && (ldy % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
+                         (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
+                         (R == nullptr || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(R) & 15) == 0));
+    if (aligned) {
+        switch (g_gemm_variant) {
+        case 1: return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        case 2: return launch_tiled<EPI, 16, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        case 9: return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        default: return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        }
+    }
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+    hipLaunchKernelGGL(gemm_nt_f32_generic<EPI>, grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N,
+                       K);
     return hipGetLastError();
 }
 

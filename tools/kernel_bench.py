@@ -34,10 +34,17 @@ ops.set_gemm_variant(0)
 B, S, heads, d = M // 128, 128, 12, 32
 qkv = rng.standard_normal((B, S, 3 * heads * d), dtype=np.float32)
 mask = np.ones((B, S), np.uint32)
-ctx, ms = ops.attention(qkv, mask, heads, iters=int(os.environ.get("KB_ITERS", 20)))
-fl = 4.0 * B * S * S * heads * d
-print(f"attention B={B} S={S} h={heads} d={d}: {ms:.4f} ms {fl/(ms*1e-3)/1e12:.2f} TFLOP/s "
-      f"{(4.0*B*S*heads*d*4)/(ms*1e-3)/1e9:.0f} GB/s algorithmic", flush=True)
+for ragged in (False, True):
+    if ragged:
+        for b in range(B):
+            mask[b, rng.integers(16, S + 1):] = 0
+    for v in (0, 1, 0, 1):
+        ops.set_attention_variant(v)
+        ctx, ms = ops.attention(qkv, mask, heads, iters=int(os.environ.get("KB_ITERS", 20)))
+        fl = 4.0 * B * S * S * heads * d
+        print(f"attention B={B} S={S} h={heads} d={d} ragged={ragged} variant={v}: {ms:.4f} ms "
+              f"{fl/(ms*1e-3)/1e12:.2f} TFLOP/s {(4.0*B*S*heads*d*4)/(ms*1e-3)/1e9:.0f} GB/s algorithmic", flush=True)
+ops.set_attention_variant(0)
 x = rng.standard_normal((M, 384), dtype=np.float32)
 g = np.ones(384, np.float32); bb = np.zeros(384, np.float32)
 y, ms = ops.layer_norm(x, g, bb, 1e-12, iters=50)
