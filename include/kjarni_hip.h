@@ -157,6 +157,9 @@ typedef struct KjarniHipKernelStat {
 } KjarniHipKernelStat;
 
 KjarniErrorCode kjarni_hip_encoder_profile_begin(KjarniHipEncoder* enc);
+/* Same, timing only the kernel kinds whose bit is set (bit k = k-th entry profile_end() returns):
+ * fewer events on the stream when only some kernels are of interest. */
+KjarniErrorCode kjarni_hip_encoder_profile_begin_kinds(KjarniHipEncoder* enc, uint32_t kinds_mask);
 KjarniErrorCode kjarni_hip_encoder_profile_end(KjarniHipEncoder* enc, KjarniHipKernelStat* stats_out,
                                                size_t capacity, size_t* count_out);
 

@@ -369,8 +369,9 @@ const char* const kKindNames[KK_COUNT] = {"embed_layernorm", "gemm_qkv", "attent
                                           "gemm_fc1", "gemm_fc2", "pool", "head"};
 }
 
-void EncoderModel::profile_begin()
+void EncoderModel::profile_begin(uint32_t kinds_mask)
 {
+    prof_mask_ = kinds_mask;
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     for (const PendingEvent& pe : prof_pending_) {
@@ -394,7 +395,8 @@ void EncoderModel::profile_begin()
 
 void EncoderModel::prof_start(int kind, hipStream_t stream, double flops, double bytes)
 {
-    if (!prof_on_) return;
+    prof_cur_active_ = prof_on_ && ((prof_mask_ >> kind) & 1u);
+    if (!prof_cur_active_) return;
     auto get = [&]() {
         hipEvent_t e;
         if (!prof_pool_.empty()) {
@@ -416,7 +418,7 @@ void EncoderModel::prof_start(int kind, hipStream_t stream, double flops, double
 
 void EncoderModel::prof_stop(hipStream_t stream)
 {
-    if (!prof_on_) return;
+    if (!prof_cur_active_) return;
     hip_check(hipEventRecord(prof_cur_stop_, stream), "hipEventRecord");
 }
 

@@ -91,7 +91,8 @@ public:
     void logits(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
                 int seq, float mask_value, float* out, hipStream_t stream);
 
-    void profile_begin();
+    // kinds_mask: bit k enables KernelKind k (all ones = every launch of the forward pass).
+    void profile_begin(uint32_t kinds_mask = 0xFFFFFFFFu);
     // Synchronises the device, resolves the events; returns KK_COUNT entries.
     std::vector<KernelStat> profile_end();
 
@@ -115,6 +116,8 @@ private:
     void prof_start(int kind, hipStream_t stream, double flops, double bytes);
     void prof_stop(hipStream_t stream);
     bool prof_on_ = false;
+    uint32_t prof_mask_ = 0xFFFFFFFFu;
+    bool prof_cur_active_ = false;
     std::vector<PendingEvent> prof_pending_;
     std::vector<hipEvent_t> prof_pool_;
     KernelStat prof_stats_[KK_COUNT];
@@ -123,7 +126,7 @@ private:
     EncoderConfig cfg_;
     int device_ = 0;
     size_t weight_bytes_ = 0;
-    int64_t chunk_tokens_ = 65536;
+    int64_t chunk_tokens_ = 131072;
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,

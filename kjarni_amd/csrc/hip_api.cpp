@@ -236,6 +236,12 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_profile_begin(KjarniHipEncoder*
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] { enc->model->profile_begin(); });
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_profile_begin_kinds(KjarniHipEncoder* enc, uint32_t kinds_mask)
+{
+    if (!enc) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] { enc->model->profile_begin(kinds_mask); });
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_profile_end(KjarniHipEncoder* enc, KjarniHipKernelStat* stats_out,
                                                              size_t capacity, size_t* count_out)
 {

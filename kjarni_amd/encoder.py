@@ -63,9 +63,19 @@ class HipEncoder:
     def set_chunk_tokens(self, tokens: int):
         check_error(lib().kjarni_hip_encoder_set_chunk_tokens(self._h, int(tokens)))
 
-    def profile_begin(self):
-        """Bracket every kernel launch with HIP events on its stream until profile_end()."""
-        check_error(lib().kjarni_hip_encoder_profile_begin(self._h))
+    KINDS = ("embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm", "gemm_fc1", "gemm_fc2",
+             "pool", "head")
+
+    def profile_begin(self, kinds=None):
+        """Bracket kernel launches with HIP events on their stream until profile_end().
+        kinds: iterable of names from KINDS to time only those kernels (default: all)."""
+        if kinds is None:
+            check_error(lib().kjarni_hip_encoder_profile_begin(self._h))
+        else:
+            mask = 0
+            for k in kinds:
+                mask |= 1 << self.KINDS.index(k)
+            check_error(lib().kjarni_hip_encoder_profile_begin_kinds(self._h, mask))
 
     def profile_end(self):
         """Returns [{kind, symbol, launches, total_ms, flops, bytes}] (algorithmic flops/bytes)."""
