@@ -1,0 +1,304 @@
+"""CPU restatement of the retrieval side: BM25, reciprocal-rank fusion, metadata
+filter, the on-disk segment format and IndexReader's search functions.
+
+TEST INFRASTRUCTURE ONLY (tests/ imports it; the product never does).
+Pure Python (small cases).  Paths below are relative to /root/reference/crates/.
+
+Pinned by the reference's own unit tests, reproduced in tests/test_search_host.py:
+kjarni-search/src/bm25.rs:200-561, kjarni-search/src/hybrid.rs:35-62,
+kjarni-rag/src/index_reader.rs:355-1048 (MetadataFilter cases),
+kjarni-rag/src/segment.rs:378-434 (segment round trip).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------- BM25
+def tokenize(text: str) -> List[str]:
+    """kjarni-search/src/bm25.rs:191-197: lowercase, split on non-alphanumeric
+    chars, keep pieces of at least 2 BYTES."""
+    out, cur = [], []
+    for ch in text.lower():
+        if ch.isalnum():
+            cur.append(ch)
+        else:
+            if cur:
+                out.append("".join(cur))
+                cur = []
+    if cur:
+        out.append("".join(cur))
+    return [t for t in out if len(t.encode("utf-8")) >= 2]
+
+
+class Bm25Index:
+    """kjarni-search/src/bm25.rs:42-189.  f32 arithmetic as in the reference."""
+
+    def __init__(self):
+        self.doc_frequencies: Dict[str, int] = {}
+        self.doc_lengths: List[int] = []
+        self.avg_doc_length = F32(0.0)
+        self.total_docs = 0
+        self.inverted_index: Dict[str, List[Tuple[int, int]]] = {}
+        self.k1, self.b, self.epsilon = F32(1.2), F32(0.75), F32(0.25)
+        self.total_length = 0
+
+    def add_document(self, doc_id: int, text: str):  # bm25.rs:108-139
+        tokens = tokenize(text)
+        if doc_id >= len(self.doc_lengths):
+            self.doc_lengths.extend([0] * (doc_id + 1 - len(self.doc_lengths)))
+        self.doc_lengths[doc_id] = len(tokens)
+        counts: Dict[str, int] = {}
+        for t in tokens:
+            counts[t] = counts.get(t, 0) + 1
+        for term, c in counts.items():
+            self.inverted_index.setdefault(term, []).append((doc_id, c))
+            self.doc_frequencies[term] = self.doc_frequencies.get(term, 0) + 1
+        self.total_docs = max(self.total_docs, doc_id + 1)
+        self.total_length += len(tokens)
+        self.avg_doc_length = F32(self.total_length) / F32(self.total_docs)
+
+    def term_frequency(self, term: str, doc_id: int) -> int:  # bm25.rs:177-188
+        for d, c in self.inverted_index.get(term, []):
+            if d == doc_id:
+                return c
+        return 0
+
+    def score(self, query_tokens: Sequence[str], doc_id: int) -> np.float32:  # bm25.rs:141-175
+        score = F32(0.0)
+        doc_length = F32(self.doc_lengths[doc_id])
+        length_norm = F32(1.0) - self.b + self.b * (doc_length / self.avg_doc_length)
+        for term in query_tokens:
+            tf = F32(self.term_frequency(term, doc_id))
+            if tf == 0:
+                continue
+            df = F32(self.doc_frequencies.get(term, 0))
+            if df == 0:
+                continue
+            idf = F32(math.log(float((F32(self.total_docs) - df + F32(0.5)) / (df + F32(0.5)) + F32(1.0))))
+            ntf = (tf * (self.k1 + F32(1.0))) / (tf + self.k1 * length_norm)
+            score = F32(score + idf * ntf)
+        return score
+
+    def search(self, query: str, limit: int) -> List[Tuple[int, float]]:  # bm25.rs:84-107
+        if self.total_docs == 0:
+            return []
+        q = tokenize(query)
+        if not q:
+            return []
+        res = []
+        for d in range(self.total_docs):
+            s = self.score(q, d)
+            if s > 0:
+                res.append((d, float(s)))
+        # the reference sorts a HashMap's entries: ties have no defined order; use ascending id
+        res.sort(key=lambda x: (-x[1], x[0]))
+        return res[:limit]
+
+    # bincode 1.x (fixed-width little-endian ints, u64 lengths) of the struct, field order as declared
+    def to_bincode(self) -> bytes:
+        def s(x: str) -> bytes:
+            b = x.encode("utf-8")
+            return struct.pack("<Q", len(b)) + b
+        out = [struct.pack("<Q", len(self.doc_frequencies))]
+        for k, v in self.doc_frequencies.items():
+            out += [s(k), struct.pack("<Q", v)]
+        out.append(struct.pack("<Q", len(self.doc_lengths)))
+        out += [struct.pack("<Q", v) for v in self.doc_lengths]
+        out += [struct.pack("<f", float(self.avg_doc_length)), struct.pack("<Q", self.total_docs)]
+        out.append(struct.pack("<Q", len(self.inverted_index)))
+        for k, postings in self.inverted_index.items():
+            out += [s(k), struct.pack("<Q", len(postings))]
+            out += [struct.pack("<QQ", d, c) for d, c in postings]
+        out.append(struct.pack("<fff", float(self.k1), float(self.b), float(self.epsilon)))
+        out.append(struct.pack("<Q", 0))  # token_to_docs: never populated by add_document
+        out.append(struct.pack("<Q", self.total_length))
+        return b"".join(out)
+
+
+# ----------------------------------------------------------------------------- RRF
+def hybrid_search(keyword: Sequence[Tuple[int, float]], semantic: Sequence[Tuple[int, float]], limit: int):
+    """kjarni-search/src/hybrid.rs:3-31: reciprocal-rank fusion, k = 60."""
+    comb: Dict[int, np.float32] = {}
+    for lst in (keyword, semantic):
+        for rank, (idx, _) in enumerate(lst):
+            comb[idx] = F32(comb.get(idx, F32(0.0)) + F32(1.0) / (F32(60.0) + F32(rank + 1)))
+    res = sorted(comb.items(), key=lambda x: (-x[1], x[0]))
+    return [(i, float(s)) for i, s in res[:limit]]
+
+
+# ----------------------------------------------------------------------------- filter
+def glob_match(pattern: str, path: str) -> bool:
+    """glob-match crate semantics used by MetadataFilter: `*` stays inside a path
+    component, `**` crosses components, `?`, `[a-z]` / `[!a]`, `{a,b}`."""
+    import re
+    def conv(p: str) -> str:
+        i, out = 0, []
+        while i < len(p):
+            c = p[i]
+            if c == "*":
+                if p[i:i + 2] == "**":
+                    i += 2
+                    if p[i:i + 1] == "/":
+                        i += 1
+                        out.append("(?:.*/)?")
+                    else:
+                        out.append(".*")
+                    continue
+                out.append("[^/]*")
+            elif c == "?":
+                out.append("[^/]")
+            elif c == "[":
+                j = p.find("]", i + 1)
+                if j < 0:
+                    out.append(re.escape(c))
+                else:
+                    body = p[i + 1:j]
+                    if body.startswith("!"):
+                        body = "^" + body[1:]
+                    out.append("[" + body + "]")
+                    i = j
+            elif c == "{":
+                j = p.find("}", i + 1)
+                if j < 0:
+                    out.append(re.escape(c))
+                else:
+                    out.append("(?:" + "|".join(conv(a) for a in p[i + 1:j].split(",")) + ")")
+                    i = j
+            else:
+                out.append(re.escape(c))
+            i += 1
+        return "".join(out)
+    return re.fullmatch(conv(pattern), path, flags=re.S) is not None
+
+
+class MetadataFilter:
+    """kjarni-rag/src/index_reader.rs:13-101."""
+
+    def __init__(self):
+        self.must_match: Dict[str, str] = {}
+        self.must_not_match: Dict[str, str] = {}
+        self.source_patterns: List[str] = []
+
+    def must(self, k, v):
+        self.must_match[k] = v
+        return self
+
+    def must_not(self, k, v):
+        self.must_not_match[k] = v
+        return self
+
+    def source(self, p):
+        self.source_patterns.append(p)
+        return self
+
+    def matches(self, md: Dict[str, str]) -> bool:
+        for k, v in self.must_match.items():
+            if md.get(k) != v:
+                return False
+        for k, v in self.must_not_match.items():
+            if md.get(k) == v:
+                return False
+        if self.source_patterns:
+            src = md.get("source")
+            if src is None:
+                return False
+            fname = os.path.basename(src) or src
+            if not any(glob_match(p, src if "/" in p else fname) for p in self.source_patterns):
+                return False
+        return True
+
+
+# ----------------------------------------------------------------------------- on-disk index
+def write_index(root: str, dimension: int, docs: Sequence[Tuple[str, np.ndarray, Dict[str, str]]],
+                max_docs_per_segment: int = 10_000, model_name: Optional[str] = None):
+    """Writes the reference's index layout: <root>/config.json (kjarni-rag/src/config.rs:5-13)
+    and <root>/segments/<id>/{vectors.bin, docs.bin, docs.idx, bm25.bin, metadata.jsonl,
+    segment.json} (kjarni-rag/src/segment.rs:84-197)."""
+    os.makedirs(os.path.join(root, "segments"), exist_ok=True)
+    cfg = dict(dimension=dimension, max_docs_per_segment=max_docs_per_segment,
+               max_segment_memory=100 * 1024 * 1024, embedding_model=None, model_name=model_name,
+               created_at=0, version=1)
+    with open(os.path.join(root, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    seg_id = 0
+    for s0 in range(0, len(docs), max_docs_per_segment):
+        chunk = docs[s0:s0 + max_docs_per_segment]
+        d = os.path.join(root, "segments", f"segment_{seg_id:08d}")
+        os.makedirs(d, exist_ok=True)
+        bm = Bm25Index()
+        offsets, cur = [], 0
+        with open(os.path.join(d, "vectors.bin"), "wb") as fv, open(os.path.join(d, "docs.bin"), "wb") as fd, \
+                open(os.path.join(d, "metadata.jsonl"), "w") as fm:
+            for i, (text, emb, md) in enumerate(chunk):
+                fv.write(np.ascontiguousarray(emb, dtype="<f4").tobytes())
+                offsets.append(cur)
+                tb = text.encode("utf-8")
+                fd.write(tb + b"\n")
+                cur += len(tb) + 1
+                fm.write(json.dumps(md or {}) + "\n")
+                bm.add_document(i, text)
+        with open(os.path.join(d, "docs.idx"), "wb") as f:
+            f.write(struct.pack("<Q", len(offsets)) + b"".join(struct.pack("<Q", o) for o in offsets))
+        with open(os.path.join(d, "bm25.bin"), "wb") as f:
+            f.write(bm.to_bincode())
+        vs = os.path.getsize(os.path.join(d, "vectors.bin"))
+        ds = os.path.getsize(os.path.join(d, "docs.bin"))
+        with open(os.path.join(d, "segment.json"), "w") as f:
+            json.dump(dict(id=seg_id, doc_count=len(chunk), dimension=dimension, created_at=0,
+                           total_bytes=vs + ds), f)
+        seg_id += 1
+
+
+class IndexOracle:
+    """IndexReader restated over in-memory documents (kjarni-rag/src/index_reader.rs:160-330);
+    segments of `max_docs_per_segment` documents, global id = position."""
+
+    def __init__(self, docs, max_docs_per_segment=10_000):
+        self.segs = [docs[i:i + max_docs_per_segment] for i in range(0, len(docs), max_docs_per_segment)]
+        self.offsets = np.cumsum([0] + [len(s) for s in self.segs]).tolist()
+        self.bm = []
+        for s in self.segs:
+            b = Bm25Index()
+            for i, (t, _, _) in enumerate(s):
+                b.add_document(i, t)
+            self.bm.append(b)
+
+    def _result(self, seg, loc, score):
+        t, _, md = self.segs[seg][loc]
+        return dict(score=float(score), document_id=self.offsets[seg] + loc, text=t, metadata=dict(md or {}))
+
+    def search_semantic(self, q, limit):
+        from oracle import oracle as O
+        allr = []
+        for si, s in enumerate(self.segs):
+            corpus = np.stack([np.asarray(e, np.float32) for _, e, _ in s])
+            idx, sc = O.search(np.asarray(q, np.float32), corpus, limit, mode=1)
+            allr += [(si, int(i), float(v)) for i, v in zip(idx, sc)]
+        allr.sort(key=lambda x: -x[2])  # stable: segment order, then the segment's own order
+        return [self._result(*r) for r in allr[:limit]]
+
+    def search_keywords(self, query, limit):
+        allr = []
+        for si, b in enumerate(self.bm):
+            allr += [(si, d, s) for d, s in b.search(query, limit)]
+        allr.sort(key=lambda x: -x[2])
+        return [self._result(*r) for r in allr[:limit]]
+
+    def search_hybrid(self, query, q, limit):
+        kw = [(r["document_id"], r["score"]) for r in self.search_keywords(query, limit * 2)]
+        sem = [(r["document_id"], r["score"]) for r in self.search_semantic(q, limit * 2)]
+        out = []
+        for gid, score in hybrid_search(kw, sem, limit):
+            seg = max(i for i, o in enumerate(self.offsets[:-1]) if o <= gid)
+            r = self._result(seg, gid - self.offsets[seg], score)
+            out.append(r)
+        return out
