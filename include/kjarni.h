@@ -24,6 +24,7 @@
 #ifndef KJARNI_H
 #define KJARNI_H
 
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -182,6 +183,70 @@ KjarniErrorCode kjarni_reranker_rerank(KjarniReranker* reranker, const char* que
 KjarniErrorCode kjarni_reranker_rerank_top_k(KjarniReranker* reranker, const char* query,
                                              const char* const* documents, size_t num_docs,
                                              size_t top_k, KjarniRerankResults* out); /* :272-322 */
+
+/* ---- Searcher: kjarni-ffi/src/searcher.rs:12-491 ------------------------------
+ * The index is the reference's segmented on-disk layout (crates/kjarni-rag/src/segment.rs,
+ * index_reader.rs); the semantic scan runs on the GPU, BM25 / rank fusion / filters on the host. */
+typedef enum KjarniSearchMode {
+    KJARNI_SEARCH_KEYWORD = 0,
+    KJARNI_SEARCH_SEMANTIC = 1,
+    KJARNI_SEARCH_HYBRID = 2,
+} KjarniSearchMode;
+
+typedef struct KjarniSearchResult {
+    float score;
+    size_t document_id;
+    char* text;
+    char* metadata_json;
+} KjarniSearchResult;
+
+typedef struct KjarniSearchResults {
+    KjarniSearchResult* results;
+    size_t len;
+} KjarniSearchResults;
+
+/* Sentinels mean "use the searcher's default": mode -1, top_k 0, use_reranker -1, threshold 0.0. */
+typedef struct KjarniSearchOptions {
+    int32_t mode;
+    size_t top_k;
+    int32_t use_reranker;
+    float threshold;
+    const char* source_pattern; /* glob on the "source" metadata value */
+    const char* filter_key;     /* metadata key that must equal filter_value */
+    const char* filter_value;
+} KjarniSearchOptions;
+
+typedef struct KjarniSearcherConfig {
+    KjarniDevice device;
+    const char* cache_dir;
+    const char* model_name;   /* NULL = "minilm-l6-v2" */
+    const char* rerank_model; /* NULL = no reranker */
+    KjarniSearchMode default_mode; /* default Hybrid */
+    size_t default_top_k;          /* default 10 */
+    int32_t quiet;
+} KjarniSearcherConfig;
+
+typedef struct KjarniSearcher KjarniSearcher;
+
+void kjarni_search_results_free(const KjarniSearchResults* results);                 /* :99-117 */
+KjarniSearchOptions kjarni_search_options_default(void);                             /* :129-140 */
+KjarniSearcherConfig kjarni_searcher_config_default(void);                           /* :154-165 */
+KjarniErrorCode kjarni_searcher_new(const KjarniSearcherConfig* config, KjarniSearcher** out); /* :172-241 */
+void kjarni_searcher_free(KjarniSearcher* searcher);                                 /* :243-250 */
+KjarniErrorCode kjarni_searcher_search(KjarniSearcher* searcher, const char* index_path, const char* query,
+                                       KjarniSearchResults* out);                    /* :253-262 */
+KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher* searcher, const char* index_path,
+                                                    const char* query, const KjarniSearchOptions* options,
+                                                    KjarniSearchResults* out);       /* :265-360 */
+/* BM25 only; needs neither a model nor a GPU. */
+KjarniErrorCode kjarni_search_keywords(const char* index_path, const char* query, size_t top_k,
+                                       KjarniSearchResults* out);                    /* :363-395 */
+bool kjarni_searcher_has_reranker(const KjarniSearcher* searcher);                   /* :398-404 */
+KjarniSearchMode kjarni_searcher_default_mode(const KjarniSearcher* searcher);       /* :407-415 */
+size_t kjarni_searcher_default_top_k(const KjarniSearcher* searcher);                /* :418-424 */
+/* Copy the name into buf (NUL-terminated, truncated to buf_len); return the size needed incl. NUL. */
+size_t kjarni_searcher_model_name(const KjarniSearcher* searcher, char* buf, size_t buf_len);     /* :427-457 */
+size_t kjarni_searcher_reranker_model(const KjarniSearcher* searcher, char* buf, size_t buf_len); /* :460-491 */
 
 #ifdef __cplusplus
 }

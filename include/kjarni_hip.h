@@ -222,6 +222,17 @@ KjarniErrorCode kjarni_tokenizer_encode_batch(const KjarniTokenizer* tok, const 
                                               const char* const* texts_b, size_t n, KjarniTokenBatch* out);
 void kjarni_token_batch_free(const KjarniTokenBatch* batch);
 
+/* ---- host-side search logic, one function at a time (parity tests) -----------------
+ * BM25 tokenizer (crates/kjarni-search/src/bm25.rs:191-197), glob-match as used by
+ * MetadataFilter (crates/kjarni-rag/src/index_reader.rs:54-76) and reciprocal-rank fusion
+ * (crates/kjarni-search/src/hybrid.rs:3-31; ids ranked best-first, outputs hold up to
+ * n_keyword + n_semantic entries). */
+KjarniErrorCode kjarni_bm25_tokenize(const char* text, KjarniStringArray* out);
+int32_t kjarni_glob_match(const char* pattern, const char* path);
+KjarniErrorCode kjarni_rrf_fuse(const size_t* keyword_ids, size_t n_keyword, const size_t* semantic_ids,
+                                size_t n_semantic, size_t limit, size_t* ids_out, float* scores_out,
+                                size_t* n_out);
+
 /* ---- device memory helpers for callers without a HIP runtime binding --------- */
 KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev);
 KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev);

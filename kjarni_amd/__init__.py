@@ -12,6 +12,7 @@ from .encoder import (COSINE_SEGMENT, COSINE_VECTOR_STORE, MASK_AUTO, MASK_NEG_1
 from .classifier import Classifier  # noqa: F401,E402
 from .embedder import Embedder  # noqa: F401,E402
 from .reranker import Reranker, RerankResult  # noqa: F401,E402
+from .searcher import Searcher, search_keywords  # noqa: F401,E402
 from .tokenizer import Tokenizer  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -128,6 +128,37 @@ class KjarniRerankResults(Structure):
         lib().kjarni_rerank_results_free(byref(self))
 
 
+class KjarniSearchResult(Structure):
+    _fields_ = [("score", c_float), ("document_id", c_size_t), ("text", c_char_p), ("metadata_json", c_char_p)]
+
+
+class KjarniSearchResults(Structure):
+    _fields_ = [("results", POINTER(KjarniSearchResult)), ("len", c_size_t)]
+
+    def to_list(self):
+        import json
+        out = []
+        for i in range(self.len):
+            r = self.results[i]
+            out.append(dict(score=float(r.score), document_id=int(r.document_id),
+                            text=r.text.decode("utf-8") if r.text else "",
+                            metadata=json.loads(r.metadata_json.decode("utf-8")) if r.metadata_json else {}))
+        return out
+
+    def free(self):
+        lib().kjarni_search_results_free(byref(self))
+
+
+class KjarniSearchOptions(Structure):
+    _fields_ = [("mode", c_int32), ("top_k", c_size_t), ("use_reranker", c_int32), ("threshold", c_float),
+                ("source_pattern", c_char_p), ("filter_key", c_char_p), ("filter_value", c_char_p)]
+
+
+class KjarniSearcherConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p), ("rerank_model", c_char_p),
+                ("default_mode", c_int32), ("default_top_k", c_size_t), ("quiet", c_int32)]
+
+
 class KjarniRerankerConfig(Structure):
     _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
                 ("model_path", c_char_p), ("quiet", c_int32)]
@@ -177,7 +208,25 @@ SIGNATURES = {
                                          POINTER(KjarniRerankResults)]),
     "kjarni_reranker_rerank_top_k": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t, c_size_t,
                                                POINTER(KjarniRerankResults)]),
+    "kjarni_search_results_free": (None, [POINTER(KjarniSearchResults)]),
+    "kjarni_search_options_default": (KjarniSearchOptions, []),
+    "kjarni_searcher_config_default": (KjarniSearcherConfig, []),
+    "kjarni_searcher_new": (c_int32, [POINTER(KjarniSearcherConfig), POINTER(c_void_p)]),
+    "kjarni_searcher_free": (None, [c_void_p]),
+    "kjarni_searcher_search": (c_int32, [c_void_p, c_char_p, c_char_p, POINTER(KjarniSearchResults)]),
+    "kjarni_searcher_search_with_options": (c_int32, [c_void_p, c_char_p, c_char_p, POINTER(KjarniSearchOptions),
+                                                      POINTER(KjarniSearchResults)]),
+    "kjarni_search_keywords": (c_int32, [c_char_p, c_char_p, c_size_t, POINTER(KjarniSearchResults)]),
+    "kjarni_searcher_has_reranker": (C.c_bool, [c_void_p]),
+    "kjarni_searcher_default_mode": (c_int32, [c_void_p]),
+    "kjarni_searcher_default_top_k": (c_size_t, [c_void_p]),
+    "kjarni_searcher_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
+    "kjarni_searcher_reranker_model": (c_size_t, [c_void_p, c_char_p, c_size_t]),
     # kjarni_hip.h
+    "kjarni_bm25_tokenize": (c_int32, [c_char_p, POINTER(KjarniStringArray)]),
+    "kjarni_glob_match": (c_int32, [c_char_p, c_char_p]),
+    "kjarni_rrf_fuse": (c_int32, [POINTER(c_size_t), c_size_t, POINTER(c_size_t), c_size_t, c_size_t,
+                                  POINTER(c_size_t), _f32p, POINTER(c_size_t)]),
     "kjarni_hip_device_count": (c_int32, []),
     "kjarni_hip_encoder_load": (c_int32, [c_char_p, c_int32, POINTER(c_void_p)]),
     "kjarni_hip_encoder_free": (None, [c_void_p]),

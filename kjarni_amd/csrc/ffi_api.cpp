@@ -15,6 +15,7 @@
 #include "../../include/kjarni_hip.h"
 #include "ffi_common.h"
 #include "json.h"
+#include "pipeline.h"
 #include "registry.h"
 #include "unicode.h"
 #include "wordpiece.h"
@@ -45,17 +46,9 @@ bool is_dir(const std::string& p)
     return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
 }
 
-// A loaded model + tokenizer.  The reference's model types are Send + Sync and
-// nothing serialises calls on a handle (crates/kjarni-transformers/src/traits.rs:33);
-// here calls on one handle share a device workspace, so they take the mutex.
-struct Pipeline {
-    std::unique_ptr<EncoderModel> model;
-    BertTokenizer tokenizer;
-    std::mutex mu;
-    std::string model_name;
-};
+}  // namespace
 
-enum class Want { Embedding, Reranking, Classification };
+namespace kjarni {
 
 // Builder semantics of crates/kjarni/src/{embedder,reranker,classifier}/model.rs:
 // model_path wins; otherwise resolve the registry name, validate architecture/task,
@@ -108,6 +101,10 @@ std::unique_ptr<Pipeline> load_pipeline(const char* cache_dir, const char* model
     return p;
 }
 
+}  // namespace kjarni
+
+namespace {
+
 // cpu/strategy.rs:43-44
 float embed_mask_value(size_t tokens) { return (tokens <= 1 || tokens >= 1000) ? kNegInf : -1e9f; }
 
@@ -141,6 +138,10 @@ void fetch(float* host, const float* dev, size_t floats)
     hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
 }
 
+}  // namespace
+
+namespace kjarni {
+
 // texts -> [n, H] embeddings.  Token-type ids are not passed on this path
 // (get_hidden_states_batch_from_ids: embed_tokens(ids, None, 0), traits.rs:79).
 std::vector<float> embed_texts(Pipeline& p, const std::vector<std::string>& texts, PoolMode pool, bool normalize)
@@ -169,6 +170,10 @@ std::vector<float> pair_logits(Pipeline& p, const BatchEncoding& be)
     fetch(out.data(), d.out, out.size());
     return out;
 }
+
+}  // namespace kjarni
+
+namespace {
 
 // crates/kjarni/src/embedder/model.rs:247-257
 float cosine_k(const float* a, const float* b, size_t n)
@@ -350,7 +355,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_reranker_new(const KjarniRerankerConfig* co
 
 KJARNI_EXPORT void kjarni_reranker_free(KjarniReranker* r) { delete r; }
 
-namespace {
+namespace kjarni {
 
 // CrossEncoder::predict_pairs (cross_encoder/model.rs:170-240): logits column 0.
 std::vector<float> rerank_scores(Pipeline& p, const std::string& query, const std::vector<std::string>& docs)
@@ -365,6 +370,10 @@ std::vector<float> rerank_scores(Pipeline& p, const std::string& query, const st
     for (size_t i = 0; i < docs.size(); ++i) scores[i] = logits[i * L];
     return scores;
 }
+
+}  // namespace kjarni
+
+namespace {
 
 KjarniErrorCode rerank_impl(KjarniReranker* r, const char* query, const char* const* documents, size_t num_docs,
                             bool have_k, size_t top_k, KjarniRerankResults* out)

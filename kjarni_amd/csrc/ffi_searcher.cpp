@@ -1,0 +1,394 @@
+// kjarni_searcher_* (crates/kjarni-ffi/src/searcher.rs:12-491) on top of the GPU cosine scan.
+//
+// Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:96-187) re-opens the index on
+// every call; so does this.  What is cached across calls is the DEVICE copy of each segment's
+// vectors.bin (keyed by path, validated by size + mtime), so the scan streams from HBM instead of
+// re-crossing PCIe per query.  BM25, rank fusion, filters and result shaping are host logic
+// (index.cpp), exactly the parts the reference also runs on the CPU.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <numeric>
+
+#include "ffi_common.h"
+#include "index.h"
+#include "pipeline.h"
+#include "unicode.h"
+
+using namespace kjarni;
+
+namespace {
+
+bool valid_utf8(const char* s) { return unicode::is_valid_utf8(s, std::strlen(s)); }
+
+char* dup_cstr(const std::string& s)
+{
+    const bool has_nul = s.find('\0') != std::string::npos;  // CString::new(..).unwrap_or_default()
+    const std::string& src = has_nul ? std::string() : s;
+    char* p = static_cast<char*>(std::malloc(src.size() + 1));
+    if (!p) throw std::bad_alloc();
+    std::memcpy(p, src.data(), src.size());
+    p[src.size()] = '\0';
+    return p;
+}
+
+struct DeviceSegment {
+    float* vectors = nullptr;
+    size_t bytes = 0;
+    int64_t mtime_ns = 0;
+};
+
+void fill_results(const std::vector<SearchHit>& hits, KjarniSearchResults* out)
+{
+    out->results = nullptr;
+    out->len = 0;
+    if (hits.empty()) return;
+    auto* arr = static_cast<KjarniSearchResult*>(std::calloc(hits.size(), sizeof(KjarniSearchResult)));
+    if (!arr) throw std::bad_alloc();
+    for (size_t i = 0; i < hits.size(); ++i) {
+        arr[i].score = hits[i].score;
+        arr[i].document_id = hits[i].document_id;
+        arr[i].text = dup_cstr(hits[i].text);
+        arr[i].metadata_json = dup_cstr(metadata_to_json(hits[i].metadata));
+    }
+    out->results = arr;
+    out->len = hits.size();
+}
+
+struct IndexOpenFailed : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+std::unique_ptr<IndexReader> open_index(const std::string& path)
+{
+    try {
+        return IndexReader::open(path);
+    } catch (const std::exception& e) {
+        throw IndexOpenFailed(std::string("Search failed: ") + e.what());
+    }
+}
+
+}  // namespace
+
+struct KjarniSearcher {
+    std::unique_ptr<Pipeline> embedder;
+    std::unique_ptr<Pipeline> reranker;  // optional
+    KjarniSearchMode default_mode = KJARNI_SEARCH_HYBRID;
+    size_t default_top_k = 10;
+    std::mutex cache_mu;
+    std::map<std::string, DeviceSegment> cache;
+
+    ~KjarniSearcher()
+    {
+        if (embedder) (void)hipSetDevice(embedder->model->device());
+        for (auto& kv : cache)
+            if (kv.second.vectors) (void)hipFree(kv.second.vectors);
+    }
+
+    // Segment::search_vectors (kjarni-rag/src/segment.rs:307-337) on the GPU.
+    std::vector<std::pair<size_t, float>> scan(const Segment& seg, const float* query, size_t limit)
+    {
+        std::vector<std::pair<size_t, float>> out;
+        const size_t n = seg.doc_count(), dim = seg.dimension();
+        if (n == 0 || limit == 0 || dim == 0) return out;
+        if (dim != (size_t)embedder->model->config().hidden) return out;  // query.len() != dimension -> empty
+        if (seg.vectors_bytes() < n * dim * sizeof(float)) return out;    // get_embedding() would return None
+        float qn = 0.0f;
+        for (size_t i = 0; i < dim; ++i) qn += query[i] * query[i];
+        if (std::sqrt(qn) < 1e-9f) return out;                            // segment.rs:315-317
+
+        std::lock_guard<std::mutex> lock(cache_mu);
+        EncoderModel& m = *embedder->model;
+        hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        struct stat st;
+        const std::string vpath = seg.dir() + "/vectors.bin";
+        if (::stat(vpath.c_str(), &st) != 0) return out;
+        const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+        DeviceSegment& ds = cache[vpath];
+        const size_t bytes = n * dim * sizeof(float);
+        if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt) {
+            if (ds.vectors) {
+                hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+                (void)hipFree(ds.vectors);
+                ds.vectors = nullptr;
+            }
+            hip_check(hipMalloc((void**)&ds.vectors, bytes), "hipMalloc(segment vectors)");
+            hip_check(hipMemcpy(ds.vectors, seg.vectors(), bytes, hipMemcpyHostToDevice), "H2D segment vectors");
+            ds.bytes = bytes;
+            ds.mtime_ns = mt;
+        }
+        const int k = (int)std::min(limit, n);
+        const size_t ws_bytes = cosine_topk_workspace_bytes(1, (int64_t)n, k);
+        const size_t q_off = 0, s_off = 256 * ((dim * 4 + 255) / 256), w_off = s_off + 256 * ((n * 4 + 255) / 256);
+        const size_t i_off = w_off + 256 * ((ws_bytes + 255) / 256), o_off = i_off + 256 * (((size_t)k * 8 + 255) / 256);
+        uint8_t* base = static_cast<uint8_t*>(m.scratch2(o_off + (size_t)k * 4 + 256));
+        float* q_d = reinterpret_cast<float*>(base + q_off);
+        float* s_d = reinterpret_cast<float*>(base + s_off);
+        int64_t* i_d = reinterpret_cast<int64_t*>(base + i_off);
+        float* o_d = reinterpret_cast<float*>(base + o_off);
+        hip_check(hipMemcpyAsync(q_d, query, dim * 4, hipMemcpyHostToDevice, nullptr), "H2D query");
+        hip_check(launch_cosine_scores(q_d, 1, ds.vectors, (int64_t)n, (int)dim, /*segment mode*/ 1, s_d, nullptr),
+                  "cosine_scores");
+        hip_check(launch_cosine_topk(s_d, 1, (int64_t)n, k, base + w_off, i_d, o_d, nullptr), "cosine_topk");
+        std::vector<int64_t> idx((size_t)k);
+        std::vector<float> sc((size_t)k);
+        hip_check(hipMemcpyAsync(idx.data(), i_d, (size_t)k * 8, hipMemcpyDeviceToHost, nullptr), "D2H idx");
+        hip_check(hipMemcpyAsync(sc.data(), o_d, (size_t)k * 4, hipMemcpyDeviceToHost, nullptr), "D2H scores");
+        hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+        for (int i = 0; i < k; ++i)
+            if (idx[(size_t)i] >= 0) out.emplace_back((size_t)idx[(size_t)i], sc[(size_t)i]);
+        return out;
+    }
+};
+
+KJARNI_EXPORT void kjarni_search_results_free(const KjarniSearchResults* r)
+{
+    if (!r) return;
+    if (r->results && r->len > 0) {
+        for (size_t i = 0; i < r->len; ++i) {
+            std::free(r->results[i].text);
+            std::free(r->results[i].metadata_json);
+        }
+        std::free(r->results);
+    }
+}
+
+KJARNI_EXPORT KjarniSearchOptions kjarni_search_options_default(void)
+{
+    KjarniSearchOptions o;
+    std::memset(&o, 0, sizeof o);
+    o.mode = -1;
+    o.top_k = 0;
+    o.use_reranker = -1;
+    o.threshold = 0.0f;
+    return o;
+}
+
+KJARNI_EXPORT KjarniSearcherConfig kjarni_searcher_config_default(void)
+{
+    KjarniSearcherConfig c;
+    std::memset(&c, 0, sizeof c);
+    c.device = KJARNI_DEVICE_CPU;
+    c.default_mode = KJARNI_SEARCH_HYBRID;
+    c.default_top_k = 10;
+    c.quiet = 0;
+    return c;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_searcher_new(const KjarniSearcherConfig* config, KjarniSearcher** out)
+{
+    if (!out) return KJARNI_ERROR_NULL_POINTER;
+    const KjarniSearcherConfig dflt = kjarni_searcher_config_default();
+    const KjarniSearcherConfig& c = config ? *config : dflt;
+    for (const char* s : {c.cache_dir, c.model_name, c.rerank_model})
+        if (s && !valid_utf8(s)) return KJARNI_ERROR_INVALID_UTF8;
+    // searcher.rs:226-229: every build error is reported as LoadFailed (a missing GPU keeps its own code).
+    try {
+        auto h = std::make_unique<KjarniSearcher>();
+        h->embedder = load_pipeline(c.cache_dir, c.model_name, nullptr, "minilm-l6-v2", Want::Embedding);
+        if (c.rerank_model) h->reranker = load_pipeline(c.cache_dir, c.rerank_model, nullptr, "", Want::Reranking);
+        h->default_mode = c.default_mode;
+        if (c.default_top_k > 0) h->default_top_k = c.default_top_k;
+        *out = h.release();
+        return KJARNI_OK;
+    } catch (const GpuUnavailable& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_GPU_UNAVAILABLE;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_LOAD_FAILED;
+    } catch (...) {
+        set_last_error("unknown error");
+        return KJARNI_ERROR_LOAD_FAILED;
+    }
+}
+
+KJARNI_EXPORT void kjarni_searcher_free(KjarniSearcher* s) { delete s; }
+
+KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher* s, const char* index_path,
+                                                                  const char* query, const KjarniSearchOptions* options,
+                                                                  KjarniSearchResults* out)
+{
+    if (!s || !index_path || !query || !out) return KJARNI_ERROR_NULL_POINTER;
+    out->results = nullptr;
+    out->len = 0;
+    if (!valid_utf8(index_path) || !valid_utf8(query)) return KJARNI_ERROR_INVALID_UTF8;
+    try {
+        // option sentinels: searcher.rs:293-310
+        KjarniSearchMode mode = s->default_mode;
+        size_t top_k = s->default_top_k;
+        bool use_reranker = s->reranker != nullptr;
+        bool has_threshold = false;
+        float threshold = 0.0f;
+        MetadataFilter filter;
+        if (options) {
+            if (options->mode >= 0)
+                mode = options->mode == 0 ? KJARNI_SEARCH_KEYWORD : options->mode == 1 ? KJARNI_SEARCH_SEMANTIC : KJARNI_SEARCH_HYBRID;
+            if (options->top_k > 0) top_k = options->top_k;
+            if (options->use_reranker >= 0) use_reranker = options->use_reranker != 0;
+            if (options->threshold > 0.0f) {
+                has_threshold = true;
+                threshold = options->threshold;
+            }
+            if (options->source_pattern && valid_utf8(options->source_pattern))
+                filter.source_patterns.push_back(options->source_pattern);
+            if (options->filter_key && options->filter_value && valid_utf8(options->filter_key) &&
+                valid_utf8(options->filter_value))
+                filter.must_match[options->filter_key] = options->filter_value;
+        }
+
+        // Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:96-187)
+        std::unique_ptr<IndexReader> reader = open_index(index_path);
+        const size_t model_dim = (size_t)s->embedder->model->config().hidden;
+        if (reader->dimension() != model_dim)
+            throw InvalidConfig("Index dimension (" + std::to_string(reader->dimension()) +
+                                ") doesn't match model dimension (" + std::to_string(model_dim) + ")");
+        const bool rerank = use_reranker && s->reranker;
+        const size_t fetch_k = rerank ? top_k * 5 : top_k;
+        const bool filtered = !filter.empty();
+        const size_t k_eff = filtered ? fetch_k * 3 : fetch_k;
+        const SegmentScanFn scan = [&](const Segment& seg, const float* q, size_t limit) { return s->scan(seg, q, limit); };
+
+        std::vector<SearchHit> results;
+        if (mode == KJARNI_SEARCH_KEYWORD) {
+            results = reader->search_keywords(query, k_eff);
+        } else {
+            // embedder.embed(query): mean pool, normalised (embedder/model.rs:118-140)
+            const std::vector<float> q = embed_texts(*s->embedder, {std::string(query)}, POOL_MEAN, true);
+            results = mode == KJARNI_SEARCH_SEMANTIC ? reader->search_semantic(q.data(), k_eff, scan)
+                                                     : reader->search_hybrid(query, q.data(), k_eff, scan);
+        }
+        if (filtered) results = reader->apply_filter(std::move(results), filter, fetch_k);
+
+        if (rerank) {
+            std::vector<std::string> texts;
+            for (const SearchHit& h : results) texts.push_back(h.text);
+            if (!texts.empty()) {
+                const std::vector<float> scores = rerank_scores(*s->reranker, query, texts);
+                std::vector<size_t> order(texts.size());
+                std::iota(order.begin(), order.end(), (size_t)0);
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return scores[a] > scores[b]; });
+                std::vector<SearchHit> nr;
+                for (size_t i = 0; i < order.size() && i < top_k; ++i) {
+                    SearchHit h = results[order[i]];
+                    h.score = scores[order[i]];
+                    nr.push_back(std::move(h));
+                }
+                results.swap(nr);
+            }
+        }
+        if (has_threshold)
+            results.erase(std::remove_if(results.begin(), results.end(), [&](const SearchHit& h) { return !(h.score >= threshold); }),
+                          results.end());
+        if (results.size() > top_k) results.resize(top_k);
+        fill_results(results, out);
+        return KJARNI_OK;
+    } catch (const InvalidConfig& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_INVALID_CONFIG;  // DimensionMismatch
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_INFERENCE_FAILED;
+    } catch (...) {
+        set_last_error("unknown error");
+        return KJARNI_ERROR_INFERENCE_FAILED;
+    }
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search(KjarniSearcher* s, const char* index_path, const char* query,
+                                                     KjarniSearchResults* out)
+{
+    const KjarniSearchOptions o = kjarni_search_options_default();
+    return kjarni_searcher_search_with_options(s, index_path, query, &o, out);
+}
+
+// Searcher::search_keywords (model.rs:79-89): BM25 only, no model and no GPU involved.
+KJARNI_EXPORT KjarniErrorCode kjarni_search_keywords(const char* index_path, const char* query, size_t top_k,
+                                                     KjarniSearchResults* out)
+{
+    if (!index_path || !query || !out) return KJARNI_ERROR_NULL_POINTER;
+    out->results = nullptr;
+    out->len = 0;
+    if (!valid_utf8(index_path) || !valid_utf8(query)) return KJARNI_ERROR_INVALID_UTF8;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        std::unique_ptr<IndexReader> reader = open_index(index_path);
+        fill_results(reader->search_keywords(query, top_k), out);
+    });
+}
+
+KJARNI_EXPORT bool kjarni_searcher_has_reranker(const KjarniSearcher* s) { return s && s->reranker; }
+KJARNI_EXPORT KjarniSearchMode kjarni_searcher_default_mode(const KjarniSearcher* s) { return s ? s->default_mode : KJARNI_SEARCH_HYBRID; }
+KJARNI_EXPORT size_t kjarni_searcher_default_top_k(const KjarniSearcher* s) { return s ? s->default_top_k : 10; }
+
+namespace {
+size_t copy_name(const std::string& name, char* buf, size_t buf_len)
+{
+    const size_t required = name.size() + 1;
+    if (!buf || buf_len == 0) return required;
+    const size_t n = std::min(name.size(), buf_len - 1);
+    std::memcpy(buf, name.data(), n);
+    buf[n] = '\0';
+    return required;
+}
+}  // namespace
+
+KJARNI_EXPORT size_t kjarni_searcher_model_name(const KjarniSearcher* s, char* buf, size_t buf_len)
+{
+    if (!s) return 0;
+    return copy_name(s->embedder->model_name, buf, buf_len);
+}
+
+KJARNI_EXPORT size_t kjarni_searcher_reranker_model(const KjarniSearcher* s, char* buf, size_t buf_len)
+{
+    if (!s || !s->reranker) return 0;
+    return copy_name(s->reranker->model_name, buf, buf_len);
+}
+
+// ---- test / tooling hooks for the host-side search logic (kjarni_hip.h) ----------------------------
+
+KJARNI_EXPORT KjarniErrorCode kjarni_bm25_tokenize(const char* text, KjarniStringArray* out)
+{
+    if (!text || !out) return KJARNI_ERROR_NULL_POINTER;
+    out->strings = nullptr;
+    out->len = 0;
+    if (!valid_utf8(text)) return KJARNI_ERROR_INVALID_UTF8;
+    return guarded(KJARNI_ERROR_UNKNOWN, [&] {
+        const std::vector<std::string> toks = Bm25Index::tokenize(text);
+        if (toks.empty()) return;
+        char** arr = static_cast<char**>(std::calloc(toks.size(), sizeof(char*)));
+        if (!arr) throw std::bad_alloc();
+        for (size_t i = 0; i < toks.size(); ++i) arr[i] = dup_cstr(toks[i]);
+        out->strings = arr;
+        out->len = toks.size();
+    });
+}
+
+KJARNI_EXPORT int32_t kjarni_glob_match(const char* pattern, const char* path)
+{
+    if (!pattern || !path) return 0;
+    return glob_match(pattern, path) ? 1 : 0;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_rrf_fuse(const size_t* keyword_ids, size_t n_keyword, const size_t* semantic_ids,
+                                              size_t n_semantic, size_t limit, size_t* ids_out, float* scores_out,
+                                              size_t* n_out)
+{
+    if (!ids_out || !scores_out || !n_out || (n_keyword && !keyword_ids) || (n_semantic && !semantic_ids))
+        return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_UNKNOWN, [&] {
+        std::vector<std::pair<size_t, float>> kw, sem;
+        for (size_t i = 0; i < n_keyword; ++i) kw.emplace_back(keyword_ids[i], 0.0f);
+        for (size_t i = 0; i < n_semantic; ++i) sem.emplace_back(semantic_ids[i], 0.0f);
+        const auto r = hybrid_search(kw, sem, limit);
+        for (size_t i = 0; i < r.size(); ++i) {
+            ids_out[i] = r[i].first;
+            scores_out[i] = r[i].second;
+        }
+        *n_out = r.size();
+    });
+}

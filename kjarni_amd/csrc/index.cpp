@@ -1,0 +1,663 @@
+#include "index.h"
+
+#include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <tuple>
+
+#include "json.h"
+#include "unicode.h"
+
+namespace kjarni {
+
+namespace {
+
+std::string slurp(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+bool is_dir(const std::string& p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+// ---- bincode 1.x reader / writer (little-endian, fixed-width ints, u64 lengths) ----
+struct BinReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    void need(size_t n) const
+    {
+        if ((size_t)(end - p) < n) throw std::runtime_error("bincode: unexpected end of data");
+    }
+    uint64_t u64()
+    {
+        need(8);
+        uint64_t v;
+        std::memcpy(&v, p, 8);
+        p += 8;
+        return v;
+    }
+    float f32()
+    {
+        need(4);
+        float v;
+        std::memcpy(&v, p, 4);
+        p += 4;
+        return v;
+    }
+    std::string str()
+    {
+        const uint64_t n = u64();
+        need(n);
+        std::string s(reinterpret_cast<const char*>(p), (size_t)n);
+        p += n;
+        return s;
+    }
+};
+
+void put_u64(std::string& o, uint64_t v) { o.append(reinterpret_cast<const char*>(&v), 8); }
+void put_f32(std::string& o, float v) { o.append(reinterpret_cast<const char*>(&v), 4); }
+void put_str(std::string& o, const std::string& s)
+{
+    put_u64(o, s.size());
+    o.append(s);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- BM25
+
+// text.to_lowercase().split(|c| !c.is_alphanumeric()).filter(|s| s.len() >= 2)   (byte length)
+std::vector<std::string> Bm25Index::tokenize(const std::string& text)
+{
+    std::vector<uint32_t> cps, low;
+    if (!unicode::decode_utf8(text.data(), text.size(), cps)) throw std::runtime_error("invalid UTF-8");
+    unicode::lowercase(cps, low);
+    std::vector<std::string> out;
+    std::string cur;
+    auto flush = [&] {
+        if (cur.size() >= 2) out.push_back(cur);
+        cur.clear();
+    };
+    for (uint32_t cp : low) {
+        if (unicode::is_alphanumeric(cp)) unicode::append_utf8(cur, cp);
+        else flush();
+    }
+    flush();
+    return out;
+}
+
+void Bm25Index::add_document(size_t doc_id, const std::string& text)
+{
+    const std::vector<std::string> tokens = tokenize(text);
+    if (doc_id >= doc_lengths.size()) doc_lengths.resize(doc_id + 1, 0);
+    doc_lengths[doc_id] = tokens.size();
+    std::vector<std::pair<std::string, uint64_t>> counts;  // first-seen order
+    std::unordered_map<std::string, size_t> pos;
+    for (const std::string& t : tokens) {
+        auto it = pos.find(t);
+        if (it == pos.end()) {
+            pos.emplace(t, counts.size());
+            counts.emplace_back(t, 1);
+        } else {
+            counts[it->second].second += 1;
+        }
+    }
+    for (const auto& kv : counts) {
+        inverted_index[kv.first].emplace_back((uint64_t)doc_id, kv.second);
+        doc_frequencies[kv.first] += 1;
+    }
+    total_docs = std::max(total_docs, doc_id + 1);
+    total_length += tokens.size();
+    avg_doc_length = (float)total_length / (float)total_docs;
+}
+
+size_t Bm25Index::term_frequency(const std::string& term, size_t doc_id) const
+{
+    auto it = inverted_index.find(term);
+    if (it == inverted_index.end()) return 0;
+    for (const auto& p : it->second)
+        if (p.first == doc_id) return (size_t)p.second;
+    return 0;
+}
+
+float Bm25Index::score(const std::vector<std::string>& q, size_t doc_id) const
+{
+    float score = 0.0f;
+    const float doc_length = (float)doc_lengths[doc_id];
+    const float length_norm = 1.0f - b + b * (doc_length / avg_doc_length);
+    for (const std::string& term : q) {
+        const float tf = (float)term_frequency(term, doc_id);
+        if (tf == 0.0f) continue;
+        auto it = doc_frequencies.find(term);
+        const float df = it == doc_frequencies.end() ? 0.0f : (float)it->second;
+        if (df == 0.0f) continue;
+        const float idf = std::log(((float)total_docs - df + 0.5f) / (df + 0.5f) + 1.0f);
+        const float ntf = (tf * (k1 + 1.0f)) / (tf + k1 * length_norm);
+        score += idf * ntf;
+    }
+    return score;
+}
+
+std::vector<std::pair<size_t, float>> Bm25Index::search(const std::string& query, size_t limit) const
+{
+    std::vector<std::pair<size_t, float>> res;
+    if (total_docs == 0) return res;
+    const std::vector<std::string> q = tokenize(query);
+    if (q.empty()) return res;
+    // Same result as scoring every document (bm25.rs:96-101), visiting only documents that contain
+    // a query term; documents whose length slot is missing cannot be scored either way.
+    std::vector<uint8_t> seen(total_docs, 0);
+    for (const std::string& term : q) {
+        auto it = inverted_index.find(term);
+        if (it == inverted_index.end()) continue;
+        for (const auto& p : it->second) {
+            const size_t d = (size_t)p.first;
+            if (d >= total_docs || d >= doc_lengths.size() || seen[d]) continue;
+            seen[d] = 1;
+            const float s = score(q, d);
+            if (s > 0.0f) res.emplace_back(d, s);
+        }
+    }
+    std::stable_sort(res.begin(), res.end(), [](const auto& x, const auto& y) {
+        if (x.second != y.second) return x.second > y.second;
+        return x.first < y.first;
+    });
+    if (res.size() > limit) res.resize(limit);
+    return res;
+}
+
+Bm25Index Bm25Index::from_bincode(const uint8_t* data, size_t len)
+{
+    BinReader r{data, data + len};
+    Bm25Index ix;
+    uint64_t n = r.u64();
+    for (uint64_t i = 0; i < n; ++i) {
+        std::string k = r.str();
+        ix.doc_frequencies[std::move(k)] = r.u64();
+    }
+    n = r.u64();
+    r.need(n * 8);
+    ix.doc_lengths.resize((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) ix.doc_lengths[(size_t)i] = r.u64();
+    ix.avg_doc_length = r.f32();
+    ix.total_docs = (size_t)r.u64();
+    n = r.u64();
+    for (uint64_t i = 0; i < n; ++i) {
+        std::string k = r.str();
+        const uint64_t m = r.u64();
+        r.need(m * 16);
+        auto& v = ix.inverted_index[std::move(k)];
+        v.reserve((size_t)m);
+        for (uint64_t j = 0; j < m; ++j) {
+            const uint64_t d = r.u64(), c = r.u64();
+            v.emplace_back(d, c);
+        }
+    }
+    ix.k1 = r.f32();
+    ix.b = r.f32();
+    ix.epsilon = r.f32();
+    n = r.u64();  // token_to_docs: HashMap<String, HashSet<usize>> (unused by search)
+    for (uint64_t i = 0; i < n; ++i) {
+        (void)r.str();
+        const uint64_t m = r.u64();
+        r.need(m * 8);
+        r.p += m * 8;
+    }
+    ix.total_length = r.p < r.end ? r.u64() : 0;  // #[serde(default)]
+    return ix;
+}
+
+std::string Bm25Index::to_bincode() const
+{
+    std::string o;
+    put_u64(o, doc_frequencies.size());
+    for (const auto& kv : doc_frequencies) {
+        put_str(o, kv.first);
+        put_u64(o, kv.second);
+    }
+    put_u64(o, doc_lengths.size());
+    for (uint64_t v : doc_lengths) put_u64(o, v);
+    put_f32(o, avg_doc_length);
+    put_u64(o, total_docs);
+    put_u64(o, inverted_index.size());
+    for (const auto& kv : inverted_index) {
+        put_str(o, kv.first);
+        put_u64(o, kv.second.size());
+        for (const auto& p : kv.second) {
+            put_u64(o, p.first);
+            put_u64(o, p.second);
+        }
+    }
+    put_f32(o, k1);
+    put_f32(o, b);
+    put_f32(o, epsilon);
+    put_u64(o, 0);
+    put_u64(o, total_length);
+    return o;
+}
+
+// ---------------------------------------------------------------------------------- RRF
+
+std::vector<std::pair<size_t, float>> hybrid_search(const std::vector<std::pair<size_t, float>>& keyword,
+                                                    const std::vector<std::pair<size_t, float>>& semantic, size_t limit)
+{
+    std::vector<std::pair<size_t, float>> comb;  // insertion order; small lists
+    auto add = [&](size_t idx, float s) {
+        for (auto& e : comb)
+            if (e.first == idx) {
+                e.second += s;
+                return;
+            }
+        comb.emplace_back(idx, s);
+    };
+    const float k = 60.0f;
+    for (size_t rank = 0; rank < keyword.size(); ++rank) add(keyword[rank].first, 1.0f / (k + (float)(rank + 1)));
+    for (size_t rank = 0; rank < semantic.size(); ++rank) add(semantic[rank].first, 1.0f / (k + (float)(rank + 1)));
+    std::stable_sort(comb.begin(), comb.end(), [](const auto& x, const auto& y) {
+        if (x.second != y.second) return x.second > y.second;
+        return x.first < y.first;
+    });
+    if (comb.size() > limit) comb.resize(limit);
+    return comb;
+}
+
+// ---------------------------------------------------------------------------------- glob
+
+namespace {
+
+bool glob_rec(const char* p, const char* pe, const char* s, const char* se)
+{
+    while (p < pe) {
+        const char c = *p;
+        if (c == '*') {
+            if (p + 1 < pe && p[1] == '*') {
+                const char* np = p + 2;
+                if (np < pe && *np == '/') {
+                    // "**/" matches zero or more whole components
+                    ++np;
+                    if (glob_rec(np, pe, s, se)) return true;
+                    for (const char* t = s; t < se; ++t)
+                        if (*t == '/' && glob_rec(np, pe, t + 1, se)) return true;
+                    return false;
+                }
+                for (const char* t = s; t <= se; ++t)
+                    if (glob_rec(np, pe, t, se)) return true;
+                return false;
+            }
+            for (const char* t = s;; ++t) {
+                if (glob_rec(p + 1, pe, t, se)) return true;
+                if (t >= se || *t == '/') return false;
+            }
+        } else if (c == '?') {
+            if (s >= se || *s == '/') return false;
+            // one UTF-8 character
+            ++s;
+            while (s < se && ((unsigned char)*s & 0xC0) == 0x80) ++s;
+            ++p;
+        } else if (c == '[') {
+            const char* close = static_cast<const char*>(std::memchr(p + 1, ']', (size_t)(pe - p - 1)));
+            if (!close) {
+                if (s >= se || *s != '[') return false;
+                ++s;
+                ++p;
+                continue;
+            }
+            if (s >= se) return false;
+            const char* q = p + 1;
+            bool neg = false;
+            if (q < close && (*q == '!' || *q == '^')) {
+                neg = true;
+                ++q;
+            }
+            bool hit = false;
+            const unsigned char ch = (unsigned char)*s;
+            while (q < close) {
+                if (q + 2 < close && q[1] == '-') {
+                    if (ch >= (unsigned char)q[0] && ch <= (unsigned char)q[2]) hit = true;
+                    q += 3;
+                } else {
+                    if (ch == (unsigned char)*q) hit = true;
+                    ++q;
+                }
+            }
+            if (hit == neg) return false;
+            ++s;
+            p = close + 1;
+        } else if (c == '{') {
+            const char* close = static_cast<const char*>(std::memchr(p + 1, '}', (size_t)(pe - p - 1)));
+            if (!close) {
+                if (s >= se || *s != '{') return false;
+                ++s;
+                ++p;
+                continue;
+            }
+            const char* a = p + 1;
+            while (a <= close) {
+                const char* comma = a;
+                while (comma < close && *comma != ',') ++comma;
+                std::string alt(a, comma);
+                alt.append(close + 1, pe);
+                if (glob_rec(alt.data(), alt.data() + alt.size(), s, se)) return true;
+                a = comma + 1;
+            }
+            return false;
+        } else {
+            if (s >= se || *s != c) return false;
+            ++s;
+            ++p;
+        }
+    }
+    return s == se;
+}
+
+}  // namespace
+
+bool glob_match(const std::string& pattern, const std::string& path)
+{
+    return glob_rec(pattern.data(), pattern.data() + pattern.size(), path.data(), path.data() + path.size());
+}
+
+bool MetadataFilter::matches(const Metadata& md) const
+{
+    for (const auto& kv : must_match) {
+        auto it = md.find(kv.first);
+        if (it == md.end() || it->second != kv.second) return false;
+    }
+    for (const auto& kv : must_not_match) {
+        auto it = md.find(kv.first);
+        if (it != md.end() && it->second == kv.second) return false;
+    }
+    if (!source_patterns.empty()) {
+        auto it = md.find("source");
+        if (it == md.end()) return false;
+        const std::string& source = it->second;
+        // Path::file_name(): last component (ignoring trailing slashes); falls back to the whole string
+        std::string trimmed = source;
+        while (trimmed.size() > 1 && trimmed.back() == '/') trimmed.pop_back();
+        const size_t slash = trimmed.rfind('/');
+        std::string filename = slash == std::string::npos ? trimmed : trimmed.substr(slash + 1);
+        if (filename.empty() || filename == "..") filename = source;
+        bool any = false;
+        for (const std::string& pat : source_patterns) {
+            const bool has_sep = pat.find('/') != std::string::npos;
+            if (glob_match(pat, has_sep ? source : filename)) {
+                any = true;
+                break;
+            }
+        }
+        if (!any) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------- Segment
+
+std::unique_ptr<Segment> Segment::open(const std::string& dir)
+{
+    std::unique_ptr<Segment> s(new Segment());
+    s->dir_ = dir;
+    const Json meta = Json::parse(slurp(dir + "/segment.json"));
+    s->doc_count_ = (size_t)meta.get_int("doc_count", 0);
+    s->dimension_ = (size_t)meta.get_int("dimension", 0);
+
+    const std::string vpath = dir + "/vectors.bin";
+    int fd = ::open(vpath.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + vpath);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        ::close(fd);
+        throw std::runtime_error("cannot stat " + vpath);
+    }
+    s->map_len_ = (size_t)st.st_size;
+    if (s->map_len_ > 0) {
+        s->map_ = mmap(nullptr, s->map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (s->map_ == MAP_FAILED) {
+            s->map_ = nullptr;
+            ::close(fd);
+            throw std::runtime_error("mmap failed: " + vpath);
+        }
+        s->vectors_ = static_cast<const float*>(s->map_);
+    }
+    ::close(fd);
+
+    const std::string idx = slurp(dir + "/docs.idx");
+    BinReader r{reinterpret_cast<const uint8_t*>(idx.data()), reinterpret_cast<const uint8_t*>(idx.data()) + idx.size()};
+    const uint64_t n = r.u64();
+    r.need(n * 8);
+    s->doc_offsets_.resize((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) s->doc_offsets_[(size_t)i] = r.u64();
+
+    const std::string bm = slurp(dir + "/bm25.bin");
+    s->bm25_ = Bm25Index::from_bincode(reinterpret_cast<const uint8_t*>(bm.data()), bm.size());
+    return s;
+}
+
+Segment::~Segment()
+{
+    if (map_) munmap(map_, map_len_);
+}
+
+std::string Segment::get_document(size_t doc_id) const
+{
+    if (doc_id >= doc_count_ || doc_id >= doc_offsets_.size()) throw std::runtime_error("Document ID out of range");
+    const std::string path = dir_ + "/docs.bin";
+    const uint64_t start = doc_offsets_[doc_id];
+    uint64_t end;
+    if (doc_id + 1 < doc_offsets_.size()) {
+        end = doc_offsets_[doc_id + 1] - 1;  // -1 for the newline
+    } else {
+        struct stat st;
+        if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot stat " + path);
+        end = (uint64_t)st.st_size - 1;
+    }
+    if (end < start) throw std::runtime_error("corrupt document offsets");
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    f.seekg((std::streamoff)start);
+    std::string buf((size_t)(end - start), '\0');
+    f.read(&buf[0], (std::streamsize)buf.size());
+    if ((uint64_t)f.gcount() != end - start) throw std::runtime_error("short read in " + path);
+    if (!unicode::is_valid_utf8(buf.data(), buf.size())) throw std::runtime_error("Invalid UTF-8 in document");
+    return buf;
+}
+
+Metadata Segment::get_metadata(size_t doc_id) const
+{
+    std::ifstream f(dir_ + "/metadata.jsonl");
+    if (!f) throw std::runtime_error("cannot open metadata.jsonl");
+    std::string line;
+    for (size_t i = 0; std::getline(f, line); ++i) {
+        if (i != doc_id) continue;
+        const Json j = Json::parse(line);
+        if (!j.is_object()) throw std::runtime_error("Invalid JSON: metadata is not an object");
+        Metadata md;
+        for (const auto& kv : j.obj) {
+            if (!kv.second.is_string()) throw std::runtime_error("Invalid JSON: metadata values must be strings");
+            md[kv.first] = kv.second.str;
+        }
+        return md;
+    }
+    throw std::runtime_error("Document ID out of range");
+}
+
+// ---------------------------------------------------------------------------------- IndexReader
+
+std::unique_ptr<IndexReader> IndexReader::open(const std::string& root)
+{
+    std::unique_ptr<IndexReader> r(new IndexReader());
+    const Json cfg = Json::parse(slurp(root + "/config.json"));
+    r->dimension_ = (size_t)cfg.get_int("dimension", 0);
+    const std::string segdir = root + "/segments";
+    if (is_dir(segdir)) {
+        std::vector<std::string> names;
+        if (DIR* d = opendir(segdir.c_str())) {
+            while (dirent* e = readdir(d)) {
+                const std::string n = e->d_name;
+                if (n == "." || n == "..") continue;
+                if (is_dir(segdir + "/" + n)) names.push_back(n);
+            }
+            closedir(d);
+        }
+        std::sort(names.begin(), names.end());  // entries.sort_by_key(file_name)
+        for (const std::string& n : names) {
+            try {
+                r->segments_.push_back(Segment::open(segdir + "/" + n));
+            } catch (const std::exception&) {
+                // index_reader.rs:178-181: a segment that fails to load is skipped with a warning
+            }
+        }
+    }
+    for (const auto& s : r->segments_) r->total_docs_ += s->doc_count();
+    return r;
+}
+
+size_t IndexReader::local_to_global(size_t seg, size_t local) const
+{
+    size_t off = 0;
+    for (size_t i = 0; i < seg; ++i) off += segments_[i]->doc_count();
+    return off + local;
+}
+
+bool IndexReader::global_to_local(size_t global, size_t& seg, size_t& local) const
+{
+    size_t off = 0;
+    for (size_t i = 0; i < segments_.size(); ++i) {
+        if (global < off + segments_[i]->doc_count()) {
+            seg = i;
+            local = global - off;
+            return true;
+        }
+        off += segments_[i]->doc_count();
+    }
+    return false;
+}
+
+std::vector<SearchHit> IndexReader::convert(const std::vector<std::tuple<size_t, size_t, float>>& rs) const
+{
+    std::vector<SearchHit> out;
+    for (const auto& t : rs) {
+        const size_t seg = std::get<0>(t), doc = std::get<1>(t);
+        try {  // filter_map(... .ok()?): a document whose text or metadata cannot be read is dropped
+            SearchHit h;
+            h.score = std::get<2>(t);
+            h.document_id = local_to_global(seg, doc);
+            h.text = segments_[seg]->get_document(doc);
+            h.metadata = segments_[seg]->get_metadata(doc);
+            out.push_back(std::move(h));
+        } catch (const std::exception&) {
+        }
+    }
+    return out;
+}
+
+static void sort_desc_truncate(std::vector<std::tuple<size_t, size_t, float>>& all, size_t limit)
+{
+    std::stable_sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return std::get<2>(x) > std::get<2>(y); });
+    if (all.size() > limit) all.resize(limit);
+}
+
+std::vector<SearchHit> IndexReader::search_semantic(const float* query, size_t limit, const SegmentScanFn& scan) const
+{
+    std::vector<std::tuple<size_t, size_t, float>> all;
+    for (size_t si = 0; si < segments_.size(); ++si)
+        for (const auto& r : scan(*segments_[si], query, limit)) all.emplace_back(si, r.first, r.second);
+    sort_desc_truncate(all, limit);
+    return convert(all);
+}
+
+std::vector<SearchHit> IndexReader::search_keywords(const std::string& query, size_t limit) const
+{
+    std::vector<std::tuple<size_t, size_t, float>> all;
+    for (size_t si = 0; si < segments_.size(); ++si)
+        for (const auto& r : segments_[si]->search_keywords(query, limit)) all.emplace_back(si, r.first, r.second);
+    sort_desc_truncate(all, limit);
+    return convert(all);
+}
+
+std::vector<SearchHit> IndexReader::search_hybrid(const std::string& query, const float* query_emb, size_t limit,
+                                                  const SegmentScanFn& scan) const
+{
+    const std::vector<SearchHit> kw = search_keywords(query, limit * 2);
+    const std::vector<SearchHit> sem = search_semantic(query_emb, limit * 2, scan);
+    std::vector<std::pair<size_t, float>> kwi, semi;
+    for (const SearchHit& h : kw) kwi.emplace_back(h.document_id, h.score);
+    for (const SearchHit& h : sem) semi.emplace_back(h.document_id, h.score);
+    std::vector<SearchHit> out;
+    for (const auto& f : hybrid_search(kwi, semi, limit)) {
+        size_t seg = 0, local = 0;
+        if (!global_to_local(f.first, seg, local)) continue;
+        try {
+            SearchHit h;
+            h.score = f.second;
+            h.document_id = f.first;
+            h.text = segments_[seg]->get_document(local);
+            h.metadata = segments_[seg]->get_metadata(local);
+            out.push_back(std::move(h));
+        } catch (const std::exception&) {
+        }
+    }
+    return out;
+}
+
+std::vector<SearchHit> IndexReader::apply_filter(std::vector<SearchHit> hits, const MetadataFilter& f, size_t limit) const
+{
+    std::vector<SearchHit> out;
+    for (SearchHit& h : hits) {
+        if (out.size() >= limit) break;
+        if (f.matches(h.metadata)) out.push_back(std::move(h));
+    }
+    return out;
+}
+
+std::string metadata_to_json(const Metadata& md)
+{
+    auto esc = [](const std::string& s) {
+        std::string o = "\"";
+        for (unsigned char c : s) {
+            switch (c) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            default:
+                if (c < 0x20) {
+                    char buf[8];
+                    std::snprintf(buf, sizeof buf, "\\u%04x", c);
+                    o += buf;
+                } else {
+                    o.push_back((char)c);
+                }
+            }
+        }
+        return o + "\"";
+    };
+    std::string o = "{";
+    bool first = true;
+    for (const auto& kv : md) {
+        if (!first) o += ",";
+        first = false;
+        o += esc(kv.first) + ":" + esc(kv.second);
+    }
+    return o + "}";
+}
+
+}  // namespace kjarni

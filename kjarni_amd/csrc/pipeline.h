@@ -1,0 +1,33 @@
+// A loaded model + tokenizer and the string-level operations built on it, shared by the
+// Embedder / Reranker / Classifier entry points (ffi_api.cpp) and the Searcher (ffi_searcher.cpp).
+#pragma once
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "encoder.h"
+#include "wordpiece.h"
+
+namespace kjarni {
+
+// The reference's model types are Send + Sync and nothing serialises calls on a handle
+// (crates/kjarni-transformers/src/traits.rs:33); here calls on one handle share a device
+// workspace, so they take the mutex.
+struct Pipeline {
+    std::unique_ptr<EncoderModel> model;
+    BertTokenizer tokenizer;
+    std::mutex mu;
+    std::string model_name;
+};
+
+enum class Want { Embedding, Reranking, Classification };
+
+std::unique_ptr<Pipeline> load_pipeline(const char* cache_dir, const char* model_name, const char* model_path,
+                                        const char* default_name, Want want);
+// texts -> [n, H] embeddings (tokenise on the host, encode + pool on the GPU).
+std::vector<float> embed_texts(Pipeline& p, const std::vector<std::string>& texts, PoolMode pool, bool normalize);
+// (query, doc_i) pairs -> scores (logit column 0).
+std::vector<float> rerank_scores(Pipeline& p, const std::string& query, const std::vector<std::string>& docs);
+
+}  // namespace kjarni

@@ -131,6 +131,11 @@ bool is_cjk(uint32_t cp) { return in_ranges(kCjk, kCjk_len, cp); }
 bool is_mark_nonspacing(uint32_t cp) { return in_ranges(kMarkNonspacing, kMarkNonspacing_len, cp); }
 bool is_whitespace(uint32_t cp) { return in_ranges(kWhitespace, kWhitespace_len, cp); }
 bool is_bert_punctuation(uint32_t cp) { return in_ranges(kPunctuation, kPunctuation_len, cp); }
+bool is_alphanumeric(uint32_t cp)
+{
+    if (cp < 0x80) return (cp >= '0' && cp <= '9') || (cp >= 'a' && cp <= 'z') || (cp >= 'A' && cp <= 'Z');
+    return in_ranges(kAlnum, kAlnum_len, cp);
+}
 
 void nfd(const std::vector<uint32_t>& in, std::vector<uint32_t>& out)
 {

@@ -18,7 +18,10 @@ code point, out of the same Rust core through its Python binding
   CJK             BertNormalizer(handle_chinese_chars)   -> padded with spaces
 
 Only the canonical combining class (needed to reorder the rare non-Mn combining
-marks after decomposition) comes from Python's unicodedata.
+marks after decomposition) comes from Python's unicodedata, and the
+alphanumeric set of the BM25 tokenizer (Rust char::is_alphanumeric =
+Alphabetic property or general category N*; crates/kjarni-search/src/bm25.rs:191-197)
+from the `regex` module's Unicode database.
 
 Run:  python tools/gen_unicode_tables.py   (about a minute)
 """
@@ -26,6 +29,7 @@ import os
 import sys
 import unicodedata
 
+import regex
 from tokenizers import normalizers, pre_tokenizers
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,6 +66,8 @@ def to_ranges(cps):
 
 def main():
     drop, space, mn, ws, punct, cjk_set = [], [], [], [], [], []
+    alnum = []
+    alnum_re = regex.compile(r"[\p{Alphabetic}\p{N}]")
     decomp, lowmap, ccc = {}, {}, {}
     S_BASE, L_BASE, V_BASE, T_BASE = 0xAC00, 0x1100, 0x1161, 0x11A7
     for cp in code_points():
@@ -99,6 +105,8 @@ def main():
                 raise SystemExit(f"unexpected pre-tokenizer split for U+{cp:04X}: {parts}")
         if cjk.normalize_str(ch) == " " + ch + " ":
             cjk_set.append(cp)
+        if alnum_re.match(ch):
+            alnum.append(cp)
         k = unicodedata.combining(ch)
         if k:
             ccc[cp] = k
@@ -144,6 +152,7 @@ def main():
         emit_ranges(f, "kWhitespace", ws)
         emit_ranges(f, "kPunctuation", punct)
         emit_ranges(f, "kCjk", cjk_set)
+        emit_ranges(f, "kAlnum", alnum)
         emit_map(f, "kDecomp", decomp)
         emit_map(f, "kLower", lowmap)
         # ccc as ranges with value
