@@ -233,6 +233,13 @@ KjarniErrorCode kjarni_rrf_fuse(const size_t* keyword_ids, size_t n_keyword, con
                                 size_t n_semantic, size_t limit, size_t* ids_out, float* scores_out,
                                 size_t* n_out);
 
+/* Retrieval over an on-disk index (the reference's segmented layout) with a caller-supplied query
+ * embedding: Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:120-187) minus the
+ * encoder and the reranker.  options->mode -1 = hybrid, top_k 0 = 10; use_reranker is ignored.
+ * text_query may be NULL in semantic mode, query_emb in keyword mode (which needs no GPU). */
+KjarniErrorCode kjarni_hip_index_search(const char* index_path, const char* text_query, const float* query_emb,
+                                        size_t dim, const KjarniSearchOptions* options, KjarniSearchResults* out);
+
 /* ---- device memory helpers for callers without a HIP runtime binding --------- */
 KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev);
 KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev);

@@ -227,6 +227,8 @@ SIGNATURES = {
     "kjarni_glob_match": (c_int32, [c_char_p, c_char_p]),
     "kjarni_rrf_fuse": (c_int32, [POINTER(c_size_t), c_size_t, POINTER(c_size_t), c_size_t, c_size_t,
                                   POINTER(c_size_t), _f32p, POINTER(c_size_t)]),
+    "kjarni_hip_index_search": (c_int32, [c_char_p, c_char_p, _f32p, c_size_t, POINTER(KjarniSearchOptions),
+                                          POINTER(KjarniSearchResults)]),
     "kjarni_hip_device_count": (c_int32, []),
     "kjarni_hip_encoder_load": (c_int32, [c_char_p, c_int32, POINTER(c_void_p)]),
     "kjarni_hip_encoder_free": (None, [c_void_p]),

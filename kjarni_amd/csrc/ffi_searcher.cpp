@@ -73,43 +73,39 @@ std::unique_ptr<IndexReader> open_index(const std::string& path)
     }
 }
 
-}  // namespace
-
-struct KjarniSearcher {
-    std::unique_ptr<Pipeline> embedder;
-    std::unique_ptr<Pipeline> reranker;  // optional
-    KjarniSearchMode default_mode = KJARNI_SEARCH_HYBRID;
-    size_t default_top_k = 10;
-    std::mutex cache_mu;
-    std::map<std::string, DeviceSegment> cache;
-
-    ~KjarniSearcher()
+// Segment::search_vectors (kjarni-rag/src/segment.rs:307-337) on the GPU, with the device copies of
+// the segments it has seen.
+class SegmentScanner {
+public:
+    explicit SegmentScanner(int device) : device_(device) {}
+    SegmentScanner(const SegmentScanner&) = delete;
+    SegmentScanner& operator=(const SegmentScanner&) = delete;
+    ~SegmentScanner()
     {
-        if (embedder) (void)hipSetDevice(embedder->model->device());
-        for (auto& kv : cache)
+        (void)hipSetDevice(device_);
+        for (auto& kv : cache_)
             if (kv.second.vectors) (void)hipFree(kv.second.vectors);
+        if (work_) (void)hipFree(work_);
     }
 
-    // Segment::search_vectors (kjarni-rag/src/segment.rs:307-337) on the GPU.
-    std::vector<std::pair<size_t, float>> scan(const Segment& seg, const float* query, size_t limit)
+    std::vector<std::pair<size_t, float>> scan(const Segment& seg, const float* query, size_t query_dim, size_t limit)
     {
         std::vector<std::pair<size_t, float>> out;
         const size_t n = seg.doc_count(), dim = seg.dimension();
         if (n == 0 || limit == 0 || dim == 0) return out;
-        if (dim != (size_t)embedder->model->config().hidden) return out;  // query.len() != dimension -> empty
-        if (seg.vectors_bytes() < n * dim * sizeof(float)) return out;    // get_embedding() would return None
+        if (dim != query_dim) return out;                               // query.len() != dimension -> empty
+        if (seg.vectors_bytes() < n * dim * sizeof(float)) return out;  // get_embedding() would return None
         float qn = 0.0f;
         for (size_t i = 0; i < dim; ++i) qn += query[i] * query[i];
-        if (std::sqrt(qn) < 1e-9f) return out;                            // segment.rs:315-317
+        if (std::sqrt(qn) < 1e-9f) return out;                          // segment.rs:315-317
 
-        std::lock_guard<std::mutex> lock(cache_mu);
-        EncoderModel& m = *embedder->model;
-        hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        std::lock_guard<std::mutex> lock(mu_);
+        hip_check(hipSetDevice(device_), "hipSetDevice");
         struct stat st;
         const std::string vpath = seg.dir() + "/vectors.bin";
         if (::stat(vpath.c_str(), &st) != 0) return out;
         const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
-        DeviceSegment& ds = cache[vpath];
+        DeviceSegment& ds = cache_[vpath];
         const size_t bytes = n * dim * sizeof(float);
         if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt) {
             if (ds.vectors) {
@@ -124,17 +120,27 @@ struct KjarniSearcher {
         }
         const int k = (int)std::min(limit, n);
         const size_t ws_bytes = cosine_topk_workspace_bytes(1, (int64_t)n, k);
-        const size_t q_off = 0, s_off = 256 * ((dim * 4 + 255) / 256), w_off = s_off + 256 * ((n * 4 + 255) / 256);
-        const size_t i_off = w_off + 256 * ((ws_bytes + 255) / 256), o_off = i_off + 256 * (((size_t)k * 8 + 255) / 256);
-        uint8_t* base = static_cast<uint8_t*>(m.scratch2(o_off + (size_t)k * 4 + 256));
-        float* q_d = reinterpret_cast<float*>(base + q_off);
-        float* s_d = reinterpret_cast<float*>(base + s_off);
-        int64_t* i_d = reinterpret_cast<int64_t*>(base + i_off);
-        float* o_d = reinterpret_cast<float*>(base + o_off);
+        auto pad = [](size_t b) { return 256 * ((b + 255) / 256); };
+        const size_t s_off = pad(dim * 4), w_off = s_off + pad(n * 4), i_off = w_off + pad(ws_bytes);
+        const size_t o_off = i_off + pad((size_t)k * 8), total = o_off + pad((size_t)k * 4);
+        if (total > work_bytes_) {
+            if (work_) {
+                hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+                (void)hipFree(work_);
+                work_ = nullptr;
+                work_bytes_ = 0;
+            }
+            hip_check(hipMalloc((void**)&work_, total), "hipMalloc(scan workspace)");
+            work_bytes_ = total;
+        }
+        float* q_d = reinterpret_cast<float*>(work_);
+        float* s_d = reinterpret_cast<float*>(work_ + s_off);
+        int64_t* i_d = reinterpret_cast<int64_t*>(work_ + i_off);
+        float* o_d = reinterpret_cast<float*>(work_ + o_off);
         hip_check(hipMemcpyAsync(q_d, query, dim * 4, hipMemcpyHostToDevice, nullptr), "H2D query");
         hip_check(launch_cosine_scores(q_d, 1, ds.vectors, (int64_t)n, (int)dim, /*segment mode*/ 1, s_d, nullptr),
                   "cosine_scores");
-        hip_check(launch_cosine_topk(s_d, 1, (int64_t)n, k, base + w_off, i_d, o_d, nullptr), "cosine_topk");
+        hip_check(launch_cosine_topk(s_d, 1, (int64_t)n, k, work_ + w_off, i_d, o_d, nullptr), "cosine_topk");
         std::vector<int64_t> idx((size_t)k);
         std::vector<float> sc((size_t)k);
         hip_check(hipMemcpyAsync(idx.data(), i_d, (size_t)k * 8, hipMemcpyDeviceToHost, nullptr), "D2H idx");
@@ -144,6 +150,84 @@ struct KjarniSearcher {
             if (idx[(size_t)i] >= 0) out.emplace_back((size_t)idx[(size_t)i], sc[(size_t)i]);
         return out;
     }
+
+private:
+    int device_;
+    std::mutex mu_;
+    std::map<std::string, DeviceSegment> cache_;
+    uint8_t* work_ = nullptr;
+    size_t work_bytes_ = 0;
+};
+
+struct ResolvedOptions {
+    KjarniSearchMode mode;
+    size_t top_k;
+    bool use_reranker;
+    bool has_threshold = false;
+    float threshold = 0.0f;
+    MetadataFilter filter;
+};
+
+// option sentinels: searcher.rs:293-310
+ResolvedOptions resolve_options(const KjarniSearchOptions* options, KjarniSearchMode default_mode, size_t default_top_k,
+                                bool default_rerank)
+{
+    ResolvedOptions r;
+    r.mode = default_mode;
+    r.top_k = default_top_k;
+    r.use_reranker = default_rerank;
+    if (!options) return r;
+    if (options->mode >= 0)
+        r.mode = options->mode == 0 ? KJARNI_SEARCH_KEYWORD : options->mode == 1 ? KJARNI_SEARCH_SEMANTIC : KJARNI_SEARCH_HYBRID;
+    if (options->top_k > 0) r.top_k = options->top_k;
+    if (options->use_reranker >= 0) r.use_reranker = options->use_reranker != 0;
+    if (options->threshold > 0.0f) {
+        r.has_threshold = true;
+        r.threshold = options->threshold;
+    }
+    if (options->source_pattern && valid_utf8(options->source_pattern))
+        r.filter.source_patterns.push_back(options->source_pattern);
+    if (options->filter_key && options->filter_value && valid_utf8(options->filter_key) &&
+        valid_utf8(options->filter_value))
+        r.filter.must_match[options->filter_key] = options->filter_value;
+    return r;
+}
+
+// The retrieval half of Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:120-160):
+// mode dispatch, 3x over-fetch + filter.  `query_emb` may be null in keyword mode.
+std::vector<SearchHit> retrieve(const IndexReader& reader, KjarniSearchMode mode, const std::string& query,
+                                const float* query_emb, size_t fetch_k, const MetadataFilter& filter,
+                                const SegmentScanFn& scan)
+{
+    const bool filtered = !filter.empty();
+    const size_t k_eff = filtered ? fetch_k * 3 : fetch_k;
+    std::vector<SearchHit> results;
+    if (mode == KJARNI_SEARCH_KEYWORD)
+        results = reader.search_keywords(query, k_eff);
+    else if (mode == KJARNI_SEARCH_SEMANTIC)
+        results = reader.search_semantic(query_emb, k_eff, scan);
+    else
+        results = reader.search_hybrid(query, query_emb, k_eff, scan);
+    if (filtered) results = reader.apply_filter(std::move(results), filter, fetch_k);
+    return results;
+}
+
+void apply_threshold_and_limit(std::vector<SearchHit>& results, const ResolvedOptions& o)
+{
+    if (o.has_threshold)
+        results.erase(std::remove_if(results.begin(), results.end(), [&](const SearchHit& h) { return !(h.score >= o.threshold); }),
+                      results.end());
+    if (results.size() > o.top_k) results.resize(o.top_k);
+}
+
+}  // namespace
+
+struct KjarniSearcher {
+    std::unique_ptr<Pipeline> embedder;
+    std::unique_ptr<Pipeline> reranker;  // optional
+    KjarniSearchMode default_mode = KJARNI_SEARCH_HYBRID;
+    size_t default_top_k = 10;
+    std::unique_ptr<SegmentScanner> scanner;
 };
 
 KJARNI_EXPORT void kjarni_search_results_free(const KjarniSearchResults* r)
@@ -192,6 +276,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_new(const KjarniSearcherConfig* co
         auto h = std::make_unique<KjarniSearcher>();
         h->embedder = load_pipeline(c.cache_dir, c.model_name, nullptr, "minilm-l6-v2", Want::Embedding);
         if (c.rerank_model) h->reranker = load_pipeline(c.cache_dir, c.rerank_model, nullptr, "", Want::Reranking);
+        h->scanner = std::make_unique<SegmentScanner>(h->embedder->model->device());
         h->default_mode = c.default_mode;
         if (c.default_top_k > 0) h->default_top_k = c.default_top_k;
         *out = h.release();
@@ -219,28 +304,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
     out->len = 0;
     if (!valid_utf8(index_path) || !valid_utf8(query)) return KJARNI_ERROR_INVALID_UTF8;
     try {
-        // option sentinels: searcher.rs:293-310
-        KjarniSearchMode mode = s->default_mode;
-        size_t top_k = s->default_top_k;
-        bool use_reranker = s->reranker != nullptr;
-        bool has_threshold = false;
-        float threshold = 0.0f;
-        MetadataFilter filter;
-        if (options) {
-            if (options->mode >= 0)
-                mode = options->mode == 0 ? KJARNI_SEARCH_KEYWORD : options->mode == 1 ? KJARNI_SEARCH_SEMANTIC : KJARNI_SEARCH_HYBRID;
-            if (options->top_k > 0) top_k = options->top_k;
-            if (options->use_reranker >= 0) use_reranker = options->use_reranker != 0;
-            if (options->threshold > 0.0f) {
-                has_threshold = true;
-                threshold = options->threshold;
-            }
-            if (options->source_pattern && valid_utf8(options->source_pattern))
-                filter.source_patterns.push_back(options->source_pattern);
-            if (options->filter_key && options->filter_value && valid_utf8(options->filter_key) &&
-                valid_utf8(options->filter_value))
-                filter.must_match[options->filter_key] = options->filter_value;
-        }
+        const ResolvedOptions o = resolve_options(options, s->default_mode, s->default_top_k, s->reranker != nullptr);
 
         // Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:96-187)
         std::unique_ptr<IndexReader> reader = open_index(index_path);
@@ -248,22 +312,15 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
         if (reader->dimension() != model_dim)
             throw InvalidConfig("Index dimension (" + std::to_string(reader->dimension()) +
                                 ") doesn't match model dimension (" + std::to_string(model_dim) + ")");
-        const bool rerank = use_reranker && s->reranker;
-        const size_t fetch_k = rerank ? top_k * 5 : top_k;
-        const bool filtered = !filter.empty();
-        const size_t k_eff = filtered ? fetch_k * 3 : fetch_k;
-        const SegmentScanFn scan = [&](const Segment& seg, const float* q, size_t limit) { return s->scan(seg, q, limit); };
-
-        std::vector<SearchHit> results;
-        if (mode == KJARNI_SEARCH_KEYWORD) {
-            results = reader->search_keywords(query, k_eff);
-        } else {
-            // embedder.embed(query): mean pool, normalised (embedder/model.rs:118-140)
-            const std::vector<float> q = embed_texts(*s->embedder, {std::string(query)}, POOL_MEAN, true);
-            results = mode == KJARNI_SEARCH_SEMANTIC ? reader->search_semantic(q.data(), k_eff, scan)
-                                                     : reader->search_hybrid(query, q.data(), k_eff, scan);
-        }
-        if (filtered) results = reader->apply_filter(std::move(results), filter, fetch_k);
+        const bool rerank = o.use_reranker && s->reranker;
+        const size_t fetch_k = rerank ? o.top_k * 5 : o.top_k;
+        const SegmentScanFn scan = [&](const Segment& seg, const float* q, size_t limit) {
+            return s->scanner->scan(seg, q, model_dim, limit);
+        };
+        std::vector<float> q;
+        if (o.mode != KJARNI_SEARCH_KEYWORD)  // embedder.embed(query): mean pool, normalised (embedder/model.rs:118-140)
+            q = embed_texts(*s->embedder, {std::string(query)}, POOL_MEAN, true);
+        std::vector<SearchHit> results = retrieve(*reader, o.mode, query, q.data(), fetch_k, o.filter, scan);
 
         if (rerank) {
             std::vector<std::string> texts;
@@ -274,7 +331,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
                 std::iota(order.begin(), order.end(), (size_t)0);
                 std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return scores[a] > scores[b]; });
                 std::vector<SearchHit> nr;
-                for (size_t i = 0; i < order.size() && i < top_k; ++i) {
+                for (size_t i = 0; i < order.size() && i < o.top_k; ++i) {
                     SearchHit h = results[order[i]];
                     h.score = scores[order[i]];
                     nr.push_back(std::move(h));
@@ -282,10 +339,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
                 results.swap(nr);
             }
         }
-        if (has_threshold)
-            results.erase(std::remove_if(results.begin(), results.end(), [&](const SearchHit& h) { return !(h.score >= threshold); }),
-                          results.end());
-        if (results.size() > top_k) results.resize(top_k);
+        apply_threshold_and_limit(results, o);
         fill_results(results, out);
         return KJARNI_OK;
     } catch (const InvalidConfig& e) {
@@ -391,4 +445,55 @@ KJARNI_EXPORT KjarniErrorCode kjarni_rrf_fuse(const size_t* keyword_ids, size_t 
         }
         *n_out = r.size();
     });
+}
+
+// Retrieval over an on-disk index with a caller-supplied query embedding: the Searcher's path minus
+// the encoder.  Keyword mode touches neither a model nor the GPU.
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, const char* text_query,
+                                                      const float* query_emb, size_t dim,
+                                                      const KjarniSearchOptions* options, KjarniSearchResults* out)
+{
+    if (!index_path || !out) return KJARNI_ERROR_NULL_POINTER;
+    out->results = nullptr;
+    out->len = 0;
+    if (!valid_utf8(index_path) || (text_query && !valid_utf8(text_query))) return KJARNI_ERROR_INVALID_UTF8;
+    try {
+        const ResolvedOptions o = resolve_options(options, KJARNI_SEARCH_HYBRID, 10, false);
+        if (o.mode != KJARNI_SEARCH_SEMANTIC && !text_query) return KJARNI_ERROR_NULL_POINTER;
+        if (o.mode != KJARNI_SEARCH_KEYWORD && !query_emb) return KJARNI_ERROR_NULL_POINTER;
+        std::unique_ptr<IndexReader> reader = open_index(index_path);
+        if (o.mode != KJARNI_SEARCH_KEYWORD && reader->dimension() != dim)
+            throw InvalidConfig("Index dimension (" + std::to_string(reader->dimension()) +
+                                ") doesn't match query dimension (" + std::to_string(dim) + ")");
+        static std::mutex mu;
+        static std::unique_ptr<SegmentScanner> scanner;
+        const SegmentScanFn scan = [&](const Segment& seg, const float* q, size_t limit) {
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                if (!scanner) {
+                    int n = 0;
+                    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw GpuUnavailable("no usable HIP device");
+                    scanner = std::make_unique<SegmentScanner>(0);
+                }
+            }
+            return scanner->scan(seg, q, dim, limit);
+        };
+        std::vector<SearchHit> results =
+            retrieve(*reader, o.mode, text_query ? text_query : "", query_emb, o.top_k, o.filter, scan);
+        apply_threshold_and_limit(results, o);
+        fill_results(results, out);
+        return KJARNI_OK;
+    } catch (const GpuUnavailable& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_GPU_UNAVAILABLE;
+    } catch (const InvalidConfig& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_INVALID_CONFIG;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_INFERENCE_FAILED;
+    } catch (...) {
+        set_last_error("unknown error");
+        return KJARNI_ERROR_INFERENCE_FAILED;
+    }
 }

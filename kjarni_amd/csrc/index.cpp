@@ -87,7 +87,7 @@ std::vector<std::string> Bm25Index::tokenize(const std::string& text)
 {
     std::vector<uint32_t> cps, low;
     if (!unicode::decode_utf8(text.data(), text.size(), cps)) throw std::runtime_error("invalid UTF-8");
-    unicode::lowercase(cps, low);
+    unicode::lowercase_str(cps, low);
     std::vector<std::string> out;
     std::string cur;
     auto flush = [&] {
@@ -279,90 +279,144 @@ std::vector<std::pair<size_t, float>> hybrid_search(const std::vector<std::pair<
 
 // ---------------------------------------------------------------------------------- glob
 
+// Restatement of the glob-match crate (0.2.1, Cargo.lock) as a recursive matcher over bytes:
+//   !pat        leading '!'s negate the result
+//   \x          x literally; a trailing backslash makes the pattern invalid (no match)
+//   ?           one byte (the crate matches over &[u8]), never '/'
+//   [a-z] [!..] byte class with ranges and escapes; a first ']' is literal
+//   *           any run without '/'
+//   **          a whole segment ("**" bounded by pattern start or '/' on the left and '/' or the end
+//               on the right) spans separators, and "**/" also matches nothing (a/**/b ~ a/b);
+//               a trailing "**" spans separators whatever precedes it; elsewhere it acts as '*'
+//   {a,b}       alternatives, nestable
 namespace {
 
-bool glob_rec(const char* p, const char* pe, const char* s, const char* se)
+bool unescape(const char*& p, const char* pe, unsigned char& c)
+{
+    c = (unsigned char)*p;
+    if (c == '\\') {
+        if (p + 1 >= pe) return false;
+        ++p;
+        c = (unsigned char)*p;
+    }
+    return true;
+}
+
+// What follows a brace alternative: the pattern text after the closing '}'.
+struct Cont {
+    const char* p;
+    const char* pe;
+    const Cont* next;
+};
+
+// `p0` is the first byte of the whole pattern (after any '!'): a "**" there has nothing to its left.
+bool glob_rec(const char* p0, const char* p, const char* pe, const Cont* cont, const char* s0, const char* s,
+              const char* se)
 {
     while (p < pe) {
         const char c = *p;
         if (c == '*') {
-            if (p + 1 < pe && p[1] == '*') {
+            const bool two = p + 1 < pe && p[1] == '*';
+            if (two) {
+                const bool left_ok = p == p0 || p[-1] == '/';
                 const char* np = p + 2;
-                if (np < pe && *np == '/') {
-                    // "**/" matches zero or more whole components
-                    ++np;
-                    if (glob_rec(np, pe, s, se)) return true;
-                    for (const char* t = s; t < se; ++t)
-                        if (*t == '/' && glob_rec(np, pe, t + 1, se)) return true;
+                while (left_ok && np + 2 < pe && np[0] == '/' && np[1] == '*' && np[2] == '*' &&
+                       (np + 3 == pe || np[3] == '/'))
+                    np += 3;  // "**/**" collapses
+                if (np == pe && !cont) return true;  // trailing "**"
+                if (left_ok && np < pe && *np == '/') {
+                    ++np;  // the segment is optional: try every segment start from here on
+                    for (const char* t = s; t <= se; ++t)
+                        if ((t == s0 || t[-1] == '/' || t == s) && glob_rec(p0, np, pe, cont, s0, t, se))
+                            return true;
                     return false;
                 }
-                for (const char* t = s; t <= se; ++t)
-                    if (glob_rec(np, pe, t, se)) return true;
-                return false;
+                // not a whole segment: behaves as '*'
+                for (const char* t = s;; ++t) {
+                    if (glob_rec(p0, np, pe, cont, s0, t, se)) return true;
+                    if (t >= se || *t == '/') return false;
+                }
             }
             for (const char* t = s;; ++t) {
-                if (glob_rec(p + 1, pe, t, se)) return true;
+                if (glob_rec(p0, p + 1, pe, cont, s0, t, se)) return true;
                 if (t >= se || *t == '/') return false;
             }
         } else if (c == '?') {
             if (s >= se || *s == '/') return false;
-            // one UTF-8 character
             ++s;
-            while (s < se && ((unsigned char)*s & 0xC0) == 0x80) ++s;
             ++p;
         } else if (c == '[') {
-            const char* close = static_cast<const char*>(std::memchr(p + 1, ']', (size_t)(pe - p - 1)));
-            if (!close) {
-                if (s >= se || *s != '[') return false;
-                ++s;
-                ++p;
-                continue;
-            }
             if (s >= se) return false;
-            const char* q = p + 1;
+            ++p;
             bool neg = false;
-            if (q < close && (*q == '!' || *q == '^')) {
+            if (p < pe && (*p == '^' || *p == '!')) {
                 neg = true;
-                ++q;
+                ++p;
             }
-            bool hit = false;
             const unsigned char ch = (unsigned char)*s;
-            while (q < close) {
-                if (q + 2 < close && q[1] == '-') {
-                    if (ch >= (unsigned char)q[0] && ch <= (unsigned char)q[2]) hit = true;
-                    q += 3;
+            bool first = true, hit = false;
+            while (p < pe && (first || *p != ']')) {
+                unsigned char lo, hi;
+                if (!unescape(p, pe, lo)) return false;
+                ++p;
+                if (p + 1 < pe && *p == '-' && p[1] != ']') {
+                    ++p;
+                    if (!unescape(p, pe, hi)) return false;
+                    ++p;
                 } else {
-                    if (ch == (unsigned char)*q) hit = true;
-                    ++q;
+                    hi = lo;
                 }
+                if (lo <= ch && ch <= hi) hit = true;
+                first = false;
             }
+            if (p >= pe) return false;  // unterminated class
+            ++p;
             if (hit == neg) return false;
             ++s;
-            p = close + 1;
         } else if (c == '{') {
-            const char* close = static_cast<const char*>(std::memchr(p + 1, '}', (size_t)(pe - p - 1)));
-            if (!close) {
-                if (s >= se || *s != '{') return false;
-                ++s;
-                ++p;
-                continue;
+            // find the matching '}' and the top-level commas
+            int depth = 0;
+            const char* close = nullptr;
+            std::vector<const char*> cuts;
+            for (const char* q = p; q < pe; ++q) {
+                if (*q == '\\') {
+                    ++q;
+                    continue;
+                }
+                if (*q == '[') {  // a class is opaque
+                    const char* r = q + 1;
+                    if (r < pe && (*r == '!' || *r == '^')) ++r;
+                    if (r < pe && *r == ']') ++r;
+                    while (r < pe && *r != ']') r += (*r == '\\') ? 2 : 1;
+                    q = r;
+                    continue;
+                }
+                if (*q == '{') ++depth;
+                else if (*q == '}') {
+                    if (--depth == 0) {
+                        close = q;
+                        break;
+                    }
+                } else if (*q == ',' && depth == 1) cuts.push_back(q);
             }
+            if (!close || depth > 10) return false;  // unbalanced / nested too deep: invalid pattern
+            cuts.push_back(close);
+            const Cont rest{close + 1, pe, cont};
             const char* a = p + 1;
-            while (a <= close) {
-                const char* comma = a;
-                while (comma < close && *comma != ',') ++comma;
-                std::string alt(a, comma);
-                alt.append(close + 1, pe);
-                if (glob_rec(alt.data(), alt.data() + alt.size(), s, se)) return true;
-                a = comma + 1;
+            for (const char* cut : cuts) {
+                if (glob_rec(p0, a, cut, &rest, s0, s, se)) return true;
+                a = cut + 1;
             }
             return false;
         } else {
-            if (s >= se || *s != c) return false;
+            unsigned char lit;
+            if (!unescape(p, pe, lit)) return false;
+            if (s >= se || (unsigned char)*s != lit) return false;
             ++s;
             ++p;
         }
     }
+    if (cont) return glob_rec(p0, cont->p, cont->pe, cont->next, s0, s, se);
     return s == se;
 }
 
@@ -370,7 +424,17 @@ bool glob_rec(const char* p, const char* pe, const char* s, const char* se)
 
 bool glob_match(const std::string& pattern, const std::string& path)
 {
-    return glob_rec(pattern.data(), pattern.data() + pattern.size(), path.data(), path.data() + path.size());
+    const char* p = pattern.data();
+    const char* pe = p + pattern.size();
+    bool negated = false;
+    while (p < pe && *p == '!') {
+        negated = !negated;
+        ++p;
+    }
+    // "!**/x": the '!' is what precedes the stars, so they are not a whole segment
+    const char* p0 = p == pattern.data() ? p : nullptr;
+    const bool m = glob_rec(p0, p, pe, nullptr, path.data(), path.data(), path.data() + path.size());
+    return m != negated;
 }
 
 bool MetadataFilter::matches(const Metadata& md) const

@@ -186,5 +186,35 @@ void lowercase(const std::vector<uint32_t>& in, std::vector<uint32_t>& out)
     }
 }
 
+// Rust str::to_lowercase: per-char mapping except U+03A3, which becomes the final form when it
+// follows (Case_Ignorable* Cased) and is not followed by (Case_Ignorable* Cased) -- Unicode's
+// Final_Sigma condition, library/alloc/src/str.rs map_uppercase_sigma.
+void lowercase_str(const std::vector<uint32_t>& in, std::vector<uint32_t>& out)
+{
+    out.clear();
+    out.reserve(in.size());
+    auto cased = [](uint32_t c) { return in_ranges(kCased, kCased_len, c); };
+    auto ignorable = [](uint32_t c) { return in_ranges(kCaseIgnorable, kCaseIgnorable_len, c); };
+    const size_t n = in.size();
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t cp = in[i];
+        if (cp == 0x3A3) {
+            size_t b = i;
+            while (b > 0 && ignorable(in[b - 1])) --b;
+            const bool before = b > 0 && cased(in[b - 1]);
+            size_t a = i + 1;
+            while (a < n && ignorable(in[a])) ++a;
+            const bool after = a < n && cased(in[a]);
+            out.push_back(before && !after ? 0x3C2 : 0x3C3);
+        } else if (cp < 0x80) {
+            out.push_back((cp >= 'A' && cp <= 'Z') ? cp + 32 : cp);
+        } else if (const UnicodeMapEntry* e = find_entry(kLower, kLower_len, cp)) {
+            for (uint32_t k = 0; k < e->len; ++k) out.push_back(kLower_pool[e->offset + k]);
+        } else {
+            out.push_back(cp);
+        }
+    }
+}
+
 }  // namespace unicode
 }  // namespace kjarni

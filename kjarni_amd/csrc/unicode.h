@@ -28,6 +28,8 @@ bool is_alphanumeric(uint32_t cp);        // Rust char::is_alphanumeric (BM25 to
 void nfd(const std::vector<uint32_t>& in, std::vector<uint32_t>& out);
 // Per-char to_lowercase (may expand, e.g. U+0130 -> "i̇").
 void lowercase(const std::vector<uint32_t>& in, std::vector<uint32_t>& out);
+// Rust str::to_lowercase: the same, plus the context-sensitive final sigma.
+void lowercase_str(const std::vector<uint32_t>& in, std::vector<uint32_t>& out);
 
 }  // namespace unicode
 }  // namespace kjarni

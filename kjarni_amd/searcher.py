@@ -110,3 +110,30 @@ def rrf_fuse(keyword_ids, semantic_ids, limit: int):
     n = C.c_size_t(0)
     check_error(lib().kjarni_rrf_fuse(kw, len(keyword_ids), sem, len(semantic_ids), limit, ids, sc, C.byref(n)))
     return [(int(ids[i]), float(sc[i])) for i in range(n.value)]
+
+
+def index_search(index_path: str, text_query: Optional[str] = None, query_emb=None, mode: Optional[str] = None,
+                 top_k: Optional[int] = None, threshold: Optional[float] = None, source_pattern: Optional[str] = None,
+                 filter_key: Optional[str] = None, filter_value: Optional[str] = None) -> List[Dict]:
+    """Index retrieval with a caller-supplied query embedding (kjarni_hip_index_search)."""
+    import numpy as np
+    opts = lib().kjarni_search_options_default()
+    if mode is not None:
+        opts.mode = _MODES[mode]
+    if top_k:
+        opts.top_k = top_k
+    if threshold:
+        opts.threshold = threshold
+    keep = [s.encode("utf-8") if s else None for s in (source_pattern, filter_key, filter_value)]
+    opts.source_pattern, opts.filter_key, opts.filter_value = keep
+    q, dim = None, 0
+    if query_emb is not None:
+        qa = np.ascontiguousarray(query_emb, dtype=np.float32)
+        q, dim = qa.ctypes.data_as(C.POINTER(C.c_float)), qa.shape[0]
+    res = KjarniSearchResults()
+    check_error(lib().kjarni_hip_index_search(index_path.encode("utf-8"),
+                                              text_query.encode("utf-8") if text_query is not None else None,
+                                              q, dim, C.byref(opts), C.byref(res)))
+    out = res.to_list()
+    res.free()
+    return out

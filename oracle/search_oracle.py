@@ -137,47 +137,131 @@ def hybrid_search(keyword: Sequence[Tuple[int, float]], semantic: Sequence[Tuple
 
 # ----------------------------------------------------------------------------- filter
 def glob_match(pattern: str, path: str) -> bool:
-    """glob-match crate semantics used by MetadataFilter: `*` stays inside a path
-    component, `**` crosses components, `?`, `[a-z]` / `[!a]`, `{a,b}`."""
+    """glob-match 0.2.1 (Cargo.lock; called at kjarni-rag/src/index_reader.rs:63-69), restated as a
+    translation to a regular expression over bytes: leading `!` negates; `\\x` is a literal x;
+    `?` one non-'/' byte (the crate matches over &[u8]); `[a-z]`/`[!a]` byte classes; `*` stays inside a path component;
+    `**` as a whole segment crosses components (and `**/` may match nothing), a trailing `**`
+    crosses components, any other `**` acts as `*`; `{a,b}` alternatives."""
     import re
-    def conv(p: str) -> str:
+
+    class Invalid(Exception):
+        pass
+
+    pat = pattern.encode("utf-8")
+    neg = False
+    k = 0
+    while k < len(pat) and pat[k:k + 1] == b"!":
+        neg = not neg
+        k += 1
+
+    def lit(b: int) -> bytes:
+        return re.escape(bytes([b]))
+
+    def conv(p: bytes, lead: bytes, is_tail: bool) -> bytes:
+        # `lead`: the pattern byte just before p (b"" at the true start); `is_tail`: p ends the pattern
         i, out = 0, []
-        while i < len(p):
-            c = p[i]
-            if c == "*":
-                if p[i:i + 2] == "**":
-                    i += 2
-                    if p[i:i + 1] == "/":
-                        i += 1
-                        out.append("(?:.*/)?")
+        n = len(p)
+        while i < n:
+            c = p[i:i + 1]
+            if c == b"*":
+                if p[i:i + 2] == b"**":
+                    left_ok = (lead == b"") if i == 0 else p[i - 1:i] == b"/"
+                    j = i + 2
+                    while left_ok and p[j:j + 3] == b"/**" and (j + 3 == n or p[j + 3:j + 4] == b"/"):
+                        j += 3
+                    if j == n and is_tail:
+                        out.append(b".*")
+                    elif left_ok and p[j:j + 1] == b"/":
+                        out.append(b"(?:.*/)?")
+                        j += 1
                     else:
-                        out.append(".*")
+                        out.append(b"[^/]*")
+                    i = j
                     continue
-                out.append("[^/]*")
-            elif c == "?":
-                out.append("[^/]")
-            elif c == "[":
-                j = p.find("]", i + 1)
-                if j < 0:
-                    out.append(re.escape(c))
-                else:
-                    body = p[i + 1:j]
-                    if body.startswith("!"):
-                        body = "^" + body[1:]
-                    out.append("[" + body + "]")
-                    i = j
-            elif c == "{":
-                j = p.find("}", i + 1)
-                if j < 0:
-                    out.append(re.escape(c))
-                else:
-                    out.append("(?:" + "|".join(conv(a) for a in p[i + 1:j].split(",")) + ")")
-                    i = j
+                out.append(b"[^/]*")
+                i += 1
+            elif c == b"?":
+                out.append(b"[^/]")
+                i += 1
+            elif c == b"[":
+                i += 1
+                negc = p[i:i + 1] in (b"^", b"!")
+                if negc:
+                    i += 1
+                items, first = [], True
+                while i < n and (first or p[i:i + 1] != b"]"):
+                    def take():
+                        nonlocal i
+                        if p[i:i + 1] == b"\\":
+                            if i + 1 >= n:
+                                raise Invalid()
+                            i += 1
+                        v = p[i]
+                        i += 1
+                        return v
+                    lo = take()
+                    if i + 1 < n and p[i:i + 1] == b"-" and p[i + 1:i + 2] != b"]":
+                        i += 1
+                        hi = take()
+                    else:
+                        hi = lo
+                    items.append((lo, hi))
+                    first = False
+                if i >= n:
+                    raise Invalid()
+                i += 1
+                allowed = [b for b in range(256) if any(lo <= b <= hi for lo, hi in items) != negc]
+                out.append(b"(?:" + b"|".join(lit(b) for b in allowed) + b")" if allowed else b"(?!)")
+            elif c == b"{":
+                depth, j, cuts, close = 0, i, [], None
+                while j < n:
+                    d = p[j:j + 1]
+                    if d == b"\\":
+                        j += 2
+                        continue
+                    if d == b"[":
+                        r = j + 1
+                        if p[r:r + 1] in (b"!", b"^"):
+                            r += 1
+                        if p[r:r + 1] == b"]":
+                            r += 1
+                        while r < n and p[r:r + 1] != b"]":
+                            r += 2 if p[r:r + 1] == b"\\" else 1
+                        j = r + 1
+                        continue
+                    if d == b"{":
+                        depth += 1
+                    elif d == b"}":
+                        depth -= 1
+                        if depth == 0:
+                            close = j
+                            break
+                    elif d == b"," and depth == 1:
+                        cuts.append(j)
+                    j += 1
+                if close is None:
+                    raise Invalid()
+                cuts.append(close)
+                alts, a0 = [], i + 1
+                for cut in cuts:
+                    alts.append(conv(p[a0:cut], p[a0 - 1:a0], False))
+                    a0 = cut + 1
+                # what follows the brace is converted knowing a '}' precedes it
+                return b"".join(out) + b"(?:" + b"|".join(alts) + b")" + conv(p[close + 1:], b"}", is_tail)
             else:
-                out.append(re.escape(c))
-            i += 1
-        return "".join(out)
-    return re.fullmatch(conv(pattern), path, flags=re.S) is not None
+                if c == b"\\":
+                    if i + 1 >= n:
+                        raise Invalid()
+                    i += 1
+                out.append(lit(p[i]))
+                i += 1
+        return b"".join(out)
+
+    try:
+        rx = conv(pat[k:], b"" if k == 0 else b"!", True)
+    except Invalid:
+        return neg
+    return (re.fullmatch(rx, path.encode("utf-8"), flags=re.S) is not None) != neg
 
 
 class MetadataFilter:
@@ -232,7 +316,7 @@ def write_index(root: str, dimension: int, docs: Sequence[Tuple[str, np.ndarray,
     seg_id = 0
     for s0 in range(0, len(docs), max_docs_per_segment):
         chunk = docs[s0:s0 + max_docs_per_segment]
-        d = os.path.join(root, "segments", f"segment_{seg_id:08d}")
+        d = os.path.join(root, "segments", f"seg_{seg_id:06d}")
         os.makedirs(d, exist_ok=True)
         bm = Bm25Index()
         offsets, cur = [], 0

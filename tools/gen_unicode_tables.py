@@ -21,6 +21,7 @@ Only the canonical combining class (needed to reorder the rare non-Mn combining
 marks after decomposition) comes from Python's unicodedata, and the
 alphanumeric set of the BM25 tokenizer (Rust char::is_alphanumeric =
 Alphabetic property or general category N*; crates/kjarni-search/src/bm25.rs:191-197)
+plus the Cased / Case_Ignorable sets behind str::to_lowercase's Final_Sigma rule
 from the `regex` module's Unicode database.
 
 Run:  python tools/gen_unicode_tables.py   (about a minute)
@@ -68,6 +69,8 @@ def main():
     drop, space, mn, ws, punct, cjk_set = [], [], [], [], [], []
     alnum = []
     alnum_re = regex.compile(r"[\p{Alphabetic}\p{N}]")
+    cased, case_ign = [], []
+    cased_re, case_ign_re = regex.compile(r"\p{Cased}"), regex.compile(r"\p{Case_Ignorable}")
     decomp, lowmap, ccc = {}, {}, {}
     S_BASE, L_BASE, V_BASE, T_BASE = 0xAC00, 0x1100, 0x1161, 0x11A7
     for cp in code_points():
@@ -107,6 +110,10 @@ def main():
             cjk_set.append(cp)
         if alnum_re.match(ch):
             alnum.append(cp)
+        if cased_re.match(ch):
+            cased.append(cp)
+        if case_ign_re.match(ch):
+            case_ign.append(cp)
         k = unicodedata.combining(ch)
         if k:
             ccc[cp] = k
@@ -153,6 +160,8 @@ def main():
         emit_ranges(f, "kPunctuation", punct)
         emit_ranges(f, "kCjk", cjk_set)
         emit_ranges(f, "kAlnum", alnum)
+        emit_ranges(f, "kCased", cased)
+        emit_ranges(f, "kCaseIgnorable", case_ign)
         emit_map(f, "kDecomp", decomp)
         emit_map(f, "kLower", lowmap)
         # ccc as ranges with value
