@@ -248,6 +248,101 @@ size_t kjarni_searcher_default_top_k(const KjarniSearcher* searcher);           
 size_t kjarni_searcher_model_name(const KjarniSearcher* searcher, char* buf, size_t buf_len);     /* :427-457 */
 size_t kjarni_searcher_reranker_model(const KjarniSearcher* searcher, char* buf, size_t buf_len); /* :460-491 */
 
+/* ---- progress + cancellation: kjarni-ffi/src/callback.rs:7-101 ---------------- */
+typedef enum KjarniProgressStage {
+    KJARNI_PROGRESS_SCANNING = 0,
+    KJARNI_PROGRESS_LOADING = 1,
+    KJARNI_PROGRESS_EMBEDDING = 2,
+    KJARNI_PROGRESS_WRITING = 3,
+    KJARNI_PROGRESS_COMMITTING = 4,
+    KJARNI_PROGRESS_SEARCHING = 5,
+    KJARNI_PROGRESS_RERANKING = 6,
+} KjarniProgressStage;
+
+typedef struct KjarniProgress {
+    KjarniProgressStage stage;
+    size_t current;
+    size_t total;        /* 0 = unknown */
+    const char* message; /* may be NULL; valid for the duration of the callback */
+} KjarniProgress;
+
+/* The struct is passed BY VALUE (callback.rs:32-33). */
+typedef void (*KjarniProgressCallbackFn)(KjarniProgress progress, void* user_data);
+
+typedef struct KjarniCancelToken KjarniCancelToken;
+KjarniCancelToken* kjarni_cancel_token_new(void);                          /* :53-58 */
+void kjarni_cancel_token_cancel(KjarniCancelToken* token);                 /* :60-67; may be called from any thread */
+bool kjarni_cancel_token_is_cancelled(const KjarniCancelToken* token);     /* :69-76; false on NULL */
+void kjarni_cancel_token_reset(KjarniCancelToken* token);                  /* :78-85 */
+void kjarni_cancel_token_free(KjarniCancelToken* token);                   /* :87-94 */
+
+/* ---- Indexer: kjarni-ffi/src/indexer.rs:14-675 ---------------------------------
+ * Files and directories -> chunks (crates/kjarni-rag/src/{loader,splitter}.rs) -> embeddings on the
+ * GPU -> the reference's segmented on-disk index (crates/kjarni-rag/src/{index_writer,segment}.rs). */
+typedef struct KjarniIndexStats {
+    size_t documents_indexed;
+    size_t chunks_created;
+    size_t dimension;
+    uint64_t size_bytes;
+    size_t files_processed;
+    size_t files_skipped;
+    uint64_t elapsed_ms;
+} KjarniIndexStats;
+
+typedef struct KjarniIndexInfo {
+    char* path;            /* owned; free with kjarni_index_info_free */
+    size_t document_count;
+    size_t segment_count;
+    size_t dimension;
+    uint64_t size_bytes;
+    char* embedding_model; /* owned, may be NULL */
+} KjarniIndexInfo;
+
+typedef struct KjarniIndexerConfig {
+    KjarniDevice device;
+    const char* cache_dir;
+    const char* model_name;       /* NULL = "minilm-l6-v2" */
+    size_t chunk_size;            /* characters; default 512 */
+    size_t chunk_overlap;         /* characters; default 50 */
+    size_t batch_size;            /* chunks per embed/progress step; default 32 */
+    const char* extensions;       /* comma separated; NULL = the default text extensions */
+    const char* exclude_patterns; /* comma separated globs */
+    int32_t recursive;            /* default 1 */
+    int32_t include_hidden;       /* default 0 */
+    size_t max_file_size;         /* bytes; default 10 MiB; 0 = keep the default */
+    int32_t quiet;
+} KjarniIndexerConfig;
+
+typedef struct KjarniIndexer KjarniIndexer;
+
+/* By VALUE, as the Rust source has it (indexer.rs:85-93). */
+void kjarni_index_info_free(KjarniIndexInfo info);
+KjarniIndexerConfig kjarni_indexer_config_default(void);                              /* :126-143 */
+KjarniErrorCode kjarni_indexer_new(const KjarniIndexerConfig* config, KjarniIndexer** out); /* :153-243 */
+void kjarni_indexer_free(KjarniIndexer* indexer);                                     /* :246-251 */
+/* Errors: index exists without force / no inputs / dimension mismatch -> INVALID_CONFIG;
+ * missing input path or index -> MODEL_NOT_FOUND; cancelled -> CANCELLED; else INFERENCE_FAILED. */
+KjarniErrorCode kjarni_indexer_create(KjarniIndexer* indexer, const char* index_path, const char* const* inputs,
+                                      size_t num_inputs, int32_t force, KjarniIndexStats* out);      /* :301-344 */
+KjarniErrorCode kjarni_indexer_create_with_callback(KjarniIndexer* indexer, const char* index_path,
+                                                    const char* const* inputs, size_t num_inputs, int32_t force,
+                                                    KjarniProgressCallbackFn progress_callback, void* user_data,
+                                                    const KjarniCancelToken* cancel_token,
+                                                    KjarniIndexStats* out);                          /* :347-433 */
+KjarniErrorCode kjarni_indexer_add(KjarniIndexer* indexer, const char* index_path, const char* const* inputs,
+                                   size_t num_inputs, size_t* documents_added);                      /* :437-483 */
+KjarniErrorCode kjarni_indexer_add_with_callback(KjarniIndexer* indexer, const char* index_path,
+                                                 const char* const* inputs, size_t num_inputs,
+                                                 KjarniProgressCallbackFn progress_callback, void* user_data,
+                                                 const KjarniCancelToken* cancel_token,
+                                                 size_t* documents_added);                           /* :486-578 */
+/* Neither needs a model or a GPU. */
+KjarniErrorCode kjarni_index_info(const char* index_path, KjarniIndexInfo* out);      /* :582-604 */
+KjarniErrorCode kjarni_index_delete(const char* index_path);                          /* :607-625 */
+size_t kjarni_indexer_model_name(const KjarniIndexer* indexer, char* buf, size_t buf_len); /* :629-657 */
+size_t kjarni_indexer_dimension(const KjarniIndexer* indexer);                        /* :660-666 */
+size_t kjarni_indexer_chunk_size(const KjarniIndexer* indexer);                       /* :669-675 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -240,6 +240,21 @@ KjarniErrorCode kjarni_rrf_fuse(const size_t* keyword_ids, size_t n_keyword, con
 KjarniErrorCode kjarni_hip_index_search(const char* index_path, const char* text_query, const float* query_emb,
                                         size_t dim, const KjarniSearchOptions* options, KjarniSearchResults* out);
 
+/* ---- indexing pipeline, one host-side piece at a time (parity tests) ----------------
+ * TextSplitter::split (crates/kjarni-rag/src/splitter.rs:68-120; separator NULL = "\n\n"),
+ * Indexer::collect_files (crates/kjarni/src/indexer/model.rs:727-810; reads recursive, include_hidden,
+ * extensions, exclude_patterns and max_file_size of the config) and IndexWriter
+ * (crates/kjarni-rag/src/index_writer.rs:12-191) driven with caller-supplied embeddings:
+ * texts[i], embeddings[i*dimension ..], metadata_json[i] (flat JSON object of strings, or NULL);
+ * append 0 = IndexWriter::open, 1 = open_existing; max_docs_per_segment 0 = 10 000. */
+KjarniErrorCode kjarni_text_split(const char* text, size_t chunk_size, size_t chunk_overlap, const char* separator,
+                                  KjarniStringArray* out);
+KjarniErrorCode kjarni_collect_files(const KjarniIndexerConfig* config, const char* const* inputs, size_t num_inputs,
+                                     KjarniStringArray* out);
+KjarniErrorCode kjarni_index_write(const char* index_path, size_t dimension, size_t max_docs_per_segment,
+                                   const char* embedding_model, const char* const* texts,
+                                   const char* const* metadata_json, const float* embeddings, size_t n, int32_t append);
+
 /* ---- device memory helpers for callers without a HIP runtime binding --------- */
 KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev);
 KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev);

@@ -159,6 +159,32 @@ class KjarniSearcherConfig(Structure):
                 ("default_mode", c_int32), ("default_top_k", c_size_t), ("quiet", c_int32)]
 
 
+class KjarniProgress(Structure):
+    _fields_ = [("stage", c_int32), ("current", c_size_t), ("total", c_size_t), ("message", c_char_p)]
+
+
+KjarniProgressCallbackFn = C.CFUNCTYPE(None, KjarniProgress, c_void_p)
+
+
+class KjarniIndexStats(Structure):
+    _fields_ = [("documents_indexed", c_size_t), ("chunks_created", c_size_t), ("dimension", c_size_t),
+                ("size_bytes", C.c_uint64), ("files_processed", c_size_t), ("files_skipped", c_size_t),
+                ("elapsed_ms", C.c_uint64)]
+
+
+class KjarniIndexInfo(Structure):
+    # char* kept as void* so the pointers survive to kjarni_index_info_free
+    _fields_ = [("path", c_void_p), ("document_count", c_size_t), ("segment_count", c_size_t),
+                ("dimension", c_size_t), ("size_bytes", C.c_uint64), ("embedding_model", c_void_p)]
+
+
+class KjarniIndexerConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p), ("chunk_size", c_size_t),
+                ("chunk_overlap", c_size_t), ("batch_size", c_size_t), ("extensions", c_char_p),
+                ("exclude_patterns", c_char_p), ("recursive", c_int32), ("include_hidden", c_int32),
+                ("max_file_size", c_size_t), ("quiet", c_int32)]
+
+
 class KjarniRerankerConfig(Structure):
     _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
                 ("model_path", c_char_p), ("quiet", c_int32)]
@@ -222,7 +248,35 @@ SIGNATURES = {
     "kjarni_searcher_default_top_k": (c_size_t, [c_void_p]),
     "kjarni_searcher_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
     "kjarni_searcher_reranker_model": (c_size_t, [c_void_p, c_char_p, c_size_t]),
+    "kjarni_cancel_token_new": (c_void_p, []),
+    "kjarni_cancel_token_cancel": (None, [c_void_p]),
+    "kjarni_cancel_token_is_cancelled": (C.c_bool, [c_void_p]),
+    "kjarni_cancel_token_reset": (None, [c_void_p]),
+    "kjarni_cancel_token_free": (None, [c_void_p]),
+    "kjarni_index_info_free": (None, [KjarniIndexInfo]),
+    "kjarni_indexer_config_default": (KjarniIndexerConfig, []),
+    "kjarni_indexer_new": (c_int32, [POINTER(KjarniIndexerConfig), POINTER(c_void_p)]),
+    "kjarni_indexer_free": (None, [c_void_p]),
+    "kjarni_indexer_create": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t, c_int32,
+                                        POINTER(KjarniIndexStats)]),
+    "kjarni_indexer_create_with_callback": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t, c_int32,
+                                                      KjarniProgressCallbackFn, c_void_p, c_void_p,
+                                                      POINTER(KjarniIndexStats)]),
+    "kjarni_indexer_add": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t, POINTER(c_size_t)]),
+    "kjarni_indexer_add_with_callback": (c_int32, [c_void_p, c_char_p, POINTER(c_char_p), c_size_t,
+                                                   KjarniProgressCallbackFn, c_void_p, c_void_p,
+                                                   POINTER(c_size_t)]),
+    "kjarni_index_info": (c_int32, [c_char_p, POINTER(KjarniIndexInfo)]),
+    "kjarni_index_delete": (c_int32, [c_char_p]),
+    "kjarni_indexer_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
+    "kjarni_indexer_dimension": (c_size_t, [c_void_p]),
+    "kjarni_indexer_chunk_size": (c_size_t, [c_void_p]),
     # kjarni_hip.h
+    "kjarni_text_split": (c_int32, [c_char_p, c_size_t, c_size_t, c_char_p, POINTER(KjarniStringArray)]),
+    "kjarni_collect_files": (c_int32, [POINTER(KjarniIndexerConfig), POINTER(c_char_p), c_size_t,
+                                       POINTER(KjarniStringArray)]),
+    "kjarni_index_write": (c_int32, [c_char_p, c_size_t, c_size_t, c_char_p, POINTER(c_char_p), POINTER(c_char_p),
+                                     _f32p, c_size_t, c_int32]),
     "kjarni_bm25_tokenize": (c_int32, [c_char_p, POINTER(KjarniStringArray)]),
     "kjarni_glob_match": (c_int32, [c_char_p, c_char_p]),
     "kjarni_rrf_fuse": (c_int32, [POINTER(c_size_t), c_size_t, POINTER(c_size_t), c_size_t, c_size_t,

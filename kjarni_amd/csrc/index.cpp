@@ -689,37 +689,40 @@ std::vector<SearchHit> IndexReader::apply_filter(std::vector<SearchHit> hits, co
     return out;
 }
 
-std::string metadata_to_json(const Metadata& md)
+// serde_json string escaping: ", \\ and control characters; everything else verbatim.
+std::string json_escape(const std::string& s)
 {
-    auto esc = [](const std::string& s) {
-        std::string o = "\"";
-        for (unsigned char c : s) {
-            switch (c) {
-            case '"': o += "\\\""; break;
-            case '\\': o += "\\\\"; break;
-            case '\n': o += "\\n"; break;
-            case '\r': o += "\\r"; break;
-            case '\t': o += "\\t"; break;
-            case '\b': o += "\\b"; break;
-            case '\f': o += "\\f"; break;
-            default:
-                if (c < 0x20) {
-                    char buf[8];
-                    std::snprintf(buf, sizeof buf, "\\u%04x", c);
-                    o += buf;
-                } else {
-                    o.push_back((char)c);
-                }
+    std::string o = "\"";
+    for (unsigned char c : s) {
+        switch (c) {
+        case '"': o += "\\\""; break;
+        case '\\': o += "\\\\"; break;
+        case '\n': o += "\\n"; break;
+        case '\r': o += "\\r"; break;
+        case '\t': o += "\\t"; break;
+        case '\b': o += "\\b"; break;
+        case '\f': o += "\\f"; break;
+        default:
+            if (c < 0x20) {
+                char buf[8];
+                std::snprintf(buf, sizeof buf, "\\u%04x", c);
+                o += buf;
+            } else {
+                o.push_back((char)c);
             }
         }
-        return o + "\"";
-    };
+    }
+    return o + "\"";
+}
+
+std::string metadata_to_json(const Metadata& md)
+{
     std::string o = "{";
     bool first = true;
     for (const auto& kv : md) {
         if (!first) o += ",";
         first = false;
-        o += esc(kv.first) + ":" + esc(kv.second);
+        o += json_escape(kv.first) + ":" + json_escape(kv.second);
     }
     return o + "}";
 }

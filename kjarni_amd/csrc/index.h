@@ -131,6 +131,7 @@ private:
     std::vector<std::unique_ptr<Segment>> segments_;
 };
 
-std::string metadata_to_json(const Metadata& md);
+std::string metadata_to_json(const Metadata& md);  // serde_json::to_string(&HashMap), keys sorted
+std::string json_escape(const std::string& s);
 
 }  // namespace kjarni

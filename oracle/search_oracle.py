@@ -386,3 +386,187 @@ class IndexOracle:
             r = self._result(seg, gid - self.offsets[seg], score)
             out.append(r)
         return out
+
+
+# ----------------------------------------------------------------------------- write side: chunking + discovery
+class TextSplitter:
+    """kjarni-rag/src/splitter.rs:44-170.  `len()` of a Rust str is BYTES (sections and the running
+    chunk are measured in bytes); oversized sections and the overlap suffix are cut in CHARACTERS."""
+
+    def __init__(self, chunk_size=1000, chunk_overlap=200, separator="\n\n"):
+        if chunk_size == 0:
+            raise ValueError("chunk_size must be greater than 0")
+        if chunk_overlap >= chunk_size:
+            raise ValueError("chunk_overlap must be less than chunk_size")
+        self.chunk_size, self.chunk_overlap, self.separator = chunk_size, chunk_overlap, separator
+
+    @staticmethod
+    def _blen(s: str) -> int:
+        return len(s.encode("utf-8"))
+
+    def _split_large(self, text: str) -> List[str]:  # splitter.rs:132-165
+        out, start, n = [], 0, len(text)
+        while start < n:
+            end = min(start + self.chunk_size, n)
+            out.append(text[start:end])
+            if end >= n:
+                break
+            start += self.chunk_size - self.chunk_overlap if 0 < self.chunk_overlap < self.chunk_size else self.chunk_size
+        return out
+
+    def split(self, text: str) -> List[str]:  # splitter.rs:68-120
+        if not text:
+            return []
+        chunks, cur = [], ""
+        for section in text.split(self.separator):
+            if not section:
+                continue
+            if self._blen(section) > self.chunk_size:
+                if cur:
+                    chunks.append(cur)
+                    cur = ""
+                chunks += self._split_large(section)
+                continue
+            would_be = self._blen(section) if not cur else self._blen(cur) + self._blen(self.separator) + self._blen(section)
+            if would_be > self.chunk_size and cur:
+                chunks.append(cur)
+                if self.chunk_overlap > 0:
+                    cur = cur if len(cur) <= self.chunk_overlap else cur[len(cur) - self.chunk_overlap:]
+                else:
+                    cur = ""
+            if cur:
+                cur += self.separator
+            cur += section
+        if cur:
+            chunks.append(cur)
+        return chunks
+
+
+TEXT_EXTENSIONS = ("txt md markdown rst org json yaml yml toml xml csv html htm css rs py js ts go java c cpp h hpp "
+                   "cs rb sh bash zsh fish ps1 sql r scala kt swift m mm lua pl php ex exs clj hs").split()
+
+
+def is_supported_file(path: str, extensions: Sequence[str] = ()) -> bool:
+    """loader.rs:181-198 / indexer/model.rs:797-813 (Path::extension, lowercased)."""
+    name = os.path.basename(path.rstrip("/"))
+    if "." not in name or name.rfind(".") == 0:
+        return False
+    ext = name[name.rfind(".") + 1:].lower()
+    return ext in (extensions if extensions else TEXT_EXTENSIONS)
+
+
+def collect_files(inputs: Sequence[str], recursive=True, include_hidden=False, extensions: Sequence[str] = (),
+                  exclude_patterns: Sequence[str] = (), max_file_size: Optional[int] = 10 * 1024 * 1024) -> List[str]:
+    """indexer/model.rs:727-795; directory entries in byte order of their names (the reference
+    inherits the OS's readdir order)."""
+    files: List[str] = []
+
+    def walk(d: str):
+        for name in sorted(os.listdir(d), key=lambda s: s.encode("utf-8", "surrogateescape")):
+            p = d + name if d.endswith("/") else d + "/" + name
+            if os.path.isdir(p) and not os.path.islink(p):
+                if recursive:
+                    walk(p)
+                continue
+            if not os.path.isfile(p):
+                continue
+            if not include_hidden and name.startswith("."):
+                continue
+            if any(glob_match(pat, p) for pat in exclude_patterns):
+                continue
+            if max_file_size is not None and os.path.getsize(p) > max_file_size:
+                continue
+            if is_supported_file(p, extensions):
+                files.append(p)
+
+    for inp in inputs:
+        if not os.path.exists(inp):
+            raise FileNotFoundError(inp)
+        if os.path.isfile(inp):
+            if is_supported_file(inp, extensions):
+                files.append(inp)
+        elif os.path.isdir(inp):
+            walk(inp)
+    return files
+
+
+def load_file_chunks(path: str, splitter: TextSplitter) -> List[Tuple[str, Dict[str, str]]]:
+    """loader.rs:85-110 + ChunkMetadata::to_hashmap (kjarni-search/src/types.rs:58-77)."""
+    with open(path, "rb") as f:
+        content = f.read().decode("utf-8")  # fs::read_to_string: invalid UTF-8 is an error
+    texts = splitter.split(content)
+    return [(t, {"source": path, "chunk_index": str(i), "total_chunks": str(len(texts))}) for i, t in enumerate(texts)]
+
+
+# ----------------------------------------------------------------------------- independent reader of the on-disk format
+def _bincode_reader(blob: bytes):
+    pos = [0]
+
+    def u64():
+        v, = struct.unpack_from("<Q", blob, pos[0])
+        pos[0] += 8
+        return v
+
+    def f32():
+        v, = struct.unpack_from("<f", blob, pos[0])
+        pos[0] += 4
+        return v
+
+    def s():
+        n = u64()
+        v = blob[pos[0]:pos[0] + n].decode("utf-8")
+        assert len(blob) >= pos[0] + n
+        pos[0] += n
+        return v
+    return u64, f32, s, pos
+
+
+def bm25_from_bincode(blob: bytes) -> "Bm25Index":
+    """bincode 1.x image of kjarni-search/src/bm25.rs:42-60, field by field."""
+    u64, f32, s, pos = _bincode_reader(blob)
+    b = Bm25Index()
+    for _ in range(u64()):
+        k = s()
+        b.doc_frequencies[k] = u64()
+    b.doc_lengths = [u64() for _ in range(u64())]
+    b.avg_doc_length = F32(f32())
+    b.total_docs = u64()
+    for _ in range(u64()):
+        k = s()
+        b.inverted_index[k] = [(u64(), u64()) for _ in range(u64())]
+    b.k1, b.b, b.epsilon = F32(f32()), F32(f32()), F32(f32())
+    for _ in range(u64()):  # token_to_docs
+        s()
+        for _ in range(u64()):
+            u64()
+    b.total_length = u64()
+    assert pos[0] == len(blob), "trailing bytes in bm25.bin"
+    return b
+
+
+def read_index(root: str) -> Dict:
+    """Everything an index directory holds, parsed without the library: config.json, index.json and,
+    per segment, segment.json / vectors / texts / metadata / BM25."""
+    out = dict(config=json.load(open(os.path.join(root, "config.json"))), segments=[], names=[])
+    ip = os.path.join(root, "index.json")
+    out["index"] = json.load(open(ip)) if os.path.exists(ip) else None
+    segdir = os.path.join(root, "segments")
+    for name in sorted(os.listdir(segdir)):
+        d = os.path.join(segdir, name)
+        meta = json.load(open(os.path.join(d, "segment.json")))
+        n, dim = meta["doc_count"], meta["dimension"]
+        vec = np.fromfile(os.path.join(d, "vectors.bin"), dtype="<f4").reshape(n, dim)
+        blob = open(os.path.join(d, "docs.idx"), "rb").read()
+        cnt, = struct.unpack_from("<Q", blob, 0)
+        offs = list(struct.unpack_from(f"<{cnt}Q", blob, 8))
+        assert len(blob) == 8 + 8 * cnt and cnt == n
+        docs = open(os.path.join(d, "docs.bin"), "rb").read()
+        ends = offs[1:] + [len(docs)]
+        texts = [docs[a:b - 1].decode("utf-8") for a, b in zip(offs, ends)]
+        assert all(docs[b - 1:b] == b"\n" for b in ends)
+        mds = [json.loads(line) for line in open(os.path.join(d, "metadata.jsonl"), encoding="utf-8").read().split("\n")[:-1]]
+        assert len(mds) == n
+        bm = bm25_from_bincode(open(os.path.join(d, "bm25.bin"), "rb").read())
+        out["segments"].append(dict(meta=meta, vectors=vec, texts=texts, metadata=mds, bm25=bm))
+        out["names"].append(name)
+    return out
