@@ -93,7 +93,7 @@ def test_create_matches_oracle_pipeline(env, tmp_path):
     events = []
     stats = ix.create(root, [env["docs"]], on_progress=lambda p: events.append(tuple(p)))
     files, chunks, processed, skipped = _expected_chunks(env["docs"], 120, 20)
-    assert len(chunks) > 30 and skipped == 1
+    assert len(chunks) > 20 and skipped == 1
     assert (stats.documents_indexed, stats.chunks_created, stats.dimension, stats.files_processed,
             stats.files_skipped) == (len(chunks), len(chunks), 384, processed, skipped)
     assert stats.size_bytes == kjarni_amd.index_info(root).size_bytes > 0
