@@ -139,6 +139,9 @@ KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const f
 void kjarni_hip_set_gemm_variant(int32_t variant);
 /* Same for the attention kernel (0 = default persistent kernel for seq <= 128, 1 = one workgroup per item). */
 void kjarni_hip_set_attention_variant(int32_t variant);
+/* Cosine scan (0 = default: from 20 queries on the dot products go through the matrix-core GEMM;
+ * 1 = always one streaming pass per 4 queries). */
+void kjarni_hip_set_cosine_variant(int32_t variant);
 
 /* ---- per-kernel timing (HIP events on the launch stream) -------------------------
  * profile_begin() switches the encoder into timed mode: every kernel launch of the

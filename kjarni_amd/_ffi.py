@@ -313,6 +313,7 @@ SIGNATURES = {
                                            c_int32, _f32p]),
     "kjarni_hip_set_gemm_variant": (None, [c_int32]),
     "kjarni_hip_set_attention_variant": (None, [c_int32]),
+    "kjarni_hip_set_cosine_variant": (None, [c_int32]),
     "kjarni_hip_encoder_profile_begin": (c_int32, [c_void_p]),
     "kjarni_hip_encoder_profile_begin_kinds": (c_int32, [c_void_p, C.c_uint32]),
     "kjarni_hip_encoder_profile_end": (c_int32, [c_void_p, POINTER(KjarniHipKernelStat), c_size_t,

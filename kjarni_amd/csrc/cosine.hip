@@ -14,7 +14,7 @@
 // scores ascending document index (what the stable sort_by over an
 // index-ordered Vec gives, vector.rs:162) -- by sorting 64-bit keys
 // (orderable score bits << 32 | ~index) with LDS bitonic networks: each block
-// reduces a segment of 16384 candidates to its best KPAD, levels repeat until
+// reduces a segment of 2048..16384 candidates to its best KPAD, levels repeat until
 // one block is left.
 #include "device_utils.h"
 #include "kernels.h"
@@ -23,13 +23,16 @@ namespace kjarni {
 
 namespace {
 
+int g_scan_variant = 0;          // 1 = never take the GEMM route (tests / measurements)
 constexpr int SCAN_NQ = 4;       // queries held in registers per pass
 constexpr int SCAN_MAX_V4 = 4;   // dim <= 1024 on the float4 path
 
 // mode 0: vector.rs:131-148   dot / max(sqrt(na)*sqrt(nb), 1e-9)
 // mode 1: segment.rs:355-371  nb < 1e-9 ? 0 : dot / (qn * nb)
+// mode 2 (internal): the row's squared norm itself
 __device__ __forceinline__ float cosine_finish(float dot, float qn2, float dn2, int mode)
 {
+    if (mode == 2) return dn2;
     if (mode == 0) {
         const float den = fmaxf(sqrtf(qn2) * sqrtf(dn2), 1e-9f);
         return dot / den;
@@ -98,6 +101,99 @@ __global__ __launch_bounds__(256) void cosine_scores_kernel(const float* __restr
     }
 }
 
+// Streaming variant for the common embedding widths.  Rows are contiguous, so a wave takes a GROUP of
+// R rows as one flat run of R*NV4 float4s and issues all T = R*NV4/64 full-width 16-byte loads before
+// touching any of them: T KiB in flight per wave instead of one (partly filled) row.  Which row a
+// lane's element belongs to is compile-time per load except at the (at most NV4<64 ? many : one) row
+// boundaries inside a load; the query is pre-permuted into the same lane order once per wave.
+template <int NV4, int R, int NQ>
+__global__ __launch_bounds__(256) void cosine_scores_stream_kernel(const float* __restrict__ queries,
+                                                                   const float* __restrict__ corpus,
+                                                                   int64_t n_groups, int mode,
+                                                                   float* __restrict__ scores,
+                                                                   int64_t score_stride)
+{
+    static_assert((R * NV4) % 64 == 0, "a group must be a whole number of wave-wide loads");
+    constexpr int T = R * NV4 / 64;
+    constexpr int DIM = NV4 * 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    f32x4 q[NQ][T];
+    float qn2[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const f32x4* qv = reinterpret_cast<const f32x4*>(queries + (int64_t)j * DIM);
+        float s = 0.0f;
+        for (int c4 = lane; c4 < NV4; c4 += 64) {
+            const f32x4 v = qv[c4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s = fmaf(v[c], v[c], s);
+        }
+        qn2[j] = wave_sum(s);
+#pragma unroll
+        for (int t = 0; t < T; ++t) q[j][t] = qv[(t * 64 + lane) % NV4];
+    }
+
+    for (int64_t g = wave; g < n_groups; g += n_waves) {
+        const f32x4* base = reinterpret_cast<const f32x4*>(corpus + g * (int64_t)(R * DIM));
+        f32x4 x[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = __builtin_nontemporal_load(base + t * 64 + lane);
+
+        float dn[R], dt[NQ][R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            dn[r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) dt[j][r] = 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float s2 = 0.0f, sq[NQ];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s2 = fmaf(x[t][c], x[t][c], s2);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                sq[j] = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sq[j] = fmaf(q[j][t][c], x[t][c], sq[j]);
+            }
+            const int r_lo = (t * 64) / NV4, r_hi = (t * 64 + 63) / NV4;  // constants after unrolling
+            if (r_lo == r_hi) {
+                dn[r_lo] += s2;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) dt[j][r_lo] += sq[j];
+            } else {
+                const int my = (t * 64 + lane) / NV4;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r >= r_lo && r <= r_hi) {
+                        const bool in = my == r;
+                        dn[r] += in ? s2 : 0.0f;
+#pragma unroll
+                        for (int j = 0; j < NQ; ++j) dt[j][r] += in ? sq[j] : 0.0f;
+                    }
+                }
+            }
+        }
+        // every lane ends up with all R results; lane r stores row r's score (one 4*R-byte store)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            float mine = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float d2 = (j == 0) ? (dn[r] = wave_sum(dn[r])) : dn[r];
+                const float dj = wave_sum(dt[j][r]);
+                const float sc = cosine_finish(dj, qn2[j], d2, mode);
+                mine = (lane == r) ? sc : mine;
+            }
+            if (lane < R) scores[(int64_t)j * score_stride + g * R + lane] = mine;
+        }
+    }
+}
+
 // Any-dim fallback: one wave per row, scalar loads.
 __global__ __launch_bounds__(256) void cosine_scores_generic_kernel(
     const float* __restrict__ queries, int nq, const float* __restrict__ corpus, int64_t n_docs,
@@ -130,9 +226,9 @@ __global__ __launch_bounds__(256) void cosine_scores_generic_kernel(
 // Top-k
 // ---------------------------------------------------------------------------
 
-constexpr int TK_TILE = 2048;          // keys sorted at once in LDS
-constexpr int TK_TILES_PER_BLOCK = 8;  // segment = 16384 candidates
-constexpr int TK_SEG = TK_TILE * TK_TILES_PER_BLOCK;
+constexpr int TK_TILE = 2048;               // candidates examined between two barriers
+constexpr int TK_PEND = 2 * TK_TILE;        // pending buffer (keys that beat the block's threshold)
+constexpr int TK_MAX_TILES_PER_BLOCK = 64;  // a block folds up to 131072 candidates into its best KPAD
 
 // Larger float -> larger uint32 (total order, -0 < +0); NaN sorts lowest.
 __device__ __forceinline__ uint32_t orderable(float f)
@@ -190,34 +286,56 @@ __device__ __forceinline__ void bitonic_merge_desc(uint64_t* keys, int n, int ti
     __syncthreads();
 }
 
-// One block reduces candidates [blk*TK_SEG, +TK_SEG) of query blockIdx.y to its
-// best KPAD keys (descending).  Level 0 reads float scores (index = position),
-// later levels read keys.  Keys >= `upper` are ignored (multi-pass k > 1024).
+// One block reduces candidates [blk*seg, +seg), seg = TK_TILE*tiles_per_block, of query blockIdx.y to its
+// best KPAD keys (descending).  Level 0 reads float scores (index = position), later levels read
+// keys.  Keys >= `upper` are ignored (multi-pass k > 1024).
+//
+// Only candidates above the block's current KPAD-th best can matter, and on anything but adversarial
+// input that threshold rises quickly: candidates that pass it are compacted into a pending buffer
+// (wave-aggregated LDS append) and the bitonic sort + merge runs only when that buffer might overflow
+// and once at the end -- typically twice per block instead of once per 2048 candidates.
 template <int KPAD>
 __global__ __launch_bounds__(256) void topk_reduce_kernel(const float* __restrict__ scores,
                                                           const uint64_t* __restrict__ in_keys,
                                                           int64_t n, int64_t in_stride,
                                                           const uint64_t* __restrict__ upper_ptr,
                                                           uint64_t* __restrict__ out_keys,
-                                                          int64_t out_stride)
+                                                          int64_t out_stride, int tiles_per_block)
 {
-    __shared__ uint64_t tile[TK_TILE];
+    __shared__ uint64_t pend[TK_PEND];
     __shared__ uint64_t best[KPAD];
-    __shared__ int any_flag;
-    const int tid = threadIdx.x;
+    __shared__ int pend_count;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int qi = blockIdx.y;
     const uint64_t upper = upper_ptr ? upper_ptr[qi] : ~0ull;
-    const int64_t seg0 = (int64_t)blockIdx.x * TK_SEG;
+    const int64_t seg0 = (int64_t)blockIdx.x * TK_TILE * tiles_per_block;
     for (int i = tid; i < KPAD; i += 256) best[i] = 0ull;
+    if (tid == 0) pend_count = 0;
     __syncthreads();
 
-    for (int tl = 0; tl < TK_TILES_PER_BLOCK; ++tl) {
+    // sort the pending keys, fold them into best[], reset the buffer
+    auto flush = [&]() {
+        const int cnt = pend_count;  // uniform: read after a barrier
+        int p2 = KPAD;
+        while (p2 < cnt) p2 <<= 1;
+        __syncthreads();  // everyone has read pend_count
+        for (int i = cnt + tid; i < p2; i += 256) pend[i] = 0ull;
+        if (tid == 0) pend_count = 0;
+        bitonic_sort_desc(pend, p2, tid);
+        // best (desc) and the reversed head of pend (asc) form a bitonic sequence whose element-wise
+        // max holds the top KPAD of the union.
+        for (int i = tid; i < KPAD; i += 256) {
+            const uint64_t a = best[i], b2 = pend[KPAD - 1 - i];
+            best[i] = a > b2 ? a : b2;
+        }
+        bitonic_merge_desc(best, KPAD, tid);
+    };
+
+    for (int tl = 0; tl < tiles_per_block; ++tl) {
         const int64_t t0 = seg0 + (int64_t)tl * TK_TILE;
         if (t0 >= n) break;
+        if (pend_count + TK_TILE > TK_PEND) flush();  // uniform branch (barrier at the end of the last tile)
         const uint64_t thr = best[KPAD - 1];
-        if (tid == 0) any_flag = 0;
-        __syncthreads();
-        bool any = false;
         for (int i = tid; i < TK_TILE; i += 256) {
             const int64_t p = t0 + i;
             uint64_t key = 0ull;
@@ -226,23 +344,19 @@ __global__ __launch_bounds__(256) void topk_reduce_kernel(const float* __restric
                              : in_keys[(int64_t)qi * in_stride + p];
                 if (key >= upper) key = 0ull;
             }
-            tile[i] = key;
-            any |= key > thr;
+            const bool take = key > thr;
+            const uint64_t m = __ballot(take);
+            if (m) {
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&pend_count, __popcll(m));
+                base = __shfl(base, leader, kWave);
+                if (take) pend[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
         }
-        if (any) any_flag = 1;
         __syncthreads();
-        const int go = any_flag;
-        __syncthreads();  // everyone has read the flag before thread 0 clears it again
-        if (!go) continue;  // nothing in this tile can enter the block's best KPAD
-        bitonic_sort_desc(tile, TK_TILE, tid);
-        // best (desc) and reversed tile head (asc) form a bitonic sequence whose
-        // element-wise max holds the top KPAD of the union.
-        for (int i = tid; i < KPAD; i += 256) {
-            const uint64_t a = best[i], b = tile[KPAD - 1 - i];
-            best[i] = a > b ? a : b;
-        }
-        bitonic_merge_desc(best, KPAD, tid);
     }
+    if (pend_count > 0) flush();
     __syncthreads();
     for (int i = tid; i < KPAD; i += 256)
         out_keys[(int64_t)qi * out_stride + (int64_t)blockIdx.x * KPAD + i] = best[i];
@@ -275,16 +389,29 @@ int kpad_for(int k)
     return p;
 }
 
-int64_t blocks_for(int64_t n) { return (n + TK_SEG - 1) / TK_SEG; }
+// Enough blocks to fill the chip (about 2048 across all queries), otherwise segments as long as
+// possible: the longer a segment, the more of it is rejected by the threshold without sorting.
+int tiles_per_block_for(int64_t n, int nq)
+{
+    const int64_t tiles = (n + TK_TILE - 1) / TK_TILE;
+    const int64_t t = (tiles * nq + 2047) / 2048;
+    return (int)(t < 1 ? 1 : (t > TK_MAX_TILES_PER_BLOCK ? TK_MAX_TILES_PER_BLOCK : t));
+}
+
+int64_t blocks_for(int64_t n, int nq)
+{
+    const int64_t seg = (int64_t)TK_TILE * tiles_per_block_for(n, nq);
+    return (n + seg - 1) / seg;
+}
 
 template <int KPAD>
 void launch_reduce(const float* scores, const uint64_t* in_keys, int64_t n, int64_t in_stride,
                    const uint64_t* upper, uint64_t* out_keys, int64_t out_stride, int nq,
                    hipStream_t stream)
 {
-    dim3 grid((unsigned)blocks_for(n), (unsigned)nq);
+    dim3 grid((unsigned)blocks_for(n, nq), (unsigned)nq);
     hipLaunchKernelGGL(topk_reduce_kernel<KPAD>, grid, dim3(256), 0, stream, scores, in_keys, n,
-                       in_stride, upper, out_keys, out_stride);
+                       in_stride, upper, out_keys, out_stride, tiles_per_block_for(n, nq));
 }
 
 void dispatch_reduce(int kpad, const float* scores, const uint64_t* in_keys, int64_t n,
@@ -304,37 +431,173 @@ void dispatch_reduce(int kpad, const float* scores, const uint64_t* in_keys, int
 
 }  // namespace
 
+namespace {
+
+// scores[j][d] holds dot(q_j, doc_d) on entry, the cosine on exit.
+__global__ __launch_bounds__(256) void cosine_finish_kernel(float* __restrict__ scores, int64_t stride,
+                                                            const float* __restrict__ qn2,
+                                                            const float* __restrict__ dn2, int64_t n4, int mode)
+{
+    const int j = blockIdx.y;
+    const float q2 = qn2[j];
+    f32x4* row = reinterpret_cast<f32x4*>(scores + (int64_t)j * stride);
+    const f32x4* dn = reinterpret_cast<const f32x4*>(dn2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = row[i];
+        const f32x4 d = dn[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = cosine_finish(v[c], q2, d[c], mode);
+        row[i] = v;
+    }
+}
+
+template <int NV4, int R, int NQ>
+void launch_stream(const float* queries, const float* corpus, int64_t n_groups, int mode, float* scores,
+                   int64_t score_stride, hipStream_t stream)
+{
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t max_blocks = 256 * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((cosine_scores_stream_kernel<NV4, R, NQ>), dim3((unsigned)blocks), dim3(256), 0, stream, queries,
+                       corpus, n_groups, mode, scores, score_stride);
+}
+
+// Rows per group for the streaming kernel (0 = width not specialised).
+int stream_rows(int dim, bool multi)
+{
+    switch (dim) {
+    case 384: return multi ? 2 : 4;
+    case 768: return 2;
+    case 1024: return multi ? 1 : 2;
+    case 512: return multi ? 2 : 4;
+    case 256: return multi ? 4 : 8;
+    case 128: return multi ? 8 : 16;
+    default: return 0;
+    }
+}
+
+template <int NQ>
+bool dispatch_stream(int dim, const float* queries, const float* corpus, int64_t n_groups, int mode, float* scores,
+                     int64_t score_stride, hipStream_t stream)
+{
+    constexpr bool M = NQ > 1;
+    switch (dim) {
+    case 384: launch_stream<96, M ? 2 : 4, NQ>(queries, corpus, n_groups, mode, scores, score_stride, stream); return true;
+    case 768: launch_stream<192, 2, NQ>(queries, corpus, n_groups, mode, scores, score_stride, stream); return true;
+    case 1024: launch_stream<256, M ? 1 : 2, NQ>(queries, corpus, n_groups, mode, scores, score_stride, stream); return true;
+    case 512: launch_stream<128, M ? 2 : 4, NQ>(queries, corpus, n_groups, mode, scores, score_stride, stream); return true;
+    case 256: launch_stream<64, M ? 4 : 8, NQ>(queries, corpus, n_groups, mode, scores, score_stride, stream); return true;
+    case 128: launch_stream<32, M ? 8 : 16, NQ>(queries, corpus, n_groups, mode, scores, score_stride, stream); return true;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+namespace {
+
+// One streaming pass over the corpus per group of SCAN_NQ queries.
+hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
+                       float* scores, int64_t score_stride, hipStream_t stream);
+
+// Many queries: the dot products are a [nq, dim] x [n_docs, dim]^T product, so the corpus is read once
+// by the matrix-core GEMM (queries as the row operand) instead of once per 4 queries; row norms come
+// from one streaming pass, then an element-wise pass turns dots into cosines in place.
+hipError_t scan_gemm(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
+                     float* scores, hipStream_t stream)
+{
+    float* tmp = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (size_t)(n_docs + nq + 8) * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    float* dn2 = tmp;
+    float* qn2 = tmp + ((n_docs + 3) / 4) * 4;
+    const int64_t n_main = n_docs / 128 * 128;
+    e = scan_passes(corpus, 1, corpus, n_docs, dim, 2, dn2, n_docs, stream);      // row norms (query unused)
+    if (e == hipSuccess) e = scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);
+    for (int q0 = 0; q0 < nq && e == hipSuccess; q0 += 128) {
+        const int m = nq - q0 < 128 ? nq - q0 : 128;
+        e = launch_gemm(queries + (int64_t)q0 * dim, dim, corpus, nullptr, nullptr, 0, scores + (int64_t)q0 * n_docs,
+                        n_docs, m, (int)n_main, dim, EPI_BIAS, stream);
+    }
+    if (e == hipSuccess) {
+        const int64_t n4 = n_main / 4;
+        int64_t bx = (n4 + 255) / 256;
+        if (bx > 4096) bx = 4096;
+        hipLaunchKernelGGL(cosine_finish_kernel, dim3((unsigned)bx, (unsigned)nq), dim3(256), 0, stream, scores, n_docs,
+                           qn2, dn2, n4, mode);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && n_main < n_docs)  // the < 128 leftover documents
+        e = scan_passes(queries, nq, corpus + n_main * dim, n_docs - n_main, dim, mode, scores + n_main, n_docs, stream);
+    const hipError_t fe = hipFreeAsync(tmp, stream);
+    return e != hipSuccess ? e : fe;
+}
+
+}  // namespace
+
 hipError_t launch_cosine_scores(const float* queries, int nq, const float* corpus, int64_t n_docs,
                                 int dim, int mode, float* scores, hipStream_t stream)
 {
     if (nq <= 0 || n_docs <= 0) return hipSuccess;
-    int64_t waves = n_docs;
-    const int64_t max_blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
-    int64_t blocks = (waves + 3) / 4;
-    if (blocks > max_blocks) blocks = max_blocks;
-    const bool fast = (dim % 4 == 0) && dim <= 256 * SCAN_MAX_V4 &&
-                      ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
-    if (fast) {
-        for (int q0 = 0; q0 < nq; q0 += SCAN_NQ) {
-            const int n = (nq - q0 < SCAN_NQ) ? (nq - q0) : SCAN_NQ;
-            hipLaunchKernelGGL(cosine_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                               queries + (int64_t)q0 * dim, n, corpus, n_docs, dim, mode,
-                               scores + (int64_t)q0 * n_docs, n_docs);
-        }
-    } else {
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) &&
+                           ((reinterpret_cast<uintptr_t>(queries) & 15) == 0) &&
+                           ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
+    // Crossover: a streaming pass per 4 queries costs about as much as the GEMM route from ~20 queries on.
+    if (nq >= 20 && aligned16 && dim % 32 == 0 && n_docs % 4 == 0 && n_docs >= 128 && n_docs < (int64_t)INT32_MAX &&
+        g_scan_variant != 1)
+        return scan_gemm(queries, nq, corpus, n_docs, dim, mode, scores, stream);
+    return scan_passes(queries, nq, corpus, n_docs, dim, mode, scores, n_docs, stream);
+}
+
+namespace {
+
+hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
+                       float* scores, int64_t score_stride, hipStream_t stream)
+{
+    const bool aligned = ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
+    const bool fast = (dim % 4 == 0) && dim <= 256 * SCAN_MAX_V4 && aligned;
+    if (!fast) {
+        int64_t blocks = (n_docs + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(cosine_scores_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                           queries, nq, corpus, n_docs, dim, mode, scores, n_docs);
+                           queries, nq, corpus, n_docs, dim, mode, scores, score_stride);
+        return hipGetLastError();
+    }
+    for (int q0 = 0; q0 < nq; q0 += SCAN_NQ) {
+        const int n = (nq - q0 < SCAN_NQ) ? (nq - q0) : SCAN_NQ;
+        const float* qp = queries + (int64_t)q0 * dim;
+        float* sp = scores + (int64_t)q0 * score_stride;
+        // whole groups through the streaming kernel, the (< R) leftover rows through the row kernel
+        int64_t done = 0;
+        const int R = (n == 1 || n == SCAN_NQ) ? stream_rows(dim, n > 1) : 0;
+        if (R > 0 && n_docs >= R) {
+            const int64_t groups = n_docs / R;
+            const bool ok = (n == 1) ? dispatch_stream<1>(dim, qp, corpus, groups, mode, sp, score_stride, stream)
+                                     : dispatch_stream<SCAN_NQ>(dim, qp, corpus, groups, mode, sp, score_stride, stream);
+            if (ok) done = groups * R;
+        }
+        if (done < n_docs) {
+            const int64_t rest = n_docs - done;
+            int64_t blocks = (rest + 3) / 4;
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            hipLaunchKernelGGL(cosine_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, qp, n,
+                               corpus + done * dim, rest, dim, mode, sp + done, score_stride);
+        }
     }
     return hipGetLastError();
 }
+
+}  // namespace
+
+void set_cosine_variant(int variant) { g_scan_variant = variant; }
 
 // Workspace: two ping-pong key buffers sized for the first level's output, plus
 // one `upper` key per query.
 size_t cosine_topk_workspace_bytes(int nq, int64_t n_docs, int k)
 {
     const int kpad = kpad_for(k < 1024 ? k : 1024);
-    const int64_t per_q = blocks_for(n_docs) * kpad;
+    const int64_t per_q = blocks_for(n_docs, nq) * kpad;
     return (size_t)(2 * per_q * nq + nq) * sizeof(uint64_t) + 256;
 }
 
@@ -344,7 +607,7 @@ hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k
     if (nq <= 0 || k <= 0) return hipSuccess;
     if (n_docs <= 0 || n_docs >= (int64_t)0xFFFFFFFF) return hipErrorInvalidValue;
     const int kpad = kpad_for(k < 1024 ? k : 1024);
-    const int64_t per_q = blocks_for(n_docs) * kpad;
+    const int64_t per_q = blocks_for(n_docs, nq) * kpad;
     uint64_t* buf_a = reinterpret_cast<uint64_t*>(workspace);
     uint64_t* buf_b = buf_a + per_q * nq;
     uint64_t* upper = buf_b + per_q * nq;
@@ -354,11 +617,11 @@ hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k
         const int take = (k - done < 1024) ? (k - done) : 1024;
         dispatch_reduce(kpad, scores, nullptr, n_docs, n_docs, done ? upper : nullptr, buf_a, per_q, nq,
                         stream);
-        int64_t n = blocks_for(n_docs) * kpad;
+        int64_t n = blocks_for(n_docs, nq) * kpad;
         uint64_t *src = buf_a, *dst = buf_b;
         while (n > kpad) {
             dispatch_reduce(kpad, nullptr, src, n, per_q, nullptr, dst, per_q, nq, stream);
-            n = blocks_for(n) * kpad;
+            n = blocks_for(n, nq) * kpad;
             uint64_t* t = src;
             src = dst;
             dst = t;

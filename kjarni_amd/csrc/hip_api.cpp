@@ -364,6 +364,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const flo
 
 KJARNI_EXPORT void kjarni_hip_set_gemm_variant(int32_t variant) { set_gemm_variant(variant); }
 KJARNI_EXPORT void kjarni_hip_set_attention_variant(int32_t variant) { set_attention_variant(variant); }
+KJARNI_EXPORT void kjarni_hip_set_cosine_variant(int32_t variant) { set_cosine_variant(variant); }
 
 // ---- cosine scan ----------------------------------------------------------------
 

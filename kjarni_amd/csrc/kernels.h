@@ -43,6 +43,7 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
 void set_gemm_variant(int variant);
 int gemm_variant();
 void set_attention_variant(int variant);  // 0 = default, 1 = non-persistent kernel
+void set_cosine_variant(int variant);     // 0 = default, 1 = streaming passes only (no GEMM route for many queries)
 
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.
 // qkv is [tokens, 3*hidden] (Q | K | V), mask is u32 [batch, seq], ctx is

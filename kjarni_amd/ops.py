@@ -65,3 +65,40 @@ def set_gemm_variant(v: int):
 
 def set_attention_variant(v: int):
     lib().kjarni_hip_set_attention_variant(int(v))
+
+
+def set_cosine_variant(v: int):
+    lib().kjarni_hip_set_cosine_variant(int(v))
+
+
+def topk(scores, k: int, device: int = 0):
+    """Top-k of a score matrix [nq, n] on the GPU (kjarni_hip_cosine_topk): (idx int64 [nq,k], score f32 [nq,k]),
+    score descending, equal scores by ascending index; entries past n are (-1, -inf)."""
+    import ctypes as C
+    from ._ffi import check_error
+    scores = np.ascontiguousarray(scores, np.float32)
+    if scores.ndim == 1:
+        scores = scores[None, :]
+    nq, n = scores.shape
+    L = lib()
+    ws_bytes = L.kjarni_hip_cosine_topk_workspace_bytes(nq, n, k)
+    bufs = []
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        check_error(L.kjarni_hip_malloc(device, max(nbytes, 16), C.byref(p)))
+        bufs.append(p)
+        return p
+    try:
+        d_sc, d_ws, d_idx, d_out = dmalloc(scores.nbytes), dmalloc(ws_bytes), dmalloc(nq * k * 8), dmalloc(nq * k * 4)
+        check_error(L.kjarni_hip_memcpy_h2d(device, d_sc, scores.ctypes.data_as(C.c_void_p), scores.nbytes))
+        check_error(L.kjarni_hip_cosine_topk(device, d_sc, nq, n, k, d_ws, d_idx, d_out, None))
+        check_error(L.kjarni_hip_synchronize(device))
+        idx = np.empty((nq, k), np.int64)
+        out = np.empty((nq, k), np.float32)
+        check_error(L.kjarni_hip_memcpy_d2h(device, idx.ctypes.data_as(C.c_void_p), d_idx, idx.nbytes))
+        check_error(L.kjarni_hip_memcpy_d2h(device, out.ctypes.data_as(C.c_void_p), d_out, out.nbytes))
+        return idx, out
+    finally:
+        for p in bufs:
+            L.kjarni_hip_free(device, p)

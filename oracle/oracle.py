@@ -99,6 +99,9 @@ def lib():
         L.ko_search.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int64, _i64p, _f32p]
         L.ko_num_threads.restype = C.c_int
         L.ko_set_num_threads.argtypes = [C.c_int]
+        # The checker runs tiny problems: an OpenMP team as wide as a 256-thread host spends its time
+        # in barriers.  Callers that time the oracle (bench.py's cpu_baseline) set the width themselves.
+        L.ko_set_num_threads(max(1, min(16, os.cpu_count() or 1)))
         _lib = L
     return _lib
 

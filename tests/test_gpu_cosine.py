@@ -87,3 +87,67 @@ def test_full_size_properties():
     # spot-check the returned scores with the oracle's scalar formula
     for i, s in zip(idx[0], sc[0]):
         assert abs(O.cosine_ks(q, corpus[i]) - s) < 1e-4
+
+
+@pytest.mark.parametrize("n,dim,nq,mode", [(5000, 384, 33, 0), (4100, 384, 64, 1), (1028, 768, 21, 0),
+                                           (2051, 384, 40, 0), (3000, 100, 25, 1), (640, 384, 130, 0)])
+def test_many_queries_gemm_route_matches_streaming_and_oracle(n, dim, nq, mode):
+    """From 20 queries on the dot products go through the matrix-core GEMM (corpus read once); shapes
+    it does not take (n % 4 != 0, dim % 32 != 0) fall back to the streaming passes.  Both must agree
+    with the oracle, zero rows and zero queries included."""
+    import kjarni_amd
+    from kjarni_amd import ops
+    corpus = _unit_rows(n, dim, seed=n) * np.float32(0.5)
+    corpus[11] = 0.0
+    queries = _unit_rows(nq, dim, seed=nq + 1) * np.float32(3.0)
+    queries[2] = 0.0
+    k = 12
+    idx, sc = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
+    ops.set_cosine_variant(1)
+    try:
+        idx1, sc1 = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
+    finally:
+        ops.set_cosine_variant(0)
+    assert idx.shape == idx1.shape == (nq, k)
+    fin = np.isfinite(sc1)
+    assert (np.isfinite(sc) == fin).all() and np.abs(sc[fin] - sc1[fin]).max() < 2e-6
+    for j in range(nq):
+        if mode == 1 and j == 2:           # zero query: Segment mode returns no hits for it (idx -1)
+            assert (idx[j] == -1).all() and (idx1[j] == -1).all()
+            continue
+        full = O.cosine_scan(queries[j], corpus, mode)
+        assert np.abs(full[idx[j]] - sc[j]).max() < 1e-4
+        ridx, rsc = O.search(queries[j], corpus, k, mode=mode)
+        assert np.abs(sc[j] - rsc).max() < 1e-4
+        bad = np.nonzero(idx[j] != ridx)[0]
+        if bad.size:
+            assert np.abs(full[idx[j][bad]] - full[ridx[bad]]).max() < 2e-6
+
+
+@pytest.mark.parametrize("n,nq,k", [(300_000, 1, 10), (300_000, 3, 100), (70_000, 2, 1500), (5000, 1, 5000),
+                                    (2_500_000, 2, 16)])
+def test_topk_adversarial_orders(n, nq, k):
+    """The selection keeps only candidates above a running threshold; ascending scores make every
+    candidate pass it (worst case), descending none, constant scores tie everywhere.  Expected order:
+    score descending, equal scores by ascending index."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(n + k)
+    rows = [np.arange(n, dtype=np.float32) / np.float32(n),                 # ascending: all pass
+            -np.arange(n, dtype=np.float32),                                # descending
+            np.zeros(n, np.float32),                                        # all tied
+            rng.integers(0, 50, n).astype(np.float32),                      # heavy ties
+            rng.standard_normal(n).astype(np.float32)]
+    rows[4][rng.integers(0, n, 50)] = np.nan                               # NaN sorts lowest
+    rows[4][rng.integers(0, n, 5)] = np.inf
+    for r0 in range(0, len(rows), nq):
+        sc = np.stack((rows + rows)[r0:r0 + nq])
+        idx, out = ops.topk(sc, k)
+        for j in range(nq):
+            s = sc[j].copy()
+            key = np.where(np.isnan(s), -np.inf, s)
+            order = np.lexsort((np.arange(n), -key))[:k]                    # score desc, index asc
+            kk = min(k, n)
+            nan_free = ~np.isnan(s[order[:kk]])
+            assert (idx[j][:kk][nan_free] == order[:kk][nan_free]).all()
+            np.testing.assert_array_equal(out[j][:kk][nan_free], s[order[:kk]][nan_free])
+            assert (idx[j][kk:] == -1).all()

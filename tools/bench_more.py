@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""The other measurements SURVEY.md section 8(d) asks for, next to bench.py's headline line.
+
+    python tools/bench_more.py [rerank] [scan] [ragged] [host] [strings] [indexer]   (default: all)
+
+One JSON line per measurement (1 GPU; the N > 1 driver is bench.py):
+  rerank   BASELINE.json configs[2] on one GPU: 100 000 synthetic (query, doc) pairs, S = 128, fp32,
+           ids/mask/types resident in HBM -> 100 000 logits.  pairs/s + fraction of the fp32 MFMA peak.
+  scan     cosine scan + top-10 over unit-norm Gaussian corpora [N, 384], N in {1e5, 1e6, 1e7}, 1 and 64
+           queries, corpus resident in HBM.  docs/s and the scan kernel's algorithmic GB/s vs 8 TB/s.
+  ragged   the headline embed workload with lengths ~ U{16..128} (right-padded): masking cost.
+  host     the headline embed workload through the host-pointer entry point: H2D of ids/mask and D2H of
+           the embeddings inside the timed region (the PCIe-inclusive rate; never the headline value).
+  strings  kjarni_embedder_encode_batch on generated ASCII sentences (tokenisation on the host included).
+  indexer  kjarni_indexer_create over a generated directory tree: chunks/s end to end.
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+S = 128
+
+
+def flops_per_row(H=384, L=6, I=1536, seq=S, head=0):
+    per_layer = 2 * seq * H * 3 * H + 2 * 2 * seq * seq * H + 2 * seq * H * H + 2 * 2 * seq * H * I
+    return L * per_layer + head
+
+
+def timed(fn, sync, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer"}
+    import numpy as np
+    import torch
+
+    import kjarni_amd
+    from kjarni_amd import _ffi
+    from tests import synth
+
+    assert torch.cuda.is_available() and kjarni_amd.device_count() >= 1, "needs an AMD GPU"
+    dev = torch.device("cuda", 0)
+    L = _ffi.lib()
+    stream = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    sync = torch.cuda.synchronize
+
+    def emit(d):
+        print(json.dumps(d), flush=True)
+
+    tmp = tempfile.mkdtemp(prefix="kjarni_bench_more_")
+    emb_dir = os.path.join(tmp, "cache", "sentence-transformers_all-MiniLM-L6-v2")
+    cfg, _ = synth.minilm_embedder(emb_dir, seed=0)
+    synth.add_tokenizer(emb_dir)
+
+    if "rerank" in which:
+        d = os.path.join(tmp, "ce")
+        cfg_r, _ = synth.minilm_cross_encoder(d, seed=1)
+        enc = kjarni_amd.HipEncoder(d, 0)
+        N = 100_000
+        ids, mask, types = synth.synthetic_pairs(N, S, seed=1)
+        t_ids, t_mask, t_types = (torch.from_numpy(a.view(np.int32)).to(dev) for a in (ids, mask, types))
+        out = torch.empty((N, enc.num_labels), dtype=torch.float32, device=dev)
+        dt = timed(lambda: enc.logits_dev(t_ids.data_ptr(), t_mask.data_ptr(), t_types.data_ptr(), N, S, out.data_ptr(),
+                                          stream=stream()), sync, steps=3, warmup=1)
+        fl = flops_per_row(head=2 * 384 * 384 + 2 * 384)
+        emit({"metric": "pairs/sec minilm-l6-v2-cross-encoder rerank (seq=128)", "value": round(N / dt, 1), "unit": "pairs/s",
+              "n_gpus": 1, "ms_per_step": round(dt * 1e3, 2), "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "BASELINE.json configs[2] on one GPU: 100 000 synthetic query-doc pairs, seq_len=128"},
+              "e2e_tflops": round(N / dt * fl / 1e12, 2),
+              "e2e_frac_fp32_mfma_peak": round(N / dt * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
+        del enc, t_ids, t_mask, t_types, out
+
+    if "ragged" in which or "host" in which:
+        enc = kjarni_amd.HipEncoder(emb_dir, 0)
+        N = 65536
+        if "ragged" in which:
+            ids, mask = synth.synthetic_ids(N, S, seed=0, ragged=True)
+            t_ids, t_mask = (torch.from_numpy(a.view(np.int32)).to(dev) for a in (ids, mask))
+            out = torch.empty((N, 384), dtype=torch.float32, device=dev)
+            dt = timed(lambda: enc.embed_dev(t_ids.data_ptr(), t_mask.data_ptr(), N, S, out.data_ptr(), stream=stream()),
+                       sync, steps=3, warmup=1)
+            emit({"metric": "sentences/sec minilm-l6-v2 batch encode (seq=128), ragged lengths U{16..128} right-padded",
+                  "value": round(N / dt, 1), "unit": "sentences/s", "n_gpus": 1, "ms_per_step": round(dt * 1e3, 2),
+                  "dtype": "f32", "data": "synthetic", "config": {"workload": "65 536 sentences padded to 128, mean length 72"},
+                  "real_tokens_per_s": round(float(mask.sum()) / dt, 0)})
+            del t_ids, t_mask, out
+        if "host" in which:
+            ids, mask = synth.synthetic_ids(N, S, seed=0)
+            dt = timed(lambda: enc.embed(ids, mask), lambda: None, steps=2, warmup=1)
+            emit({"metric": "sentences/sec minilm-l6-v2 batch encode (seq=128), host pointers (H2D ids/mask + D2H embeddings timed)",
+                  "value": round(N / dt, 1), "unit": "sentences/s", "n_gpus": 1, "ms_per_step": round(dt * 1e3, 2),
+                  "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": "65 536 sentences x 128 through kjarni_hip_encoder_embed_host (pageable host memory)"}})
+        del enc
+
+    if "scan" in which:
+        dim, k = 384, 10
+        for n in (100_000, 1_000_000, 10_000_000):
+            g = torch.Generator(device=dev).manual_seed(2)
+            corpus = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
+            corpus /= torch.linalg.vector_norm(corpus, dim=1, keepdim=True)
+            for nq in (1, 64):
+                q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
+                scores = torch.empty((nq, n), dtype=torch.float32, device=dev)
+                ws = torch.empty(L.kjarni_hip_cosine_topk_workspace_bytes(nq, n, k), dtype=torch.uint8, device=dev)
+                idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+                sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+
+                def scan():
+                    _ffi.check_error(L.kjarni_hip_cosine_scores(0, q.data_ptr(), nq, corpus.data_ptr(), n, dim, 1,
+                                                                scores.data_ptr(), stream()))
+
+                def topk():
+                    _ffi.check_error(L.kjarni_hip_cosine_topk(0, scores.data_ptr(), nq, n, k, ws.data_ptr(), idx.data_ptr(),
+                                                              sc.data_ptr(), stream()))
+                steps = 20 if n <= 1_000_000 else 5
+                t_scan = timed(scan, sync, steps, 2)
+                t_topk = timed(topk, sync, steps, 2)
+                t_all = timed(lambda: (scan(), topk()), sync, steps, 2)
+                ref_idx = torch.topk(q @ corpus.T if n <= 1_000_000 else scores, k, dim=1).indices
+                same = bool(torch.equal(torch.sort(ref_idx, dim=1).values, torch.sort(idx, dim=1).values))
+                passes = (nq + 3) // 4  # the kernel streams the corpus once per group of 4 queries
+                alg = n * dim * 4
+                emit({"metric": "docs/sec cosine scan + top-10 (dim 384)", "value": round(n * nq / t_all, 0), "unit": "doc-queries/s",
+                      "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"corpus [{n}, 384] unit-norm Gaussian rows resident in HBM, {nq} quer{'y' if nq == 1 else 'ies'}, k=10"},
+                      "topk_set_equals_torch_topk": same, "ms_scan": round(t_scan * 1e3, 4), "ms_topk": round(t_topk * 1e3, 4), "ms_total": round(t_all * 1e3, 4),
+                      "roofline": {"kernel": "cosine_scores_kernel", "bound": "hbm",
+                                   "achieved": round(alg / t_scan / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(alg / t_scan / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                                   "algorithmic_bytes_per_launch": alg, "corpus_passes_in_kernel": passes,
+                                   "streamed_gbs": round(alg * passes / t_scan / 1e9, 1)}})
+                del scores, ws, idx, sc, q
+            del corpus
+            torch.cuda.empty_cache()
+
+    if "strings" in which:
+        rng = np.random.default_rng(0)
+        vocab = json.load(open(os.path.join(emb_dir, "tokenizer.json")))["model"]["vocab"]
+        words = [w for w in vocab if w.isalpha() and len(w) > 2][:4000] or ["alpha", "beta", "gamma"]
+        n = 65536
+        texts = [" ".join(rng.choice(words, 100)) for _ in range(n)]
+        emb = kjarni_amd.Embedder("minilm-l6-v2", cache_dir=os.path.join(tmp, "cache"))
+        emb.encode_batch(texts[:1024])
+        t0 = time.perf_counter()
+        out = emb.encode_batch(texts)
+        dt = time.perf_counter() - t0
+        tok = kjarni_amd.Tokenizer(os.path.join(emb_dir, "tokenizer.json"), 512)
+        t0 = time.perf_counter()
+        ids, mask, _ = tok.encode_batch(texts)
+        dt_tok = time.perf_counter() - t0
+        emit({"metric": "sentences/sec kjarni_embedder_encode_batch (strings in, host tokenisation included)",
+              "value": round(n / dt, 1), "unit": "sentences/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": f"{n} generated 100-word ASCII sentences, padded length {ids.shape[1]}"},
+              "tokenise_only_sentences_per_s": round(n / dt_tok, 1), "host_threads": os.cpu_count(), "rows": int(out.shape[0])})
+        del emb
+
+    if "indexer" in which:
+        rng = np.random.default_rng(0)
+        words = ["alpha", "beta", "gamma", "delta", "kernel", "vector", "index", "search", "wave", "matrix", "iceland", "river"]
+        docs = os.path.join(tmp, "docs")
+        os.makedirs(docs)
+        for i in range(400):
+            paras = [" ".join(rng.choice(words, int(rng.integers(20, 80)))) + "." for _ in range(40)]
+            with open(os.path.join(docs, f"doc{i:04d}.txt"), "w") as f:
+                f.write("\n\n".join(paras))
+        ix = kjarni_amd.Indexer(cache_dir=os.path.join(tmp, "cache"), quiet=True)
+        ix.create(os.path.join(tmp, "warm"), [os.path.join(docs, "doc0000.txt")])
+        t0 = time.perf_counter()
+        st = ix.create(os.path.join(tmp, "index"), [docs])
+        dt = time.perf_counter() - t0
+        emit({"metric": "chunks/sec kjarni_indexer_create (files -> chunks -> embeddings -> segments on disk)",
+              "value": round(st.documents_indexed / dt, 1), "unit": "chunks/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": f"400 generated text files, chunk_size 512 / overlap 50 / batch_size 32 (defaults): "
+                                     f"{st.documents_indexed} chunks, index {st.size_bytes} bytes"},
+              "elapsed_ms": st.elapsed_ms})
+
+
+if __name__ == "__main__":
+    main()
