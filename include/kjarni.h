@@ -343,6 +343,18 @@ size_t kjarni_indexer_model_name(const KjarniIndexer* indexer, char* buf, size_t
 size_t kjarni_indexer_dimension(const KjarniIndexer* indexer);                        /* :660-666 */
 size_t kjarni_indexer_chunk_size(const KjarniIndexer* indexer);                       /* :669-675 */
 
+/* ---- by-value twins of the frees ------------------------------------------------------
+ * The reference's committed cbindgen header and its C# / Python bindings pass these structs BY VALUE
+ * (crates/kjarni-ffi/include/kjarni.h:440-455, 534, 581, 734; bindings/csharp/Kjarni/Native.cs:376-394),
+ * the Rust source by pointer.  The canonical names above follow the Rust source; a binding written
+ * against the header binds these instead and keeps its declarations. */
+void kjarni_float_array_free_by_value(KjarniFloatArray arr);
+void kjarni_float_2d_array_free_by_value(KjarniFloat2DArray arr);
+void kjarni_string_array_free_by_value(KjarniStringArray arr);
+void kjarni_class_results_free_by_value(KjarniClassResults results);
+void kjarni_rerank_results_free_by_value(KjarniRerankResults results);
+void kjarni_search_results_free_by_value(KjarniSearchResults results);
+
 #ifdef __cplusplus
 }
 #endif

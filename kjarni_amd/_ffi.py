@@ -271,6 +271,12 @@ SIGNATURES = {
     "kjarni_indexer_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
     "kjarni_indexer_dimension": (c_size_t, [c_void_p]),
     "kjarni_indexer_chunk_size": (c_size_t, [c_void_p]),
+    "kjarni_float_array_free_by_value": (None, [KjarniFloatArray]),
+    "kjarni_float_2d_array_free_by_value": (None, [KjarniFloat2DArray]),
+    "kjarni_string_array_free_by_value": (None, [KjarniStringArray]),
+    "kjarni_class_results_free_by_value": (None, [KjarniClassResults]),
+    "kjarni_rerank_results_free_by_value": (None, [KjarniRerankResults]),
+    "kjarni_search_results_free_by_value": (None, [KjarniSearchResults]),
     # kjarni_hip.h
     "kjarni_text_split": (c_int32, [c_char_p, c_size_t, c_size_t, c_char_p, POINTER(KjarniStringArray)]),
     "kjarni_collect_files": (c_int32, [POINTER(KjarniIndexerConfig), POINTER(c_char_p), c_size_t,

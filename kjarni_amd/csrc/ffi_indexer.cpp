@@ -644,3 +644,15 @@ KJARNI_EXPORT KjarniErrorCode kjarni_index_write(const char* index_path, size_t 
         w->commit();
     });
 }
+
+// ---- by-value twins of the frees ---------------------------------------------------------------
+// The reference's stale cbindgen header and its C# / Python bindings declare the frees BY VALUE
+// (crates/kjarni-ffi/include/kjarni.h:440-455, bindings/csharp/Kjarni/Native.cs:376-394) while the
+// Rust source takes pointers.  A binding generated from that header can bind these names instead
+// (e.g. DllImport EntryPoint = "kjarni_float_array_free_by_value") and keep its declarations.
+KJARNI_EXPORT void kjarni_float_array_free_by_value(KjarniFloatArray arr) { kjarni_float_array_free(&arr); }
+KJARNI_EXPORT void kjarni_float_2d_array_free_by_value(KjarniFloat2DArray arr) { kjarni_float_2d_array_free(&arr); }
+KJARNI_EXPORT void kjarni_string_array_free_by_value(KjarniStringArray arr) { kjarni_string_array_free(&arr); }
+KJARNI_EXPORT void kjarni_class_results_free_by_value(KjarniClassResults results) { kjarni_class_results_free(&results); }
+KJARNI_EXPORT void kjarni_rerank_results_free_by_value(KjarniRerankResults results) { kjarni_rerank_results_free(&results); }
+KJARNI_EXPORT void kjarni_search_results_free_by_value(KjarniSearchResults results) { kjarni_search_results_free(&results); }

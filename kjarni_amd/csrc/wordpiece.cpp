@@ -1,5 +1,8 @@
 #include "wordpiece.h"
 
+#include <exception>
+#include <thread>
+
 #include <algorithm>
 #include <fstream>
 #include <sstream>
@@ -403,17 +406,48 @@ BatchEncoding BertTokenizer::pad_batch(std::vector<Encoding>& encs)
     return out;
 }
 
+namespace {
+
+// The `tokenizers` crate encodes a batch on its rayon pool; here a batch large enough to matter is
+// split over a few host threads (encode() is const and touches no shared mutable state).
+template <class F>
+void parallel_rows(size_t n, F&& fn)
+{
+    size_t workers = std::thread::hardware_concurrency();
+    if (workers > 16) workers = 16;
+    if (workers > n / 64) workers = n / 64;
+    if (workers < 2) {
+        for (size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> errs(workers);
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back([&, w] {
+            try {
+                for (size_t i = n * w / workers, e = n * (w + 1) / workers; i < e; ++i) fn(i);
+            } catch (...) {
+                errs[w] = std::current_exception();
+            }
+        });
+    for (std::thread& t : pool) t.join();
+    for (const std::exception_ptr& e : errs)
+        if (e) std::rethrow_exception(e);
+}
+
+}  // namespace
+
 BatchEncoding BertTokenizer::encode_batch(const std::vector<std::string>& texts) const
 {
     std::vector<Encoding> encs(texts.size());
-    for (size_t i = 0; i < texts.size(); ++i) encs[i] = encode(texts[i], nullptr);
+    parallel_rows(texts.size(), [&](size_t i) { encs[i] = encode(texts[i], nullptr); });
     return pad_batch(encs);
 }
 
 BatchEncoding BertTokenizer::encode_batch_pairs(const std::vector<std::pair<std::string, std::string>>& pairs) const
 {
     std::vector<Encoding> encs(pairs.size());
-    for (size_t i = 0; i < pairs.size(); ++i) encs[i] = encode(pairs[i].first, &pairs[i].second);
+    parallel_rows(pairs.size(), [&](size_t i) { encs[i] = encode(pairs[i].first, &pairs[i].second); });
     return pad_batch(encs);
 }
 

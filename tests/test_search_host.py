@@ -328,3 +328,18 @@ def test_reference_lifecycle_documents_and_metadata(tmp_path):
     assert [(x["document_id"], x["text"], x["metadata"]) for x in r] == [(2, "Banana is yellow", {})]
     r = search_keywords(root, "fruit", 10)
     assert r[0]["text"] == "Apple is a fruit" and r[0]["metadata"] == {"category": "fruit"}
+
+
+def test_by_value_free_twins():
+    """The stale cbindgen header / C# / Python bindings free by value (Native.cs:376-394); the twins take
+    exactly that calling convention."""
+    L = _ffi.lib()
+    arr = _ffi.KjarniStringArray()
+    assert L.kjarni_bm25_tokenize(b"hello big world", C.byref(arr)) == 0 and arr.len == 3
+    L.kjarni_string_array_free_by_value(arr)
+    res = _ffi.KjarniSearchResults()
+    L.kjarni_search_results_free_by_value(res)                    # empty = {NULL, 0}
+    L.kjarni_float_array_free_by_value(_ffi.KjarniFloatArray())
+    L.kjarni_float_2d_array_free_by_value(_ffi.KjarniFloat2DArray())
+    L.kjarni_class_results_free_by_value(_ffi.KjarniClassResults())
+    L.kjarni_rerank_results_free_by_value(_ffi.KjarniRerankResults())

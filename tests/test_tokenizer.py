@@ -168,3 +168,24 @@ def test_hypothesis_random_text():
         assert got[2].tolist() == [e.type_ids for e in enc]
 
     run()
+
+
+def test_large_batch_is_split_over_threads_and_identical():
+    """Batches of >= 512 rows are tokenised on several host threads (the `tokenizers` crate uses its
+    rayon pool); the result must be what row-at-a-time encoding gives, pairs included."""
+    from tokenizers import Tokenizer as HFTokenizer
+    rng = np.random.default_rng(0)
+    words = ["hello", "world", "unaffable", "Reykjavík", "naïve", "東京", "x", "1234", "!!", "the", "quick"]
+    texts = [" ".join(rng.choice(words, int(rng.integers(0, 30)))) for _ in range(3000)]
+    seconds = [" ".join(rng.choice(words, int(rng.integers(1, 20)))) for _ in range(3000)]
+    tok = Tokenizer(TOK_JSON, 32)
+    hf = HFTokenizer.from_file(TOK_JSON)
+    hf.enable_truncation(max_length=32)
+    hf.enable_padding(pad_id=0, pad_token="[PAD]")
+    ids, mask, types = tok.encode_batch(texts)
+    enc = hf.encode_batch(texts)
+    assert ids.tolist() == [e.ids for e in enc] and mask.tolist() == [e.attention_mask for e in enc]
+    ids, mask, types = tok.encode_batch(texts, seconds)
+    enc = hf.encode_batch(list(zip(texts, seconds)))
+    assert ids.tolist() == [e.ids for e in enc] and types.tolist() == [e.type_ids for e in enc]
+    assert mask.tolist() == [e.attention_mask for e in enc]
