@@ -343,6 +343,95 @@ size_t kjarni_indexer_model_name(const KjarniIndexer* indexer, char* buf, size_t
 size_t kjarni_indexer_dimension(const KjarniIndexer* indexer);                        /* :660-666 */
 size_t kjarni_indexer_chunk_size(const KjarniIndexer* indexer);                       /* :669-675 */
 
+/* ---- streamed tokens: kjarni-ffi/src/callback.rs:36-47 -------------------------------- */
+typedef struct KjarniToken {
+    const char* text; /* valid for the duration of the callback */
+    uint32_t token_id;
+    bool is_special;
+} KjarniToken;
+
+/* Return false to stop the stream.  The struct is passed BY VALUE. */
+typedef bool (*KjarniTokenCallbackFn)(KjarniToken token, void* user_data);
+
+/* ---- Transcriber (Whisper) ---------------------------------------------------------------
+ * NOT part of the reference's kjarni-ffi crate: the reference exposes transcription only through its
+ * Rust API (crates/kjarni/src/transcriber/{builder,model,types,validation}.rs).  This group mirrors that
+ * API in the style of the groups above so the C#/Go/Python front-ends can reach it the same way.
+ * Pipeline per 30-second chunk (crates/kjarni-models/src/models/whisper/transcriber.rs:85-460):
+ * log-mel -> conv stem -> encoder -> greedy decode, all on the GPU; WAV decoding, resampling, chunking,
+ * timestamp parsing and stitching on the host. */
+typedef enum KjarniTranscribeTask {
+    KJARNI_TASK_TRANSCRIBE = 0,
+    KJARNI_TASK_TRANSLATE = 1,
+} KjarniTranscribeTask;
+
+typedef struct KjarniTranscriberConfig {
+    KjarniDevice device;
+    const char* cache_dir;
+    const char* model_name; /* NULL = "whisper-small"; builder.rs:145-159 names plus tiny/base/medium */
+    const char* model_path; /* local directory with config.json, tokenizer.json, model.safetensors */
+    const char* language;   /* NULL = auto (stubbed as English, transcriber.rs:277-279) */
+    KjarniTranscribeTask task;
+    int32_t timestamps;     /* parse timestamp tokens into timed segments */
+    size_t max_tokens_per_chunk; /* default 448; 1..4096 (validation.rs:52-64) */
+    int32_t quiet;
+} KjarniTranscriberConfig;
+
+typedef struct KjarniTranscriptionSegment {
+    float start; /* seconds */
+    float end;
+    char* text;
+} KjarniTranscriptionSegment;
+
+typedef struct KjarniTranscription {       /* types.rs:34-55 */
+    char* text;
+    KjarniTranscriptionSegment* segments;
+    size_t num_segments;
+    char* language;
+    float duration_secs;
+} KjarniTranscription;
+
+typedef enum KjarniTranscriptionStage {    /* types.rs:78-88 */
+    KJARNI_TRANSCRIPTION_LOADING_AUDIO = 0,
+    KJARNI_TRANSCRIPTION_ENCODING = 1,
+    KJARNI_TRANSCRIPTION_DECODING = 2,
+    KJARNI_TRANSCRIPTION_STITCHING = 3,
+} KjarniTranscriptionStage;
+
+typedef struct KjarniTranscriptionProgress {
+    KjarniTranscriptionStage stage;
+    size_t current;
+    size_t total;        /* 0 = unknown */
+    const char* message; /* may be NULL */
+} KjarniTranscriptionProgress;
+
+typedef void (*KjarniTranscriptionProgressFn)(KjarniTranscriptionProgress progress, void* user_data);
+
+typedef struct KjarniTranscriber KjarniTranscriber;
+
+KjarniTranscriberConfig kjarni_transcriber_config_default(void);
+/* Errors: unknown model / bad language / bad max_tokens -> INVALID_CONFIG (builder.rs:118-127); files not on
+ * disk -> MODEL_NOT_FOUND; no GPU -> GPU_UNAVAILABLE; anything else -> LOAD_FAILED. */
+KjarniErrorCode kjarni_transcriber_new(const KjarniTranscriberConfig* config, KjarniTranscriber** out);
+void kjarni_transcriber_free(KjarniTranscriber* transcriber);
+void kjarni_transcription_free(const KjarniTranscription* transcription);
+/* Transcriber::transcribe_audio (model.rs:91-106): mono f32 samples, resampled linearly to 16 kHz when needed. */
+KjarniErrorCode kjarni_transcriber_transcribe_audio(KjarniTranscriber* transcriber, const float* samples, size_t num_samples,
+                                                    uint32_t sample_rate, KjarniTranscription* out);
+/* Transcriber::transcribe_file (model.rs:72-88): WAV (PCM 8/16/24/32, float 32); missing / not a file ->
+ * MODEL_NOT_FOUND, unsupported extension -> INVALID_CONFIG, unreadable audio -> INFERENCE_FAILED. */
+KjarniErrorCode kjarni_transcriber_transcribe_file(KjarniTranscriber* transcriber, const char* path, KjarniTranscription* out);
+/* The same with the progress callback (model.rs:301-318), the per-token stream of stream_audio (model.rs:196-262;
+ * on_token returning false ends the stream, the text so far is still returned) and a cancel token -> CANCELLED. */
+KjarniErrorCode kjarni_transcriber_transcribe_audio_with_callbacks(
+    KjarniTranscriber* transcriber, const float* samples, size_t num_samples, uint32_t sample_rate,
+    KjarniTranscriptionProgressFn progress, void* progress_user_data, KjarniTokenCallbackFn on_token, void* token_user_data,
+    const KjarniCancelToken* cancel_token, KjarniTranscription* out);
+KjarniErrorCode kjarni_transcriber_transcribe_file_with_callbacks(
+    KjarniTranscriber* transcriber, const char* path, KjarniTranscriptionProgressFn progress, void* progress_user_data,
+    KjarniTokenCallbackFn on_token, void* token_user_data, const KjarniCancelToken* cancel_token, KjarniTranscription* out);
+size_t kjarni_transcriber_model_name(const KjarniTranscriber* transcriber, char* buf, size_t buf_len);
+
 /* ---- by-value twins of the frees ------------------------------------------------------
  * The reference's committed cbindgen header and its C# / Python bindings pass these structs BY VALUE
  * (crates/kjarni-ffi/include/kjarni.h:440-455, 534, 581, 734; bindings/csharp/Kjarni/Native.cs:376-394),

@@ -258,6 +258,39 @@ KjarniErrorCode kjarni_index_write(const char* index_path, size_t dimension, siz
                                    const char* embedding_model, const char* const* texts,
                                    const char* const* metadata_json, const float* embeddings, size_t n, int32_t append);
 
+/* ---- Whisper, one stage at a time (parity tests, benchmarks) ----------------------------
+ * model_dir holds config.json (WhisperConfig, crates/kjarni-models/src/models/whisper/config.rs:11-37),
+ * tokenizer.json and model.safetensors with the HF tensor names of config.rs:81-190. */
+typedef struct KjarniHipWhisper KjarniHipWhisper;
+KjarniErrorCode kjarni_hip_whisper_load(const char* model_dir, int32_t device, KjarniHipWhisper** out);
+void kjarni_hip_whisper_free(KjarniHipWhisper* whisper);
+KjarniErrorCode kjarni_hip_whisper_dims(const KjarniHipWhisper* whisper, int32_t* d_model, int32_t* n_mels, int32_t* vocab,
+                                        int32_t* encoder_frames);
+/* compute_mel_spectrogram, MelConfig::whisper() (crates/kjarni-transformers/src/audio/mel.rs:44-136):
+ * mel_out f32 [n_mels, 3000]. */
+KjarniErrorCode kjarni_hip_whisper_log_mel(KjarniHipWhisper* whisper, const float* samples, size_t num_samples, float* mel_out);
+/* WhisperModel::encode_mel (whisper/transcriber.rs:122-141): mel f32 [n_mels, frames] -> hidden_out f32
+ * [frames/2, d_model] (may be NULL: the result stays on the device for the decoder). */
+KjarniErrorCode kjarni_hip_whisper_encode_mel(KjarniHipWhisper* whisper, const float* mel, int32_t frames, float* hidden_out);
+/* log-mel + encode without leaving the device. */
+KjarniErrorCode kjarni_hip_whisper_encode_audio(KjarniHipWhisper* whisper, const float* samples, size_t num_samples,
+                                                float* hidden_out);
+/* Decoder over the current encoder output (cpu_decoder.rs:399-516): begin = cross K/V + empty cache; forward runs
+ * n <= 8 new tokens; hidden_out f32 [n, d_model] (final-normed), logits_out f32 [vocab] of the last row. */
+KjarniErrorCode kjarni_hip_whisper_decode_begin(KjarniHipWhisper* whisper);
+KjarniErrorCode kjarni_hip_whisper_decode_forward(KjarniHipWhisper* whisper, const uint32_t* ids, int32_t n, float* hidden_out,
+                                                  float* logits_out);
+/* decode_chunk's loop (transcriber.rs:144-240): generated ids, *n_out = how many (may exceed capacity). */
+KjarniErrorCode kjarni_hip_whisper_greedy(KjarniHipWhisper* whisper, const uint32_t* prompt, int32_t n_prompt, int32_t timestamps,
+                                          size_t max_tokens, uint32_t* ids_out, size_t capacity, size_t* n_out);
+KjarniErrorCode kjarni_hip_whisper_decode_text(const KjarniHipWhisper* whisper, const uint32_t* ids, size_t n, int32_t skip_special,
+                                               char** out);
+/* Host-only: load_audio with the Transcriber's loader config (audio/loader.rs:125-208: mono, 16 kHz, linear
+ * resampling) and the ByteLevel decode of `tokenizers` (Tokenizer::decode). */
+KjarniErrorCode kjarni_audio_load_wav(const char* path, KjarniFloatArray* out, uint32_t* original_sample_rate);
+KjarniErrorCode kjarni_bytelevel_decode(const char* tokenizer_json_path, const uint32_t* ids, size_t n, int32_t skip_special,
+                                        char** out);
+
 /* ---- device memory helpers for callers without a HIP runtime binding --------- */
 KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev);
 KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev);

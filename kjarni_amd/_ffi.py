@@ -185,6 +185,35 @@ class KjarniIndexerConfig(Structure):
                 ("max_file_size", c_size_t), ("quiet", c_int32)]
 
 
+class KjarniToken(Structure):
+    _fields_ = [("text", c_char_p), ("token_id", C.c_uint32), ("is_special", C.c_bool)]
+
+
+KjarniTokenCallbackFn = C.CFUNCTYPE(C.c_bool, KjarniToken, c_void_p)
+
+
+class KjarniTranscriberConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p), ("model_path", c_char_p),
+                ("language", c_char_p), ("task", c_int32), ("timestamps", c_int32), ("max_tokens_per_chunk", c_size_t),
+                ("quiet", c_int32)]
+
+
+class KjarniTranscriptionSegment(Structure):
+    _fields_ = [("start", c_float), ("end", c_float), ("text", c_char_p)]
+
+
+class KjarniTranscription(Structure):
+    _fields_ = [("text", c_char_p), ("segments", POINTER(KjarniTranscriptionSegment)), ("num_segments", c_size_t),
+                ("language", c_char_p), ("duration_secs", c_float)]
+
+
+class KjarniTranscriptionProgress(Structure):
+    _fields_ = [("stage", c_int32), ("current", c_size_t), ("total", c_size_t), ("message", c_char_p)]
+
+
+KjarniTranscriptionProgressFn = C.CFUNCTYPE(None, KjarniTranscriptionProgress, c_void_p)
+
+
 class KjarniRerankerConfig(Structure):
     _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
                 ("model_path", c_char_p), ("quiet", c_int32)]
@@ -271,6 +300,19 @@ SIGNATURES = {
     "kjarni_indexer_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
     "kjarni_indexer_dimension": (c_size_t, [c_void_p]),
     "kjarni_indexer_chunk_size": (c_size_t, [c_void_p]),
+    "kjarni_transcriber_config_default": (KjarniTranscriberConfig, []),
+    "kjarni_transcriber_new": (c_int32, [POINTER(KjarniTranscriberConfig), POINTER(c_void_p)]),
+    "kjarni_transcriber_free": (None, [c_void_p]),
+    "kjarni_transcription_free": (None, [POINTER(KjarniTranscription)]),
+    "kjarni_transcriber_transcribe_audio": (c_int32, [c_void_p, _f32p, c_size_t, C.c_uint32, POINTER(KjarniTranscription)]),
+    "kjarni_transcriber_transcribe_file": (c_int32, [c_void_p, c_char_p, POINTER(KjarniTranscription)]),
+    "kjarni_transcriber_transcribe_audio_with_callbacks": (c_int32, [
+        c_void_p, _f32p, c_size_t, C.c_uint32, KjarniTranscriptionProgressFn, c_void_p, KjarniTokenCallbackFn, c_void_p,
+        c_void_p, POINTER(KjarniTranscription)]),
+    "kjarni_transcriber_transcribe_file_with_callbacks": (c_int32, [
+        c_void_p, c_char_p, KjarniTranscriptionProgressFn, c_void_p, KjarniTokenCallbackFn, c_void_p, c_void_p,
+        POINTER(KjarniTranscription)]),
+    "kjarni_transcriber_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
     "kjarni_float_array_free_by_value": (None, [KjarniFloatArray]),
     "kjarni_float_2d_array_free_by_value": (None, [KjarniFloat2DArray]),
     "kjarni_string_array_free_by_value": (None, [KjarniStringArray]),
@@ -278,6 +320,18 @@ SIGNATURES = {
     "kjarni_rerank_results_free_by_value": (None, [KjarniRerankResults]),
     "kjarni_search_results_free_by_value": (None, [KjarniSearchResults]),
     # kjarni_hip.h
+    "kjarni_hip_whisper_load": (c_int32, [c_char_p, c_int32, POINTER(c_void_p)]),
+    "kjarni_hip_whisper_free": (None, [c_void_p]),
+    "kjarni_hip_whisper_dims": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "kjarni_hip_whisper_log_mel": (c_int32, [c_void_p, _f32p, c_size_t, _f32p]),
+    "kjarni_hip_whisper_encode_mel": (c_int32, [c_void_p, _f32p, c_int32, _f32p]),
+    "kjarni_hip_whisper_encode_audio": (c_int32, [c_void_p, _f32p, c_size_t, _f32p]),
+    "kjarni_hip_whisper_decode_begin": (c_int32, [c_void_p]),
+    "kjarni_hip_whisper_decode_forward": (c_int32, [c_void_p, _u32p, c_int32, _f32p, _f32p]),
+    "kjarni_hip_whisper_greedy": (c_int32, [c_void_p, _u32p, c_int32, c_int32, c_size_t, _u32p, c_size_t, POINTER(c_size_t)]),
+    "kjarni_hip_whisper_decode_text": (c_int32, [c_void_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
+    "kjarni_audio_load_wav": (c_int32, [c_char_p, POINTER(KjarniFloatArray), POINTER(C.c_uint32)]),
+    "kjarni_bytelevel_decode": (c_int32, [c_char_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
     "kjarni_text_split": (c_int32, [c_char_p, c_size_t, c_size_t, c_char_p, POINTER(KjarniStringArray)]),
     "kjarni_collect_files": (c_int32, [POINTER(KjarniIndexerConfig), POINTER(c_char_p), c_size_t,
                                        POINTER(KjarniStringArray)]),

@@ -1,0 +1,425 @@
+// Kernels of the Whisper path that the BERT-family encoder does not already have: the log-mel front
+// end around two GEMMs (DFT, mel filterbank), im2col for the two strided convolutions, and the
+// single-sequence decoder step (row GEMV with fused epilogues, cached attention, filtered argmax).
+//
+//   log-mel        crates/kjarni-transformers/src/audio/mel.rs:60-262
+//   conv1d         mel.rs:331-371 (as im2col + the projection GEMM)
+//   decoder step   cpu/encoder_decoder/cpu_decoder.rs:457-516, decoder_cross_attn.rs:71-120,
+//                  encoder_decoder/decoder_self_attn.rs:52-146
+//   token choice   crates/kjarni-models/src/models/whisper/transcriber.rs:243-270
+#include "device_utils.h"
+#include "whisper_kernels.h"
+
+namespace kjarni {
+
+namespace {
+
+constexpr float kMaskValue = -1e9f;  // utils/masks.rs MASK_VALUE
+
+// ---- log-mel ------------------------------------------------------------------------------------
+
+// frames[f, i] = padded[f*hop + i] * window[i]  (i < n_fft; columns up to ld are zero), where `padded`
+// is the signal reflect-padded by n_fft/2 on both sides (mel.rs:139-160).  A frame that would run past
+// the padded signal is all zero (the reference's loop breaks there and leaves zeros).
+__global__ __launch_bounds__(256) void mel_frames_kernel(const float* __restrict__ audio, int64_t n,
+                                                         const float* __restrict__ window, int n_fft, int hop,
+                                                         int n_frames, int ld, float* __restrict__ frames)
+{
+    const int f = blockIdx.x;
+    const int pad = n_fft / 2;
+    const int64_t n_padded = n + 2 * (int64_t)pad;
+    const bool live = (int64_t)f * hop + n_fft <= n_padded;
+    for (int i = threadIdx.x; i < ld; i += 256) {
+        float v = 0.0f;
+        if (live && i < n_fft) {
+            const int64_t j = (int64_t)f * hop + i;
+            int64_t src;
+            if (j < pad) {
+                src = pad - j;                       // left reflection: audio[pad], ..., audio[1]
+                if (src >= n) src = n - 1;
+            } else if (j < pad + n) {
+                src = j - pad;
+            } else {
+                const int64_t r = j - pad - n;       // right reflection: audio[n-2], audio[n-3], ...
+                src = (n >= 2 + r) ? n - 2 - r : 0;
+            }
+            v = audio[src] * window[i];
+        }
+        frames[(int64_t)f * ld + i] = v;
+    }
+}
+
+// power[f, k] = |X_k|^2 computed as the reference does: mag = sqrt(re*re + im*im); mag*mag
+// (mel.rs:108-110, 256-258).  re at column k, im at column im_off + k of the DFT GEMM's output.
+__global__ __launch_bounds__(256) void mel_power_kernel(const float* __restrict__ dft, int ld_dft, int im_off,
+                                                        int n_bins, int ld_out, int64_t n_frames,
+                                                        float* __restrict__ power)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_frames * ld_out) return;
+    const int64_t f = idx / ld_out;
+    const int k = (int)(idx % ld_out);
+    float v = 0.0f;
+    if (k < n_bins) {
+        const float re = dft[f * ld_dft + k], im = dft[f * ld_dft + im_off + k];
+        const float mag = sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+        v = __fmul_rn(mag, mag);
+    }
+    power[idx] = v;
+}
+
+__device__ __forceinline__ uint32_t orderable_f32(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_orderable_f32(uint32_t o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+// log10(max(x, 1e-10)) in place over the first n_mels columns + global maximum (whisper_log_mel,
+// mel.rs:124-136).  *max_bits must be zeroed before the launch.
+__global__ __launch_bounds__(256) void mel_log_max_kernel(float* __restrict__ mel, int ld, int n_mels,
+                                                          int64_t n_frames, uint32_t* __restrict__ max_bits)
+{
+    __shared__ float red[4];
+    float mx = -INFINITY;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n_frames * n_mels;
+         idx += (int64_t)gridDim.x * 256) {
+        const int64_t f = idx / n_mels;
+        const int m = (int)(idx % n_mels);
+        const float v = log10f(fmaxf(mel[f * ld + m], 1e-10f));
+        mel[f * ld + m] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(max_bits, orderable_f32(mx));
+    }
+}
+
+// out[f, m] = (max(x, max - 8) + 4) / 4, written time-major with row stride ld_out.
+__global__ __launch_bounds__(256) void mel_normalize_kernel(const float* __restrict__ mel, int ld, int n_mels,
+                                                            int64_t n_frames, const uint32_t* __restrict__ max_bits,
+                                                            int ld_out, float* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_frames * n_mels) return;
+    const int64_t f = idx / n_mels;
+    const int m = (int)(idx % n_mels);
+    const float mx = from_orderable_f32(*max_bits);
+    out[f * ld_out + m] = (fmaxf(mel[f * ld + m], mx - 8.0f) + 4.0f) / 4.0f;
+}
+
+// ---- convolution as im2col ------------------------------------------------------------------------
+
+// cols[t, k*C + c] = x[t*stride + k - pad, c] (zero outside, zero for columns >= 3*C): the GEMM against
+// the weight re-laid as [out, k*C + c] is conv1d(kernel 3) of mel.rs:331-371 on time-major data.
+__global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ x, int64_t ldx, int t_in, int channels,
+                                                      int stride, int pad, int t_out, int ld_cols,
+                                                      float* __restrict__ cols)
+{
+    const int t = blockIdx.x;
+    for (int j = threadIdx.x; j < ld_cols; j += 256) {
+        float v = 0.0f;
+        if (j < 3 * channels) {
+            const int k = j / channels, c = j - k * channels;
+            const int ti = t * stride + k - pad;
+            if (ti >= 0 && ti < t_in) v = x[(int64_t)ti * ldx + c];
+        }
+        cols[(int64_t)t * ld_cols + j] = v;
+    }
+    (void)t_out;
+}
+
+// x[r, :] += table[(r % period) (+ offset), :]   (position rows; rows beyond the table are left alone)
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, int64_t rows, int hidden, int period,
+                                                       const float* __restrict__ table, int table_rows)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * hidden) return;
+    const int64_t r = idx / hidden;
+    const int p = (int)(r % period);
+    if (p < table_rows) x[idx] += table[(int64_t)p * hidden + (idx - r * hidden)];
+}
+
+// ---- decoder step ---------------------------------------------------------------------------------
+
+// h[s, :] = word[ids[s], :] (* sqrt(H) when scaled) + pos[offset + s, :]   (Embeddings::forward as the
+// seq2seq decoder calls it, cpu_decoder.rs:432-439; ids >= vocab leave zeros as in the encoder path)
+__global__ __launch_bounds__(256) void decoder_embed_kernel(const uint32_t* __restrict__ ids, int n, int hidden, int vocab,
+                                                            const float* __restrict__ word, const float* __restrict__ pos,
+                                                            int max_pos, int offset, float scale, float* __restrict__ out)
+{
+    const int s = blockIdx.x;
+    const uint32_t id = ids[s];
+    const int p = offset + s;
+    for (int i = threadIdx.x; i < hidden; i += 256) {
+        float v = 0.0f;
+        if (id < (uint32_t)vocab) v = word[(int64_t)id * hidden + i] * scale;
+        if (pos && p < max_pos) v += pos[(int64_t)p * hidden + i];
+        out[(int64_t)s * hidden + i] = v;
+    }
+    (void)n;
+}
+
+constexpr int GEMV_MAX_ROWS = 8;
+
+// Y[r, n] = epi(X[r, :] . W[n, :] + bias[n]) (+ R[r, n]) for a handful of rows r: one wave per output
+// column, the weight row streamed once with 16-byte loads and reused for every input row.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ X, int64_t ldx, int rows,
+                                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                                        const float* __restrict__ R, int64_t ldr, int n_out, int k,
+                                                        float* __restrict__ Y, int64_t ldy)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_out) return;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + n * (int64_t)k);
+    float acc[GEMV_MAX_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) acc[r] = 0.0f;
+    const int k4 = k >> 2;
+    for (int i = lane; i < k4; i += 64) {
+        const f32x4 w = w4[i];
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+            if (r < rows) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r] = fmaf(x[c], w[c], acc[r]);
+            }
+        }
+    }
+    const float b = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+        if (r < rows) {
+            float v = wave_sum(acc[r]) + b;
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            if (EPI == EPI_BIAS_RESIDUAL) v += R[r * ldr + n];
+            if (lane == 0) Y[r * ldy + n] = v;
+        }
+    }
+}
+
+// One workgroup per (head, query row): scores over the cached keys, the reference's softmax
+// (exp(x - max) * (1/sum)), weighted sum of the cached values.  K rows are ldk floats apart with head h
+// at columns [h*d, h*d + d); same for V.  causal_base >= 0: query row s sees keys <= causal_base + s
+// (apply_causal_mask, utils/masks.rs:103-113: masked scores are OVERWRITTEN with -1e9).
+__global__ __launch_bounds__(256) void decode_attention_kernel(const float* __restrict__ q, int64_t ldq,
+                                                               const float* __restrict__ K, int64_t ldk,
+                                                               const float* __restrict__ V, int64_t ldv, int n_keys,
+                                                               int head_dim, float scale, int causal_base,
+                                                               float* __restrict__ ctx, int64_t ldc)
+{
+    extern __shared__ float smem[];
+    float* qs = smem;                       // [head_dim]
+    float* sc = smem + head_dim;            // [n_keys]
+    float* part = sc + n_keys;              // [256]
+    __shared__ float red[4];
+    const int h = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const int col0 = h * head_dim;
+    for (int i = tid; i < head_dim; i += 256) qs[i] = q[(int64_t)s * ldq + col0 + i];
+    __syncthreads();
+
+    float mx = -INFINITY;
+    for (int t = tid; t < n_keys; t += 256) {
+        const float* kr = K + (int64_t)t * ldk + col0;
+        float dot = 0.0f;
+        for (int i = 0; i < head_dim; i += 4) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot = fmaf(qs[i + c], kv[c], dot);
+        }
+        float v = dot * scale;
+        if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
+        sc[t] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+    for (int t = tid; t < n_keys; t += 256) {
+        const float e = expf(sc[t] - mx);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    const float inv = sum > 0.0f ? 1.0f / sum : 1.0f;
+
+    // context: thread (g, j) sums keys t = g, g + G, ... for output column j
+    const int G = 256 / head_dim;  // head_dim in {32, 64, 128}
+    const int j = tid % head_dim, g = tid / head_dim;
+    float acc = 0.0f;
+    if (g < G)
+        for (int t = g; t < n_keys; t += G) acc = fmaf(sc[t] * inv, V[(int64_t)t * ldv + col0 + j], acc);
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < head_dim) {
+        float v = 0.0f;
+        for (int gg = 0; gg < G; ++gg) v += part[gg * head_dim + tid];
+        ctx[(int64_t)s * ldc + col0 + tid] = v;
+    }
+}
+
+// WhisperModel::pick_token (transcriber.rs:243-270): argmax over the ids that may be produced;
+// Iterator::max_by returns the LAST of equal maxima.
+__global__ __launch_bounds__(1024) void pick_token_kernel(const float* __restrict__ logits, int vocab, int first_special,
+                                                          int eos, int timestamp_begin, int allow_timestamps,
+                                                          int32_t* __restrict__ out)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = -1;
+    for (int i = threadIdx.x; i < vocab; i += 1024) {
+        const bool ok = i < first_special || i == eos || (allow_timestamps && i >= timestamp_begin);
+        if (!ok) continue;
+        const float v = logits[i];
+        if (idx < 0 || v >= best) {  // i ascends per thread: >= keeps the last maximum
+            best = v;
+            idx = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, kWave);
+        const int oi = __shfl_xor(idx, off, kWave);
+        if (oi >= 0 && (idx < 0 || ov > best || (ov == best && oi > idx))) {
+            best = ov;
+            idx = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        bv[threadIdx.x >> 6] = best;
+        bi[threadIdx.x >> 6] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bi[w] >= 0 && (idx < 0 || bv[w] > best || (bv[w] == best && bi[w] > idx))) {
+                best = bv[w];
+                idx = bi[w];
+            }
+        *out = idx >= 0 ? idx : eos;
+    }
+}
+
+}  // namespace
+
+// ---- launchers --------------------------------------------------------------------------------------
+
+hipError_t launch_mel_frames(const float* audio, int64_t n_samples, const float* window, int n_fft, int hop,
+                             int n_frames, int ld, float* frames, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mel_frames_kernel, dim3((unsigned)n_frames), dim3(256), 0, stream, audio, n_samples, window,
+                       n_fft, hop, n_frames, ld, frames);
+    return hipGetLastError();
+}
+
+hipError_t launch_mel_power(const float* dft, int ld_dft, int im_off, int n_bins, int ld_out, int64_t n_frames,
+                            float* power, hipStream_t stream)
+{
+    const int64_t total = n_frames * ld_out;
+    hipLaunchKernelGGL(mel_power_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dft, ld_dft,
+                       im_off, n_bins, ld_out, n_frames, power);
+    return hipGetLastError();
+}
+
+hipError_t launch_mel_log_normalize(float* mel, int ld, int n_mels, int64_t n_frames, uint32_t* max_scratch,
+                                    int ld_out, float* out, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(max_scratch, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int64_t total = n_frames * n_mels;
+    int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(mel_log_max_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, mel, ld,
+                       n_mels, n_frames, max_scratch);
+    hipLaunchKernelGGL(mel_normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, mel, ld, n_mels, n_frames,
+                       max_scratch, ld_out, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col3(const float* x, int64_t ldx, int t_in, int channels, int stride, int pad, int t_out,
+                          int ld_cols, float* cols, hipStream_t stream)
+{
+    hipLaunchKernelGGL(im2col3_kernel, dim3((unsigned)t_out), dim3(256), 0, stream, x, ldx, t_in, channels, stride, pad,
+                       t_out, ld_cols, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_rows(float* x, int64_t rows, int hidden, int period, const float* table, int table_rows,
+                           hipStream_t stream)
+{
+    const int64_t total = rows * hidden;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, rows, hidden,
+                       period, table, table_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int vocab, const float* word, const float* pos,
+                                int max_pos, int offset, int scale_embeddings, float* out, hipStream_t stream)
+{
+    const float scale = scale_embeddings ? sqrtf((float)hidden) : 1.0f;
+    hipLaunchKernelGGL(decoder_embed_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, n, hidden, vocab, word, pos,
+                       max_pos, offset, scale, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_rows(const float* X, int64_t ldx, int rows, const float* W, const float* bias, const float* R,
+                            int64_t ldr, int n_out, int k, float* Y, int64_t ldy, GemmEpilogue epi, hipStream_t stream)
+{
+    if (rows <= 0 || n_out <= 0) return hipSuccess;
+    if (rows > GEMV_MAX_ROWS || (k & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15) ||
+        (reinterpret_cast<uintptr_t>(W) & 15))
+        return launch_gemm(X, ldx, W, bias, R, ldr, Y, ldy, rows, n_out, k, epi, stream);
+    const dim3 grid((unsigned)((n_out + 3) / 4));
+    switch (epi) {
+    case EPI_BIAS:
+        hipLaunchKernelGGL(gemv_rows_kernel<EPI_BIAS>, grid, dim3(256), 0, stream, X, ldx, rows, W, bias, R, ldr, n_out, k, Y, ldy);
+        break;
+    case EPI_BIAS_GELU:
+        hipLaunchKernelGGL(gemv_rows_kernel<EPI_BIAS_GELU>, grid, dim3(256), 0, stream, X, ldx, rows, W, bias, R, ldr, n_out, k, Y, ldy);
+        break;
+    case EPI_BIAS_RESIDUAL:
+        hipLaunchKernelGGL(gemv_rows_kernel<EPI_BIAS_RESIDUAL>, grid, dim3(256), 0, stream, X, ldx, rows, W, bias, R, ldr, n_out, k, Y, ldy);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
+                                   int64_t ldv, int n_keys, int heads, int head_dim, int causal_base, float* ctx,
+                                   int64_t ldc, hipStream_t stream)
+{
+    if (rows <= 0 || n_keys <= 0) return hipSuccess;
+    if (head_dim > 256 || 256 % head_dim != 0 || (head_dim & 3)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(head_dim + n_keys + 256) * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attention_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(256), lds, stream, q, ldq, K,
+                       ldk, V, ldv, n_keys, head_dim, 1.0f / sqrtf((float)head_dim), causal_base, ctx, ldc);
+    return hipGetLastError();
+}
+
+hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
+                             int allow_timestamps, int32_t* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pick_token_kernel, dim3(1), dim3(1024), 0, stream, logits, vocab, first_special, eos,
+                       timestamp_begin, allow_timestamps, out);
+    return hipGetLastError();
+}
+
+}  // namespace kjarni

@@ -178,3 +178,142 @@ def add_tokenizer(model_dir: str) -> str:
     dst = os.path.join(model_dir, "tokenizer.json")
     shutil.copyfile(GOLDEN_TOKENIZER, dst)
     return dst
+
+
+# ----------------------------------------------------------------------------- Whisper
+WHISPER_BASE = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8,
+                    encoder_ffn_dim=2048, decoder_ffn_dim=2048, vocab_size=51865, max_source_positions=1500,
+                    max_target_positions=448, num_mel_bins=80)
+WHISPER_TEST = dict(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4, decoder_attention_heads=4,
+                    encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=51865, max_source_positions=1500,
+                    max_target_positions=448, num_mel_bins=80)
+
+
+def bytes_to_unicode() -> Dict[int, str]:
+    """GPT-2 byte-level alphabet (`tokenizers` ByteLevel)."""
+    bs = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return {b: chr(c) for b, c in zip(bs, cs)}
+
+
+def whisper_tokenizer_json(path: str, vocab_size: int = 51865) -> str:
+    """A byte-level BPE tokenizer.json with Whisper's id layout: ids < 50257 ordinary tokens (the 256 byte
+    symbols first, then generated byte strings, some of them not valid UTF-8 on their own), 50257.. special
+    tokens (<|endoftext|>, <|startoftranscript|>, languages, tasks, <|notimestamps|>, <|0.00|> ...)."""
+    b2u = bytes_to_unicode()
+    vocab = {}
+    for b in range(256):
+        vocab[b2u[b]] = b
+    rng = np.random.default_rng(7)
+    words = [b" the", b" quick", b" brown", b" fox", b"ing", b"ed", b" Reykjav", b"\xc3\xadk", b" \xe6\x9d\xb1", b"\xe4\xba\xac",
+             b" caf", b"\xc3", b"\xa9", b"!", b" world", b" hello", b".", b",", b" \xf0\x9f", b"\x99\x82"]
+    i = 256
+    for w in words:
+        tok = "".join(b2u[x] for x in w)
+        if tok not in vocab:
+            vocab[tok] = i
+            i += 1
+    while i < 50257:
+        n = int(rng.integers(2, 6))
+        raw = bytes(rng.integers(97, 123, n).tolist())
+        if rng.random() < 0.5:
+            raw = b" " + raw
+        tok = "".join(b2u[x] for x in raw)
+        if tok in vocab:
+            continue
+        vocab[tok] = i
+        i += 1
+    names = {50257: "<|endoftext|>", 50258: "<|startoftranscript|>", 50259: "<|en|>", 50260: "<|zh|>", 50261: "<|de|>",
+             50262: "<|is|>", 50359: "<|transcribe|>", 50360: "<|translate|>", 50363: "<|notimestamps|>"}
+    added = []
+    for tid in range(50257, vocab_size):
+        if tid >= 50364:
+            content = f"<|{(tid - 50364) * 0.02:.2f}|>"
+        else:
+            content = names.get(tid, f"<|special_{tid}|>")
+        added.append(dict(id=tid, content=content, single_word=False, lstrip=False, rstrip=False, normalized=False,
+                          special=True))
+    spec = {"version": "1.0", "truncation": None, "padding": None, "added_tokens": added, "normalizer": None,
+            "pre_tokenizer": {"type": "ByteLevel", "add_prefix_space": False, "trim_offsets": True, "use_regex": True},
+            "post_processor": None,
+            "decoder": {"type": "ByteLevel", "add_prefix_space": True, "trim_offsets": True, "use_regex": True},
+            "model": {"type": "BPE", "dropout": None, "unk_token": None, "continuing_subword_prefix": None,
+                      "end_of_word_suffix": None, "fuse_unk": False, "byte_fallback": False, "ignore_merges": False,
+                      "vocab": vocab, "merges": []}}
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(spec, f, ensure_ascii=False)
+    return path
+
+
+def whisper_tensors(cfg: dict, seed: int = 0, std: float = 0.05) -> Dict[str, np.ndarray]:
+    """Random-init tensors with the HF names of crates/kjarni-models/src/models/whisper/config.rs:81-190
+    (k_proj has no bias, as in the released checkpoints)."""
+    rng = np.random.default_rng(seed)
+    H, C = cfg["d_model"], cfg["num_mel_bins"]
+
+    def w(*shape, s=std):
+        return (rng.standard_normal(shape) * s).astype(np.float32)
+
+    def ln(pre, t):
+        t[f"{pre}.weight"] = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+        t[f"{pre}.bias"] = w(H, s=0.02)
+
+    def attn(pre, t):
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            t[f"{pre}.{n}.weight"] = w(H, H)
+            if n != "k_proj":
+                t[f"{pre}.{n}.bias"] = w(H, s=0.02)
+
+    t: Dict[str, np.ndarray] = {}
+    t["model.encoder.conv1.weight"], t["model.encoder.conv1.bias"] = w(H, C, 3, s=0.1), w(H, s=0.02)
+    t["model.encoder.conv2.weight"], t["model.encoder.conv2.bias"] = w(H, H, 3), w(H, s=0.02)
+    t["model.encoder.embed_positions.weight"] = w(cfg["max_source_positions"], H, s=0.1)
+    for i in range(cfg["encoder_layers"]):
+        pre = f"model.encoder.layers.{i}"
+        attn(f"{pre}.self_attn", t)
+        ln(f"{pre}.self_attn_layer_norm", t)
+        t[f"{pre}.fc1.weight"], t[f"{pre}.fc1.bias"] = w(cfg["encoder_ffn_dim"], H), w(cfg["encoder_ffn_dim"], s=0.02)
+        t[f"{pre}.fc2.weight"], t[f"{pre}.fc2.bias"] = w(H, cfg["encoder_ffn_dim"]), w(H, s=0.02)
+        ln(f"{pre}.final_layer_norm", t)
+    ln("model.encoder.layer_norm", t)
+    t["model.decoder.embed_tokens.weight"] = w(cfg["vocab_size"], H, s=0.1)
+    t["model.decoder.embed_positions.weight"] = w(cfg["max_target_positions"], H, s=0.1)
+    for i in range(cfg["decoder_layers"]):
+        pre = f"model.decoder.layers.{i}"
+        attn(f"{pre}.self_attn", t)
+        ln(f"{pre}.self_attn_layer_norm", t)
+        attn(f"{pre}.encoder_attn", t)
+        ln(f"{pre}.encoder_attn_layer_norm", t)
+        t[f"{pre}.fc1.weight"], t[f"{pre}.fc1.bias"] = w(cfg["decoder_ffn_dim"], H), w(cfg["decoder_ffn_dim"], s=0.02)
+        t[f"{pre}.fc2.weight"], t[f"{pre}.fc2.bias"] = w(H, cfg["decoder_ffn_dim"]), w(H, s=0.02)
+        ln(f"{pre}.final_layer_norm", t)
+    ln("model.decoder.layer_norm", t)
+    return t
+
+
+def whisper_model(path: str, seed: int = 0, base: bool = False, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+    cfg = dict(WHISPER_BASE if base else WHISPER_TEST, model_type="whisper", activation_function="gelu",
+               decoder_start_token_id=50258, eos_token_id=50257, bos_token_id=50257, pad_token_id=50256,
+               scale_embedding=False, architectures=["WhisperForConditionalGeneration"])
+    cfg.update(over)
+    t = whisper_tensors(cfg, seed)
+    write_model_dir(path, cfg, t)
+    whisper_tokenizer_json(os.path.join(path, "tokenizer.json"), cfg["vocab_size"])
+    return cfg, t
+
+
+def synthetic_audio(seconds: float, seed: int = 0, rate: int = 16000) -> np.ndarray:
+    """Tones + a chirp + broadband noise: no frequency bin is empty, so log-mel comparisons are well conditioned."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * rate)
+    t = np.arange(n) / rate
+    x = 0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 1330 * t + 0.5) + \
+        0.15 * np.sin(2 * np.pi * (300 + 900 * t / max(seconds, 1e-3)) * t) + 0.05 * rng.standard_normal(n)
+    env = 0.6 + 0.4 * np.sin(2 * np.pi * 0.7 * t)
+    return (x * env).astype(np.float32)
