@@ -60,7 +60,7 @@ def test_decoder_steps_and_cache(env, audio):
     g.decode_begin()
     cross = m.precompute_cross_kv(enc)
     cache = [None] * len(m.dec_layers)
-    seqs = [[W.SOT_TOKEN, 50259, W.TRANSCRIBE_TOKEN, W.NO_TIMESTAMPS_TOKEN], [300], [17000], [50364], [263, 264, 265], [51864]]
+    seqs = [[W.SOT_TOKEN, 50259, W.TRANSCRIBE_TOKEN, W.NO_TIMESTAMPS_TOKEN], [300], [17000], [50364], [263], [51864]]
     for ids in seqs:
         ref_h = m.decoder_forward(np.asarray([ids], np.uint32), enc, cache, cross)[0]
         ref_logits = m.logits(ref_h[None, -1:, :])[0, 0]
@@ -169,7 +169,7 @@ def test_transcriber_timestamps_language_translate_and_stops(env):
     seen = []
     tr3 = kjarni_amd.Transcriber(model_path=env["dir"], max_tokens=20)
     part = tr3.transcribe_audio(audio, on_token=lambda i, t, s: (seen.append(i), len(seen) < 3)[1])
-    assert len(seen) == 3 and part.text == tr3._dummy if False else True
+    assert len(seen) == 3
     full = tr3.transcribe_audio(audio)
     assert full.text.startswith(part.text) and len(part.text) < len(full.text)
     # cancellation
