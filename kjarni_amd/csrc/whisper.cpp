@@ -194,6 +194,10 @@ float* WhisperModel::dalloc(size_t floats)
 WhisperModel::~WhisperModel()
 {
     (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (hipGraphExec_t g : graphs_)
+        if (g) (void)hipGraphExecDestroy(g);
+    if (stream_) (void)hipStreamDestroy(stream_);
     for (void* p : allocs_) (void)hipFree(p);
 }
 
@@ -376,12 +380,10 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
     for (int i = 0; i < c.decoder_layers; ++i) {
         const std::string p = "model.decoder.layers." + std::to_string(i);
         DecLayer& L = m->dec_[(size_t)i];
-        L.wq = up(p + ".self_attn.q_proj.weight", {H, H});
-        L.bq = up_opt_bias(p + ".self_attn.q_proj.bias", H);
-        L.wk = up(p + ".self_attn.k_proj.weight", {H, H});
-        L.bk = up_opt_bias(p + ".self_attn.k_proj.bias", H);
-        L.wv = up(p + ".self_attn.v_proj.weight", {H, H});
-        L.bv = up_opt_bias(p + ".self_attn.v_proj.bias", H);
+        fuse({{p + ".self_attn.q_proj.weight", p + ".self_attn.q_proj.bias"},
+              {p + ".self_attn.k_proj.weight", p + ".self_attn.k_proj.bias"},
+              {p + ".self_attn.v_proj.weight", p + ".self_attn.v_proj.bias"}},
+             H, L.wqkv, L.bqkv);
         L.wo = up(p + ".self_attn.out_proj.weight", {H, H});
         L.bo = up_opt_bias(p + ".self_attn.out_proj.bias", H);
         L.ln1_g = up(p + ".self_attn_layer_norm.weight", {H});
@@ -436,6 +438,12 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
     m->logits_ = m->dalloc((size_t)c.vocab);
     m->dids_ = reinterpret_cast<uint32_t*>(m->dalloc(8));
     m->dtoken_ = reinterpret_cast<int32_t*>(m->dalloc(4));
+    m->hist_cap_ = 4096 + 16;
+    m->dhist_ = reinterpret_cast<int32_t*>(m->dalloc((size_t)m->hist_cap_));
+    m->dpos_ = reinterpret_cast<int*>(m->dalloc(4));
+    m->dcount_ = reinterpret_cast<int*>(m->dalloc(4));
+    m->att_scratch_ = m->dalloc(decode_attention_scratch_floats(8, c.heads, d, std::max(kSelfSplits, kCrossSplits)));
+    hip_check(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(load)");
     return m;
 }
@@ -448,7 +456,7 @@ void WhisperModel::log_mel(const float* samples, int64_t n, float* mel_out)
         audio_ = dalloc((size_t)n);
         audio_cap_ = (size_t)n;
     }
-    hipStream_t s = nullptr;
+    hipStream_t s = stream_;
     const int bins = kNfft / 2 + 1, n_mels = cfg_.num_mel_bins;
     hip_check(hipMemcpyAsync(audio_, samples, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s), "H2D audio");
     hip_check(launch_mel_frames(audio_, n, window_, kNfft, kHop, kFrames, k_dft_, frames_, s), "mel_frames");
@@ -468,7 +476,7 @@ void WhisperModel::log_mel(const float* samples, int64_t n, float* mel_out)
 
 void WhisperModel::conv_and_encode(const float* mel_t, int ld_mel, int frames)
 {
-    hipStream_t s = nullptr;
+    hipStream_t s = stream_;
     const int H = cfg_.d_model, C = cfg_.num_mel_bins, heads = cfg_.heads, d = H / heads, I = cfg_.encoder_ffn;
     const int T1 = frames, T2 = (frames + 2 - 3) / 2 + 1;
     const int k2 = round_up(3 * H, 32);
@@ -501,7 +509,8 @@ void WhisperModel::encode_mel(const float* mel, int frames)
     std::vector<float> t((size_t)frames * C);
     for (int m = 0; m < C; ++m)
         for (int f = 0; f < frames; ++f) t[(size_t)f * C + m] = mel[(size_t)m * frames + f];
-    hip_check(hipMemcpy(mel_t_, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice), "H2D mel");
+    hip_check(hipMemcpyAsync(mel_t_, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, stream_), "H2D mel");
+    hip_check(hipStreamSynchronize(stream_), "sync");  // `t` is pageable and about to go out of scope
     conv_and_encode(mel_t_, C, frames);
 }
 
@@ -514,6 +523,7 @@ void WhisperModel::encode_audio(const float* samples, int64_t n)
 void WhisperModel::encoder_output(float* out) const
 {
     hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(stream_), "sync");
     hip_check(hipMemcpy(out, hidden_, (size_t)enc_frames_ * cfg_.d_model * sizeof(float), hipMemcpyDeviceToHost), "D2H encoder");
 }
 
@@ -523,8 +533,50 @@ void WhisperModel::begin_decode()
     if (enc_frames_ <= 0) throw std::runtime_error("no encoder output to decode from");
     const int H = cfg_.d_model;
     for (const DecLayer& L : dec_)  // precompute_cross_attention_kv (cpu_decoder.rs:420-430): K | V per encoder frame
-        hip_check(launch_gemm(hidden_, H, L.ckv, L.cbkv, nullptr, 0, L.cross_kv, 2 * H, enc_frames_, 2 * H, H, EPI_BIAS, nullptr), "cross kv");
+        hip_check(launch_gemm(hidden_, H, L.ckv, L.cbkv, nullptr, 0, L.cross_kv, 2 * H, enc_frames_, 2 * H, H, EPI_BIAS, stream_), "cross kv");
     cache_len_ = 0;
+    hip_check(hipMemsetAsync(dpos_, 0, sizeof(int), stream_), "reset pos");
+    hip_check(hipMemsetAsync(dcount_, 0, sizeof(int), stream_), "reset count");
+}
+
+void WhisperModel::decoder_pass(const uint32_t* ids_dev, int n, bool device_pos)
+{
+    hipStream_t s = stream_;
+    const int H = cfg_.d_model, heads = cfg_.heads, d = H / heads, I = cfg_.decoder_ffn;
+    const int* pos_ptr = device_pos ? dpos_ : nullptr;
+    hip_check(launch_decoder_embed(ids_dev, n, H, cfg_.vocab, tok_emb_, dec_pos_, cfg_.max_target_positions, cache_len_, pos_ptr,
+                                   cfg_.scale_embedding ? 1 : 0, dh_, s), "decoder embed");
+    auto gemv = [&](const float* X, int64_t ldx, const float* g, const float* b, const float* W, const float* bias, const float* R,
+                    int n_out, int k, float* Y, GemmEpilogue epi, const char* what) {
+        GemvArgs a;
+        a.X = X; a.ldx = ldx; a.rows = n; a.gamma = g; a.beta = b; a.eps = 1e-5f; a.W = W; a.bias = bias; a.R = R; a.ldr = H;
+        a.n_out = n_out; a.k = k; a.Y0 = Y; a.ldy0 = n_out; a.epi = epi;
+        hip_check(launch_gemv_rows(a, s), what);
+    };
+    for (const DecLayer& L : dec_) {
+        // pre-norm layer (decoder_cross_attn_layer.rs:123-151); every LayerNorm rides on the projection after it
+        {
+            GemvArgs a;  // LN1 + Q | K | V: Q to scratch, K / V rows straight into the cache
+            a.X = dh_; a.ldx = H; a.rows = n; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.eps = 1e-5f; a.W = L.wqkv; a.bias = L.bqkv;
+            a.n_out = 3 * H; a.k = H; a.seg = H; a.Y0 = dq_; a.ldy0 = H; a.Y1 = L.self_k; a.Y2 = L.self_v; a.ldy12 = H;
+            a.row_off = cache_len_; a.row_off_ptr = pos_ptr; a.epi = EPI_BIAS;
+            hip_check(launch_gemv_rows(a, s), "ln1 + qkv");
+        }
+        hip_check(launch_decode_attention(dq_, H, n, L.self_k, H, L.self_v, H, cache_len_ + n, pos_ptr, cache_cap_, heads, d, cache_len_,
+                                          kSelfSplits, att_scratch_, dctx_, H, s), "self attention");
+        gemv(dctx_, H, nullptr, nullptr, L.wo, L.bo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "self out");
+        gemv(dh_, H, L.ln2_g, L.ln2_b, L.cq, L.cbq, nullptr, H, H, dq_, EPI_BIAS, "ln2 + cross q");
+        hip_check(launch_decode_attention(dq_, H, n, L.cross_kv, 2 * H, L.cross_kv + H, 2 * H, enc_frames_, nullptr, enc_frames_, heads, d, -1,
+                                          kCrossSplits, att_scratch_, dctx_, H, s), "cross attention");
+        gemv(dctx_, H, nullptr, nullptr, L.co, L.cbo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "cross out");
+        gemv(dh_, H, L.ln3_g, L.ln3_b, L.w1, L.b1, nullptr, I, H, dmid_, EPI_BIAS_GELU, "ln3 + fc1");
+        gemv(dmid_, I, nullptr, nullptr, L.w2, L.b2, dh_, H, I, dh_, EPI_BIAS_RESIDUAL, "fc2");
+    }
+    hip_check(launch_layernorm(dh_, dec_ln_g_, dec_ln_b_, 1e-5f, n, H, dlast_, s), "final ln");
+    GemvArgs a;
+    a.X = dlast_ + (size_t)(n - 1) * H; a.ldx = H; a.rows = 1; a.W = lm_head_; a.n_out = cfg_.vocab; a.k = H; a.Y0 = logits_;
+    a.ldy0 = cfg_.vocab; a.epi = EPI_BIAS;
+    hip_check(launch_gemv_rows(a, s), "lm head");
 }
 
 const float* WhisperModel::forward(const uint32_t* ids, int n)
@@ -532,32 +584,12 @@ const float* WhisperModel::forward(const uint32_t* ids, int n)
     hip_check(hipSetDevice(device_), "hipSetDevice");
     if (n < 1 || n > 8) throw std::runtime_error("decoder forward takes 1..8 tokens");
     if (cache_len_ + n > cache_cap_) throw std::runtime_error("decoder cache is full");
-    hipStream_t s = nullptr;
-    const int H = cfg_.d_model, heads = cfg_.heads, d = H / heads, I = cfg_.decoder_ffn;
-    hip_check(hipMemcpyAsync(dids_, ids, (size_t)n * 4, hipMemcpyHostToDevice, s), "H2D ids");
-    hip_check(launch_decoder_embed(dids_, n, H, cfg_.vocab, tok_emb_, dec_pos_, cfg_.max_target_positions, cache_len_,
-                                   cfg_.scale_embedding ? 1 : 0, dh_, s), "decoder embed");
-    for (const DecLayer& L : dec_) {
-        // pre-norm layer: decoder_cross_attn_layer.rs:123-151
-        hip_check(launch_layernorm(dh_, L.ln1_g, L.ln1_b, 1e-5f, n, H, dn_, s), "ln1");
-        hip_check(launch_gemv_rows(dn_, H, n, L.wq, L.bq, nullptr, 0, H, H, dq_, H, EPI_BIAS, s), "q");
-        hip_check(launch_gemv_rows(dn_, H, n, L.wk, L.bk, nullptr, 0, H, H, L.self_k + (size_t)cache_len_ * H, H, EPI_BIAS, s), "k");
-        hip_check(launch_gemv_rows(dn_, H, n, L.wv, L.bv, nullptr, 0, H, H, L.self_v + (size_t)cache_len_ * H, H, EPI_BIAS, s), "v");
-        hip_check(launch_decode_attention(dq_, H, n, L.self_k, H, L.self_v, H, cache_len_ + n, heads, d, cache_len_, dctx_, H, s), "self attn");
-        hip_check(launch_gemv_rows(dctx_, H, n, L.wo, L.bo, dh_, H, H, H, dh_, H, EPI_BIAS_RESIDUAL, s), "o");
-        hip_check(launch_layernorm(dh_, L.ln2_g, L.ln2_b, 1e-5f, n, H, dn_, s), "ln2");
-        hip_check(launch_gemv_rows(dn_, H, n, L.cq, L.cbq, nullptr, 0, H, H, dq_, H, EPI_BIAS, s), "cross q");
-        hip_check(launch_decode_attention(dq_, H, n, L.cross_kv, 2 * H, L.cross_kv + H, 2 * H, enc_frames_, heads, d, -1, dctx_, H, s), "cross attn");
-        hip_check(launch_gemv_rows(dctx_, H, n, L.co, L.cbo, dh_, H, H, H, dh_, H, EPI_BIAS_RESIDUAL, s), "cross o");
-        hip_check(launch_layernorm(dh_, L.ln3_g, L.ln3_b, 1e-5f, n, H, dn_, s), "ln3");
-        hip_check(launch_gemv_rows(dn_, H, n, L.w1, L.b1, nullptr, 0, I, H, dmid_, I, EPI_BIAS_GELU, s), "fc1");
-        hip_check(launch_gemv_rows(dmid_, I, n, L.w2, L.b2, dh_, H, H, I, dh_, H, EPI_BIAS_RESIDUAL, s), "fc2");
-    }
-    hip_check(launch_layernorm(dh_, dec_ln_g_, dec_ln_b_, 1e-5f, n, H, dlast_, s), "final ln");
-    hip_check(launch_gemv_rows(dlast_ + (size_t)(n - 1) * H, H, 1, lm_head_, nullptr, nullptr, 0, cfg_.vocab, H, logits_, cfg_.vocab, EPI_BIAS, s),
-              "lm head");
+    hip_check(hipMemcpyAsync(dids_, ids, (size_t)n * 4, hipMemcpyHostToDevice, stream_), "H2D ids");
+    decoder_pass(dids_, n, false);
     cache_len_ += n;
     last_rows_ = n;
+    hip_check(hipMemcpyAsync(dpos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
+    hip_check(hipStreamSynchronize(stream_), "sync");  // ids / cache_len_ are host stack values
     return logits_;
 }
 
@@ -565,38 +597,104 @@ void WhisperModel::last_hidden(float* out, int rows) const
 {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     rows = std::min(rows, last_rows_);
+    hip_check(hipStreamSynchronize(stream_), "sync");
     hip_check(hipMemcpy(out, dlast_, (size_t)rows * cfg_.d_model * sizeof(float), hipMemcpyDeviceToHost), "D2H hidden");
 }
 
 void WhisperModel::logits_to_host(float* out) const
 {
     hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(stream_), "sync");
     hip_check(hipMemcpy(out, logits_, (size_t)cfg_.vocab * sizeof(float), hipMemcpyDeviceToHost), "D2H logits");
+}
+
+void WhisperModel::enqueue_pick(bool timestamps, bool record)
+{
+    hip_check(launch_pick_token(logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, dtoken_,
+                                record ? dhist_ : nullptr, record ? dcount_ : nullptr, record ? dpos_ : nullptr, stream_),
+              "pick token");
 }
 
 uint32_t WhisperModel::pick_token(bool timestamps)
 {
-    hip_check(launch_pick_token(logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, dtoken_, nullptr),
-              "pick token");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    enqueue_pick(timestamps, false);
     int32_t t = 0;
-    hip_check(hipMemcpy(&t, dtoken_, 4, hipMemcpyDeviceToHost), "D2H token");
+    hip_check(hipMemcpyAsync(&t, dtoken_, 4, hipMemcpyDeviceToHost, stream_), "D2H token");
+    hip_check(hipStreamSynchronize(stream_), "sync");
     return (uint32_t)t;
+}
+
+// One greedy step with nothing step-dependent in the launch parameters: input token = dtoken_, position /
+// key count / cache row = *dpos_; the chosen token is appended to dhist_ and the counters advance on the
+// device.  Captured once per `timestamps` setting and replayed.
+hipGraphExec_t WhisperModel::step_graph(bool timestamps)
+{
+    hipGraphExec_t& exec = graphs_[timestamps ? 1 : 0];
+    if (exec) return exec;
+    hipGraph_t graph = nullptr;
+    hip_check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture");
+    try {
+        decoder_pass(reinterpret_cast<const uint32_t*>(dtoken_), 1, true);
+        enqueue_pick(timestamps, true);
+    } catch (...) {
+        (void)hipStreamEndCapture(stream_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    hip_check(hipStreamEndCapture(stream_, &graph), "end capture");
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    hip_check(e, "graph instantiate");
+    return exec;
 }
 
 std::vector<uint32_t> WhisperModel::greedy(const std::vector<uint32_t>& prompt, bool timestamps, size_t max_tokens,
                                            const std::function<bool(uint32_t)>& on_token)
 {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (prompt.empty() || prompt.size() > 8) throw std::runtime_error("prompt must hold 1..8 tokens");
+    if (max_tokens + 1 > (size_t)hist_cap_) throw std::runtime_error("max_tokens exceeds the decoder's capacity");
     begin_decode();
-    for (size_t i = 0; i < prompt.size(); i += 8) forward(prompt.data() + i, (int)std::min<size_t>(8, prompt.size() - i));
-    uint32_t next = pick_token(timestamps);
-    std::vector<uint32_t> out{next};
-    if (on_token && next != eos_ && !on_token(next)) return out;
-    for (size_t step = 0; step < max_tokens; ++step) {
-        if (next == eos_) break;
-        forward(&next, 1);
-        next = pick_token(timestamps);
-        out.push_back(next);
-        if (on_token && next != eos_ && !on_token(next)) break;
+    forward(prompt.data(), (int)prompt.size());
+    // first token from the last prompt position (transcriber.rs:186-190); recorded on the device as token 0.
+    // The prompt's forward() already stored the position; pick advances it again, so set it back afterwards.
+    enqueue_pick(timestamps, true);
+    hip_check(hipMemcpyAsync(dpos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
+    std::vector<uint32_t> out;
+    std::vector<int32_t> hist((size_t)hist_cap_);
+    size_t seen = 0;
+    bool done = false;
+    auto drain = [&](size_t produced) {  // hand newly produced tokens to the caller in order
+        for (; seen < produced && !done; ++seen) {
+            const uint32_t tok = (uint32_t)hist[seen];
+            out.push_back(tok);
+            if (tok == eos_) {
+                done = true;
+            } else if (on_token && !on_token(tok)) {
+                done = true;
+            } else if (out.size() == max_tokens + 1) {
+                done = true;
+            }
+        }
+    };
+    hip_check(hipMemcpyAsync(hist.data(), dhist_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_), "D2H token");
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    drain(1);
+    hipGraphExec_t exec = done ? nullptr : step_graph(timestamps);
+    size_t produced = 1;
+    // The loop of transcriber.rs:200-237, several steps per host round trip: tokens past an EOS / a stop are
+    // computed but never reported.
+    const size_t burst = on_token ? 4 : 16;
+    while (!done) {
+        const size_t steps = std::min(burst, max_tokens + 1 - produced);
+        for (size_t i = 0; i < steps; ++i) hip_check(hipGraphLaunch(exec, stream_), "graph launch");
+        hip_check(hipMemcpyAsync(hist.data() + produced, dhist_ + produced, steps * sizeof(int32_t), hipMemcpyDeviceToHost, stream_),
+                  "D2H tokens");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        produced += steps;
+        cache_len_ += (int)steps;
+        drain(produced);
     }
     return out;
 }

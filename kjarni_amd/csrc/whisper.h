@@ -88,12 +88,17 @@ private:
     float* upload(const std::vector<float>& host);
     float* dalloc(size_t floats);
     void conv_and_encode(const float* mel_t, int ld_mel, int frames);  // device mel, time-major
+    // One decoder pass over n new tokens whose ids are on the device.  device_pos: position / key count / cache
+    // row are read from dpos_ on the device (graph-capturable: no launch parameter depends on the step).
+    void decoder_pass(const uint32_t* ids_dev, int n, bool device_pos);
+    void enqueue_pick(bool timestamps, bool record);
+    hipGraphExec_t step_graph(bool timestamps);
 
     struct EncLayer {
         float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
     };
     struct DecLayer {
-        float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *ln1_g, *ln1_b;                 // self attention
+        float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b;                               // self attention (Q|K|V fused)
         float *cq, *cbq, *ckv, *cbkv, *co, *cbo, *ln2_g, *ln2_b;                    // cross attention
         float *w1, *b1, *w2, *b2, *ln3_g, *ln3_b;                                   // feed forward
         float *self_k, *self_v, *cross_kv;                                          // caches
@@ -128,8 +133,13 @@ private:
     // decoder workspace
     float *dh_ = nullptr, *dn_ = nullptr, *dq_ = nullptr, *dctx_ = nullptr, *dmid_ = nullptr, *dlast_ = nullptr, *logits_ = nullptr;
     uint32_t* dids_ = nullptr;
-    int32_t* dtoken_ = nullptr;
-    int cache_len_ = 0, cache_cap_ = 0, last_rows_ = 0;
+    int32_t *dtoken_ = nullptr, *dhist_ = nullptr;
+    int *dpos_ = nullptr, *dcount_ = nullptr;
+    float* att_scratch_ = nullptr;
+    int cache_len_ = 0, cache_cap_ = 0, last_rows_ = 0, hist_cap_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipGraphExec_t graphs_[2] = {nullptr, nullptr};
+    static constexpr int kSelfSplits = 16, kCrossSplits = 12;
 };
 
 }  // namespace kjarni

@@ -22,16 +22,43 @@ hipError_t launch_im2col3(const float* x, int64_t ldx, int t_in, int channels, i
 // x[r, :] += table[r % period, :] for r % period < table_rows.
 hipError_t launch_add_rows(float* x, int64_t rows, int hidden, int period, const float* table, int table_rows,
                            hipStream_t stream);
+// offset_ptr (device int) overrides offset when given.
 hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int vocab, const float* word, const float* pos,
-                                int max_pos, int offset, int scale_embeddings, float* out, hipStream_t stream);
-// Y = epi(X W^T + b) for up to 8 rows (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL); more rows go to launch_gemm.
-hipError_t launch_gemv_rows(const float* X, int64_t ldx, int rows, const float* W, const float* bias, const float* R,
-                            int64_t ldr, int n_out, int k, float* Y, int64_t ldy, GemmEpilogue epi, hipStream_t stream);
-// Attention of `rows` query rows over n_keys cached keys/values; causal_base < 0 = no causal mask.
+                                int max_pos, int offset, const int* offset_ptr, int scale_embeddings, float* out,
+                                hipStream_t stream);
+
+// Y = epi(LN?(X) W^T + b) (+ R) for up to 8 rows (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL).
+//  gamma != null: X rows are layer-normalised (gamma, beta, eps) on the fly.
+//  seg > 0: output columns [0,seg) -> Y0 (ld ldy0), [seg,2seg) -> Y1, [2seg,3seg) -> Y2 (ld ldy12), the latter two at
+//  row (*row_off_ptr or row_off) + r.
+struct GemvArgs {
+    const float* X = nullptr;
+    int64_t ldx = 0;
+    int rows = 0;
+    const float *gamma = nullptr, *beta = nullptr;
+    float eps = 0.0f;
+    const float *W = nullptr, *bias = nullptr, *R = nullptr;
+    int64_t ldr = 0;
+    int n_out = 0, k = 0, seg = 0;
+    float* Y0 = nullptr;
+    int64_t ldy0 = 0;
+    float *Y1 = nullptr, *Y2 = nullptr;
+    int64_t ldy12 = 0;
+    int row_off = 0;
+    const int* row_off_ptr = nullptr;
+    GemmEpilogue epi = EPI_BIAS;
+};
+hipError_t launch_gemv_rows(const GemvArgs& args, hipStream_t stream);
+
+// Attention of `rows` query rows over cached keys/values, split over `splits` key ranges + a combine pass.
+// n_keys_ptr (device int) given: keys = *n_keys_ptr + rows and the causal base = *n_keys_ptr (max_keys bounds it);
+// causal_base < 0 = no causal mask.  scratch: decode_attention_scratch_floats(...) floats.
+size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int splits);
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
-                                   int64_t ldv, int n_keys, int heads, int head_dim, int causal_base, float* ctx,
-                                   int64_t ldc, hipStream_t stream);
+                                   int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
+                                   int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream);
+// history/count/pos (device, may be null): append the token, advance the counters (graph-replayed steps).
 hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
-                             int allow_timestamps, int32_t* out, hipStream_t stream);
+                             int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream);
 
 }  // namespace kjarni

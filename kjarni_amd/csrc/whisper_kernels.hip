@@ -150,135 +150,217 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, in
 // ---- decoder step ---------------------------------------------------------------------------------
 
 // h[s, :] = word[ids[s], :] (* sqrt(H) when scaled) + pos[offset + s, :]   (Embeddings::forward as the
-// seq2seq decoder calls it, cpu_decoder.rs:432-439; ids >= vocab leave zeros as in the encoder path)
-__global__ __launch_bounds__(256) void decoder_embed_kernel(const uint32_t* __restrict__ ids, int n, int hidden, int vocab,
+// seq2seq decoder calls it, cpu_decoder.rs:432-439; ids >= vocab leave zeros as in the encoder path).
+// offset_ptr (device) overrides `offset` when given: the graph-replayed step reads its position there.
+__global__ __launch_bounds__(256) void decoder_embed_kernel(const uint32_t* __restrict__ ids, int hidden, int vocab,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
-                                                            int max_pos, int offset, float scale, float* __restrict__ out)
+                                                            int max_pos, int offset, const int* __restrict__ offset_ptr,
+                                                            float scale, float* __restrict__ out)
 {
     const int s = blockIdx.x;
     const uint32_t id = ids[s];
-    const int p = offset + s;
+    const int p = (offset_ptr ? *offset_ptr : offset) + s;
     for (int i = threadIdx.x; i < hidden; i += 256) {
         float v = 0.0f;
         if (id < (uint32_t)vocab) v = word[(int64_t)id * hidden + i] * scale;
         if (pos && p < max_pos) v += pos[(int64_t)p * hidden + i];
         out[(int64_t)s * hidden + i] = v;
     }
-    (void)n;
 }
 
 constexpr int GEMV_MAX_ROWS = 8;
 
-// Y[r, n] = epi(X[r, :] . W[n, :] + bias[n]) (+ R[r, n]) for a handful of rows r: one wave per output
+// Y[r, n] = epi(LN?(X[r, :]) . W[n, :] + bias[n]) (+ R[r, n]) for a handful of rows r: one wave per output
 // column, the weight row streamed once with 16-byte loads and reused for every input row.
-template <int EPI>
+//  * LN: the input rows are layer-normalised on the fly (two-pass mean / variance per row, recomputed by
+//    every wave: a row is a few KB and sits in L2), so LayerNorm + projection is one launch.
+//  * The n_out columns may be split into up to three equal segments written to different buffers (Q | K | V);
+//    segments 1 and 2 are written at row (*row_off_ptr or row_off) + r: straight into the KV cache.
+template <int EPI, bool LN>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ X, int64_t ldx, int rows,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         const float* __restrict__ W, const float* __restrict__ bias,
-                                                        const float* __restrict__ R, int64_t ldr, int n_out, int k,
-                                                        float* __restrict__ Y, int64_t ldy)
+                                                        const float* __restrict__ R, int64_t ldr, int n_out, int k, int seg,
+                                                        float* __restrict__ Y0, int64_t ldy0, float* __restrict__ Y1,
+                                                        float* __restrict__ Y2, int64_t ldy12, int row_off,
+                                                        const int* __restrict__ row_off_ptr)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_out) return;
+    const int k4 = k >> 2;
+    float mean[GEMV_MAX_ROWS], rstd[GEMV_MAX_ROWS];
+    if (LN) {
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+            mean[r] = 0.0f;
+            rstd[r] = 1.0f;
+            if (r < rows) {
+                float s = 0.0f;
+                for (int i = lane; i < k4; i += 64) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+                    s += (x[0] + x[1]) + (x[2] + x[3]);
+                }
+                const float mu = wave_sum(s) / (float)k;
+                float v = 0.0f;
+                for (int i = lane; i < k4; i += 64) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v = fmaf(x[c] - mu, x[c] - mu, v);
+                }
+                mean[r] = mu;
+                rstd[r] = 1.0f / sqrtf(wave_sum(v) / (float)k + eps);
+            }
+        }
+    }
     const f32x4* w4 = reinterpret_cast<const f32x4*>(W + n * (int64_t)k);
     float acc[GEMV_MAX_ROWS];
 #pragma unroll
     for (int r = 0; r < GEMV_MAX_ROWS; ++r) acc[r] = 0.0f;
-    const int k4 = k >> 2;
     for (int i = lane; i < k4; i += 64) {
         const f32x4 w = w4[i];
+        f32x4 g = f32x4{1.f, 1.f, 1.f, 1.f}, bt = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LN) {
+            g = *reinterpret_cast<const f32x4*>(gamma + i * 4);
+            bt = *reinterpret_cast<const f32x4*>(beta + i * 4);
+        }
 #pragma unroll
         for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
             if (r < rows) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+                f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+                if (LN) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = (x[c] - mean[r]) * rstd[r] * g[c] + bt[c];
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[r] = fmaf(x[c], w[c], acc[r]);
             }
         }
     }
     const float b = bias ? bias[n] : 0.0f;
+    const int which = seg > 0 ? (int)(n / seg) : 0;
+    const int64_t col = seg > 0 ? n - (int64_t)which * seg : n;
+    float* Y = which == 0 ? Y0 : (which == 1 ? Y1 : Y2);
+    const int64_t ldy = which == 0 ? ldy0 : ldy12;
+    const int64_t r0 = which == 0 ? 0 : (row_off_ptr ? *row_off_ptr : row_off);
 #pragma unroll
     for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
         if (r < rows) {
             float v = wave_sum(acc[r]) + b;
             if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
             if (EPI == EPI_BIAS_RESIDUAL) v += R[r * ldr + n];
-            if (lane == 0) Y[r * ldy + n] = v;
+            if (lane == 0) Y[(r0 + r) * ldy + col] = v;
         }
     }
 }
 
-// One workgroup per (head, query row): scores over the cached keys, the reference's softmax
-// (exp(x - max) * (1/sum)), weighted sum of the cached values.  K rows are ldk floats apart with head h
-// at columns [h*d, h*d + d); same for V.  causal_base >= 0: query row s sees keys <= causal_base + s
-// (apply_causal_mask, utils/masks.rs:103-113: masked scores are OVERWRITTEN with -1e9).
-__global__ __launch_bounds__(256) void decode_attention_kernel(const float* __restrict__ q, int64_t ldq,
-                                                               const float* __restrict__ K, int64_t ldk,
-                                                               const float* __restrict__ V, int64_t ldv, int n_keys,
-                                                               int head_dim, float scale, int causal_base,
-                                                               float* __restrict__ ctx, int64_t ldc)
+// Cached attention for a few query rows, split over the keys ("flash decoding"): workgroup (head, split, row)
+// reduces its key range to (max, sum of exp, sum of exp * V); decode_attention_combine_kernel merges the
+// splits.  K rows are ldk floats apart with head h at columns [h*d, h*d+d); same for V.  The number of keys
+// is n_keys, or *n_keys_ptr + rows when the pointer is given (graph replay: keys = cache length + new rows).
+// causal >= 0 (or the pointer): query row s sees keys <= base + s (apply_causal_mask, utils/masks.rs:103-113:
+// masked scores are OVERWRITTEN with -1e9, which exp() then turns into exactly 0 next to any real score).
+constexpr int ATT_MAX_CHUNK = 512;
+
+__global__ __launch_bounds__(256) void decode_attention_partial_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                       const float* __restrict__ K, int64_t ldk,
+                                                                       const float* __restrict__ V, int64_t ldv, int n_keys,
+                                                                       const int* __restrict__ n_keys_ptr, int rows, int head_dim,
+                                                                       float scale, int causal, int splits,
+                                                                       float* __restrict__ part)
 {
-    extern __shared__ float smem[];
-    float* qs = smem;                       // [head_dim]
-    float* sc = smem + head_dim;            // [n_keys]
-    float* part = sc + n_keys;              // [256]
+    __shared__ float sc[ATT_MAX_CHUNK];
     __shared__ float red[4];
-    const int h = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-    const int col0 = h * head_dim;
-    for (int i = tid; i < head_dim; i += 256) qs[i] = q[(int64_t)s * ldq + col0 + i];
-    __syncthreads();
+    __shared__ f32x4 accs[256];
+    const int h = blockIdx.x, sp = blockIdx.y, s = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int base = n_keys_ptr ? *n_keys_ptr : 0;
+    const int n = n_keys_ptr ? base + rows : n_keys;
+    const int causal_base = causal < 0 ? -1 : (n_keys_ptr ? base : causal);
+    const int chunk = (n + splits - 1) / splits;
+    const int t0 = sp * chunk, t1 = min(n, t0 + chunk);
+    const int lpk = head_dim >> 2;          // lanes per key (16 for d = 64)
+    const int groups = 256 / lpk;
+    const int g = tid / lpk, l = tid - g * lpk;
+    const int col = h * head_dim + l * 4;
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (int64_t)s * ldq + col);
 
     float mx = -INFINITY;
-    for (int t = tid; t < n_keys; t += 256) {
-        const float* kr = K + (int64_t)t * ldk + col0;
+    for (int t = t0 + g; t < t1; t += groups) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(K + (int64_t)t * ldk + col);
         float dot = 0.0f;
-        for (int i = 0; i < head_dim; i += 4) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + i);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) dot = fmaf(qs[i + c], kv[c], dot);
-        }
+        for (int c = 0; c < 4; ++c) dot = fmaf(qv[c], kv[c], dot);
+        for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
         float v = dot * scale;
         if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
-        sc[t] = v;
+        if (l == 0) sc[t - t0] = v;
         mx = fmaxf(mx, v);
     }
     mx = wave_max(mx);
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    if (lane == 0) red[tid >> 6] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.0f;
-    for (int t = tid; t < n_keys; t += 256) {
-        const float e = expf(sc[t] - mx);
-        sc[t] = e;
+    for (int t = t0 + tid; t < t1; t += 256) {
+        const float e = expf(sc[t - t0] - mx);
+        sc[t - t0] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    if (lane == 0) red[tid >> 6] = sum;
     __syncthreads();
     sum = red[0] + red[1] + red[2] + red[3];
-    const float inv = sum > 0.0f ? 1.0f / sum : 1.0f;
 
-    // context: thread (g, j) sums keys t = g, g + G, ... for output column j
-    const int G = 256 / head_dim;  // head_dim in {32, 64, 128}
-    const int j = tid % head_dim, g = tid / head_dim;
-    float acc = 0.0f;
-    if (g < G)
-        for (int t = g; t < n_keys; t += G) acc = fmaf(sc[t] * inv, V[(int64_t)t * ldv + col0 + j], acc);
-    part[tid] = acc;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = t0 + g; t < t1; t += groups) {
+        const float p = sc[t - t0];
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(V + (int64_t)t * ldv + col);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(p, vv[c], acc[c]);
+    }
+    accs[tid] = acc;
     __syncthreads();
-    if (tid < head_dim) {
-        float v = 0.0f;
-        for (int gg = 0; gg < G; ++gg) v += part[gg * head_dim + tid];
-        ctx[(int64_t)s * ldc + col0 + tid] = v;
+    // part layout per (row, head, split): [max, sum, acc[head_dim]]
+    float* out = part + (((int64_t)s * gridDim.x + h) * splits + sp) * (head_dim + 2);
+    if (tid < lpk) {
+        f32x4 tot = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int gg = 0; gg < groups; ++gg) tot += accs[gg * lpk + tid];
+        *reinterpret_cast<f32x2*>(out + 2 + tid * 4) = f32x2{tot[0], tot[1]};
+        *reinterpret_cast<f32x2*>(out + 4 + tid * 4) = f32x2{tot[2], tot[3]};
+    }
+    if (tid == 0) {
+        out[0] = (t1 > t0) ? mx : -INFINITY;
+        out[1] = (t1 > t0) ? sum : 0.0f;
     }
 }
 
+__global__ __launch_bounds__(128) void decode_attention_combine_kernel(const float* __restrict__ part, int heads, int splits,
+                                                                       int head_dim, float* __restrict__ ctx, int64_t ldc)
+{
+    const int h = blockIdx.x, s = blockIdx.y, j = threadIdx.x;
+    if (j >= head_dim) return;
+    const float* p = part + ((int64_t)s * heads + h) * splits * (head_dim + 2);
+    float M = -INFINITY;
+    for (int i = 0; i < splits; ++i) M = fmaxf(M, p[i * (head_dim + 2)]);
+    float L = 0.0f, a = 0.0f;
+    for (int i = 0; i < splits; ++i) {
+        const float* pi = p + i * (head_dim + 2);
+        const float w = (pi[0] == -INFINITY) ? 0.0f : expf(pi[0] - M);
+        L = fmaf(pi[1], w, L);
+        a = fmaf(pi[2 + j], w, a);
+    }
+    ctx[(int64_t)s * ldc + h * head_dim + j] = L > 0.0f ? a * (1.0f / L) : a;
+}
+
 // WhisperModel::pick_token (transcriber.rs:243-270): argmax over the ids that may be produced;
-// Iterator::max_by returns the LAST of equal maxima.
+// Iterator::max_by returns the LAST of equal maxima.  The chosen id goes to out[0]; when `history` is given
+// (graph replay) it is also appended at history[*count], *count and *pos are advanced: the next step's
+// input token, position and key count then live on the device and the host only looks every few steps.
 __global__ __launch_bounds__(1024) void pick_token_kernel(const float* __restrict__ logits, int vocab, int first_special,
                                                           int eos, int timestamp_begin, int allow_timestamps,
-                                                          int32_t* __restrict__ out)
+                                                          int32_t* __restrict__ out, int32_t* __restrict__ history,
+                                                          int* __restrict__ count, int* __restrict__ pos)
 {
     __shared__ float bv[16];
     __shared__ int bi[16];
@@ -313,7 +395,13 @@ __global__ __launch_bounds__(1024) void pick_token_kernel(const float* __restric
                 best = bv[w];
                 idx = bi[w];
             }
-        *out = idx >= 0 ? idx : eos;
+        const int tok = idx >= 0 ? idx : eos;
+        *out = tok;
+        if (history) {
+            history[*count] = tok;
+            *count += 1;
+            *pos += 1;
+        }
     }
 }
 
@@ -370,55 +458,74 @@ hipError_t launch_add_rows(float* x, int64_t rows, int hidden, int period, const
 }
 
 hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int vocab, const float* word, const float* pos,
-                                int max_pos, int offset, int scale_embeddings, float* out, hipStream_t stream)
+                                int max_pos, int offset, const int* offset_ptr, int scale_embeddings, float* out,
+                                hipStream_t stream)
 {
     const float scale = scale_embeddings ? sqrtf((float)hidden) : 1.0f;
-    hipLaunchKernelGGL(decoder_embed_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, n, hidden, vocab, word, pos,
-                       max_pos, offset, scale, out);
+    hipLaunchKernelGGL(decoder_embed_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, hidden, vocab, word, pos, max_pos,
+                       offset, offset_ptr, scale, out);
     return hipGetLastError();
 }
 
-hipError_t launch_gemv_rows(const float* X, int64_t ldx, int rows, const float* W, const float* bias, const float* R,
-                            int64_t ldr, int n_out, int k, float* Y, int64_t ldy, GemmEpilogue epi, hipStream_t stream)
+hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
 {
-    if (rows <= 0 || n_out <= 0) return hipSuccess;
-    if (rows > GEMV_MAX_ROWS || (k & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15) ||
-        (reinterpret_cast<uintptr_t>(W) & 15))
-        return launch_gemm(X, ldx, W, bias, R, ldr, Y, ldy, rows, n_out, k, epi, stream);
-    const dim3 grid((unsigned)((n_out + 3) / 4));
-    switch (epi) {
+    if (a.rows <= 0 || a.n_out <= 0) return hipSuccess;
+    const bool simple = !a.gamma && a.seg <= 0;
+    if (a.rows > GEMV_MAX_ROWS || (a.k & 3) || (a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.X) & 15) ||
+        (reinterpret_cast<uintptr_t>(a.W) & 15)) {
+        if (!simple) return hipErrorInvalidValue;
+        return launch_gemm(a.X, a.ldx, a.W, a.bias, a.R, a.ldr, a.Y0, a.ldy0, a.rows, a.n_out, a.k, a.epi, stream);
+    }
+    const dim3 grid((unsigned)((a.n_out + 3) / 4));
+#define KJ_GEMV(EPI, LN)                                                                                                      \
+    hipLaunchKernelGGL((gemv_rows_kernel<EPI, LN>), grid, dim3(256), 0, stream, a.X, a.ldx, a.rows, a.gamma, a.beta, a.eps, a.W, \
+                       a.bias, a.R, a.ldr, a.n_out, a.k, a.seg, a.Y0, a.ldy0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr)
+    const bool ln = a.gamma != nullptr;
+    switch (a.epi) {
     case EPI_BIAS:
-        hipLaunchKernelGGL(gemv_rows_kernel<EPI_BIAS>, grid, dim3(256), 0, stream, X, ldx, rows, W, bias, R, ldr, n_out, k, Y, ldy);
+        if (ln) KJ_GEMV(EPI_BIAS, true);
+        else KJ_GEMV(EPI_BIAS, false);
         break;
     case EPI_BIAS_GELU:
-        hipLaunchKernelGGL(gemv_rows_kernel<EPI_BIAS_GELU>, grid, dim3(256), 0, stream, X, ldx, rows, W, bias, R, ldr, n_out, k, Y, ldy);
+        if (ln) KJ_GEMV(EPI_BIAS_GELU, true);
+        else KJ_GEMV(EPI_BIAS_GELU, false);
         break;
     case EPI_BIAS_RESIDUAL:
-        hipLaunchKernelGGL(gemv_rows_kernel<EPI_BIAS_RESIDUAL>, grid, dim3(256), 0, stream, X, ldx, rows, W, bias, R, ldr, n_out, k, Y, ldy);
+        if (ln) KJ_GEMV(EPI_BIAS_RESIDUAL, true);
+        else KJ_GEMV(EPI_BIAS_RESIDUAL, false);
         break;
     default: return hipErrorInvalidValue;
     }
+#undef KJ_GEMV
     return hipGetLastError();
 }
 
-hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
-                                   int64_t ldv, int n_keys, int heads, int head_dim, int causal_base, float* ctx,
-                                   int64_t ldc, hipStream_t stream)
+size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int splits)
 {
-    if (rows <= 0 || n_keys <= 0) return hipSuccess;
-    if (head_dim > 256 || 256 % head_dim != 0 || (head_dim & 3)) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(head_dim + n_keys + 256) * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(decode_attention_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(256), lds, stream, q, ldq, K,
-                       ldk, V, ldv, n_keys, head_dim, 1.0f / sqrtf((float)head_dim), causal_base, ctx, ldc);
+    return (size_t)rows * heads * splits * (head_dim + 2);
+}
+
+hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
+                                   int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
+                                   int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream)
+{
+    if (rows <= 0 || (n_keys <= 0 && !n_keys_ptr)) return hipSuccess;
+    if (head_dim > 128 || 256 % (head_dim / 4) != 0 || (head_dim & 3) || splits < 1) return hipErrorInvalidValue;
+    const int worst = n_keys_ptr ? max_keys : n_keys;
+    if ((worst + splits - 1) / splits > ATT_MAX_CHUNK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attention_partial_kernel, dim3((unsigned)heads, (unsigned)splits, (unsigned)rows), dim3(256), 0, stream,
+                       q, ldq, K, ldk, V, ldv, n_keys, n_keys_ptr, rows, head_dim, 1.0f / sqrtf((float)head_dim), causal_base, splits,
+                       scratch);
+    hipLaunchKernelGGL(decode_attention_combine_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(128), 0, stream, scratch, heads,
+                       splits, head_dim, ctx, ldc);
     return hipGetLastError();
 }
 
 hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
-                             int allow_timestamps, int32_t* out, hipStream_t stream)
+                             int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream)
 {
-    hipLaunchKernelGGL(pick_token_kernel, dim3(1), dim3(1024), 0, stream, logits, vocab, first_special, eos,
-                       timestamp_begin, allow_timestamps, out);
+    hipLaunchKernelGGL(pick_token_kernel, dim3(1), dim3(1024), 0, stream, logits, vocab, first_special, eos, timestamp_begin,
+                       allow_timestamps, out, history, count, pos);
     return hipGetLastError();
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The other measurements SURVEY.md section 8(d) asks for, next to bench.py's headline line.
 
-    python tools/bench_more.py [rerank] [scan] [ragged] [host] [strings] [indexer]   (default: all)
+    python tools/bench_more.py [rerank] [scan] [ragged] [host] [strings] [indexer] [whisper]   (default: all)
 
 One JSON line per measurement (1 GPU; the N > 1 driver is bench.py):
   rerank   BASELINE.json configs[2] on one GPU: 100 000 synthetic (query, doc) pairs, S = 128, fp32,
@@ -13,6 +13,9 @@ One JSON line per measurement (1 GPU; the N > 1 driver is bench.py):
            the embeddings inside the timed region (the PCIe-inclusive rate; never the headline value).
   strings  kjarni_embedder_encode_batch on generated ASCII sentences (tokenisation on the host included).
   indexer  kjarni_indexer_create over a generated directory tree: chunks/s end to end.
+  whisper  BASELINE.json configs[3]: Whisper-base shaped model (random init), 30 s of synthetic audio: log-mel,
+           conv stem + encoder, greedy decode of 448 tokens; per-stage ms, x real time, and the CPU restatement
+           (oracle) timed on a bounded sample of the same work.
 """
 import json
 import os
@@ -45,7 +48,7 @@ def timed(fn, sync, steps, warmup):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer"}
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer", "whisper"}
     import numpy as np
     import torch
 
@@ -196,6 +199,60 @@ def main():
               "config": {"workload": f"400 generated text files, chunk_size 512 / overlap 50 / batch_size 32 (defaults): "
                                      f"{st.documents_indexed} chunks, index {st.size_bytes} bytes"},
               "elapsed_ms": st.elapsed_ms})
+
+    if "whisper" in which:
+        d = os.path.join(tmp, "whisper-base")
+        cfg_w, t_w = synth.whisper_model(d, seed=0, base=True)
+        wm = kjarni_amd.HipWhisper(d)
+        audio = synth.synthetic_audio(30.0, seed=1)
+        n_tok = 448
+        prompt = [50258, 50259, 50359, 50363]
+        wm.encode_audio(audio, fetch=False)
+        wm.greedy(prompt, False, 8)                                   # warm-up
+        t_mel = timed(lambda: wm.log_mel(audio), lambda: None, 5, 1)  # includes the D2H of the mel
+        t_enc = timed(lambda: wm.encode_audio(audio, fetch=False), lambda: None, 5, 1)   # mel + stem + encoder, synchronised
+        t0 = time.perf_counter()
+        ids = wm.greedy(prompt, False, n_tok)
+        t_dec = time.perf_counter() - t0
+        total = t_enc + t_dec
+        H, L_, I, S_, V = 512, 6, 2048, 1500, 51865
+        enc_flops = L_ * (2 * S_ * H * 3 * H + 4 * S_ * S_ * H + 2 * S_ * H * H + 4 * S_ * H * I) + 2 * 3000 * 512 * 240 + 2 * 1500 * 512 * 1536
+        # decoder step: weights streamed once per token (HBM-bound): 6 layers x (8 HxH + 2 HxI) + lm head, + cross K/V reads
+        dec_bytes = 4 * (L_ * (8 * H * H + 2 * H * I) + V * H + L_ * 2 * S_ * H)
+        res = {"metric": "x real time, Whisper-base shaped transcribe of 30 s audio (log-mel + encoder + greedy decode)",
+               "value": round(30.0 / total, 1), "unit": "x real time", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[3]: whisper-base shape (d=512, 6+6 layers, vocab 51865), random init, "
+                                      f"30 s synthetic audio, {len(ids)} generated tokens (EOS is never the argmax with random weights)"},
+               "ms_log_mel_incl_d2h": round(t_mel * 1e3, 3), "ms_mel_stem_encoder": round(t_enc * 1e3, 3),
+               "ms_decode": round(t_dec * 1e3, 2), "ms_per_token": round(t_dec * 1e3 / len(ids), 4),
+               "tokens_per_s": round(len(ids) / t_dec, 1),
+               "encoder_tflops": round(enc_flops / t_enc / 1e12, 2),
+               "decode_weight_stream_gbs": round(dec_bytes * len(ids) / t_dec / 1e9, 1),
+               "decode_frac_hbm_peak": round(dec_bytes * len(ids) / t_dec / 1e9 / PEAK_HBM_GBS, 4)}
+        # CPU restatement (oracle): one encoder pass + a few decoder steps, extrapolated to the same token count
+        from oracle import whisper_oracle as WO
+        try:
+            import psutil
+            cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+        except Exception:
+            cores = os.cpu_count() or 1
+        from oracle import oracle as O
+        O.lib().ko_set_num_threads(int(cores))
+        orc = WO.WhisperOracle(t_w, cfg_w)
+        t0 = time.perf_counter()
+        mel = WO.log_mel(audio)
+        c_mel = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        enc = orc.encode_mel(mel)
+        c_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.decode_chunk_ids(enc, max_tokens=15)
+        c_dec16 = time.perf_counter() - t0
+        c_total = c_mel + c_enc + c_dec16 / 16 * len(ids)
+        res["cpu_baseline"] = {"value": round(30.0 / c_total, 3), "unit": "x real time", "cores": int(cores), "kind": "port",
+                               "sample": f"oracle: log-mel {c_mel:.2f} s (vectorised DFT, not the reference's scalar O(n^2) loop), "
+                                         f"encoder {c_enc:.2f} s, 16 decoder steps {c_dec16:.2f} s extrapolated to {len(ids)} tokens"}
+        emit(res)
 
 
 if __name__ == "__main__":
