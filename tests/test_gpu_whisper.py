@@ -180,3 +180,34 @@ def test_transcriber_timestamps_language_translate_and_stops(env):
     assert b"cancelled" in _ffi.lib().kjarni_last_error_message()
     with pytest.raises(Exception):
         tr3.transcribe_file("/nonexistent/audio.wav")
+
+
+def test_full_size_whisper_base_shape(tmp_path):
+    """BASELINE.json configs[3] shape (d_model 512, 6 + 6 layers, 8 heads, ffn 2048): encoder output and the first
+    decoder steps against the oracle, then properties the oracle would take too long for: greedy decoding is
+    deterministic, stops at max_tokens and never emits a suppressed id."""
+    import kjarni_amd
+    d = str(tmp_path / "openai_whisper-base")
+    cfg, t = synth.whisper_model(d, seed=11, base=True)
+    g = kjarni_amd.HipWhisper(d)
+    m = W.WhisperOracle(t, cfg)
+    audio = synth.synthetic_audio(30.0, seed=12)
+    enc = m.encode_mel(W.log_mel(audio))
+    got = g.encode_audio(audio)
+    assert got.shape == (1500, 512)
+    assert np.abs(got - enc[0]).max() < 5e-4, np.abs(got - enc[0]).max()      # 6 layers on top of the f32 DFT noise
+    g.encode_mel(W.log_mel(audio), fetch=False)                                 # same mel on both sides: 1e-4
+    g.decode_begin()
+    cross = m.precompute_cross_kv(enc)
+    cache = [None] * len(m.dec_layers)
+    for ids in ([W.SOT_TOKEN, 50259, W.TRANSCRIBE_TOKEN, W.NO_TIMESTAMPS_TOKEN], [1234], [40000]):
+        ref_h = m.decoder_forward(np.asarray([ids], np.uint32), enc, cache, cross)[0]
+        h, logits = g.decode_forward(ids)
+        assert np.abs(h - ref_h).max() < TOL
+        assert np.abs(logits - m.logits(ref_h[None, -1:, :])[0, 0]).max() < TOL
+    prompt = m.prompt_tokens(50259, False, False)
+    a = g.greedy(prompt, False, 60)
+    b = g.greedy(prompt, False, 60)
+    assert a == b and len(a) <= 61 and all(t < W.FIRST_SPECIAL_TOKEN or t == W.EOT_TOKEN for t in a)
+    ts = g.greedy(m.prompt_tokens(50259, False, True), True, 40)
+    assert all(t < W.FIRST_SPECIAL_TOKEN or t == W.EOT_TOKEN or t >= W.TIMESTAMP_BEGIN for t in ts)
