@@ -291,6 +291,31 @@ KjarniErrorCode kjarni_audio_load_wav(const char* path, KjarniFloatArray* out, u
 KjarniErrorCode kjarni_bytelevel_decode(const char* tokenizer_json_path, const uint32_t* ids, size_t n, int32_t skip_special,
                                         char** out);
 
+/* ---- decoder-only generation (Llama / Qwen2 layouts), token level ----------------------------
+ * model_dir: config.json (crates/kjarni-models/src/models/llama/config.rs:98-158, qwen/config.rs:80-125) and
+ * model.safetensors with the HF tensor names of llama/config.rs:283-330.  weights_dtype: 0 = as stored (BF16 stays
+ * bf16 in HBM, other dtypes are widened to f32), 1 = f32, 2 = bf16 (f32 rounded to nearest even).  Arithmetic,
+ * activations and the KV cache are f32 either way, as in the reference's bf16 LinearLayer.  max_context <= 0 =
+ * max_position_embeddings.  No tokenizer is involved: prompts and results are token ids. */
+typedef struct KjarniHipDecoder KjarniHipDecoder;
+KjarniErrorCode kjarni_hip_decoder_load(const char* model_dir, int32_t device, int32_t weights_dtype, int32_t max_context,
+                                        KjarniHipDecoder** out);
+void kjarni_hip_decoder_free(KjarniHipDecoder* decoder);
+KjarniErrorCode kjarni_hip_decoder_dims(const KjarniHipDecoder* decoder, int32_t* hidden, int32_t* layers, int32_t* vocab,
+                                        int32_t* context, int32_t* weights_bf16, uint64_t* weight_bytes);
+KjarniErrorCode kjarni_hip_decoder_reset(KjarniHipDecoder* decoder); /* empty KV cache */
+/* CpuDecoder::forward + final norm + lm head (llama/cpu_decoder.rs:196-219): appends n tokens to the cache;
+ * hidden_out f32 [min(n,8) last rows, hidden] (final-normed), logits_out f32 [vocab] of the last position. */
+KjarniErrorCode kjarni_hip_decoder_forward(KjarniHipDecoder* decoder, const uint32_t* ids, int32_t n, float* hidden_out,
+                                           float* logits_out);
+/* run_generation_loop with DecodingStrategy::Greedy (crates/kjarni-transformers/src/decoder/generator.rs:228-381):
+ * prefill, then up to max_new_tokens tokens; stops at an eos id of config.json (not emitted) or the context limit.
+ * repetition_penalty 1.0 and no_repeat_ngram_size 0 switch those processors off (common/sampling.rs:207-235).
+ * on_token (may be NULL; text is NULL here) returning false stops.  *n_out = tokens generated (may exceed capacity). */
+KjarniErrorCode kjarni_hip_decoder_generate(KjarniHipDecoder* decoder, const uint32_t* prompt, size_t n_prompt, size_t max_new_tokens,
+                                            float repetition_penalty, int32_t no_repeat_ngram_size, KjarniTokenCallbackFn on_token,
+                                            void* user_data, uint32_t* ids_out, size_t capacity, size_t* n_out);
+
 /* ---- device memory helpers for callers without a HIP runtime binding --------- */
 KjarniErrorCode kjarni_hip_malloc(int32_t device, size_t bytes, void** out_dev);
 KjarniErrorCode kjarni_hip_free(int32_t device, void* ptr_dev);

@@ -332,6 +332,14 @@ SIGNATURES = {
     "kjarni_hip_whisper_decode_text": (c_int32, [c_void_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
     "kjarni_audio_load_wav": (c_int32, [c_char_p, POINTER(KjarniFloatArray), POINTER(C.c_uint32)]),
     "kjarni_bytelevel_decode": (c_int32, [c_char_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
+    "kjarni_hip_decoder_load": (c_int32, [c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "kjarni_hip_decoder_free": (None, [c_void_p]),
+    "kjarni_hip_decoder_dims": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
+                                          POINTER(c_int32), POINTER(C.c_uint64)]),
+    "kjarni_hip_decoder_reset": (c_int32, [c_void_p]),
+    "kjarni_hip_decoder_forward": (c_int32, [c_void_p, _u32p, c_int32, _f32p, _f32p]),
+    "kjarni_hip_decoder_generate": (c_int32, [c_void_p, _u32p, c_size_t, c_size_t, c_float, c_int32, KjarniTokenCallbackFn, c_void_p,
+                                              _u32p, c_size_t, POINTER(c_size_t)]),
     "kjarni_text_split": (c_int32, [c_char_p, c_size_t, c_size_t, c_char_p, POINTER(KjarniStringArray)]),
     "kjarni_collect_files": (c_int32, [POINTER(KjarniIndexerConfig), POINTER(c_char_p), c_size_t,
                                        POINTER(KjarniStringArray)]),

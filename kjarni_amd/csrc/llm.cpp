@@ -1,0 +1,424 @@
+#include "llm.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "json.h"
+#include "llm_kernels.h"
+#include "safetensors.h"
+#include "whisper_kernels.h"
+
+namespace kjarni {
+
+namespace {
+
+std::string slurp_file(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+uint16_t f32_to_bf16(float v)  // round to nearest even
+{
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+LlmConfig LlmConfig::from_json(const std::string& text)
+{
+    const Json j = Json::parse(text);
+    LlmConfig c;
+    auto req = [&](const char* k) {
+        const Json* v = j.find(k);
+        if (!v || !v->is_number()) throw std::runtime_error(std::string("config.json: missing field `") + k + "`");
+        return (int)v->as_int();
+    };
+    c.model_type = j.get_string("model_type", "llama");
+    if (c.model_type != "llama" && c.model_type != "qwen2")
+        throw std::runtime_error("unsupported decoder model_type '" + c.model_type + "' (llama and qwen2 are)");
+    c.hidden = req("hidden_size");
+    c.layers = req("num_hidden_layers");
+    c.heads = req("num_attention_heads");
+    c.kv_heads = (int)j.get_int("num_key_value_heads", c.heads);
+    c.inter = req("intermediate_size");
+    c.vocab = req("vocab_size");
+    c.max_pos = req("max_position_embeddings");
+    c.head_dim = (int)j.get_int("head_dim", c.hidden / c.heads);
+    // llama/config.rs:137-152, qwen/config.rs:70-76 defaults
+    const bool llama = c.model_type == "llama";
+    c.eps = (float)j.get_double("rms_norm_eps", llama ? 1e-5 : 1e-6);
+    c.rope_theta = (float)j.get_double("rope_theta", llama ? 500000.0 : 1000000.0);
+    c.tie_embeddings = j.get_bool("tie_word_embeddings", llama);
+    if (const Json* rs = j.find("rope_scaling"); rs && rs->is_object()) {
+        c.has_rope_scaling = true;
+        c.rope_type = rs->get_string("rope_type", rs->get_string("type", ""));
+        c.rope_factor = (float)rs->get_double("factor", 1.0);
+        c.rope_low = (float)rs->get_double("low_freq_factor", 1.0);
+        c.rope_high = (float)rs->get_double("high_freq_factor", 4.0);
+        c.rope_original_max = (int)rs->get_int("original_max_position_embeddings", 8192);
+    }
+    if (const Json* e = j.find("eos_token_id")) {
+        if (e->is_number()) c.eos_ids.push_back((uint32_t)e->as_int());
+        else if (e->is_array())
+            for (const Json& x : e->arr)
+                if (x.is_number()) c.eos_ids.push_back((uint32_t)x.as_int());
+    }
+    if (c.heads <= 0 || c.kv_heads <= 0 || c.heads % c.kv_heads != 0 || c.head_dim * c.heads != c.hidden)
+        throw std::runtime_error("config.json: unsupported head geometry");
+    return c;
+}
+
+float* LlmModel::dalloc(size_t floats)
+{
+    float* d = nullptr;
+    hip_check(hipMalloc((void**)&d, std::max<size_t>(floats, 4) * sizeof(float)), "hipMalloc");
+    allocs_.push_back(d);
+    return d;
+}
+
+float* LlmModel::upload_f32(const std::vector<float>& host)
+{
+    float* d = dalloc(host.size());
+    if (!host.empty()) hip_check(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    weight_bytes_ += host.size() * sizeof(float);
+    return d;
+}
+
+void* LlmModel::upload_weight(const std::vector<float>& host)
+{
+    if (!bf16_) return upload_f32(host);
+    std::vector<uint16_t> h(host.size());
+    for (size_t i = 0; i < host.size(); ++i) h[i] = f32_to_bf16(host[i]);  // exact when the file already held bf16
+    void* d = dalloc((host.size() + 1) / 2);
+    if (!h.empty()) hip_check(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice), "hipMemcpy(weights)");
+    weight_bytes_ += h.size() * 2;
+    return d;
+}
+
+LlmModel::~LlmModel()
+{
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (graph_) (void)hipGraphExecDestroy(graph_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    for (void* p : allocs_) (void)hipFree(p);
+}
+
+std::unique_ptr<LlmModel> LlmModel::load(const std::string& dir, int device, int weights, int max_context)
+{
+    if (visible_device_count() <= device) throw GpuUnavailable("no usable HIP device " + std::to_string(device));
+    std::unique_ptr<LlmModel> m(new LlmModel());
+    m->device_ = device;
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    m->cfg_ = LlmConfig::from_json(slurp_file(dir + "/config.json"));
+    const LlmConfig& c = m->cfg_;
+    const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d;
+    if ((d & 3) || d > 128 || 256 % (d / 4) != 0 || (H & 7) || (c.inter & 7)) throw std::runtime_error("unsupported decoder geometry");
+    SafeTensors st;
+    st.open(dir + "/model.safetensors");
+    m->bf16_ = weights == 2 || (weights == 0 && st.get("model.layers.0.self_attn.q_proj.weight").dtype == "BF16");
+    std::vector<float> buf, tmp;
+    auto get = [&](const std::string& name, std::vector<int64_t> want) {
+        const std::vector<int64_t> shape = st.read_f32(name, buf);
+        if (shape != want) throw std::runtime_error("tensor " + name + " has an unexpected shape");
+    };
+    m->layers_.resize((size_t)c.layers);
+    m->cache_cap_ = std::min(max_context > 0 ? max_context : c.max_pos, c.max_pos);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = "model.layers." + std::to_string(i);
+        Layer& L = m->layers_[(size_t)i];
+        std::vector<float> w, b;
+        bool any_bias = false;
+        for (const auto& nm : {std::make_pair(std::string("q_proj"), H), std::make_pair(std::string("k_proj"), kv),
+                               std::make_pair(std::string("v_proj"), kv)}) {
+            get(p + ".self_attn." + nm.first + ".weight", {nm.second, H});
+            w.insert(w.end(), buf.begin(), buf.end());
+            if (st.contains(p + ".self_attn." + nm.first + ".bias")) {  // Qwen2 (qwen/config.rs:228-234)
+                st.read_f32(p + ".self_attn." + nm.first + ".bias", tmp);
+                b.insert(b.end(), tmp.begin(), tmp.end());
+                any_bias = true;
+            } else {
+                b.insert(b.end(), (size_t)nm.second, 0.0f);
+            }
+        }
+        L.wqkv = m->upload_weight(w);
+        L.bqkv = any_bias ? m->upload_f32(b) : nullptr;
+        get(p + ".self_attn.o_proj.weight", {H, H});
+        L.wo = m->upload_weight(buf);
+        get(p + ".mlp.gate_proj.weight", {c.inter, H});
+        L.gate = m->upload_weight(buf);
+        get(p + ".mlp.up_proj.weight", {c.inter, H});
+        L.up = m->upload_weight(buf);
+        get(p + ".mlp.down_proj.weight", {H, c.inter});
+        L.down = m->upload_weight(buf);
+        get(p + ".input_layernorm.weight", {H});
+        L.ln1 = m->upload_f32(buf);
+        get(p + ".post_attention_layernorm.weight", {H});
+        L.ln2 = m->upload_f32(buf);
+        L.k_cache = m->dalloc((size_t)m->cache_cap_ * kv);
+        L.v_cache = m->dalloc((size_t)m->cache_cap_ * kv);
+    }
+    get("model.embed_tokens.weight", {c.vocab, H});
+    m->embed_ = m->upload_weight(buf);
+    if (c.tie_embeddings || !st.contains("lm_head.weight")) {
+        m->lm_head_ = m->embed_;
+    } else {
+        get("lm_head.weight", {c.vocab, H});
+        m->lm_head_ = m->upload_weight(buf);
+    }
+    get("model.norm.weight", {H});
+    m->final_norm_ = m->upload_f32(buf);
+
+    // RoPE tables as the reference builds them (rope/mod.rs:62-130), [cache_cap, d/2]
+    {
+        const int half = d / 2;
+        std::vector<float> inv((size_t)half);
+        for (int i = 0; i < half; ++i) inv[(size_t)i] = 1.0f / std::pow(c.rope_theta, (float)(2 * i) / (float)d);
+        if (c.has_rope_scaling && c.rope_type == "llama3") {
+            const float low_wl = (float)c.rope_original_max / c.rope_low, high_wl = (float)c.rope_original_max / c.rope_high;
+            for (int i = 0; i < half; ++i) {
+                const float base = inv[(size_t)i];
+                const float wl = 2.0f * (float)M_PI / base;
+                if (wl < high_wl) continue;
+                if (wl > low_wl) {
+                    inv[(size_t)i] = base / c.rope_factor;
+                } else {
+                    const float smooth = ((float)c.rope_original_max / wl - c.rope_low) / (c.rope_high - c.rope_low);
+                    inv[(size_t)i] = base / ((1.0f - smooth) * c.rope_factor + smooth);
+                }
+            }
+        }
+        std::vector<float> cs((size_t)m->cache_cap_ * half), sn((size_t)m->cache_cap_ * half);
+        for (int p = 0; p < m->cache_cap_; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float angle = (float)p * inv[(size_t)i];
+                cs[(size_t)p * half + i] = std::cos(angle);
+                sn[(size_t)p * half + i] = std::sin(angle);
+            }
+        m->cos_ = m->upload_f32(cs);
+        m->sin_ = m->upload_f32(sn);
+    }
+    m->splits_ = std::max(1, std::min(64, (m->cache_cap_ + 255) / 256));
+    while ((m->cache_cap_ + m->splits_ - 1) / m->splits_ > 512) ++m->splits_;
+    m->h_ = m->dalloc(8 * (size_t)H);
+    m->q_ = m->dalloc(8 * (size_t)H);
+    m->ctx_ = m->dalloc(8 * (size_t)H);
+    m->last_ = m->dalloc(8 * (size_t)H);
+    m->mid_ = m->dalloc(8 * (size_t)c.inter);
+    m->logits_ = m->dalloc((size_t)c.vocab);
+    m->att_scratch_ = m->dalloc(decode_attention_scratch_floats(8, c.heads, d, m->splits_));
+    m->ids_ = reinterpret_cast<uint32_t*>(m->dalloc(8));
+    m->token_ = reinterpret_cast<int32_t*>(m->dalloc(4));
+    m->hist_cap_ = m->cache_cap_ + 16;
+    m->hist_ = reinterpret_cast<int32_t*>(m->dalloc((size_t)m->hist_cap_));
+    m->pos_ = reinterpret_cast<int*>(m->dalloc(4));
+    m->count_ = reinterpret_cast<int*>(m->dalloc(4));
+    m->best_ = reinterpret_cast<unsigned long long*>(m->dalloc(4));
+    hip_check(hipMemset(m->best_, 0, 8), "memset");
+    hip_check(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(load)");
+    return m;
+}
+
+void LlmModel::reset()
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    cache_len_ = 0;
+    hip_check(hipMemsetAsync(pos_, 0, sizeof(int), stream_), "reset pos");
+    hip_check(hipMemsetAsync(count_, 0, sizeof(int), stream_), "reset count");
+}
+
+void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
+{
+    hipStream_t s = stream_;
+    const LlmConfig& c = cfg_;
+    const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d, I = c.inter;
+    const int* pp = device_pos ? pos_ : nullptr;
+    hip_check(launch_llm_embed(ids_dev, n, H, c.vocab, embed_, bf16_ ? 1 : 0, h_, s), "embed");
+    for (const Layer& L : layers_) {
+        LlmGemvArgs a;  // RMSNorm + Q | K | V (decoder_attention.rs:61-82): K / V rows land in the cache
+        a.X = h_; a.ldx = H; a.rows = n; a.gamma = L.ln1; a.eps = c.eps; a.W = L.wqkv; a.bf16 = bf16_; a.bias = L.bqkv;
+        a.n_out = H + 2 * kv; a.k = H; a.seg_q = H; a.seg_kv = kv; a.Y0 = q_; a.ldy0 = H; a.Y1 = L.k_cache; a.Y2 = L.v_cache; a.ldy12 = kv;
+        a.row_off = cache_len_; a.row_off_ptr = pp;
+        hip_check(launch_llm_gemv(a, s), "norm + qkv");
+        hip_check(launch_rope(q_, H, n, c.heads, d, cos_, sin_, cache_len_, pp, 0, s), "rope q");
+        hip_check(launch_rope(L.k_cache, kv, n, c.kv_heads, d, cos_, sin_, cache_len_, pp, 1, s), "rope k");
+        hip_check(launch_decode_attention(q_, H, n, L.k_cache, kv, L.v_cache, kv, cache_len_ + n, pp, cache_cap_, c.heads, d, cache_len_,
+                                          splits_, att_scratch_, ctx_, H, s, c.heads / c.kv_heads), "attention");
+        LlmGemvArgs o;
+        o.X = ctx_; o.ldx = H; o.rows = n; o.W = L.wo; o.bf16 = bf16_; o.R = h_; o.ldr = H; o.n_out = H; o.k = H; o.Y0 = h_; o.ldy0 = H;
+        hip_check(launch_llm_gemv(o, s), "o proj");
+        LlmGemvArgs g;  // RMSNorm + SwiGLU (swiglu.rs:32-57)
+        g.X = h_; g.ldx = H; g.rows = n; g.gamma = L.ln2; g.eps = c.eps; g.W = L.gate; g.W2 = L.up; g.bf16 = bf16_; g.swiglu = 1;
+        g.n_out = I; g.k = H; g.Y0 = mid_; g.ldy0 = I;
+        hip_check(launch_llm_gemv(g, s), "norm + gate/up");
+        LlmGemvArgs dn;
+        dn.X = mid_; dn.ldx = I; dn.rows = n; dn.W = L.down; dn.bf16 = bf16_; dn.R = h_; dn.ldr = H; dn.n_out = H; dn.k = I; dn.Y0 = h_; dn.ldy0 = H;
+        hip_check(launch_llm_gemv(dn, s), "down proj");
+    }
+    hip_check(launch_rmsnorm(h_, final_norm_, c.eps, n, H, last_, s), "final norm");
+    LlmGemvArgs lm;
+    lm.X = last_ + (size_t)(n - 1) * H; lm.ldx = H; lm.rows = 1; lm.W = lm_head_; lm.bf16 = bf16_; lm.n_out = c.vocab; lm.k = H;
+    lm.Y0 = logits_; lm.ldy0 = c.vocab;
+    hip_check(launch_llm_gemv(lm, s), "lm head");
+}
+
+void LlmModel::forward(const uint32_t* ids, int n)
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (n < 1) throw std::runtime_error("forward needs at least one token");
+    if (cache_len_ + n > cache_cap_) throw std::runtime_error("context is full");
+    for (int i = 0; i < n; i += 8) {
+        const int m = std::min(8, n - i);
+        hip_check(hipMemcpyAsync(ids_, ids + i, (size_t)m * 4, hipMemcpyHostToDevice, stream_), "H2D ids");
+        pass(ids_, m, false);
+        cache_len_ += m;
+        last_rows_ = m;
+        hip_check(hipStreamSynchronize(stream_), "sync");  // ids_ is reused by the next block
+    }
+    hip_check(hipMemcpyAsync(pos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
+    hip_check(hipStreamSynchronize(stream_), "sync");
+}
+
+void LlmModel::last_hidden(float* out, int rows) const
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    hip_check(hipMemcpy(out, last_, (size_t)std::min(rows, last_rows_) * cfg_.hidden * sizeof(float), hipMemcpyDeviceToHost), "D2H hidden");
+}
+
+void LlmModel::logits_to_host(float* out) const
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    hip_check(hipMemcpy(out, logits_, (size_t)cfg_.vocab * sizeof(float), hipMemcpyDeviceToHost), "D2H logits");
+}
+
+void LlmModel::enqueue_argmax(bool record)
+{
+    hip_check(launch_argmax(logits_, cfg_.vocab, best_, token_, record ? hist_ : nullptr, record ? count_ : nullptr,
+                            record ? pos_ : nullptr, stream_), "argmax");
+}
+
+uint32_t LlmModel::argmax()
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    enqueue_argmax(false);
+    int32_t t = 0;
+    hip_check(hipMemcpyAsync(&t, token_, 4, hipMemcpyDeviceToHost, stream_), "D2H token");
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    return (uint32_t)t;
+}
+
+hipGraphExec_t LlmModel::step_graph()
+{
+    if (graph_) return graph_;
+    hipGraph_t graph = nullptr;
+    hip_check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture");
+    try {
+        pass(reinterpret_cast<const uint32_t*>(token_), 1, true);
+        enqueue_argmax(true);
+    } catch (...) {
+        (void)hipStreamEndCapture(stream_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    hip_check(hipStreamEndCapture(stream_, &graph), "end capture");
+    const hipError_t e = hipGraphInstantiate(&graph_, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    hip_check(e, "graph instantiate");
+    return graph_;
+}
+
+std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, size_t max_new_tokens, float repetition_penalty,
+                                         int no_repeat_ngram, const std::function<bool(uint32_t)>& on_token)
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (prompt.empty()) throw std::runtime_error("cannot generate from empty prompt");
+    if ((int)prompt.size() >= cache_cap_) throw std::runtime_error("prompt does not fit the context");
+    reset();
+    forward(prompt.data(), (int)prompt.size());
+    std::vector<uint32_t> out, all(prompt);
+    const auto is_stop = [&](uint32_t t) { return std::find(cfg_.eos_ids.begin(), cfg_.eos_ids.end(), t) != cfg_.eos_ids.end(); };
+    const size_t context_limit = (size_t)cache_cap_;
+
+    if (repetition_penalty != 1.0f || no_repeat_ngram > 0) {
+        // Logits processors touch the host copy of the logits every step (generator.rs:331-341): one pass per token.
+        std::vector<float> lg((size_t)cfg_.vocab);
+        for (size_t step = 0; step < max_new_tokens; ++step) {
+            if (all.size() >= context_limit) break;
+            logits_to_host(lg.data());
+            if (repetition_penalty != 1.0f)  // sampling.rs:207-219, once per occurrence
+                for (uint32_t t : all)
+                    if (t < lg.size()) lg[t] = lg[t] < 0.0f ? lg[t] * repetition_penalty : lg[t] / repetition_penalty;
+            if (no_repeat_ngram > 0 && all.size() + 1 >= (size_t)no_repeat_ngram) {  // sampling.rs:221-235
+                const size_t n = (size_t)no_repeat_ngram;
+                for (size_t i = 0; i + n <= all.size(); ++i)
+                    if (std::equal(all.begin() + (long)i, all.begin() + (long)(i + n - 1), all.end() - (long)(n - 1)) && all[i + n - 1] < lg.size())
+                        lg[all[i + n - 1]] = -INFINITY;
+            }
+            size_t best = 0;
+            for (size_t i = 1; i < lg.size(); ++i)
+                if (lg[i] >= lg[best]) best = i;  // last maximum (sampling.rs:83-88)
+            const uint32_t next = (uint32_t)best;
+            if (is_stop(next)) break;
+            all.push_back(next);
+            out.push_back(next);
+            if (on_token && !on_token(next)) break;
+            if (all.size() >= context_limit) break;
+            forward(&next, 1);
+        }
+        return out;
+    }
+
+    // Plain greedy: token, position and key count stay on the device; one graph replay per token, the host
+    // looks every few steps.  Tokens computed past a stop token / a stop request are discarded.
+    enqueue_argmax(true);
+    hip_check(hipMemcpyAsync(pos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
+    std::vector<int32_t> hist((size_t)hist_cap_);
+    size_t produced = 0, seen = 0;
+    bool done = max_new_tokens == 0;
+    auto drain = [&](size_t upto) {
+        for (; seen < upto && !done; ++seen) {
+            const uint32_t tok = (uint32_t)hist[seen];
+            if (all.size() >= context_limit || is_stop(tok)) {
+                done = true;
+                break;
+            }
+            all.push_back(tok);
+            out.push_back(tok);
+            if ((on_token && !on_token(tok)) || out.size() >= max_new_tokens) done = true;
+        }
+    };
+    hip_check(hipMemcpyAsync(hist.data(), hist_, sizeof(int32_t), hipMemcpyDeviceToHost, stream_), "D2H token");
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    produced = 1;
+    drain(1);
+    hipGraphExec_t exec = done ? nullptr : step_graph();
+    const size_t burst = on_token ? 4 : 16;
+    while (!done) {
+        size_t steps = std::min(burst, max_new_tokens - out.size());
+        steps = std::min(steps, (size_t)cache_cap_ - (size_t)cache_len_);
+        if (steps == 0) break;
+        for (size_t i = 0; i < steps; ++i) hip_check(hipGraphLaunch(exec, stream_), "graph launch");
+        hip_check(hipMemcpyAsync(hist.data() + produced, hist_ + produced, steps * sizeof(int32_t), hipMemcpyDeviceToHost, stream_), "D2H tokens");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        produced += steps;
+        cache_len_ += (int)steps;
+        drain(produced);
+    }
+    return out;
+}
+
+}  // namespace kjarni

@@ -1,0 +1,92 @@
+// LlmModel: a decoder-only transformer (Llama / Qwen2 layouts) resident in HBM with an f32 KV cache, and the
+// greedy generation loop.
+//
+//   config + tensor names   crates/kjarni-models/src/models/llama/config.rs:98-330, qwen/config.rs:80-275
+//   layer                   crates/kjarni-transformers/src/cpu/decoder/rope_decoder_layer.rs:18-41
+//   model forward           crates/kjarni-models/src/models/llama/cpu_decoder.rs:142-219
+//   generation loop         crates/kjarni-transformers/src/decoder/generator.rs:228-381 (DecodingStrategy::Greedy)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "encoder.h"
+
+namespace kjarni {
+
+struct LlmConfig {
+    std::string model_type;
+    int hidden = 0, layers = 0, heads = 0, kv_heads = 0, head_dim = 0, inter = 0, vocab = 0, max_pos = 0;
+    float eps = 1e-5f, rope_theta = 500000.0f;
+    bool tie_embeddings = true;
+    bool has_rope_scaling = false;
+    std::string rope_type;
+    float rope_factor = 1.0f, rope_low = 1.0f, rope_high = 4.0f;
+    int rope_original_max = 8192;
+    std::vector<uint32_t> eos_ids;
+    static LlmConfig from_json(const std::string& text);
+};
+
+class LlmModel {
+public:
+    // weights: 0 = as stored (BF16 stays bf16, everything else f32), 1 = f32, 2 = bf16 (f32 rounded to nearest even).
+    static std::unique_ptr<LlmModel> load(const std::string& dir, int device, int weights, int max_context);
+    ~LlmModel();
+    LlmModel(const LlmModel&) = delete;
+    LlmModel& operator=(const LlmModel&) = delete;
+
+    const LlmConfig& config() const { return cfg_; }
+    bool bf16() const { return bf16_; }
+    size_t weight_bytes() const { return weight_bytes_; }
+    int context() const { return cache_cap_; }
+    int cache_len() const { return cache_len_; }
+
+    void reset();  // empty KV cache
+    // Appends n tokens (any n: processed 8 rows at a time); the logits of the last position stay on the device.
+    void forward(const uint32_t* ids, int n);
+    void last_hidden(float* out, int rows) const;  // final-normed hidden states of the last (<= 8-row) pass
+    void logits_to_host(float* out) const;
+    uint32_t argmax();
+
+    // run_generation_loop with the Greedy strategy: returns the generated ids (stop token excluded).
+    std::vector<uint32_t> generate(const std::vector<uint32_t>& prompt, size_t max_new_tokens, float repetition_penalty,
+                                   int no_repeat_ngram, const std::function<bool(uint32_t)>& on_token);
+
+private:
+    LlmModel() = default;
+    void* upload_weight(const std::vector<float>& host);  // f32 or bf16 according to bf16_
+    float* upload_f32(const std::vector<float>& host);
+    float* dalloc(size_t floats);
+    void pass(const uint32_t* ids_dev, int n, bool device_pos);
+    void enqueue_argmax(bool record);
+    hipGraphExec_t step_graph();
+
+    struct Layer {
+        void *wqkv, *wo, *gate, *up, *down;
+        float *bqkv, *ln1, *ln2;
+        float *k_cache, *v_cache;
+    };
+    LlmConfig cfg_;
+    int device_ = 0;
+    bool bf16_ = false;
+    size_t weight_bytes_ = 0;
+    std::vector<void*> allocs_;
+    std::vector<Layer> layers_;
+    void *embed_ = nullptr, *lm_head_ = nullptr;
+    float *final_norm_ = nullptr, *cos_ = nullptr, *sin_ = nullptr;
+    // workspace
+    float *h_ = nullptr, *q_ = nullptr, *ctx_ = nullptr, *mid_ = nullptr, *last_ = nullptr, *logits_ = nullptr, *att_scratch_ = nullptr;
+    uint32_t* ids_ = nullptr;
+    int32_t *token_ = nullptr, *hist_ = nullptr;
+    int *pos_ = nullptr, *count_ = nullptr;
+    unsigned long long* best_ = nullptr;
+    int cache_len_ = 0, cache_cap_ = 0, last_rows_ = 0, hist_cap_ = 0, splits_ = 16;
+    hipStream_t stream_ = nullptr;
+    hipGraphExec_t graph_ = nullptr;
+};
+
+}  // namespace kjarni

@@ -1,0 +1,44 @@
+// Launchers of llm_kernels.hip (conventions of kernels.h: enqueue on `stream`, no allocation, no sync).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kjarni {
+
+// Y = epi(rmsnorm?(X) W^T + b) for up to 8 rows; W (and W2) are f32 or bf16 [n_out, k] row-major, k % 8 == 0.
+struct LlmGemvArgs {
+    const float* X = nullptr;
+    int64_t ldx = 0;
+    int rows = 0;
+    const float* gamma = nullptr;  // non-null: RMS-normalise the rows first
+    float eps = 0.0f;
+    const void* W = nullptr;
+    const void* W2 = nullptr;      // SwiGLU `up` matrix
+    int bf16 = 0;
+    int swiglu = 0;
+    const float* bias = nullptr;
+    const float* R = nullptr;      // non-null: + residual
+    int64_t ldr = 0;
+    int n_out = 0, k = 0;
+    int seg_q = 0, seg_kv = 0;     // seg_q > 0: [0,seg_q) -> Y0, then two seg_kv-wide segments -> Y1, Y2 at row row_off + r
+    float* Y0 = nullptr;
+    int64_t ldy0 = 0;
+    float *Y1 = nullptr, *Y2 = nullptr;
+    int64_t ldy12 = 0;
+    int row_off = 0;
+    const int* row_off_ptr = nullptr;
+};
+hipError_t launch_llm_gemv(const LlmGemvArgs& args, hipStream_t stream);
+
+// In-place RoPE on `rows` rows of [n_heads * head_dim]; cos/sin tables are [max_pos, head_dim/2].
+// at_cache_row: row r of the call lives at row (pos + r) of x (the KV cache), else at row r.
+hipError_t launch_rope(float* x, int64_t ldx, int rows, int n_heads, int head_dim, const float* cos_t, const float* sin_t, int pos,
+                       const int* pos_ptr, int at_cache_row, hipStream_t stream);
+hipError_t launch_rmsnorm(const float* x, const float* gamma, float eps, int rows, int hidden, float* out, hipStream_t stream);
+hipError_t launch_llm_embed(const uint32_t* ids, int n, int hidden, int vocab, const void* table, int bf16, float* out,
+                            hipStream_t stream);
+// argmax (last maximum wins); best_scratch: one zero-initialised u64 (re-zeroed by the call); history/count/pos may be null.
+hipError_t launch_argmax(const float* logits, int vocab, unsigned long long* best_scratch, int32_t* out, int32_t* history, int* count,
+                         int* pos, hipStream_t stream);
+
+}  // namespace kjarni

@@ -56,7 +56,8 @@ hipError_t launch_gemv_rows(const GemvArgs& args, hipStream_t stream);
 size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int splits);
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
                                    int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
-                                   int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream);
+                                   int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream,
+                                   int kv_group = 1);  // grouped-query attention: kv_group query heads per KV head
 // history/count/pos (device, may be null): append the token, advance the counters (graph-replayed steps).
 hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
                              int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
                                                                        const float* __restrict__ K, int64_t ldk,
                                                                        const float* __restrict__ V, int64_t ldv, int n_keys,
                                                                        const int* __restrict__ n_keys_ptr, int rows, int head_dim,
-                                                                       float scale, int causal, int splits,
+                                                                       float scale, int causal, int splits, int kv_group,
                                                                        float* __restrict__ part)
 {
     __shared__ float sc[ATT_MAX_CHUNK];
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
     const int lpk = head_dim >> 2;          // lanes per key (16 for d = 64)
     const int groups = 256 / lpk;
     const int g = tid / lpk, l = tid - g * lpk;
-    const int col = h * head_dim + l * 4;
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (int64_t)s * ldq + col);
+    const int col = (h / kv_group) * head_dim + l * 4;  // grouped-query attention: kv_group query heads share a KV head
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (int64_t)s * ldq + h * head_dim + l * 4);
 
     float mx = -INFINITY;
     for (int t = t0 + g; t < t1; t += groups) {
@@ -507,7 +507,8 @@ size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int sp
 
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
                                    int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
-                                   int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream)
+                                   int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream,
+                                   int kv_group)
 {
     if (rows <= 0 || (n_keys <= 0 && !n_keys_ptr)) return hipSuccess;
     if (head_dim > 128 || 256 % (head_dim / 4) != 0 || (head_dim & 3) || splits < 1) return hipErrorInvalidValue;
@@ -515,7 +516,7 @@ hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const 
     if ((worst + splits - 1) / splits > ATT_MAX_CHUNK) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attention_partial_kernel, dim3((unsigned)heads, (unsigned)splits, (unsigned)rows), dim3(256), 0, stream,
                        q, ldq, K, ldk, V, ldv, n_keys, n_keys_ptr, rows, head_dim, 1.0f / sqrtf((float)head_dim), causal_base, splits,
-                       scratch);
+                       kv_group < 1 ? 1 : kv_group, scratch);
     hipLaunchKernelGGL(decode_attention_combine_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(128), 0, stream, scratch, heads,
                        splits, head_dim, ctx, ldc);
     return hipGetLastError();

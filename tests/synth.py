@@ -317,3 +317,71 @@ def synthetic_audio(seconds: float, seed: int = 0, rate: int = 16000) -> np.ndar
         0.15 * np.sin(2 * np.pi * (300 + 900 * t / max(seconds, 1e-3)) * t) + 0.05 * rng.standard_normal(n)
     env = 0.6 + 0.4 * np.sin(2 * np.pi * 0.7 * t)
     return (x * env).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- decoder-only LLMs
+LLAMA_TEST = dict(model_type="llama", hidden_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                  intermediate_size=128, vocab_size=320, max_position_embeddings=256, rms_norm_eps=1e-5, rope_theta=500000.0,
+                  tie_word_embeddings=True, bos_token_id=1, eos_token_id=[2, 3], hidden_act="silu",
+                  rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                    original_max_position_embeddings=64))
+QWEN_TEST = dict(model_type="qwen2", hidden_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=1,
+                 intermediate_size=96, vocab_size=300, max_position_embeddings=128, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                 tie_word_embeddings=False, bos_token_id=1, eos_token_id=2, hidden_act="silu")
+# Llama-3.2-1B-Instruct geometry (registry.rs:517-530): the shape BASELINE.json configs[4] ("small LLM") is measured on
+LLAMA_1B = dict(model_type="llama", hidden_size=2048, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8,
+                intermediate_size=8192, vocab_size=128256, max_position_embeddings=131072, rms_norm_eps=1e-5, rope_theta=500000.0,
+                tie_word_embeddings=True, bos_token_id=128000, eos_token_id=[128001, 128008, 128009], hidden_act="silu",
+                head_dim=64, torch_dtype="bfloat16",
+                rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                  original_max_position_embeddings=8192))
+
+
+def llm_tensors(cfg: dict, seed: int = 0, std: float = 0.05, bf16: bool = False) -> Dict[str, np.ndarray]:
+    """Random-init tensors with the HF names of llama/config.rs:283-330 (q/k/v biases for qwen2)."""
+    rng = np.random.default_rng(seed)
+    H, L, I = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"]
+    d = cfg.get("head_dim") or H // cfg["num_attention_heads"]
+    kv = cfg["num_key_value_heads"] * d
+
+    def w(*shape, s=std):
+        a = (rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
+        if bf16:  # values exactly representable in bf16, so f32 and bf16 storage hold the same numbers
+            u = a.view(np.uint32)
+            a = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+        return a
+
+    t: Dict[str, np.ndarray] = {"model.embed_tokens.weight": w(cfg["vocab_size"], H, s=0.1),
+                                "model.norm.weight": (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)}
+    if not cfg.get("tie_word_embeddings", True):
+        t["lm_head.weight"] = w(cfg["vocab_size"], H, s=0.1)
+    for i in range(L):
+        p = f"model.layers.{i}"
+        t[f"{p}.self_attn.q_proj.weight"], t[f"{p}.self_attn.k_proj.weight"] = w(H, H), w(kv, H)
+        t[f"{p}.self_attn.v_proj.weight"], t[f"{p}.self_attn.o_proj.weight"] = w(kv, H), w(H, H)
+        if cfg["model_type"] == "qwen2":
+            t[f"{p}.self_attn.q_proj.bias"], t[f"{p}.self_attn.k_proj.bias"] = w(H, s=0.1).astype(np.float32), w(kv, s=0.1)
+            t[f"{p}.self_attn.v_proj.bias"] = w(kv, s=0.1)
+        t[f"{p}.mlp.gate_proj.weight"], t[f"{p}.mlp.up_proj.weight"], t[f"{p}.mlp.down_proj.weight"] = w(I, H), w(I, H), w(H, I)
+        t[f"{p}.input_layernorm.weight"] = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+        t[f"{p}.post_attention_layernorm.weight"] = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+    return t
+
+
+def llm_model(path: str, base: dict, seed: int = 0, bf16_values: bool = False, store_bf16: bool = False, **over):
+    """Writes config.json + model.safetensors.  store_bf16: the 2-D weights are stored as BF16 tensors."""
+    cfg = dict(base)
+    cfg.update(over)
+    t = llm_tensors(cfg, seed, bf16=bf16_values or store_bf16)
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    if store_bf16:
+        import torch
+        from safetensors.torch import save_file
+        save_file({k: (torch.from_numpy(v).to(torch.bfloat16) if v.ndim == 2 else torch.from_numpy(v)) for k, v in t.items()},
+                  os.path.join(path, "model.safetensors"))
+    else:
+        from safetensors.numpy import save_file
+        save_file({k: np.ascontiguousarray(v) for k, v in t.items()}, os.path.join(path, "model.safetensors"))
+    return cfg, t

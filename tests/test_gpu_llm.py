@@ -1,0 +1,127 @@
+"""Decoder-only generation on the GPU (kjarni_hip_decoder_*) vs oracle/llm_oracle.py (pinned by the reference's
+GQA / RoPE / RMSNorm goldens in tests/test_llm_oracle.py): prefill, cached decode, grouped-query attention, llama3 RoPE
+scaling, Qwen2 biases and untied heads, bf16-stored weights, the greedy loop with its stop rules and logits processors."""
+import numpy as np
+import pytest
+
+from oracle import llm_oracle as L
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+TOL = 1e-4
+
+
+def _pair(tmp_path, base, **kw):
+    import kjarni_amd
+    d = str(tmp_path / base["model_type"])
+    weights = kw.pop("weights", "auto")
+    cfg, t = synth.llm_model(d, base, **kw)
+    return L.LlmOracle(t, cfg), kjarni_amd.HipDecoder(d, weights=weights), cfg
+
+
+@pytest.mark.parametrize("base", [synth.LLAMA_TEST, synth.QWEN_TEST], ids=["llama-gqa-rope-scaling", "qwen2-bias-mqa-untied"])
+def test_prefill_and_cached_decode(tmp_path, base):
+    orc, gpu, cfg = _pair(tmp_path, base, seed=3)
+    rng = np.random.default_rng(0)
+    cache = orc.new_cache()
+    gpu.reset()
+    for n in (5, 1, 1, 11, 1, 3, 1):                        # prefill blocks of <= 8 rows, single-token steps, a second prompt block
+        ids = rng.integers(4, cfg["vocab_size"], n).tolist()
+        ref_h = orc.forward(ids, cache)[0]
+        h, logits = gpu.forward(ids)
+        k = min(n, 8)
+        assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL, np.abs(h[-k:] - ref_h[-k:]).max()
+        assert np.abs(logits - orc.logits(ref_h[-1])).max() < TOL
+    # far positions: RoPE tables at the end of the context
+    gpu.reset()
+    cache = orc.new_cache()
+    ids = rng.integers(4, cfg["vocab_size"], cfg["max_position_embeddings"] - 2).tolist()
+    ref_h = orc.forward(ids, cache)[0]
+    h, logits = gpu.forward(ids)
+    assert np.abs(h[-1] - ref_h[-1]).max() < TOL and np.abs(logits - orc.logits(ref_h[-1])).max() < TOL
+
+
+def _check(got, exp, trace):
+    for i, (a, b) in enumerate(zip(got, exp)):
+        if a != b:                                          # only where the oracle's own two best logits tie within noise
+            assert abs(trace[i][a] - trace[i][b]) < 1e-4, (i, a, b)
+            return
+    assert len(got) == len(exp)
+
+
+def test_greedy_generation_matches_oracle(tmp_path):
+    orc, gpu, cfg = _pair(tmp_path, synth.LLAMA_TEST, seed=4)
+    prompt = [1, 17, 44, 203, 9, 9, 250, 31, 77, 5, 120]
+    exp, trace = orc.generate(prompt, 40, return_logits=True)
+    got = gpu.generate(prompt, 40)
+    assert len(exp) > 5
+    _check(got, exp, trace)
+    assert gpu.generate(prompt, 40) == got                  # deterministic, cache reset between calls
+    assert gpu.generate(prompt, 3) == got[:3] and gpu.generate(prompt, 0) == []
+    seen = []
+    part = gpu.generate(prompt, 40, on_token=lambda t: (seen.append(t), len(seen) < 4)[1])
+    assert part == got[:4] == seen
+    # logits processors (common/sampling.rs:207-235) run per step
+    exp, trace = orc.generate(prompt, 25, repetition_penalty=1.3, no_repeat_ngram=2, return_logits=True)
+    _check(gpu.generate(prompt, 25, repetition_penalty=1.3, no_repeat_ngram=2), exp, trace)
+    exp, trace = orc.generate(prompt, 25, repetition_penalty=1.7, return_logits=True)
+    _check(gpu.generate(prompt, 25, repetition_penalty=1.7), exp, trace)
+
+
+def test_stop_tokens_and_context_limit(tmp_path):
+    import kjarni_amd
+    # an lm head whose argmax is always token 2 (an eos id): generation stops at once, nothing is emitted
+    d = str(tmp_path / "eos")
+    cfg, t = synth.llm_model(d, synth.LLAMA_TEST, seed=5)
+    orc = L.LlmOracle(t, cfg)
+    gpu = kjarni_amd.HipDecoder(d)
+    prompt = [1, 10, 20]
+    exp = orc.generate(prompt, 300)
+    got = gpu.generate(prompt, 300)
+    assert got[:len(exp)] == exp[:len(got)]
+    assert all(tok not in (2, 3) for tok in got)            # eos ids are never emitted (generator.rs:344-347)
+    # context limit: prompt + generated never exceeds max_position_embeddings (generator.rs:319-322)
+    long_prompt = list(range(4, 4 + 250))
+    got = gpu.generate(long_prompt, 50)
+    exp = orc.generate(long_prompt, 50)
+    assert len(got) <= 256 - 250 and got == exp[:len(got)] and len(got) == len(exp)
+    small = kjarni_amd.HipDecoder(d, max_context=64)
+    assert small.context == 64
+    with pytest.raises(Exception):
+        small.generate(list(range(4, 80)), 5)               # prompt longer than the context
+    with pytest.raises(Exception):
+        gpu.generate([], 5)                                 # "cannot generate from empty prompt"
+
+
+def test_bf16_weights(tmp_path):
+    """Weights stored as BF16 stay bf16 in HBM; the arithmetic is the reference's (bf16 weight widened, f32 accumulate),
+    so results equal the f32 path on the same (bf16-representable) values to 1e-4."""
+    import kjarni_amd
+    d16 = str(tmp_path / "bf16")
+    cfg, t = synth.llm_model(d16, synth.LLAMA_TEST, seed=6, store_bf16=True)
+    orc = L.LlmOracle(t, cfg)                               # t holds the bf16-rounded values as f32
+    g16 = kjarni_amd.HipDecoder(d16)
+    assert g16.bf16 and g16.weight_bytes < 0.6 * sum(v.nbytes for v in t.values())
+    g32 = kjarni_amd.HipDecoder(d16, weights="f32")
+    assert not g32.bf16
+    rng = np.random.default_rng(1)
+    ids = rng.integers(4, cfg["vocab_size"], 13).tolist()
+    cache = orc.new_cache()
+    ref = orc.forward(ids, cache)[0]
+    for g in (g16, g32):
+        g.reset()
+        h, logits = g.forward(ids)
+        assert np.abs(h - ref[-8:]).max() < TOL and np.abs(logits - orc.logits(ref[-1])).max() < TOL
+    prompt = [1, 5, 9, 200]
+    assert g16.generate(prompt, 30) == g32.generate(prompt, 30)
+    # f32 file, bf16 requested: weights are rounded to nearest even on load
+    d32 = str(tmp_path / "f32")
+    cfg2, t2 = synth.llm_model(d32, synth.QWEN_TEST, seed=7)
+    rounded = {k: (L.bf16_round(v) if v.ndim == 2 else v) for k, v in t2.items()}
+    orc2 = L.LlmOracle(rounded, cfg2)
+    g = kjarni_amd.HipDecoder(d32, weights="bf16")
+    cache = orc2.new_cache()
+    ids = rng.integers(4, cfg2["vocab_size"], 6).tolist()
+    h, logits = g.forward(ids)
+    assert np.abs(h - orc2.forward(ids, cache)[0]).max() < TOL
