@@ -305,7 +305,8 @@ KjarniErrorCode kjarni_hip_decoder_dims(const KjarniHipDecoder* decoder, int32_t
                                         int32_t* context, int32_t* weights_bf16, uint64_t* weight_bytes);
 KjarniErrorCode kjarni_hip_decoder_reset(KjarniHipDecoder* decoder); /* empty KV cache */
 /* CpuDecoder::forward + final norm + lm head (llama/cpu_decoder.rs:196-219): appends n tokens to the cache;
- * hidden_out f32 [min(n,8) last rows, hidden] (final-normed), logits_out f32 [vocab] of the last position. */
+ * the prompt is processed 8 rows at a time and hidden_out receives the final-normed rows of the LAST block,
+ * f32 [((n-1) mod 8) + 1, hidden]; logits_out f32 [vocab] of the last position.  Either may be NULL. */
 KjarniErrorCode kjarni_hip_decoder_forward(KjarniHipDecoder* decoder, const uint32_t* ids, int32_t n, float* hidden_out,
                                            float* logits_out);
 /* run_generation_loop with DecodingStrategy::Greedy (crates/kjarni-transformers/src/decoder/generator.rs:228-381):

@@ -31,7 +31,7 @@ class HipDecoder:
 
     def forward(self, ids: Sequence[int], fetch: bool = True):
         a = np.ascontiguousarray(ids, np.uint32)
-        hidden = np.empty((min(a.size, 8), self.hidden), np.float32) if fetch else None
+        hidden = np.empty(((a.size - 1) % 8 + 1, self.hidden), np.float32) if fetch else None   # rows of the last 8-row block
         logits = np.empty(self.vocab, np.float32) if fetch else None
         f = lambda x: x.ctypes.data_as(C.POINTER(C.c_float)) if x is not None else None  # noqa: E731
         check_error(lib().kjarni_hip_decoder_forward(self._h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size, f(hidden), f(logits)))

@@ -30,7 +30,7 @@ def test_prefill_and_cached_decode(tmp_path, base):
         ids = rng.integers(4, cfg["vocab_size"], n).tolist()
         ref_h = orc.forward(ids, cache)[0]
         h, logits = gpu.forward(ids)
-        k = min(n, 8)
+        k = (n - 1) % 8 + 1                                   # the hook returns the rows of the last 8-row block
         assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL, np.abs(h[-k:] - ref_h[-k:]).max()
         assert np.abs(logits - orc.logits(ref_h[-1])).max() < TOL
     # far positions: RoPE tables at the end of the context
@@ -112,7 +112,7 @@ def test_bf16_weights(tmp_path):
     for g in (g16, g32):
         g.reset()
         h, logits = g.forward(ids)
-        assert np.abs(h - ref[-8:]).max() < TOL and np.abs(logits - orc.logits(ref[-1])).max() < TOL
+        assert np.abs(h - ref[-5:]).max() < TOL and np.abs(logits - orc.logits(ref[-1])).max() < TOL
     prompt = [1, 5, 9, 200]
     assert g16.generate(prompt, 30) == g32.generate(prompt, 30)
     # f32 file, bf16 requested: weights are rounded to nearest even on load
