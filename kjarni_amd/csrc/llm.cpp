@@ -247,6 +247,10 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
     const int* pp = device_pos ? pos_ : nullptr;
     hip_check(launch_llm_embed(ids_dev, n, H, c.vocab, embed_, bf16_ ? 1 : 0, h_, s), "embed");
     for (const Layer& L : layers_) {
+        if (n == 1) {  // decode step: norm + projection + rotation in one launch
+            hip_check(launch_llm_qkv_rope(h_, L.ln1, c.eps, L.wqkv, bf16_ ? 1 : 0, L.bqkv, H, c.heads, c.kv_heads, d, cos_, sin_, q_,
+                                          L.k_cache, L.v_cache, cache_len_, pp, s), "norm + qkv + rope");
+        } else {
         LlmGemvArgs a;  // RMSNorm + Q | K | V (decoder_attention.rs:61-82): K / V rows land in the cache
         a.X = h_; a.ldx = H; a.rows = n; a.gamma = L.ln1; a.eps = c.eps; a.W = L.wqkv; a.bf16 = bf16_; a.bias = L.bqkv;
         a.n_out = H + 2 * kv; a.k = H; a.seg_q = H; a.seg_kv = kv; a.Y0 = q_; a.ldy0 = H; a.Y1 = L.k_cache; a.Y2 = L.v_cache; a.ldy12 = kv;
@@ -254,6 +258,7 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
         hip_check(launch_llm_gemv(a, s), "norm + qkv");
         hip_check(launch_rope(q_, H, n, c.heads, d, cos_, sin_, cache_len_, pp, 0, s), "rope q");
         hip_check(launch_rope(L.k_cache, kv, n, c.kv_heads, d, cos_, sin_, cache_len_, pp, 1, s), "rope k");
+        }
         hip_check(launch_decode_attention(q_, H, n, L.k_cache, kv, L.v_cache, kv, cache_len_ + n, pp, cache_cap_, c.heads, d, cache_len_,
                                           splits_, att_scratch_, ctx_, H, s, c.heads / c.kv_heads), "attention");
         LlmGemvArgs o;

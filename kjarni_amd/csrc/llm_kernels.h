@@ -29,6 +29,13 @@ struct LlmGemvArgs {
     const int* row_off_ptr = nullptr;
 };
 hipError_t launch_llm_gemv(const LlmGemvArgs& args, hipStream_t stream);
+void set_llm_gemv_variant(int variant);  // 0 = default (single-row kernel for rows == 1), 1 = always the multi-row kernel
+
+// One new token: RMSNorm + Q|K|V projection + RoPE in one launch; Q -> Q[n_heads*head_dim], K / V -> row `pos`
+// (or *pos_ptr) of the caches [*, n_kv_heads*head_dim].  W is the fused [Q;K;V] matrix.
+hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, const void* W, int bf16, const float* bias, int k,
+                               int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
+                               float* Vc, int pos, const int* pos_ptr, hipStream_t stream);
 
 // In-place RoPE on `rows` rows of [n_heads * head_dim]; cos/sin tables are [max_pos, head_dim/2].
 // at_cache_row: row r of the call lives at row (pos + r) of x (the KV cache), else at row r.

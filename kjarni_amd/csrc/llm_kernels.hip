@@ -16,6 +16,7 @@ namespace kjarni {
 namespace {
 
 constexpr int LLM_MAX_ROWS = 8;
+int g_llm_gemv_variant = 0;  // 1 = always the multi-row kernel (tests / measurements)
 
 
 struct F8 {
@@ -131,6 +132,207 @@ __global__ __launch_bounds__(256) void llm_gemv_kernel(const float* __restrict__
     }
 }
 
+// Single-row variant (the decode step).  The input row is normalised once per WORKGROUP into LDS (the
+// multi-row kernel re-reads it from L2 for every output column, which costs more L2 bandwidth than the bf16
+// weights cost HBM bandwidth); each wave then streams OPW weight rows, with all of a row's 16-byte loads in
+// flight before the first FMA.
+constexpr int G1_OPW = 2;        // outputs per wave
+constexpr int G1_MAX_K = 16384;  // 64 KiB of LDS
+
+template <typename WT, int EPI, bool NORM>
+__global__ __launch_bounds__(256) void llm_gemv1_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
+                                                        const WT* __restrict__ W, const WT* __restrict__ W2,
+                                                        const float* __restrict__ bias, const float* __restrict__ R, int n_out,
+                                                        int k, int seg_q, int seg_kv, float* __restrict__ Y0,
+                                                        float* __restrict__ Y1, float* __restrict__ Y2, int64_t ldy12, int row_off,
+                                                        const int* __restrict__ row_off_ptr)
+{
+    extern __shared__ float xs[];  // [k]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k8 = k >> 3;
+    float rms = 1.0f;
+    if (NORM) {
+        float s = 0.0f;
+        for (int i = tid; i < k8; i += 256) {
+            const F8 x = load8(X, i);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s = fmaf(x.v[c], x.v[c], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)k + eps);
+    }
+    for (int i = tid; i < k8; i += 256) {
+        F8 x = load8(X, i);
+        if (NORM) {
+            const F8 g = load8(gamma, i);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x.v[c] = (x.v[c] / rms) * g.v[c];
+        }
+        *reinterpret_cast<f32x4*>(xs + i * 8) = f32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
+        *reinterpret_cast<f32x4*>(xs + i * 8 + 4) = f32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
+    }
+    __syncthreads();
+
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * G1_OPW;
+#pragma unroll
+    for (int j = 0; j < G1_OPW; ++j) {
+        const int64_t n = n0 + j;
+        if (n >= n_out) break;
+        const WT* w_row = W + n * (int64_t)k;
+        const WT* w2_row = EPI == LE_SWIGLU ? W2 + n * (int64_t)k : nullptr;
+        float acc = 0.0f, acc2 = 0.0f;
+        for (int i0 = lane; i0 < k8; i0 += 256) {  // four chunks per lane per trip: 4 (8 with SwiGLU) loads in flight
+            F8 w[4], u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * 64;
+                if (i < k8) {
+                    w[q] = load8(w_row, i);
+                    if (EPI == LE_SWIGLU) u[q] = load8(w2_row, i);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * 64;
+                if (i < k8) {
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 8);
+                    const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + i * 8 + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc = fmaf(xa[c], w[q].v[c], acc);
+                        acc = fmaf(xb[c], w[q].v[4 + c], acc);
+                        if (EPI == LE_SWIGLU) {
+                            acc2 = fmaf(xa[c], u[q].v[c], acc2);
+                            acc2 = fmaf(xb[c], u[q].v[4 + c], acc2);
+                        }
+                    }
+                }
+            }
+        }
+        float v = wave_sum(acc) + (bias ? bias[n] : 0.0f);
+        if (EPI == LE_SWIGLU) {
+            const float up = wave_sum(acc2);
+            v = (v / (1.0f + expf(-v))) * up;
+        }
+        if (EPI == LE_RESIDUAL) v += R[n];
+        if (lane == 0) {
+            int which = 0;
+            int64_t col = n;
+            if (seg_q > 0 && n >= seg_q) {
+                which = 1 + (int)((n - seg_q) / seg_kv);
+                col = (n - seg_q) - (int64_t)(which - 1) * seg_kv;
+            }
+            float* Y = which == 0 ? Y0 : (which == 1 ? Y1 : Y2);
+            const int64_t r0 = which == 0 ? 0 : (row_off_ptr ? *row_off_ptr : row_off);
+            Y[which == 0 ? col : r0 * ldy12 + col] = v;
+        }
+    }
+}
+
+// Decode-step fusion of RMSNorm + Q|K|V projection + RoPE (decoder_attention.rs:61-97 for one new token): the
+// normalised row sits in LDS as above; a wave owns the PAIR of output columns (i, i + d/2) of one head, so it can
+// rotate them itself (rope/mod.rs:156-176) before Q goes to scratch and K to its cache row; V columns go in pairs
+// of neighbours without rotation.
+template <typename WT>
+__global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
+                                                           const WT* __restrict__ W, const float* __restrict__ bias, int k,
+                                                           int n_heads, int n_kv_heads, int head_dim, const float* __restrict__ cos_t,
+                                                           const float* __restrict__ sin_t, float* __restrict__ Q,
+                                                           float* __restrict__ Kc, float* __restrict__ Vc, int pos,
+                                                           const int* __restrict__ pos_ptr)
+{
+    extern __shared__ float xs[];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k8 = k >> 3, half = head_dim >> 1;
+    float s = 0.0f;
+    for (int i = tid; i < k8; i += 256) {
+        const F8 x = load8(X, i);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s = fmaf(x.v[c], x.v[c], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)k + eps);
+    for (int i = tid; i < k8; i += 256) {
+        F8 x = load8(X, i);
+        const F8 g = load8(gamma, i);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x.v[c] = (x.v[c] / rms) * g.v[c];
+        *reinterpret_cast<f32x4*>(xs + i * 8) = f32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
+        *reinterpret_cast<f32x4*>(xs + i * 8 + 4) = f32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
+    }
+    __syncthreads();
+
+    const int q_dim = n_heads * head_dim, kv_dim = n_kv_heads * head_dim;
+    const int q_tasks = q_dim / 2, k_tasks = kv_dim / 2, v_tasks = kv_dim / 2;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= q_tasks + k_tasks + v_tasks) return;
+    int n_a, n_b;  // the two output columns (rows of W) of this wave
+    int kind;      // 0 = Q, 1 = K, 2 = V
+    if (task < q_tasks + k_tasks) {
+        kind = task < q_tasks ? 0 : 1;
+        const int t = kind == 0 ? task : task - q_tasks;
+        const int head = t / half, i = t - head * half;
+        n_a = (kind == 0 ? 0 : q_dim) + head * head_dim + i;
+        n_b = n_a + half;
+    } else {
+        kind = 2;
+        n_a = q_dim + kv_dim + 2 * (task - q_tasks - k_tasks);
+        n_b = n_a + 1;
+    }
+    const WT* wa = W + (int64_t)n_a * k;
+    const WT* wb = W + (int64_t)n_b * k;
+    float acc_a = 0.0f, acc_b = 0.0f;
+    for (int i0 = lane; i0 < k8; i0 += 256) {
+        F8 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * 64;
+            if (i < k8) {
+                a[q] = load8(wa, i);
+                b[q] = load8(wb, i);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * 64;
+            if (i < k8) {
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 8);
+                const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + i * 8 + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc_a = fmaf(xa[c], a[q].v[c], acc_a);
+                    acc_a = fmaf(xb[c], a[q].v[4 + c], acc_a);
+                    acc_b = fmaf(xa[c], b[q].v[c], acc_b);
+                    acc_b = fmaf(xb[c], b[q].v[4 + c], acc_b);
+                }
+            }
+        }
+    }
+    float va = wave_sum(acc_a) + (bias ? bias[n_a] : 0.0f);
+    float vb = wave_sum(acc_b) + (bias ? bias[n_b] : 0.0f);
+    if (lane != 0) return;
+    const int p = pos_ptr ? *pos_ptr : pos;
+    if (kind == 2) {
+        const int col = n_a - q_dim - kv_dim;
+        Vc[(int64_t)p * kv_dim + col] = va;
+        Vc[(int64_t)p * kv_dim + col + 1] = vb;
+        return;
+    }
+    const int col = kind == 0 ? n_a : n_a - q_dim;
+    const int i = col % head_dim;  // < half
+    const float c = cos_t[(int64_t)p * half + i], sn = sin_t[(int64_t)p * half + i];
+    const float ra = va * c - vb * sn, rb = va * sn + vb * c;
+    float* out = kind == 0 ? Q : Kc + (int64_t)p * kv_dim;
+    out[col] = ra;
+    out[col + half] = rb;
+}
+
 // In-place rotation of `rows` rows of [n_heads * d] (rope/mod.rs:156-176): pairs (i, i + d/2), position =
 // (*pos_ptr | pos) + row; x may start at row (*row_off_ptr | row_off) of a cache.
 __global__ __launch_bounds__(256) void rope_kernel(float* __restrict__ x, int64_t ldx, int rows, int n_heads, int head_dim,
@@ -232,14 +434,43 @@ __global__ void argmax_finalize_kernel(unsigned long long* __restrict__ best, in
 template <typename WT>
 static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
 {
-    const dim3 grid((unsigned)((a.n_out + 3) / 4));
     const WT* W = static_cast<const WT*>(a.W);
     const WT* W2 = static_cast<const WT*>(a.W2);
+    const bool norm = a.gamma != nullptr;
+    // Staging the row in LDS pays when it also has to be normalised (otherwise every wave redoes the statistics); plain
+    // projections keep the one-wave-per-column kernel, whose 4x larger grid hides latency better.
+    if (a.rows == 1 && norm && a.k <= G1_MAX_K && g_llm_gemv_variant == 0) {
+        const dim3 grid1((unsigned)((a.n_out + 4 * G1_OPW - 1) / (4 * G1_OPW)));
+        const size_t lds = (size_t)a.k * sizeof(float);
+#define KJ_LLM1(EPI, NORM)                                                                                                            \
+    do {                                                                                                                              \
+        auto kern = llm_gemv1_kernel<WT, EPI, NORM>;                                                                                  \
+        if (lds > 48 * 1024) {                                                                                                        \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                     (int)lds);                                                                       \
+            if (e != hipSuccess) return e;                                                                                            \
+        }                                                                                                                             \
+        hipLaunchKernelGGL(kern, grid1, dim3(256), lds, stream, a.X, a.gamma, a.eps, W, W2, a.bias, a.R, a.n_out, a.k, a.seg_q,       \
+                           a.seg_kv, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr);                                            \
+    } while (0)
+        if (a.swiglu) {
+            if (norm) KJ_LLM1(LE_SWIGLU, true);
+            else KJ_LLM1(LE_SWIGLU, false);
+        } else if (a.R) {
+            if (norm) KJ_LLM1(LE_RESIDUAL, true);
+            else KJ_LLM1(LE_RESIDUAL, false);
+        } else {
+            if (norm) KJ_LLM1(LE_NONE, true);
+            else KJ_LLM1(LE_NONE, false);
+        }
+#undef KJ_LLM1
+        return hipGetLastError();
+    }
+    const dim3 grid((unsigned)((a.n_out + 3) / 4));
 #define KJ_LLM(EPI, NORM)                                                                                                       \
     hipLaunchKernelGGL((llm_gemv_kernel<WT, EPI, NORM>), grid, dim3(256), 0, stream, a.X, a.ldx, a.rows, a.gamma, a.eps, W, W2,  \
                        a.bias, a.R, a.ldr, a.n_out, a.k, a.seg_q, a.seg_kv, a.Y0, a.ldy0, a.Y1, a.Y2, a.ldy12, a.row_off,       \
                        a.row_off_ptr)
-    const bool norm = a.gamma != nullptr;
     if (a.swiglu) {
         if (norm) KJ_LLM(LE_SWIGLU, true);
         else KJ_LLM(LE_SWIGLU, false);
@@ -251,6 +482,36 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
         else KJ_LLM(LE_NONE, false);
     }
 #undef KJ_LLM
+    return hipGetLastError();
+}
+
+void set_llm_gemv_variant(int v) { g_llm_gemv_variant = v; }
+
+hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, const void* W, int bf16, const float* bias, int k,
+                               int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
+                               float* Vc, int pos, const int* pos_ptr, hipStream_t stream)
+{
+    if ((k & 7) || k > G1_MAX_K || (head_dim & 1)) return hipErrorInvalidValue;
+    const int tasks = (n_heads * head_dim + 2 * n_kv_heads * head_dim) / 2;
+    const dim3 grid((unsigned)((tasks + 3) / 4));
+    const size_t lds = (size_t)k * sizeof(float);
+    if (bf16) {
+        auto kern = llm_qkv_rope_kernel<uint16_t>;
+        if (lds > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, X, gamma, eps, static_cast<const uint16_t*>(W), bias, k, n_heads, n_kv_heads,
+                           head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr);
+    } else {
+        auto kern = llm_qkv_rope_kernel<float>;
+        if (lds > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, X, gamma, eps, static_cast<const float*>(W), bias, k, n_heads, n_kv_heads,
+                           head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr);
+    }
     return hipGetLastError();
 }
 

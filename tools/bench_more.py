@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The other measurements SURVEY.md section 8(d) asks for, next to bench.py's headline line.
 
-    python tools/bench_more.py [rerank] [scan] [ragged] [host] [strings] [indexer] [whisper]   (default: all)
+    python tools/bench_more.py [rerank] [scan] [ragged] [host] [strings] [indexer] [whisper] [llm]   (default: all)
 
 One JSON line per measurement (1 GPU; the N > 1 driver is bench.py):
   rerank   BASELINE.json configs[2] on one GPU: 100 000 synthetic (query, doc) pairs, S = 128, fp32,
@@ -16,6 +16,8 @@ One JSON line per measurement (1 GPU; the N > 1 driver is bench.py):
   whisper  BASELINE.json configs[3]: Whisper-base shaped model (random init), 30 s of synthetic audio: log-mel,
            conv stem + encoder, greedy decode of 448 tokens; per-stage ms, x real time, and the CPU restatement
            (oracle) timed on a bounded sample of the same work.
+  llm      BASELINE.json configs[4]: Llama-3.2-1B-shaped decoder (random init), weights bf16 in HBM, f32 KV cache:
+           prefill of a 128-token prompt and greedy decode of 256 tokens; tokens/s and the weight stream vs HBM peak.
 """
 import json
 import os
@@ -48,7 +50,7 @@ def timed(fn, sync, steps, warmup):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer", "whisper"}
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer", "whisper", "llm"}
     import numpy as np
     import torch
 
@@ -252,6 +254,56 @@ def main():
         res["cpu_baseline"] = {"value": round(30.0 / c_total, 3), "unit": "x real time", "cores": int(cores), "kind": "port",
                                "sample": f"oracle: log-mel {c_mel:.2f} s (vectorised DFT, not the reference's scalar O(n^2) loop), "
                                          f"encoder {c_enc:.2f} s, 16 decoder steps {c_dec16:.2f} s extrapolated to {len(ids)} tokens"}
+        emit(res)
+
+    if "llm" in which:
+        d = os.path.join(tmp, "llama-1b")
+        cfg_l, t_l = synth.llm_model(d, synth.LLAMA_1B, seed=0, store_bf16=True, max_position_embeddings=4096, eos_token_id=[])
+        dec = kjarni_amd.HipDecoder(d, max_context=2048)
+        prompt = np.random.default_rng(0).integers(1000, 100000, 128).tolist()
+        n_new = 256
+        dec.generate(prompt, 8)                                               # warm-up (graph capture)
+        t0 = time.perf_counter()
+        dec.reset()
+        dec.forward(prompt, fetch=False)
+        t_prefill = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out = dec.generate(prompt, n_new)
+        t_total = time.perf_counter() - t0
+        t_dec = t_total - t_prefill
+        kv_dim = cfg_l["num_key_value_heads"] * 64
+        kv_bytes = 2 * cfg_l["num_hidden_layers"] * kv_dim * 4 * (128 + n_new / 2)   # average cache read per step
+        per_tok = dec.weight_bytes + kv_bytes
+        res = {"metric": "tokens/sec greedy decode, Llama-3.2-1B shape, bf16 weights, batch 1", "value": round(len(out) / t_dec, 1),
+               "unit": "tokens/s", "n_gpus": 1, "dtype": "bf16 weights, f32 activations/accumulate/KV", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[4]: Llama-3.2-1B geometry (2048 hidden, 16 layers, 32/8 heads, vocab 128256), "
+                                      f"random init, 128-token prompt, {len(out)} generated tokens"},
+               "ms_prefill_128": round(t_prefill * 1e3, 2), "prefill_tokens_per_s": round(128 / t_prefill, 1),
+               "ms_per_token": round(t_dec * 1e3 / len(out), 4), "weight_bytes": dec.weight_bytes,
+               "roofline": {"kernel": "llm_gemv_kernel (weight stream) + decode_attention", "bound": "hbm",
+                            "achieved": round(per_tok * len(out) / t_dec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(per_tok * len(out) / t_dec / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                            "algorithmic_bytes_per_token": int(per_tok)}}
+        from oracle import llm_oracle as LO
+        from oracle import oracle as O
+        try:
+            import psutil
+            cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+        except Exception:
+            cores = os.cpu_count() or 1
+        O.lib().ko_set_num_threads(int(cores))
+        orc = LO.LlmOracle(t_l, cfg_l)
+        cache = orc.new_cache()
+        t0 = time.perf_counter()
+        h = orc.forward(prompt[:16], cache)
+        c_pre = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in range(4):
+            h = orc.forward([int(out[i])], cache)
+            orc.logits(h[0, -1])
+        c_dec = (time.perf_counter() - t0) / 4
+        res["cpu_baseline"] = {"value": round(1.0 / c_dec, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+                               "sample": f"oracle: 16-token prefill {c_pre:.2f} s, 4 decode steps at {c_dec * 1e3:.0f} ms each (f32 weights)"}
         emit(res)
 
 
