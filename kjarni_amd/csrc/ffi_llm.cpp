@@ -4,6 +4,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <cstdlib>
+#include "llm_kernels.h"
 #include "../../include/kjarni_hip.h"
 #include "ffi_common.h"
 #include "llm.h"
@@ -21,6 +23,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_decoder_load(const char* model_dir, int
     if (!model_dir || !out) return KJARNI_ERROR_NULL_POINTER;
     if (weights_dtype < 0 || weights_dtype > 2) return KJARNI_ERROR_INVALID_CONFIG;
     return guarded(KJARNI_ERROR_LOAD_FAILED, [&] {
+        if (const char* v = std::getenv("KJARNI_HIP_LLM_GEMV")) set_llm_gemv_variant(std::atoi(v));  // kernel A/B measurements only
         auto h = std::make_unique<KjarniHipDecoder>();
         h->model = LlmModel::load(model_dir, device, weights_dtype, max_context);
         *out = h.release();

@@ -232,6 +232,104 @@ __global__ __launch_bounds__(256) void llm_gemv1_kernel(const float* __restrict_
     }
 }
 
+// Single-row GEMV with the K dimension split over the four waves of a workgroup.  A workgroup owns OPW output
+// columns; lane t of the block keeps chunks t, t+256, ... of the input row in registers (normalised in place when
+// NORM — the sum of squares is reduced once through LDS), issues every weight load of its slice before the first
+// FMA (OPW x chunks x 16 bytes per lane in flight) and the four per-wave partial sums meet in LDS.  Compared with
+// one wave per column this puts 4x more workgroups on the chip for the narrow projections (o, down) and reads the
+// input row once per OPW columns instead of once per column.
+constexpr int SK_MAX_CHUNKS = 8;  // k <= 8 * 256 * 8 = 16384
+
+template <typename WT, int EPI, bool NORM, int OPW, int CH>
+__global__ __launch_bounds__(256) void llm_gemv_splitk_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
+                                                              const WT* __restrict__ W, const WT* __restrict__ W2,
+                                                              const float* __restrict__ bias, const float* __restrict__ R,
+                                                              int n_out, int k, float* __restrict__ Y)
+{
+    constexpr int NM = EPI == LE_SWIGLU ? 2 : 1;
+    __shared__ float red[4];
+    __shared__ float part[4][NM * OPW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k8 = k >> 3;
+    F8 x[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = tid + c * 256;
+        if (i < k8) x[c] = load8(X, i);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c].v[e] = 0.0f;
+        }
+    }
+    const int64_t n0 = (int64_t)blockIdx.x * OPW;
+    // Weight loads do not depend on the statistics: issue them first so the reduction overlaps their latency.
+    F8 w[OPW][CH], u[EPI == LE_SWIGLU ? OPW : 1][CH];
+#pragma unroll
+    for (int o = 0; o < OPW; ++o) {
+        const int64_t n = n0 + o < n_out ? n0 + o : n_out - 1;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = tid + c * 256;
+            if (i < k8) {
+                w[o][c] = load8(W + n * (int64_t)k, i);
+                if (EPI == LE_SWIGLU) u[o][c] = load8(W2 + n * (int64_t)k, i);
+            }
+        }
+    }
+    if (NORM) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(x[c].v[e], x[c].v[e], s);
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)k + eps);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = tid + c * 256;
+            if (i < k8) {
+                const F8 g = load8(gamma, i);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c].v[e] = (x[c].v[e] / rms) * g.v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OPW; ++o) {
+        float acc = 0.0f, acc2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = tid + c * 256;
+            if (i < k8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc = fmaf(x[c].v[e], w[o][c].v[e], acc);
+                    if (EPI == LE_SWIGLU) acc2 = fmaf(x[c].v[e], u[o][c].v[e], acc2);
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (EPI == LE_SWIGLU) acc2 = wave_sum(acc2);
+        if (lane == 0) {
+            part[wave][o] = acc;
+            if (EPI == LE_SWIGLU) part[wave][OPW + o] = acc2;
+        }
+    }
+    __syncthreads();
+    if (tid < OPW && n0 + tid < n_out) {
+        const int64_t n = n0 + tid;
+        float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + (bias ? bias[n] : 0.0f);
+        if (EPI == LE_SWIGLU) {
+            const float up = (part[0][OPW + tid] + part[1][OPW + tid]) + (part[2][OPW + tid] + part[3][OPW + tid]);
+            v = (v / (1.0f + expf(-v))) * up;
+        }
+        if (EPI == LE_RESIDUAL) v += R[n];
+        Y[n] = v;
+    }
+}
+
 // Decode-step fusion of RMSNorm + Q|K|V projection + RoPE (decoder_attention.rs:61-97 for one new token): the
 // normalised row sits in LDS as above; a wave owns the PAIR of output columns (i, i + d/2) of one head, so it can
 // rotate them itself (rope/mod.rs:156-176) before Q goes to scratch and K to its cache row; V columns go in pairs
@@ -439,7 +537,50 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
     const bool norm = a.gamma != nullptr;
     // Staging the row in LDS pays when it also has to be normalised (otherwise every wave redoes the statistics); plain
     // projections keep the one-wave-per-column kernel, whose 4x larger grid hides latency better.
-    if (a.rows == 1 && norm && a.k <= G1_MAX_K && g_llm_gemv_variant == 0) {
+    if (a.rows == 1 && a.seg_q == 0 && a.k <= SK_MAX_CHUNKS * 2048 && (g_llm_gemv_variant == 0 || g_llm_gemv_variant >= 3)) {
+        const int chunks = (a.k / 8 + 255) / 256;
+        // Two columns per workgroup measured best on every projection of the 1B / 8B shapes (1, 4 and 8 were 2-18 %
+        // slower end to end): the chip wants many small workgroups more than it wants deep per-lane load queues.
+        int opw = 2;
+        if (g_llm_gemv_variant >= 3) opw = 1 << (g_llm_gemv_variant - 3);  // measurements: 3 -> 1, 4 -> 2, 5 -> 4, 6 -> 8
+        if (opw > 8) opw = 8;
+        if (chunks > 2 && opw > 4) opw = 4;
+        if (chunks > 4 && opw > 2) opw = 2;
+        if (a.swiglu && chunks > 2 && opw > 2) opw = 2;
+        const dim3 gridk((unsigned)((a.n_out + opw - 1) / opw));
+#define KJ_SK3(EPI, NORM, OPW, CH)                                                                                                    \
+    hipLaunchKernelGGL((llm_gemv_splitk_kernel<WT, EPI, NORM, OPW, CH>), gridk, dim3(256), 0, stream, a.X, a.gamma, a.eps, W, W2,      \
+                       a.bias, a.R, a.n_out, a.k, a.Y0)
+#define KJ_SK2(EPI, NORM, OPW)                                                                                                        \
+    do {                                                                                                                              \
+        if (chunks <= 1) KJ_SK3(EPI, NORM, OPW, 1);                                                                                   \
+        else if (chunks <= 2) KJ_SK3(EPI, NORM, OPW, 2);                                                                              \
+        else if (chunks <= 4) KJ_SK3(EPI, NORM, (OPW > 4 ? 4 : OPW), 4);                                                              \
+        else KJ_SK3(EPI, NORM, (OPW > 2 ? 2 : OPW), 8);                                                                               \
+    } while (0)
+#define KJ_SK1(EPI, NORM)                                                                                                             \
+    do {                                                                                                                              \
+        if (opw == 1) KJ_SK2(EPI, NORM, 1);                                                                                           \
+        else if (opw == 2) KJ_SK2(EPI, NORM, 2);                                                                                      \
+        else if (opw == 4) KJ_SK2(EPI, NORM, 4);                                                                                      \
+        else KJ_SK2(EPI, NORM, 8);                                                                                                    \
+    } while (0)
+        if (a.swiglu) {
+            if (norm) KJ_SK1(LE_SWIGLU, true);
+            else KJ_SK1(LE_SWIGLU, false);
+        } else if (a.R) {
+            if (norm) KJ_SK1(LE_RESIDUAL, true);
+            else KJ_SK1(LE_RESIDUAL, false);
+        } else {
+            if (norm) KJ_SK1(LE_NONE, true);
+            else KJ_SK1(LE_NONE, false);
+        }
+#undef KJ_SK1
+#undef KJ_SK2
+#undef KJ_SK3
+        return hipGetLastError();
+    }
+    if (a.rows == 1 && norm && a.k <= G1_MAX_K && g_llm_gemv_variant != 1) {
         const dim3 grid1((unsigned)((a.n_out + 4 * G1_OPW - 1) / (4 * G1_OPW)));
         const size_t lds = (size_t)a.k * sizeof(float);
 #define KJ_LLM1(EPI, NORM)                                                                                                            \
