@@ -343,6 +343,74 @@ size_t kjarni_indexer_model_name(const KjarniIndexer* indexer, char* buf, size_t
 size_t kjarni_indexer_dimension(const KjarniIndexer* indexer);                        /* :660-666 */
 size_t kjarni_indexer_chunk_size(const KjarniIndexer* indexer);                       /* :669-675 */
 
+/* ---- Chat (decoder-only LLMs): kjarni-ffi/src/chat.rs:13-758 -----------------------------------
+ * model_name is a registry name ("llama3.2-1b-instruct", "qwen2.5-0.5b-instruct", ...): it selects the
+ * architecture, the chat template (Llama 3 / ChatML) and the directory <cache_dir>/<org>_<repo>.  The reference
+ * never reads model_path (chat.rs:190-250); here a non-NULL model_path replaces that directory (config.json,
+ * tokenizer.json, model.safetensors, optional generation_config.json), everything else still follows model_name.
+ * Both device values run on the MI355X; KJARNI_HIP_DEVICE picks the ordinal, KJARNI_HIP_CHAT_CONTEXT the KV-cache
+ * capacity in tokens (default 32768, the model's max_position_embeddings is what kjarni_chat_context_size reports).
+ * Errors of kjarni_chat_new (chat.rs:126-139): unknown name / files not on disk -> MODEL_NOT_FOUND; encoder, seq2seq,
+ * speech or template-less model -> INVALID_CONFIG; no GPU -> GPU_UNAVAILABLE; anything else -> LOAD_FAILED
+ * (including the architectures this library does not build: Mistral, Phi-3). */
+typedef struct KjarniChatConfig {      /* chat.rs:13-30 */
+    KjarniDevice device;
+    const char* cache_dir;     /* NULL = default cache */
+    const char* model_name;    /* required */
+    const char* model_path;    /* NULL = <cache_dir>/<org>_<repo> */
+    const char* system_prompt; /* NULL = the template's default system prompt */
+    int32_t mode;              /* 0 default (temperature 0.7, 512 new tokens), 1 creative (0.9, 1024), 2 reasoning (0.3, 2048) */
+    int32_t quiet;
+} KjarniChatConfig;
+
+typedef struct KjarniGenerationConfig { /* chat.rs:32-49; negative = keep the resolved default */
+    float temperature;
+    int32_t top_k;
+    float top_p;
+    float min_p;
+    float repetition_penalty;
+    int32_t max_new_tokens;
+    int32_t do_sample;         /* -1 default, 0 greedy, 1 sample */
+} KjarniGenerationConfig;
+
+/* Receives each generated token's text; return false to stop. */
+typedef bool (*KjarniStreamCallbackFn)(const char* text, void* user_data);
+
+typedef struct KjarniChat KjarniChat;
+typedef struct KjarniChatConversation KjarniChatConversation;
+
+KjarniChatConfig kjarni_chat_config_default(void);                                   /* chat.rs:56-67 */
+KjarniGenerationConfig kjarni_generation_config_default(void);                       /* :70-81 */
+KjarniErrorCode kjarni_chat_new(const KjarniChatConfig* config, KjarniChat** out);   /* :174-250 */
+void kjarni_chat_free(KjarniChat* chat);                                             /* :253-258 */
+/* One-shot message with the configured (or the template's default) system prompt; the reply is trimmed and a
+ * trailing template stop sequence is stripped (crates/kjarni/src/chat/model.rs:283-303).  Free with kjarni_string_free. */
+KjarniErrorCode kjarni_chat_send(KjarniChat* chat, const char* message, const KjarniGenerationConfig* gen_config,
+                                 char** out);                                         /* :271-322 */
+/* The same, one callback per generated token (single-token decode, special tokens included); the cancel token is
+ * looked at before each callback. */
+KjarniErrorCode kjarni_chat_stream(KjarniChat* chat, const char* message, const KjarniGenerationConfig* gen_config,
+                                   KjarniStreamCallbackFn callback, void* user_data,
+                                   const KjarniCancelToken* cancel_token);            /* :338-401 */
+/* roles[i]: 0 system (restarts the history), 1 user, 2 assistant; anything else -> INVALID_CONFIG. */
+KjarniErrorCode kjarni_chat_send_with_history(KjarniChat* chat, const int32_t* roles, const char* const* contents,
+                                              size_t history_len, const char* message,
+                                              const KjarniGenerationConfig* gen_config, char** out); /* :403-484 */
+/* Stateful conversation: the handle owns the history and must not outlive its chat. */
+KjarniErrorCode kjarni_chat_conversation_new(KjarniChat* chat, KjarniChatConversation** out);        /* :487-511 */
+void kjarni_chat_conversation_free(KjarniChatConversation* convo);                                   /* :514-519 */
+KjarniErrorCode kjarni_chat_conversation_send(KjarniChatConversation* convo, const char* message,
+                                              const KjarniGenerationConfig* gen_config, char** out); /* :521-583 */
+KjarniErrorCode kjarni_chat_conversation_stream(KjarniChatConversation* convo, const char* message,
+                                                const KjarniGenerationConfig* gen_config,
+                                                KjarniStreamCallbackFn callback, void* user_data,
+                                                const KjarniCancelToken* cancel_token);              /* :589-693 */
+size_t kjarni_chat_conversation_len(const KjarniChatConversation* convo);                            /* :699-707 */
+void kjarni_chat_conversation_clear(KjarniChatConversation* convo, int32_t keep_system);             /* :709-717 */
+/* Without a buffer: the name's byte length; with one: bytes copied, NUL excluded (chat.rs:723-745). */
+size_t kjarni_chat_model_name(const KjarniChat* chat, char* buf, size_t buf_len);
+size_t kjarni_chat_context_size(const KjarniChat* chat);                                             /* :747-758 */
+
 /* ---- streamed tokens: kjarni-ffi/src/callback.rs:36-47 -------------------------------- */
 typedef struct KjarniToken {
     const char* text; /* valid for the duration of the callback */

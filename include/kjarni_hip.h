@@ -324,6 +324,63 @@ KjarniErrorCode kjarni_hip_memcpy_h2d(int32_t device, void* dst_dev, const void*
 KjarniErrorCode kjarni_hip_memcpy_d2h(int32_t device, void* dst, const void* src_dev, size_t bytes);
 KjarniErrorCode kjarni_hip_synchronize(int32_t device);
 
+/* ---- chat, one stage at a time (host side; parity tests) ---------------------------------------
+ * Byte-level BPE tokenizer: the `tokenizers` 0.22.1 pipeline for Llama 3 / Qwen 2 / GPT-2 style tokenizer.json
+ * (added-token extraction, NFC, Split + ByteLevel, BPE with merge ranks and ignore_merges), as the reference calls
+ * it: encode(text, add_special_tokens = false) (crates/kjarni-transformers/src/decoder/generator.rs:141-146),
+ * right-truncated to max_length when non-zero (pipeline/decoder/loader.rs:115-120), decode(ids, skip_special). */
+typedef struct KjarniBpeTokenizer KjarniBpeTokenizer;
+KjarniErrorCode kjarni_bpe_tokenizer_load(const char* tokenizer_json_path, KjarniBpeTokenizer** out);
+void kjarni_bpe_tokenizer_free(KjarniBpeTokenizer* tokenizer);
+KjarniErrorCode kjarni_bpe_tokenizer_encode(const KjarniBpeTokenizer* tokenizer, const char* text, size_t max_length, uint32_t* ids_out,
+                                            size_t capacity, size_t* n_out);
+KjarniErrorCode kjarni_bpe_tokenizer_decode(const KjarniBpeTokenizer* tokenizer, const uint32_t* ids, size_t n, int32_t skip_special,
+                                            char** out);
+KjarniErrorCode kjarni_bpe_tokenizer_pre_tokenize(const KjarniBpeTokenizer* tokenizer, const char* text, KjarniStringArray* out);
+
+/* ChatTemplate::apply (crates/kjarni-transformers/src/chat/{llama3,chatml,mistral}.rs): template_kind 0 = Llama 3
+ * (for_generation), 1 = ChatML, 2 = Mistral; roles 0 system / 1 user / 2 assistant. */
+KjarniErrorCode kjarni_chat_template_apply(int32_t template_kind, const int32_t* roles, const char* const* contents, size_t n, char** out);
+
+/* sample_token's distribution (crates/kjarni-transformers/src/common/sampling.rs:89-108): top-k, top-p, min-p
+ * (negative = not set), temperature, softmax; probs_out[vocab] holds 0 for filtered tokens.  kjarni_sample_from_probs
+ * is sample_from_probs (:173-184) for a given draw; kjarni_logits_process applies the repetition penalty (:8-27) and
+ * the no-repeat-n-gram ban (:29-57, 0 = off) in place. */
+KjarniErrorCode kjarni_sampling_distribution(const float* logits, size_t vocab, float temperature, int64_t top_k, float top_p, float min_p,
+                                             float* probs_out);
+uint32_t kjarni_sample_from_probs(const float* probs, size_t vocab, float uniform);
+KjarniErrorCode kjarni_logits_process(float* logits, size_t vocab, const uint32_t* tokens, size_t n_tokens, float repetition_penalty,
+                                      size_t no_repeat_ngram);
+
+/* resolve_generation_config (crates/kjarni/src/generation/resolution.rs:8-85) over the model defaults
+ * (llama/model.rs:373-396, qwen/model.rs:261-282, or generation_config_json when it deserializes as
+ * HFGenerationDefaults) and the chat mode (mode < 0: no mode defaults, the bare Generator). */
+typedef struct KjarniResolvedGeneration {
+    int32_t strategy;          /* 0 greedy, 1 sample, 2 beam search */
+    float temperature;
+    int64_t top_k;             /* -1 = None */
+    float top_p;               /* < 0 = None */
+    float min_p;               /* < 0 = None */
+    float repetition_penalty;
+    size_t no_repeat_ngram_size;
+    int64_t max_new_tokens;    /* -1 = None */
+    size_t max_length;
+    int32_t add_bos_token;
+} KjarniResolvedGeneration;
+KjarniErrorCode kjarni_generation_resolve(const char* model_type, size_t max_position_embeddings, const char* generation_config_json,
+                                          int32_t mode, const KjarniGenerationConfig* runtime, KjarniResolvedGeneration* out);
+
+/* On a live chat handle: the resolved config of a call, the prompt the template produces (roles == NULL and n == 0:
+ * Chat::create_conversation; otherwise Chat::history_to_conversation; message appended as the user turn when non-NULL),
+ * the token ids DecoderGenerator::encode produces for a prompt (BOS rule included), and the seed of the sampler's
+ * generator (the reference draws from rand::thread_rng()). */
+KjarniErrorCode kjarni_hip_chat_resolve(const KjarniChat* chat, const KjarniGenerationConfig* runtime, KjarniResolvedGeneration* out);
+KjarniErrorCode kjarni_hip_chat_format_prompt(const KjarniChat* chat, const int32_t* roles, const char* const* contents, size_t n,
+                                              const char* message, char** out);
+KjarniErrorCode kjarni_hip_chat_encode(const KjarniChat* chat, const char* prompt, const KjarniGenerationConfig* runtime, uint32_t* ids_out,
+                                       size_t capacity, size_t* n_out);
+void kjarni_hip_chat_seed(KjarniChat* chat, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,6 +214,25 @@ class KjarniTranscriptionProgress(Structure):
 KjarniTranscriptionProgressFn = C.CFUNCTYPE(None, KjarniTranscriptionProgress, c_void_p)
 
 
+class KjarniChatConfig(Structure):
+    _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p), ("model_path", c_char_p),
+                ("system_prompt", c_char_p), ("mode", c_int32), ("quiet", c_int32)]
+
+
+class KjarniGenerationConfig(Structure):
+    _fields_ = [("temperature", c_float), ("top_k", c_int32), ("top_p", c_float), ("min_p", c_float),
+                ("repetition_penalty", c_float), ("max_new_tokens", c_int32), ("do_sample", c_int32)]
+
+
+class KjarniResolvedGeneration(Structure):
+    _fields_ = [("strategy", c_int32), ("temperature", c_float), ("top_k", c_int64), ("top_p", c_float), ("min_p", c_float),
+                ("repetition_penalty", c_float), ("no_repeat_ngram_size", c_size_t), ("max_new_tokens", c_int64),
+                ("max_length", c_size_t), ("add_bos_token", c_int32)]
+
+
+KjarniStreamCallbackFn = C.CFUNCTYPE(C.c_bool, c_char_p, c_void_p)
+
+
 class KjarniRerankerConfig(Structure):
     _fields_ = [("device", c_int32), ("cache_dir", c_char_p), ("model_name", c_char_p),
                 ("model_path", c_char_p), ("quiet", c_int32)]
@@ -332,6 +351,38 @@ SIGNATURES = {
     "kjarni_hip_whisper_decode_text": (c_int32, [c_void_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
     "kjarni_audio_load_wav": (c_int32, [c_char_p, POINTER(KjarniFloatArray), POINTER(C.c_uint32)]),
     "kjarni_bytelevel_decode": (c_int32, [c_char_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
+    "kjarni_chat_config_default": (KjarniChatConfig, []),
+    "kjarni_generation_config_default": (KjarniGenerationConfig, []),
+    "kjarni_chat_new": (c_int32, [POINTER(KjarniChatConfig), POINTER(c_void_p)]),
+    "kjarni_chat_free": (None, [c_void_p]),
+    "kjarni_chat_send": (c_int32, [c_void_p, c_char_p, POINTER(KjarniGenerationConfig), POINTER(c_void_p)]),
+    "kjarni_chat_stream": (c_int32, [c_void_p, c_char_p, POINTER(KjarniGenerationConfig), KjarniStreamCallbackFn, c_void_p, c_void_p]),
+    "kjarni_chat_send_with_history": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_char_p), c_size_t, c_char_p,
+                                                POINTER(KjarniGenerationConfig), POINTER(c_void_p)]),
+    "kjarni_chat_conversation_new": (c_int32, [c_void_p, POINTER(c_void_p)]),
+    "kjarni_chat_conversation_free": (None, [c_void_p]),
+    "kjarni_chat_conversation_send": (c_int32, [c_void_p, c_char_p, POINTER(KjarniGenerationConfig), POINTER(c_void_p)]),
+    "kjarni_chat_conversation_stream": (c_int32, [c_void_p, c_char_p, POINTER(KjarniGenerationConfig), KjarniStreamCallbackFn,
+                                                  c_void_p, c_void_p]),
+    "kjarni_chat_conversation_len": (c_size_t, [c_void_p]),
+    "kjarni_chat_conversation_clear": (None, [c_void_p, c_int32]),
+    "kjarni_chat_model_name": (c_size_t, [c_void_p, c_char_p, c_size_t]),
+    "kjarni_chat_context_size": (c_size_t, [c_void_p]),
+    "kjarni_bpe_tokenizer_load": (c_int32, [c_char_p, POINTER(c_void_p)]),
+    "kjarni_bpe_tokenizer_free": (None, [c_void_p]),
+    "kjarni_bpe_tokenizer_encode": (c_int32, [c_void_p, c_char_p, c_size_t, _u32p, c_size_t, POINTER(c_size_t)]),
+    "kjarni_bpe_tokenizer_decode": (c_int32, [c_void_p, _u32p, c_size_t, c_int32, POINTER(c_void_p)]),
+    "kjarni_bpe_tokenizer_pre_tokenize": (c_int32, [c_void_p, c_char_p, POINTER(KjarniStringArray)]),
+    "kjarni_chat_template_apply": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_char_p), c_size_t, POINTER(c_void_p)]),
+    "kjarni_sampling_distribution": (c_int32, [_f32p, c_size_t, c_float, c_int64, c_float, c_float, _f32p]),
+    "kjarni_sample_from_probs": (C.c_uint32, [_f32p, c_size_t, c_float]),
+    "kjarni_logits_process": (c_int32, [_f32p, c_size_t, _u32p, c_size_t, c_float, c_size_t]),
+    "kjarni_generation_resolve": (c_int32, [c_char_p, c_size_t, c_char_p, c_int32, POINTER(KjarniGenerationConfig),
+                                            POINTER(KjarniResolvedGeneration)]),
+    "kjarni_hip_chat_resolve": (c_int32, [c_void_p, POINTER(KjarniGenerationConfig), POINTER(KjarniResolvedGeneration)]),
+    "kjarni_hip_chat_format_prompt": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_char_p), c_size_t, c_char_p, POINTER(c_void_p)]),
+    "kjarni_hip_chat_encode": (c_int32, [c_void_p, c_char_p, POINTER(KjarniGenerationConfig), _u32p, c_size_t, POINTER(c_size_t)]),
+    "kjarni_hip_chat_seed": (None, [c_void_p, C.c_uint64]),
     "kjarni_hip_decoder_load": (c_int32, [c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "kjarni_hip_decoder_free": (None, [c_void_p]),
     "kjarni_hip_decoder_dims": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),

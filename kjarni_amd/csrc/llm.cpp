@@ -74,6 +74,10 @@ LlmConfig LlmConfig::from_json(const std::string& text)
             for (const Json& x : e->arr)
                 if (x.is_number()) c.eos_ids.push_back((uint32_t)x.as_int());
     }
+    if (const Json* b = j.find("bos_token_id"); b && b->is_number()) {
+        c.has_bos = true;
+        c.bos_id = (uint32_t)b->as_int();
+    }
     if (c.heads <= 0 || c.kv_heads <= 0 || c.heads % c.kv_heads != 0 || c.head_dim * c.heads != c.hidden)
         throw std::runtime_error("config.json: unsupported head geometry");
     return c;
@@ -349,34 +353,48 @@ hipGraphExec_t LlmModel::step_graph()
 std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, size_t max_new_tokens, float repetition_penalty,
                                          int no_repeat_ngram, const std::function<bool(uint32_t)>& on_token)
 {
+    GenerateOptions o;
+    o.max_new_tokens = max_new_tokens;
+    o.repetition_penalty = repetition_penalty;
+    o.no_repeat_ngram = no_repeat_ngram;
+    return generate(prompt, o, on_token);
+}
+
+std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, const GenerateOptions& opt,
+                                         const std::function<bool(uint32_t)>& on_token)
+{
     hip_check(hipSetDevice(device_), "hipSetDevice");
     if (prompt.empty()) throw std::runtime_error("cannot generate from empty prompt");
-    if ((int)prompt.size() >= cache_cap_) throw std::runtime_error("prompt does not fit the context");
+    if ((int)prompt.size() > cache_cap_) throw std::runtime_error("prompt does not fit the context");
+    if (opt.sample && !opt.uniform) throw std::runtime_error("sampling needs a uniform source");
     reset();
     forward(prompt.data(), (int)prompt.size());
     std::vector<uint32_t> out, all(prompt);
-    const auto is_stop = [&](uint32_t t) { return std::find(cfg_.eos_ids.begin(), cfg_.eos_ids.end(), t) != cfg_.eos_ids.end(); };
-    const size_t context_limit = (size_t)cache_cap_;
+    const std::vector<uint32_t>& stops = opt.stop_ids.empty() ? cfg_.eos_ids : opt.stop_ids;
+    const auto is_stop = [&](uint32_t t) { return std::find(stops.begin(), stops.end(), t) != stops.end(); };
+    // generator.rs:243-246 and 309-317: stop at the model's context and at max_len = prompt + max_new_tokens | max_length.
+    const size_t max_len = opt.max_len ? opt.max_len : prompt.size() + opt.max_new_tokens;
+    const size_t context_limit = std::min((size_t)cache_cap_, max_len);
+    const size_t max_new_tokens = opt.max_new_tokens;
+    const float repetition_penalty = opt.repetition_penalty;
+    const int no_repeat_ngram = opt.no_repeat_ngram;
 
-    if (repetition_penalty != 1.0f || no_repeat_ngram > 0) {
-        // Logits processors touch the host copy of the logits every step (generator.rs:331-341): one pass per token.
-        std::vector<float> lg((size_t)cfg_.vocab);
+    if (opt.sample || repetition_penalty != 1.0f || no_repeat_ngram > 0) {
+        // Logits processors and sampling work on the host copy of the logits (generator.rs:331-343): one pass per token.
+        std::vector<float> lg((size_t)cfg_.vocab), probs;
+        std::vector<uint32_t> ids;
         for (size_t step = 0; step < max_new_tokens; ++step) {
             if (all.size() >= context_limit) break;
             logits_to_host(lg.data());
-            if (repetition_penalty != 1.0f)  // sampling.rs:207-219, once per occurrence
-                for (uint32_t t : all)
-                    if (t < lg.size()) lg[t] = lg[t] < 0.0f ? lg[t] * repetition_penalty : lg[t] / repetition_penalty;
-            if (no_repeat_ngram > 0 && all.size() + 1 >= (size_t)no_repeat_ngram) {  // sampling.rs:221-235
-                const size_t n = (size_t)no_repeat_ngram;
-                for (size_t i = 0; i + n <= all.size(); ++i)
-                    if (std::equal(all.begin() + (long)i, all.begin() + (long)(i + n - 1), all.end() - (long)(n - 1)) && all[i + n - 1] < lg.size())
-                        lg[all[i + n - 1]] = -INFINITY;
+            apply_repetition_penalty(lg, all, repetition_penalty);
+            if (no_repeat_ngram > 0) apply_no_repeat_ngram(lg, all, (size_t)no_repeat_ngram);
+            uint32_t next;
+            if (opt.sample) {
+                sampling_distribution(lg, opt.sampling, ids, probs);
+                next = sample_from_distribution(ids, probs, opt.uniform(), lg.size());
+            } else {
+                next = argmax_last(lg);
             }
-            size_t best = 0;
-            for (size_t i = 1; i < lg.size(); ++i)
-                if (lg[i] >= lg[best]) best = i;  // last maximum (sampling.rs:83-88)
-            const uint32_t next = (uint32_t)best;
             if (is_stop(next)) break;
             all.push_back(next);
             out.push_back(next);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "encoder.h"
+#include "sampling.h"
 
 namespace kjarni {
 
@@ -28,7 +29,21 @@ struct LlmConfig {
     float rope_factor = 1.0f, rope_low = 1.0f, rope_high = 4.0f;
     int rope_original_max = 8192;
     std::vector<uint32_t> eos_ids;
+    bool has_bos = false;
+    uint32_t bos_id = 0;
     static LlmConfig from_json(const std::string& text);
+};
+
+// One run of run_generation_loop (generator.rs:228-381).
+struct GenerateOptions {
+    size_t max_new_tokens = 0;
+    size_t max_len = 0;  // prompt + generated cap (generator.rs:243-246); 0 = prompt + max_new_tokens
+    float repetition_penalty = 1.0f;
+    int no_repeat_ngram = 0;
+    bool sample = false;  // DecodingStrategy::Sample(params) instead of Greedy
+    SamplingParams sampling;
+    std::vector<uint32_t> stop_ids;  // empty: every eos_token_id of config.json
+    std::function<float()> uniform;  // the draw in [0, 1) for each sampled token
 };
 
 class LlmModel {
@@ -55,6 +70,9 @@ public:
     // run_generation_loop with the Greedy strategy: returns the generated ids (stop token excluded).
     std::vector<uint32_t> generate(const std::vector<uint32_t>& prompt, size_t max_new_tokens, float repetition_penalty,
                                    int no_repeat_ngram, const std::function<bool(uint32_t)>& on_token);
+    // The same loop with a sampling strategy, explicit stop tokens and the max_length cap.
+    std::vector<uint32_t> generate(const std::vector<uint32_t>& prompt, const GenerateOptions& options,
+                                   const std::function<bool(uint32_t)>& on_token);
 
 private:
     LlmModel() = default;

@@ -137,6 +137,8 @@ bool is_alphanumeric(uint32_t cp)
     return in_ranges(kAlnum, kAlnum_len, cp);
 }
 
+int combining_class(uint32_t cp) { return cp < 0x300 ? 0 : (int)ccc(cp); }
+
 void nfd(const std::vector<uint32_t>& in, std::vector<uint32_t>& out)
 {
     out.clear();

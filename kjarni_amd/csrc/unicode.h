@@ -24,6 +24,7 @@ bool is_mark_nonspacing(uint32_t cp);     // unicode_categories Mn
 bool is_whitespace(uint32_t cp);          // Rust char::is_whitespace
 bool is_bert_punctuation(uint32_t cp);    // ascii punctuation or Unicode P*
 bool is_alphanumeric(uint32_t cp);        // Rust char::is_alphanumeric (BM25 tokenizer)
+int combining_class(uint32_t cp);         // canonical combining class
 // Canonical decomposition (NFD) of a sequence, with canonical reordering.
 void nfd(const std::vector<uint32_t>& in, std::vector<uint32_t>& out);
 // Per-char to_lowercase (may expand, e.g. U+0130 -> "i̇").
