@@ -16,6 +16,7 @@ from .searcher import Searcher, search_keywords  # noqa: F401,E402
 from .indexer import CancelToken, Indexer, index_delete, index_info  # noqa: F401,E402
 from .transcriber import HipWhisper, Transcriber  # noqa: F401,E402
 from .decoder import HipDecoder  # noqa: F401,E402
+from .chat import BpeTokenizer, Chat, ChatConversation, GenerationConfig  # noqa: F401,E402
 from .tokenizer import Tokenizer  # noqa: F401,E402
 
 __version__ = "0.1.0"
