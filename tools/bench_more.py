@@ -50,7 +50,7 @@ def timed(fn, sync, steps, warmup):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer", "whisper", "llm"}
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer", "whisper", "llm", "chat"}
     import numpy as np
     import torch
 
@@ -305,6 +305,50 @@ def main():
         res["cpu_baseline"] = {"value": round(1.0 / c_dec, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
                                "sample": f"oracle: 16-token prefill {c_pre:.2f} s, 4 decode steps at {c_dec * 1e3:.0f} ms each (f32 weights)"}
         emit(res)
+
+    if "chat" in which:
+        # The string-level path of the C ABI (kjarni_chat_send / kjarni_chat_stream) on the same Llama-1B shape: template,
+        # BPE encode, prefill, decode with the sampler, per-token text.  The tokenizer is the small Llama-3-style fixture
+        # (the model's 128 256-row head is kept, so the sampler sees a full-size vocabulary).
+        import shutil
+        from kjarni_amd.chat import Chat, GenerationConfig
+        d = os.path.join(tmp, "llama-1b-chat")
+        synth.llm_model(d, synth.LLAMA_1B, seed=0, store_bf16=True, max_position_embeddings=4096, bos_token_id=700, eos_token_id=[701])
+        shutil.copy(os.path.join(ROOT, "tests", "golden", "bpe_llama3_tokenizer.json"), os.path.join(d, "tokenizer.json"))
+        chat = Chat("llama3.2-1b-instruct", model_path=d)
+        message = "Summarise the history of Iceland in three paragraphs, please. " * 4
+        n_prompt = len(chat.encode(chat.format_prompt(None, message)))
+        n_new = 256
+        rows = {}
+        for label, g in [("greedy", GenerationConfig(do_sample=False, max_new_tokens=n_new)),
+                         ("sample_default", GenerationConfig(max_new_tokens=n_new)),
+                         ("sample_top_k40_rep1.1", GenerationConfig(max_new_tokens=n_new, top_k=40, repetition_penalty=1.1))]:
+            chat.seed(1)
+            chat.send(message, GenerationConfig(do_sample=g.do_sample, max_new_tokens=8))   # warm-up
+            pieces = []
+            first = []
+            t0 = time.perf_counter()
+
+            def on_token(text, pieces=pieces, first=first, t0=t0):
+                if not pieces:
+                    first.append(time.perf_counter() - t0)
+                pieces.append(text)
+                return True
+
+            chat.stream(message, on_token, g)
+            dt = time.perf_counter() - t0
+            rows[label] = {"tokens": len(pieces), "ms_to_first_token": round(first[0] * 1e3, 2) if first else None,
+                           "tokens_per_s_after_first": round((len(pieces) - 1) / (dt - first[0]), 1) if len(pieces) > 1 else None,
+                           "ms_total": round(dt * 1e3, 1)}
+        t0 = time.perf_counter()
+        for _ in range(20):
+            chat.encode(chat.format_prompt(None, message))
+        t_enc = (time.perf_counter() - t0) / 20
+        emit({"metric": "chat tokens/sec through kjarni_chat_stream, Llama-3.2-1B shape, bf16 weights", "unit": "tokens/s",
+              "value": rows["greedy"]["tokens_per_s_after_first"], "n_gpus": 1, "data": "synthetic",
+              "config": {"workload": f"Llama-3.2-1B geometry, random init, {n_prompt}-token templated prompt, {n_new} new tokens; "
+                                     "greedy = device-resident graph loop, sample = logits to the host + sampler per token"},
+              "prompt_tokens": n_prompt, "ms_template_plus_bpe_encode": round(t_enc * 1e3, 3), "runs": rows})
 
 
 if __name__ == "__main__":
