@@ -2,11 +2,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
 
 #include "json.h"
+#include "kernels.h"
 #include "llm_kernels.h"
 #include "safetensors.h"
 #include "whisper_kernels.h"
@@ -283,18 +285,98 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
     hip_check(launch_llm_gemv(lm, s), "lm head");
 }
 
+// Prompt rows through the fp32 matrix cores (prefill_gemm_kernel) instead of 8-row GEMV passes: per layer RMSNorm ->
+// Q, K, V projections (K and V rows land in the cache) -> RoPE -> causal attention over the cache -> o-proj + residual
+// -> RMSNorm -> gate, up -> silu(gate) * up -> down-proj + residual; same formulas as pass().  After the last layer the
+// final norm runs on the last (n - 1) % 8 + 1 rows (what last_hidden() exposes) and the lm head on the last row.
+void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
+{
+    hipStream_t s = stream_;
+    const LlmConfig& c = cfg_;
+    const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d, I = c.inter;
+    const int wb = bf16_ ? 1 : 0;
+    constexpr int kChunk = 1024;
+    if (!ph_) {
+        prefill_cap_ = kChunk;
+        const size_t P = (size_t)prefill_cap_;
+        ph_ = dalloc(P * H);
+        pn_ = dalloc(P * H);
+        pq_ = dalloc(P * H);
+        pctx_ = dalloc(P * H);
+        pg_ = dalloc(P * I);
+        pu_ = dalloc(P * I);
+        pids_ = reinterpret_cast<uint32_t*>(dalloc(P));
+    }
+    const size_t wsz = bf16_ ? 2 : 4;
+    auto at = [&](const void* w, size_t elems) { return static_cast<const void*>(static_cast<const char*>(w) + elems * wsz); };
+    for (int done = 0; done < n; done += prefill_cap_) {
+        const int m = std::min(prefill_cap_, n - done);
+        hip_check(hipMemcpyAsync(pids_, ids_host + done, (size_t)m * 4, hipMemcpyHostToDevice, s), "H2D ids");
+        hip_check(launch_llm_embed(pids_, m, H, c.vocab, embed_, wb, ph_, s), "embed");
+        for (const Layer& L : layers_) {
+            float* k_rows = L.k_cache + (size_t)cache_len_ * kv;
+            float* v_rows = L.v_cache + (size_t)cache_len_ * kv;
+            hip_check(launch_rmsnorm(ph_, L.ln1, c.eps, m, H, pn_, s), "rmsnorm 1");
+            hip_check(launch_prefill_gemm(pn_, H, L.wqkv, wb, L.bqkv, nullptr, 0, pq_, H, m, H, H, s), "q proj");
+            hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)H * H), wb, L.bqkv ? L.bqkv + H : nullptr, nullptr, 0, k_rows, kv, m, kv, H, s),
+                      "k proj");
+            hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)(H + kv) * H), wb, L.bqkv ? L.bqkv + H + kv : nullptr, nullptr, 0, v_rows, kv, m,
+                                          kv, H, s), "v proj");
+            hip_check(launch_rope(pq_, H, m, c.heads, d, cos_, sin_, cache_len_, nullptr, 0, s), "rope q");
+            hip_check(launch_rope(L.k_cache, kv, m, c.kv_heads, d, cos_, sin_, cache_len_, nullptr, 1, s), "rope k");
+            if (prefill_attention_supported(d)) {
+                hip_check(launch_prefill_attention(pq_, H, m, L.k_cache, kv, L.v_cache, kv, cache_len_, c.heads, d, c.heads / c.kv_heads, pctx_, H, s),
+                          "attention");
+            } else {
+                for (int r = 0; r < m; r += 8) {  // 8 query rows at a time against everything cached up to them
+                    const int rows = std::min(8, m - r);
+                    hip_check(launch_decode_attention(pq_ + (size_t)r * H, H, rows, L.k_cache, kv, L.v_cache, kv, cache_len_ + r + rows, nullptr,
+                                                      cache_cap_, c.heads, d, cache_len_ + r, splits_, att_scratch_, pctx_ + (size_t)r * H, H, s,
+                                                      c.heads / c.kv_heads), "attention");
+                }
+            }
+            hip_check(launch_prefill_gemm(pctx_, H, L.wo, wb, nullptr, ph_, H, ph_, H, m, H, H, s), "o proj");
+            hip_check(launch_rmsnorm(ph_, L.ln2, c.eps, m, H, pn_, s), "rmsnorm 2");
+            hip_check(launch_prefill_gemm(pn_, H, L.gate, wb, nullptr, nullptr, 0, pg_, I, m, I, H, s), "gate");
+            hip_check(launch_prefill_gemm(pn_, H, L.up, wb, nullptr, nullptr, 0, pu_, I, m, I, H, s), "up");
+            hip_check(launch_swiglu_mul(pg_, pu_, (size_t)m * I, s), "swiglu");
+            hip_check(launch_prefill_gemm(pg_, I, L.down, wb, nullptr, ph_, H, ph_, H, m, H, I, s), "down proj");
+        }
+        cache_len_ += m;
+        if (done + m == n) {
+            const int rows = (n - 1) % 8 + 1;
+            hip_check(launch_rmsnorm(ph_ + (size_t)(m - rows) * H, final_norm_, c.eps, rows, H, last_, s), "final norm");
+            LlmGemvArgs lm;
+            lm.X = last_ + (size_t)(rows - 1) * H; lm.ldx = H; lm.rows = 1; lm.W = lm_head_; lm.bf16 = bf16_; lm.n_out = c.vocab; lm.k = H;
+            lm.Y0 = logits_; lm.ldy0 = c.vocab;
+            hip_check(launch_llm_gemv(lm, s), "lm head");
+            last_rows_ = rows;
+        }
+        hip_check(hipStreamSynchronize(s), "sync");  // pids_ and the activations are reused by the next chunk
+    }
+}
+
 void LlmModel::forward(const uint32_t* ids, int n)
 {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     if (n < 1) throw std::runtime_error("forward needs at least one token");
     if (cache_len_ + n > cache_cap_) throw std::runtime_error("context is full");
-    for (int i = 0; i < n; i += 8) {
-        const int m = std::min(8, n - i);
-        hip_check(hipMemcpyAsync(ids_, ids + i, (size_t)m * 4, hipMemcpyHostToDevice, stream_), "H2D ids");
-        pass(ids_, m, false);
-        cache_len_ += m;
-        last_rows_ = m;
-        hip_check(hipStreamSynchronize(stream_), "sync");  // ids_ is reused by the next block
+    static const int kMinGemmRows = [] {
+        const char* v = std::getenv("KJARNI_HIP_LLM_PREFILL_MIN");  // measurements: rows from which the matrix-core route is used
+        return v ? std::atoi(v) : 24;
+    }();
+    const int kvd = cfg_.kv_heads * cfg_.head_dim;
+    if (n >= kMinGemmRows && cfg_.hidden % 32 == 0 && cfg_.inter % 32 == 0 && kvd % 4 == 0 && cfg_.head_dim % 2 == 0) {
+        prefill_rows(ids, n);
+    } else {
+        for (int i = 0; i < n; i += 8) {
+            const int m = std::min(8, n - i);
+            hip_check(hipMemcpyAsync(ids_, ids + i, (size_t)m * 4, hipMemcpyHostToDevice, stream_), "H2D ids");
+            pass(ids_, m, false);
+            cache_len_ += m;
+            last_rows_ = m;
+            hip_check(hipStreamSynchronize(stream_), "sync");  // ids_ is reused by the next block
+        }
     }
     hip_check(hipMemcpyAsync(pos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
     hip_check(hipStreamSynchronize(stream_), "sync");

@@ -80,6 +80,7 @@ private:
     float* upload_f32(const std::vector<float>& host);
     float* dalloc(size_t floats);
     void pass(const uint32_t* ids_dev, int n, bool device_pos);
+    void prefill_rows(const uint32_t* ids_host, int n);  // n new tokens through the matrix-core GEMMs
     void enqueue_argmax(bool record);
     hipGraphExec_t step_graph();
 
@@ -103,6 +104,10 @@ private:
     int *pos_ = nullptr, *count_ = nullptr;
     unsigned long long* best_ = nullptr;
     int cache_len_ = 0, cache_cap_ = 0, last_rows_ = 0, hist_cap_ = 0, splits_ = 16;
+    // prefill workspace (allocated on first use)
+    float *ph_ = nullptr, *pn_ = nullptr, *pq_ = nullptr, *pctx_ = nullptr, *pg_ = nullptr, *pu_ = nullptr;
+    uint32_t* pids_ = nullptr;
+    int prefill_cap_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraphExec_t graph_ = nullptr;
 };

@@ -37,6 +37,19 @@ hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, co
                                int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
                                float* Vc, int pos, const int* pos_ptr, hipStream_t stream);
 
+// Prefill: Y[M, N] = A[M, K] . W[N, K]^T + bias (+ R) on the fp32 matrix cores, W bf16 or f32; K % 32 == 0.  R may alias Y.
+hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int bf16, const float* bias, const float* R, int64_t ldr, float* Y,
+                               int64_t ldy, int M, int N, int K, hipStream_t stream);
+
+// Prefill: causal grouped-query attention of `rows` new rows (positions base .. base + rows - 1) over the cache rows
+// 0 .. base + rows - 1; head_dim in {16, 32, 64, 128}.
+bool prefill_attention_supported(int head_dim);
+hipError_t launch_prefill_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V, int64_t ldv, int base,
+                                    int heads, int head_dim, int kv_group, float* ctx, int64_t ldc, hipStream_t stream);
+
+// Prefill: gate = silu(gate) * up (n multiple of 4).
+hipError_t launch_swiglu_mul(float* gate, const float* up, size_t n, hipStream_t stream);
+
 // In-place RoPE on `rows` rows of [n_heads * head_dim]; cos/sin tables are [max_pos, head_dim/2].
 // at_cache_row: row r of the call lives at row (pos + r) of x (the KV cache), else at row r.
 hipError_t launch_rope(float* x, int64_t ldx, int rows, int n_heads, int head_dim, const float* cos_t, const float* sin_t, int pos,

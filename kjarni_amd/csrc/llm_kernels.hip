@@ -527,6 +527,211 @@ __global__ void argmax_finalize_kernel(unsigned long long* __restrict__ best, in
     }
 }
 
+// Prompt-row projections on the fp32 matrix cores: Y[M, N] = A[M, K] . W[N, K]^T (+ bias) (+ R), W in bf16 or f32 as
+// stored.  The encoder's 128 x 128 GEMM (gemm.hip) is sized for 10^5 rows; a prompt has 10^2..10^3, where one
+// 128 x 128 x 2048 tile keeps a CU busy for ~110 us while most CUs have no tile at all.  So: 64 x 64 block tiles
+// (4 waves, one 32 x 32 MFMA tile each) -- 4x more workgroups of a quarter the work --, BK = 32, operands
+// double-buffered in LDS with the next tile's global loads in flight during the MFMAs, bf16 weights widened when they
+// are written to LDS (the same widening the GEMV kernels do).  v_mfma_f32_32x32x2_f32 is an exact k-ordered f32 fma
+// chain, so the arithmetic class is the GEMV's; only the summation order differs.
+constexpr int PG_BM = 64, PG_BN = 64, PG_BK = 32, PG_STRIDE = PG_BK + 4;
+
+template <typename WT, bool RESIDUAL>
+__global__ __launch_bounds__(256) void prefill_gemm_kernel(const float* __restrict__ A, int64_t lda, const WT* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
+                                                           int64_t ldy, int M, int N, int K, int m_tiles)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2][PG_BM * PG_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sB[2][PG_BN * PG_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give every XCD one contiguous run of tiles
+    // (row tiles fastest), so the tiles sharing a weight panel sit behind the same L2.
+    const int64_t nwg = gridDim.x;
+    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int64_t q8 = nwg / 8, r8 = nwg % 8;
+    const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int m0 = (int)(bid % m_tiles) * PG_BM;
+    const int n0 = (int)(bid / m_tiles) * PG_BN;
+
+    // A: 64 x 32 floats = 512 float4, two per thread.  W: f32 the same; bf16: 64 x 32 halves = 256 x 16 bytes, one per thread.
+    const int a_row = tid >> 3, a_c4 = tid & 7;
+    const float* a_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_ptr[i] = A + (int64_t)min(m0 + a_row + 32 * i, M - 1) * lda + a_c4 * 4;
+    constexpr bool BF16 = sizeof(WT) == 2;
+    const int b_row = BF16 ? (tid >> 2) : a_row, b_c = BF16 ? (tid & 3) * 8 : a_c4 * 4;
+    const WT* b_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b_ptr[i] = W + (int64_t)min(n0 + b_row + 32 * i, N - 1) * K + b_c;
+    f32x4 ga[2], gb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ga[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
+        if (BF16) {
+            const F8 w = load8(reinterpret_cast<const uint16_t*>(b_ptr[0]) + k0, 0);
+            gb[0] = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+            gb[1] = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gb[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(b_ptr[i]) + k0);
+        }
+    };
+    auto store = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&sA[stage][(a_row + 32 * i) * PG_STRIDE + a_c4 * 4]) = ga[i];
+        if (BF16) {
+            *reinterpret_cast<f32x4*>(&sB[stage][b_row * PG_STRIDE + b_c]) = gb[0];
+            *reinterpret_cast<f32x4*>(&sB[stage][b_row * PG_STRIDE + b_c + 4]) = gb[1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&sB[stage][(b_row + 32 * i) * PG_STRIDE + b_c]) = gb[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nk = K / PG_BK;
+    const int fa = (wr * 32 + l31) * PG_STRIDE + half * 4, fb = (wc * 32 + l31) * PG_STRIDE + half * 4;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load((kt + 1) * PG_BK);
+#pragma unroll
+        for (int kk = 0; kk < PG_BK / 8; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[cur][fa + kk * 8]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&sB[cur][fb + kk * 8]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) store(cur ^ 1);
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col < N) {
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + acc_row(r, half);
+            if (row < M) {
+                float v = acc[r] + bv;
+                if (RESIDUAL) v += R[(int64_t)row * ldr + col];
+                Y[(int64_t)row * ldy + col] = v;
+            }
+        }
+    }
+}
+
+// Causal grouped-query attention for a block of prompt rows against the KV cache (decoder_attention.rs:99-160 with the
+// causal mask of utils/masks.rs:103-113), flash style: one workgroup per (32 query rows, head), 64-key tiles of K and V
+// staged in LDS, running (max, sum, output) per query -- the [rows, keys] score matrix never exists.  8 threads per
+// query: each scores 8 keys of the tile (keys kg, kg+8, ...: neighbouring threads read neighbouring K rows) and owns
+// head_dim / 8 output columns.  Masked keys contribute exactly 0, as exp(-1e9 - max) does in the reference.
+constexpr int PA_Q = 32, PA_K = 64;
+
+template <int DPT>
+__global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __restrict__ q, int64_t ldq, int rows,
+                                                                const float* __restrict__ K, int64_t ldk,
+                                                                const float* __restrict__ V, int64_t ldv, int base, int kv_group,
+                                                                float scale, float* __restrict__ ctx, int64_t ldc)
+{
+    constexpr int D = 8 * DPT, LD = D + 4;
+    extern __shared__ __attribute__((aligned(16))) float pa_smem[];
+    float* sQ = pa_smem;               // [PA_Q][LD]
+    float* sK = sQ + PA_Q * LD;        // [PA_K][LD]
+    float* sV = sK + PA_K * LD;        // [PA_K][LD]
+    float* sP = sV + PA_K * LD;        // [PA_Q][PA_K + 4]
+    const int tid = threadIdx.x, qi = tid >> 3, kg = tid & 7;
+    const int h = blockIdx.y, hk = h / kv_group;
+    const int q0 = blockIdx.x * PA_Q;
+    const int q_row = q0 + qi;
+    const bool valid = q_row < rows;
+    const int limit = base + q_row;                                   // last visible key of this query
+    const int last_key = base + min(rows, q0 + PA_Q) - 1;             // last key any query of the block sees
+    for (int i = tid; i < PA_Q * (D / 4); i += 256) {
+        const int r = i / (D / 4), c4 = i - r * (D / 4);
+        const int row = min(q0 + r, rows - 1);
+        *reinterpret_cast<f32x4*>(sQ + r * LD + c4 * 4) = *reinterpret_cast<const f32x4*>(q + (int64_t)row * ldq + h * D + c4 * 4);
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    float o[DPT];
+#pragma unroll
+    for (int c = 0; c < DPT; ++c) o[c] = 0.0f;
+    for (int k0 = 0; k0 <= last_key; k0 += PA_K) {
+        __syncthreads();  // previous tile fully consumed (and sQ written, first trip)
+        for (int i = tid; i < PA_K * (D / 4); i += 256) {
+            const int r = i / (D / 4), c4 = i - r * (D / 4);
+            const int key = min(k0 + r, last_key);
+            *reinterpret_cast<f32x4*>(sK + r * LD + c4 * 4) = *reinterpret_cast<const f32x4*>(K + (int64_t)key * ldk + hk * D + c4 * 4);
+            *reinterpret_cast<f32x4*>(sV + r * LD + c4 * 4) = *reinterpret_cast<const f32x4*>(V + (int64_t)key * ldv + hk * D + c4 * 4);
+        }
+        __syncthreads();
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int c4 = 0; c4 < D / 4; ++c4) {
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(sQ + qi * LD + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(sK + (kg + 8 * j) * LD + c4 * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[j] = fmaf(qv[c], kv[c], acc[j]);
+            }
+        }
+        float tile_max = -INFINITY;
+        bool vis[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] *= scale;
+            vis[j] = valid && (k0 + kg + 8 * j) <= limit;
+            if (vis[j]) tile_max = fmaxf(tile_max, acc[j]);
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) tile_max = fmaxf(tile_max, __shfl_xor(tile_max, off, kWave));
+        const float m_new = fmaxf(m_run, tile_max);
+        float psum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = vis[j] ? expf(acc[j] - m_new) : 0.0f;
+            psum += p;
+            sP[qi * (PA_K + 4) + kg + 8 * j] = p;
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) psum += __shfl_xor(psum, off, kWave);
+        const float alpha = (m_new == -INFINITY || m_run == -INFINITY) ? (m_run == -INFINITY ? 0.0f : 1.0f) : expf(m_run - m_new);
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int c = 0; c < DPT; ++c) o[c] *= alpha;
+        m_run = m_new;
+        __syncthreads();  // the tile's probabilities are in LDS
+        for (int j = 0; j < PA_K; ++j) {
+            const float p = sP[qi * (PA_K + 4) + j];
+#pragma unroll
+            for (int c = 0; c < DPT; ++c) o[c] = fmaf(p, sV[j * LD + kg * DPT + c], o[c]);
+        }
+    }
+    if (valid) {
+        const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+#pragma unroll
+        for (int c = 0; c < DPT; ++c) ctx[(int64_t)q_row * ldc + h * D + kg * DPT + c] = o[c] * inv;
+    }
+}
+
+// Prefill: silu(gate) * up over [rows, inter] (swiglu.rs:32-57).
+__global__ __launch_bounds__(256) void swiglu_mul_kernel(float* __restrict__ gate, const float* __restrict__ up, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(gate + i * 4);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(up + i * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g[c] = (g[c] / (1.0f + expf(-g[c]))) * u[c];
+        *reinterpret_cast<f32x4*>(gate + i * 4) = g;
+    }
+}
+
 }  // namespace
 
 template <typename WT>
@@ -627,6 +832,68 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
 }
 
 void set_llm_gemv_variant(int v) { g_llm_gemv_variant = v; }
+
+hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int bf16, const float* bias, const float* R, int64_t ldr, float* Y,
+                               int64_t ldy, int M, int N, int K, hipStream_t stream)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (K % PG_BK || lda % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return hipErrorInvalidValue;
+    const int m_tiles = (M + PG_BM - 1) / PG_BM, n_tiles = (N + PG_BN - 1) / PG_BN;
+    const dim3 grid((unsigned)(m_tiles * n_tiles));
+#define KJ_PG(WT, RES)                                                                                                              \
+    hipLaunchKernelGGL((prefill_gemm_kernel<WT, RES>), grid, dim3(256), 0, stream, A, lda, static_cast<const WT*>(W), bias, R, ldr, Y, ldy, \
+                       M, N, K, m_tiles)
+    if (bf16) {
+        if (R) KJ_PG(uint16_t, true);
+        else KJ_PG(uint16_t, false);
+    } else {
+        if (R) KJ_PG(float, true);
+        else KJ_PG(float, false);
+    }
+#undef KJ_PG
+    return hipGetLastError();
+}
+
+bool prefill_attention_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
+
+hipError_t launch_prefill_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V, int64_t ldv, int base,
+                                    int heads, int head_dim, int kv_group, float* ctx, int64_t ldc, hipStream_t stream)
+{
+    if (rows <= 0) return hipSuccess;
+    if (!prefill_attention_supported(head_dim)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((rows + PA_Q - 1) / PA_Q), (unsigned)heads);
+    const int LD = head_dim + 4;
+    const size_t lds = ((size_t)(PA_Q + 2 * PA_K) * LD + (size_t)PA_Q * (PA_K + 4)) * sizeof(float);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+#define KJ_PA(DPT)                                                                                                                      \
+    do {                                                                                                                                \
+        auto kern = prefill_attention_kernel<DPT>;                                                                                      \
+        if (lds > 48 * 1024) {                                                                                                          \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                                     (int)lds);                                                                         \
+            if (e != hipSuccess) return e;                                                                                              \
+        }                                                                                                                               \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q, ldq, rows, K, ldk, V, ldv, base, kv_group < 1 ? 1 : kv_group, scale,  \
+                           ctx, ldc);                                                                                                   \
+    } while (0)
+    switch (head_dim) {
+    case 16: KJ_PA(2); break;
+    case 32: KJ_PA(4); break;
+    case 64: KJ_PA(8); break;
+    default: KJ_PA(16); break;
+    }
+#undef KJ_PA
+    return hipGetLastError();
+}
+
+hipError_t launch_swiglu_mul(float* gate, const float* up, size_t n, hipStream_t stream)
+{
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((n4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(swiglu_mul_kernel, dim3(grid), dim3(256), 0, stream, gate, up, n4);
+    return hipGetLastError();
+}
 
 hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, const void* W, int bf16, const float* bias, int k,
                                int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
