@@ -114,6 +114,7 @@ void* LlmModel::upload_weight(const std::vector<float>& host)
 
 LlmModel::~LlmModel()
 {
+    if (host_logits_) (void)hipHostFree(host_logits_);
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (graph_) (void)hipGraphExecDestroy(graph_);
@@ -463,26 +464,39 @@ std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, co
 
     if (opt.sample || repetition_penalty != 1.0f || no_repeat_ngram > 0) {
         // Logits processors and sampling work on the host copy of the logits (generator.rs:331-343): one pass per token.
-        std::vector<float> lg((size_t)cfg_.vocab), probs;
+        // The logits land in a pinned host buffer (one async copy per token at full PCIe rate).
+        if (!host_logits_) hip_check(hipHostMalloc((void**)&host_logits_, (size_t)cfg_.vocab * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+        float* lg = host_logits_;
+        const size_t vocab = (size_t)cfg_.vocab;
+        std::vector<float> probs;
         std::vector<uint32_t> ids;
+        hipGraphExec_t exec = nullptr;
         for (size_t step = 0; step < max_new_tokens; ++step) {
             if (all.size() >= context_limit) break;
-            logits_to_host(lg.data());
-            apply_repetition_penalty(lg, all, repetition_penalty);
-            if (no_repeat_ngram > 0) apply_no_repeat_ngram(lg, all, (size_t)no_repeat_ngram);
+            hip_check(hipMemcpyAsync(lg, logits_, vocab * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H logits");
+            hip_check(hipStreamSynchronize(stream_), "sync");
+            apply_repetition_penalty(lg, vocab, all, repetition_penalty);
+            if (no_repeat_ngram > 0) apply_no_repeat_ngram(lg, vocab, all, (size_t)no_repeat_ngram);
             uint32_t next;
             if (opt.sample) {
-                sampling_distribution(lg, opt.sampling, ids, probs);
-                next = sample_from_distribution(ids, probs, opt.uniform(), lg.size());
+                sampling_distribution(lg, vocab, opt.sampling, ids, probs);
+                next = sample_from_distribution(ids, probs, opt.uniform(), vocab);
             } else {
-                next = argmax_last(lg);
+                next = argmax_last(lg, vocab);
             }
             if (is_stop(next)) break;
             all.push_back(next);
             out.push_back(next);
             if (on_token && !on_token(next)) break;
             if (all.size() >= context_limit) break;
-            forward(&next, 1);
+            // The step itself is the replayed graph of the greedy loop: it reads its input token from token_ (overwritten
+            // here with the host's choice; the graph's own argmax result is ignored) and advances position and key count
+            // on the device.
+            if (!exec) exec = step_graph();
+            const int32_t tok = (int32_t)next;
+            hip_check(hipMemcpyAsync(token_, &tok, sizeof(tok), hipMemcpyHostToDevice, stream_), "H2D token");
+            hip_check(hipGraphLaunch(exec, stream_), "graph launch");
+            cache_len_ += 1;
         }
         return out;
     }

@@ -7,45 +7,139 @@
 #include <limits>
 #include <random>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace kjarni {
 
-void apply_repetition_penalty(std::vector<float>& logits, const std::vector<uint32_t>& tokens, float penalty)
+void apply_repetition_penalty(float* logits, size_t vocab, const std::vector<uint32_t>& tokens, float penalty)
 {
     if (penalty == 1.0f) return;
     for (uint32_t t : tokens) {  // once per occurrence, like the reference
-        if (t >= logits.size()) continue;
+        if (t >= vocab) continue;
         const float s = logits[t];
         logits[t] = s < 0.0f ? s * penalty : s / penalty;
     }
 }
 
-void apply_no_repeat_ngram(std::vector<float>& logits, const std::vector<uint32_t>& tokens, size_t n)
+void apply_no_repeat_ngram(float* logits, size_t vocab, const std::vector<uint32_t>& tokens, size_t n)
 {
     if (n == 0 || tokens.size() + 1 < n) return;
     const size_t len = tokens.size();
     for (size_t i = 0; i + n <= len; ++i) {
         if (!std::equal(tokens.begin() + (ptrdiff_t)i, tokens.begin() + (ptrdiff_t)(i + n - 1), tokens.end() - (ptrdiff_t)(n - 1))) continue;
         const uint32_t banned = tokens[i + n - 1];
-        if (banned < logits.size()) logits[banned] = -std::numeric_limits<float>::infinity();
+        if (banned < vocab) logits[banned] = -std::numeric_limits<float>::infinity();
     }
 }
 
-uint32_t argmax_last(const std::vector<float>& logits)
+uint32_t argmax_last(const float* logits, size_t vocab)
 {
     size_t best = 0;
-    for (size_t i = 1; i < logits.size(); ++i)
+    for (size_t i = 1; i < vocab; ++i)
         if (logits[i] >= logits[best]) best = i;
     return (uint32_t)best;
 }
 
 namespace {
 
-// softmax_inplace over the survivors, summed in ascending id order (masked entries would add exactly 0).
+constexpr float kNegInf = -std::numeric_limits<float>::infinity();
+
+// ---- full-vocabulary passes --------------------------------------------------------------------------
+// The reference runs softmax_inplace over the whole vocabulary up to three times per token (scalar exp, running sum).
+// Here the whole-vocabulary work is one max pass and one exp pass, 8 lanes wide when the CPU has AVX2 (expf by range
+// reduction + degree-6 polynomial, < 2 ulp), followed by the reference's own running sum in index order: top-p / min-p
+// cut-offs hang on the rounding of that 10^5-term f32 sum, so its order is kept.
+
+float max_scalar(const float* v, size_t n)
+{
+    float mx = kNegInf;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, v[i]);
+    return mx;
+}
+
+void exp_scalar(const float* v, size_t n, float mx, float inv_temp, float* out)
+{
+    for (size_t i = 0; i < n; ++i) out[i] = std::exp((v[i] - mx) * inv_temp);
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,fma"))) float max_avx2(const float* v, size_t n)
+{
+    __m256 m = _mm256_set1_ps(kNegInf);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) m = _mm256_max_ps(m, _mm256_loadu_ps(v + i));
+    float lanes[8];
+    _mm256_storeu_ps(lanes, m);
+    float mx = kNegInf;
+    for (float x : lanes) mx = std::max(mx, x);
+    for (; i < n; ++i) mx = std::max(mx, v[i]);
+    return mx;
+}
+
+__attribute__((target("avx2,fma"))) inline __m256 exp_avx2(__m256 x)
+{
+    // exp(x) for x <= 0: n = round(x / ln 2), r = x - n ln 2 (two-step), e^r by a degree-6 polynomial, scale by 2^n.
+    const __m256 lo = _mm256_set1_ps(-87.33654f);
+    const __m256 under = _mm256_cmp_ps(x, lo, _CMP_LT_OQ);
+    x = _mm256_max_ps(x, lo);
+    const __m256 nf = _mm256_round_ps(_mm256_mul_ps(x, _mm256_set1_ps(1.44269504088896341f)), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+    __m256 r = _mm256_fnmadd_ps(nf, _mm256_set1_ps(0.693359375f), x);
+    r = _mm256_fnmadd_ps(nf, _mm256_set1_ps(-2.12194440e-4f), r);
+    __m256 p = _mm256_set1_ps(1.9875691500e-4f);
+    p = _mm256_fmadd_ps(p, r, _mm256_set1_ps(1.3981999507e-3f));
+    p = _mm256_fmadd_ps(p, r, _mm256_set1_ps(8.3334519073e-3f));
+    p = _mm256_fmadd_ps(p, r, _mm256_set1_ps(4.1665795894e-2f));
+    p = _mm256_fmadd_ps(p, r, _mm256_set1_ps(1.6666665459e-1f));
+    p = _mm256_fmadd_ps(p, r, _mm256_set1_ps(5.0000001201e-1f));
+    p = _mm256_fmadd_ps(p, _mm256_mul_ps(r, r), _mm256_add_ps(r, _mm256_set1_ps(1.0f)));
+    const __m256i e = _mm256_slli_epi32(_mm256_add_epi32(_mm256_cvtps_epi32(nf), _mm256_set1_epi32(127)), 23);
+    return _mm256_andnot_ps(under, _mm256_mul_ps(p, _mm256_castsi256_ps(e)));
+}
+
+__attribute__((target("avx2,fma"))) void exp_all_avx2(const float* v, size_t n, float mx, float inv_temp, float* out)
+{
+    const __m256 vm = _mm256_set1_ps(mx), vt = _mm256_set1_ps(inv_temp);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) _mm256_storeu_ps(out + i, exp_avx2(_mm256_mul_ps(_mm256_sub_ps(_mm256_loadu_ps(v + i), vm), vt)));
+    for (; i < n; ++i) out[i] = std::exp((v[i] - mx) * inv_temp);
+}
+
+const bool kHaveAvx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+#else
+const bool kHaveAvx2 = false;
+#endif
+
+constexpr size_t kVectorFrom = 4096;  // below this the scalar loops (bit-identical to the reference's order) are used
+
+float vec_max(const float* v, size_t n)
+{
+#if defined(__x86_64__)
+    if (kHaveAvx2 && n >= kVectorFrom) return max_avx2(v, n);
+#endif
+    return max_scalar(v, n);
+}
+
+// out[i] = exp((v[i] - mx) * inv_temp); returns their running sum in index order.
+float vec_sum_exp(const float* v, size_t n, float mx, float inv_temp, float* out)
+{
+#if defined(__x86_64__)
+    if (kHaveAvx2 && n >= kVectorFrom) exp_all_avx2(v, n, mx, inv_temp, out);
+    else
+#endif
+        exp_scalar(v, n, mx, inv_temp, out);
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; ++i) sum += out[i];
+    return sum;
+}
+
+// softmax_inplace over a (small) survivor list, summed in ascending id order exactly as the reference does.
 void softmax(const std::vector<float>& vals, std::vector<float>& probs)
 {
     probs.resize(vals.size());
     if (vals.empty()) return;
-    float mx = -std::numeric_limits<float>::infinity();
+    float mx = kNegInf;
     for (float v : vals) mx = std::max(mx, v);
     float sum = 0.0f;
     for (size_t i = 0; i < vals.size(); ++i) {
@@ -58,39 +152,86 @@ void softmax(const std::vector<float>& vals, std::vector<float>& probs)
     }
 }
 
+// First threshold for sorted_prefix from a 1/8-wide histogram of (max - value): the distance below the maximum that
+// holds `count` values, or `mass` of the sum of `weights` (the exp values), plus one bin of margin.
+float tau_for_count(const float* vals, size_t n, float mx, size_t count)
+{
+    constexpr int kBins = 512;  // covers 64 below the maximum
+    std::vector<uint32_t> hist(kBins + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const float d = (mx - vals[i]) * 8.0f;
+        hist[d < (float)kBins ? (int)d : kBins]++;
+    }
+    size_t seen = 0;
+    for (int b = 0; b < kBins; ++b) {
+        seen += hist[b];
+        if (seen >= count) return (float)(b + 2) / 8.0f;
+    }
+    return 1e31f;
+}
+
+float tau_for_mass(const float* vals, const float* weights, size_t n, float mx, double mass)
+{
+    constexpr int kBins = 512;
+    std::vector<double> hist(kBins + 1, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+        const float d = (mx - vals[i]) * 8.0f;
+        hist[d < (float)kBins ? (int)d : kBins] += weights[i];
+    }
+    double seen = 0.0;
+    for (int b = 0; b < kBins; ++b) {
+        seen += hist[b];
+        if (seen > mass) return (float)(b + 2) / 8.0f;
+    }
+    return 1e31f;
+}
+
 // Positions of `vals` in the reference's sort order (value descending, stable = ascending position), produced
 // lazily: `enough(prefix)` is called with ever longer exact prefixes of that order until it returns true or the
-// prefix is the whole array.
-std::vector<uint32_t> sorted_prefix(const std::vector<float>& vals, const std::function<bool(const std::vector<uint32_t>&)>& enough)
+// prefix is the whole array.  tau0: first threshold below the maximum.
+std::vector<uint32_t> sorted_prefix(const float* vals, size_t n, float mx, float tau0,
+                                    const std::function<bool(const std::vector<uint32_t>&)>& enough)
 {
-    const size_t n = vals.size();
     std::vector<uint32_t> cand;
     if (n == 0) return cand;
-    float mx = -std::numeric_limits<float>::infinity();
-    for (float v : vals) mx = std::max(mx, v);
     const auto by_value = [&](uint32_t a, uint32_t b) { return vals[a] > vals[b] || (vals[a] == vals[b] && a < b); };
-    float tau = 10.0f;
+    float tau = tau0;
+    float upper = std::numeric_limits<float>::infinity();  // values >= upper are already in `cand`, sorted
     for (;;) {
         const bool all = !(tau < 1e30f) || !std::isfinite(mx);
-        const float floor = mx - tau;
-        cand.clear();
-        for (size_t i = 0; i < n; ++i)
-            if (all || vals[i] >= floor) cand.push_back((uint32_t)i);
-        std::sort(cand.begin(), cand.end(), by_value);
+        const float floor = all ? kNegInf : mx - tau;
+        // the next band [floor, upper): everything in it sorts after everything already collected
+        const size_t before = cand.size();
+        for (size_t i = 0; i < n; ++i) {
+            const float v = vals[i];
+            if ((all ? !(v >= upper) : (v >= floor && v < upper))) cand.push_back((uint32_t)i);
+        }
+        std::sort(cand.begin() + (ptrdiff_t)before, cand.end(), by_value);
         if (all || cand.size() == n || enough(cand)) return cand;
-        tau *= 4.0f;
+        upper = floor;
+        tau = tau < 64.0f ? tau + 2.0f : tau * 2.0f;
     }
 }
 
 }  // namespace
 
-void sampling_distribution(const std::vector<float>& logits, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs)
+void sampling_distribution(const float* logits, size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs)
 {
-    const size_t vocab = logits.size();
-    ids.resize(vocab);
-    for (size_t i = 0; i < vocab; ++i) ids[i] = (uint32_t)i;
-    std::vector<float> vals(logits);
-    auto keep = [&](std::vector<uint32_t>& positions) {  // survivors by position, back to ascending id order
+    // Survivors: everything (`all`, values read straight from `logits`) until a filter shrinks the set to (ids, vals).
+    bool all = true, have_exps = false;
+    std::vector<float> vals, exps;
+    ids.clear();
+    probs.clear();
+    if (vocab == 0) return;
+    const float mx_all = vec_max(logits, vocab);
+    auto shrink_from_all = [&](std::vector<uint32_t>& positions) {  // positions index `logits`
+        std::sort(positions.begin(), positions.end());
+        ids = positions;
+        vals.resize(ids.size());
+        for (size_t i = 0; i < ids.size(); ++i) vals[i] = logits[ids[i]];
+        all = false;
+    };
+    auto shrink = [&](std::vector<uint32_t>& positions) {  // positions index (ids, vals)
         std::sort(positions.begin(), positions.end());
         std::vector<uint32_t> nid(positions.size());
         std::vector<float> nval(positions.size());
@@ -102,46 +243,106 @@ void sampling_distribution(const std::vector<float>& logits, const SamplingParam
         vals.swap(nval);
     };
 
-    if (p.top_k >= 0 && (size_t)p.top_k < vals.size()) {  // top_k_filtering
+    if (p.top_k >= 0 && (size_t)p.top_k < vocab) {  // top_k_filtering
         const size_t k = (size_t)p.top_k;
-        std::vector<uint32_t> order = sorted_prefix(vals, [&](const std::vector<uint32_t>& c) { return c.size() >= k; });
+        std::vector<uint32_t> order = sorted_prefix(logits, vocab, mx_all, tau_for_count(logits, vocab, mx_all, k),
+                                                    [&](const std::vector<uint32_t>& c) { return c.size() >= k; });
         order.resize(std::min(order.size(), k));
-        keep(order);
+        shrink_from_all(order);
     }
-    if (p.top_p >= 0.0f && !vals.empty()) {  // top_p_filtering: keep through the first token that pushes the mass past p
-        softmax(vals, probs);
+    if (p.top_p >= 0.0f) {  // top_p_filtering: keep through the first token that pushes the mass past p
         size_t cut = 0;
         bool found = false;
-        auto scan = [&](const std::vector<uint32_t>& c) {
-            float cumulative = 0.0f;
-            for (size_t i = 0; i < c.size(); ++i) {
-                cumulative += probs[c[i]];
-                if (cumulative > p.top_p) {
-                    cut = i;
-                    found = true;
-                    return true;
+        if (all) {
+            exps.resize(vocab);
+            const float sum = vec_sum_exp(logits, vocab, mx_all, 1.0f, exps.data());
+            have_exps = true;
+            const float scale = sum > 0.0f ? 1.0f / sum : 1.0f;
+            auto scan = [&](const std::vector<uint32_t>& c) {
+                float cumulative = 0.0f;
+                for (size_t i = 0; i < c.size(); ++i) {
+                    cumulative += exps[c[i]] * scale;
+                    if (cumulative > p.top_p) {
+                        cut = i;
+                        found = true;
+                        return true;
+                    }
                 }
+                return false;
+            };
+            const float tau0 = tau_for_mass(logits, exps.data(), vocab, mx_all, (double)p.top_p * (double)sum);
+            std::vector<uint32_t> order = sorted_prefix(logits, vocab, mx_all, tau0, scan);
+            if (!found) scan(order);
+            if (found) {
+                order.resize(cut + 1);
+                shrink_from_all(order);
             }
-            return false;
-        };
-        std::vector<uint32_t> order = sorted_prefix(vals, scan);
-        if (!found) scan(order);
-        if (found) {
-            order.resize(cut + 1);
-            keep(order);
+        } else if (!vals.empty()) {
+            softmax(vals, probs);
+            float mx = kNegInf;
+            for (float v : vals) mx = std::max(mx, v);
+            auto scan = [&](const std::vector<uint32_t>& c) {
+                float cumulative = 0.0f;
+                for (size_t i = 0; i < c.size(); ++i) {
+                    cumulative += probs[c[i]];
+                    if (cumulative > p.top_p) {
+                        cut = i;
+                        found = true;
+                        return true;
+                    }
+                }
+                return false;
+            };
+            std::vector<uint32_t> order = sorted_prefix(vals.data(), vals.size(), mx, 4.0f, scan);
+            if (!found) scan(order);
+            if (found) {
+                order.resize(cut + 1);
+                shrink(order);
+            }
         }
     }
-    if (p.min_p >= 0.0f && !vals.empty()) {  // min_p_filtering
-        softmax(vals, probs);
-        float max_prob = 0.0f;
-        for (float q : probs) max_prob = std::max(max_prob, q);
-        const float cutoff = max_prob * p.min_p;
-        std::vector<uint32_t> pos;
-        for (size_t i = 0; i < probs.size(); ++i)
-            if (!(probs[i] < cutoff)) pos.push_back((uint32_t)i);
-        keep(pos);
+    if (p.min_p >= 0.0f) {  // min_p_filtering
+        if (all) {
+            float sum = 0.0f;
+            if (have_exps) {
+                for (size_t i = 0; i < vocab; ++i) sum += exps[i];
+            } else {
+                exps.resize(vocab);
+                sum = vec_sum_exp(logits, vocab, mx_all, 1.0f, exps.data());
+            }
+            const float scale = sum > 0.0f ? 1.0f / sum : 1.0f;
+            const float max_prob = std::max(0.0f, 1.0f * scale);  // exp(0) * scale
+            const float cutoff = max_prob * p.min_p;
+            // prob >= cutoff  <=>  logit >= max + ln(min_p) up to rounding: gather with slack, decide exactly
+            const float slack = p.min_p > 0.0f ? -std::log(p.min_p) + 1e-3f : std::numeric_limits<float>::infinity();
+            std::vector<uint32_t> pos;
+            for (size_t i = 0; i < vocab; ++i)
+                if (!(logits[i] < mx_all - slack) && !(exps[i] * scale < cutoff)) pos.push_back((uint32_t)i);
+            if (pos.size() < vocab) shrink_from_all(pos);
+        } else if (!vals.empty()) {
+            softmax(vals, probs);
+            float max_prob = 0.0f;
+            for (float q : probs) max_prob = std::max(max_prob, q);
+            const float cutoff = max_prob * p.min_p;
+            std::vector<uint32_t> pos;
+            for (size_t i = 0; i < probs.size(); ++i)
+                if (!(probs[i] < cutoff)) pos.push_back((uint32_t)i);
+            shrink(pos);
+        }
     }
     const float temp = p.temperature < 1e-5f ? 1.0f : p.temperature;
+    if (all) {  // temperature only: the whole vocabulary is the distribution
+        ids.resize(vocab);
+        for (size_t i = 0; i < vocab; ++i) ids[i] = (uint32_t)i;
+        probs.resize(vocab);
+        // (x / t) - max(x / t) == (x - max) / t for t > 0 up to rounding
+        const float sum = vec_sum_exp(logits, vocab, mx_all, 1.0f / temp, probs.data());
+        if (sum > 0.0f) {
+            const float scale = 1.0f / sum;
+            for (float& q : probs) q *= scale;
+        }
+        return;
+    }
     for (float& v : vals) v /= temp;
     softmax(vals, probs);
 }

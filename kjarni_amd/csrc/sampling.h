@@ -20,15 +20,28 @@ struct SamplingParams {
     float min_p = -1.0f;  // < 0: not set
 };
 
-void apply_repetition_penalty(std::vector<float>& logits, const std::vector<uint32_t>& tokens, float penalty);
-void apply_no_repeat_ngram(std::vector<float>& logits, const std::vector<uint32_t>& tokens, size_t ngram);
+void apply_repetition_penalty(float* logits, size_t vocab, const std::vector<uint32_t>& tokens, float penalty);
+void apply_no_repeat_ngram(float* logits, size_t vocab, const std::vector<uint32_t>& tokens, size_t ngram);
+inline void apply_repetition_penalty(std::vector<float>& logits, const std::vector<uint32_t>& tokens, float penalty)
+{
+    apply_repetition_penalty(logits.data(), logits.size(), tokens, penalty);
+}
+inline void apply_no_repeat_ngram(std::vector<float>& logits, const std::vector<uint32_t>& tokens, size_t ngram)
+{
+    apply_no_repeat_ngram(logits.data(), logits.size(), tokens, ngram);
+}
 
 // Greedy: the LAST maximum (Iterator::max_by keeps the later of equal elements).
-uint32_t argmax_last(const std::vector<float>& logits);
+uint32_t argmax_last(const float* logits, size_t vocab);
+inline uint32_t argmax_last(const std::vector<float>& logits) { return argmax_last(logits.data(), logits.size()); }
 
 // The distribution sample_token draws from: surviving token ids in ascending order and their probabilities.
-void sampling_distribution(const std::vector<float>& logits, const SamplingParams& p, std::vector<uint32_t>& ids,
-                           std::vector<float>& probs);
+void sampling_distribution(const float* logits, size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs);
+inline void sampling_distribution(const std::vector<float>& logits, const SamplingParams& p, std::vector<uint32_t>& ids,
+                                  std::vector<float>& probs)
+{
+    sampling_distribution(logits.data(), logits.size(), p, ids, probs);
+}
 // sample_from_probs over the full vocabulary: first index whose running sum reaches `uniform`, else vocab - 1.
 uint32_t sample_from_distribution(const std::vector<uint32_t>& ids, const std::vector<float>& probs, float uniform, size_t vocab);
 
