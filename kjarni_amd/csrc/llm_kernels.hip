@@ -238,23 +238,24 @@ __global__ __launch_bounds__(256) void llm_gemv1_kernel(const float* __restrict_
 // FMA (OPW x chunks x 16 bytes per lane in flight) and the four per-wave partial sums meet in LDS.  Compared with
 // one wave per column this puts 4x more workgroups on the chip for the narrow projections (o, down) and reads the
 // input row once per OPW columns instead of once per column.
-constexpr int SK_MAX_CHUNKS = 8;  // k <= 8 * 256 * 8 = 16384
+constexpr int SK_MAX_CHUNKS = 8;  // k <= 8 * 256 * 8 = 16384 with 4 waves; long rows (k >= 8192) use 16 waves per workgroup
 
-template <typename WT, int EPI, bool NORM, int OPW, int CH>
-__global__ __launch_bounds__(256) void llm_gemv_splitk_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
+template <typename WT, int EPI, bool NORM, int OPW, int CH, int NW>
+__global__ __launch_bounds__(64 * NW) void llm_gemv_splitk_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
                                                               const WT* __restrict__ W, const WT* __restrict__ W2,
                                                               const float* __restrict__ bias, const float* __restrict__ R,
                                                               int n_out, int k, float* __restrict__ Y)
 {
     constexpr int NM = EPI == LE_SWIGLU ? 2 : 1;
-    __shared__ float red[4];
-    __shared__ float part[4][NM * OPW];
+    constexpr int THREADS = 64 * NW;
+    __shared__ float red[NW];
+    __shared__ float part[NW][NM * OPW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k8 = k >> 3;
     F8 x[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int i = tid + c * 256;
+        const int i = tid + c * THREADS;
         if (i < k8) x[c] = load8(X, i);
         else {
 #pragma unroll
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void llm_gemv_splitk_kernel(const float* __res
         const int64_t n = n0 + o < n_out ? n0 + o : n_out - 1;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int i = tid + c * 256;
+            const int i = tid + c * THREADS;
             if (i < k8) {
                 w[o][c] = load8(W + n * (int64_t)k, i);
                 if (EPI == LE_SWIGLU) u[o][c] = load8(W2 + n * (int64_t)k, i);
@@ -285,10 +286,13 @@ __global__ __launch_bounds__(256) void llm_gemv_splitk_kernel(const float* __res
         s = wave_sum(s);
         if (lane == 0) red[wave] = s;
         __syncthreads();
-        const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)k + eps);
+        float total = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) total += red[wv];
+        const float rms = sqrtf(total / (float)k + eps);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int i = tid + c * 256;
+            const int i = tid + c * THREADS;
             if (i < k8) {
                 const F8 g = load8(gamma, i);
 #pragma unroll
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256) void llm_gemv_splitk_kernel(const float* __res
         float acc = 0.0f, acc2 = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int i = tid + c * 256;
+            const int i = tid + c * THREADS;
             if (i < k8) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -320,9 +324,14 @@ __global__ __launch_bounds__(256) void llm_gemv_splitk_kernel(const float* __res
     __syncthreads();
     if (tid < OPW && n0 + tid < n_out) {
         const int64_t n = n0 + tid;
-        float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + (bias ? bias[n] : 0.0f);
+        float v = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) v += part[wv][tid];
+        v += bias ? bias[n] : 0.0f;
         if (EPI == LE_SWIGLU) {
-            const float up = (part[0][OPW + tid] + part[1][OPW + tid]) + (part[2][OPW + tid] + part[3][OPW + tid]);
+            float up = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) up += part[wv][OPW + tid];
             v = (v / (1.0f + expf(-v))) * up;
         }
         if (EPI == LE_RESIDUAL) v += R[n];
@@ -743,19 +752,29 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
     // Staging the row in LDS pays when it also has to be normalised (otherwise every wave redoes the statistics); plain
     // projections keep the one-wave-per-column kernel, whose 4x larger grid hides latency better.
     if (a.rows == 1 && a.seg_q == 0 && a.k <= SK_MAX_CHUNKS * 2048 && (g_llm_gemv_variant == 0 || g_llm_gemv_variant >= 3)) {
-        const int chunks = (a.k / 8 + 255) / 256;
-        // Two columns per workgroup measured best on every projection of the 1B / 8B shapes (1, 4 and 8 were 2-18 %
-        // slower end to end): the chip wants many small workgroups more than it wants deep per-lane load queues.
+        // Long rows (down-proj: k = 8192 .. 14336) are spread over 16 waves per workgroup: a quarter of the loads per lane,
+        // four times the waves in flight, at the same two columns per workgroup.
+        const bool wide = a.k >= 8192 && g_llm_gemv_variant != 7;
+        const int threads = wide ? 1024 : 256;
+        const int chunks = (a.k / 8 + threads - 1) / threads;
+        // Two columns per workgroup measured best on every projection of the 1B and 8B shapes (1, 4 and 8 were 2-18 % slower
+        // end to end): the chip wants many small workgroups more than it wants deep per-lane load queues.
         int opw = 2;
-        if (g_llm_gemv_variant >= 3) opw = 1 << (g_llm_gemv_variant - 3);  // measurements: 3 -> 1, 4 -> 2, 5 -> 4, 6 -> 8
+        if (g_llm_gemv_variant >= 3 && g_llm_gemv_variant <= 6) opw = 1 << (g_llm_gemv_variant - 3);  // measurements: 3 -> 1 ... 6 -> 8
         if (opw > 8) opw = 8;
         if (chunks > 2 && opw > 4) opw = 4;
         if (chunks > 4 && opw > 2) opw = 2;
         if (a.swiglu && chunks > 2 && opw > 2) opw = 2;
+        if (wide && opw > 2) opw = 2;  // the 16-wave kernel is instantiated for <= 2 columns
         const dim3 gridk((unsigned)((a.n_out + opw - 1) / opw));
+#define KJ_SK4(EPI, NORM, OPW, CH, NW)                                                                                                \
+    hipLaunchKernelGGL((llm_gemv_splitk_kernel<WT, EPI, NORM, OPW, CH, NW>), gridk, dim3(64 * NW), 0, stream, a.X, a.gamma, a.eps, W, \
+                       W2, a.bias, a.R, a.n_out, a.k, a.Y0)
 #define KJ_SK3(EPI, NORM, OPW, CH)                                                                                                    \
-    hipLaunchKernelGGL((llm_gemv_splitk_kernel<WT, EPI, NORM, OPW, CH>), gridk, dim3(256), 0, stream, a.X, a.gamma, a.eps, W, W2,      \
-                       a.bias, a.R, a.n_out, a.k, a.Y0)
+    do {                                                                                                                              \
+        if (wide) KJ_SK4(EPI, NORM, (OPW > 2 ? 2 : OPW), (CH > 2 ? 2 : CH), 16);                                                      \
+        else KJ_SK4(EPI, NORM, OPW, CH, 4);                                                                                           \
+    } while (0)
 #define KJ_SK2(EPI, NORM, OPW)                                                                                                        \
     do {                                                                                                                              \
         if (chunks <= 1) KJ_SK3(EPI, NORM, OPW, 1);                                                                                   \
@@ -780,6 +799,7 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
             if (norm) KJ_SK1(LE_NONE, true);
             else KJ_SK1(LE_NONE, false);
         }
+#undef KJ_SK4
 #undef KJ_SK1
 #undef KJ_SK2
 #undef KJ_SK3

@@ -385,3 +385,56 @@ def llm_model(path: str, base: dict, seed: int = 0, bf16_values: bool = False, s
         from safetensors.numpy import save_file
         save_file({k: np.ascontiguousarray(v) for k, v in t.items()}, os.path.join(path, "model.safetensors"))
     return cfg, t
+
+
+# Llama-3.1-8B-Instruct geometry (registry.rs:577-590)
+LLAMA_8B = dict(model_type="llama", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                intermediate_size=14336, vocab_size=128256, max_position_embeddings=131072, rms_norm_eps=1e-5, rope_theta=500000.0,
+                tie_word_embeddings=False, bos_token_id=128000, eos_token_id=[128001, 128008, 128009], hidden_act="silu",
+                head_dim=128, torch_dtype="bfloat16",
+                rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                  original_max_position_embeddings=8192))
+
+
+def llm_model_streamed(path: str, base: dict, seed: int = 0, std: float = 0.02, **over):
+    """config.json + model.safetensors with BF16 matrices written tensor by tensor (multi-GB shapes never sit in memory whole)."""
+    cfg = dict(base)
+    cfg.update(over)
+    H, L, I, V = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"], cfg["vocab_size"]
+    d = cfg.get("head_dim") or H // cfg["num_attention_heads"]
+    kv = cfg["num_key_value_heads"] * d
+    specs = [("model.embed_tokens.weight", (V, H))]
+    for i in range(L):
+        p = f"model.layers.{i}"
+        specs += [(p + ".self_attn.q_proj.weight", (H, H)), (p + ".self_attn.k_proj.weight", (kv, H)), (p + ".self_attn.v_proj.weight", (kv, H)),
+                  (p + ".self_attn.o_proj.weight", (H, H)), (p + ".mlp.gate_proj.weight", (I, H)), (p + ".mlp.up_proj.weight", (I, H)),
+                  (p + ".mlp.down_proj.weight", (H, I)), (p + ".input_layernorm.weight", (H,)), (p + ".post_attention_layernorm.weight", (H,))]
+    specs.append(("model.norm.weight", (H,)))
+    if not cfg.get("tie_word_embeddings", True):
+        specs.append(("lm_head.weight", (V, H)))
+    header, off = {}, 0
+    for name, shape in specs:
+        n = int(np.prod(shape))
+        nbytes = n * (2 if len(shape) == 2 else 4)
+        header[name] = {"dtype": "BF16" if len(shape) == 2 else "F32", "shape": list(shape), "data_offsets": [off, off + nbytes]}
+        off += nbytes
+    blob = json.dumps(header, separators=(",", ":")).encode()
+    blob += b" " * ((8 - len(blob) % 8) % 8)
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, indent=1)
+    rng = np.random.default_rng(seed)
+    with open(os.path.join(path, "model.safetensors"), "wb") as f:
+        f.write(len(blob).to_bytes(8, "little"))
+        f.write(blob)
+        for name, shape in specs:
+            n = int(np.prod(shape))
+            if len(shape) == 1:
+                f.write((1.0 + 0.1 * rng.standard_normal(n, dtype=np.float32)).astype("<f4").tobytes())
+                continue
+            for start in range(0, n, 1 << 26):
+                m = min(1 << 26, n - start)
+                x = rng.standard_normal(m, dtype=np.float32) * np.float32(std)
+                f.write((x.view(np.uint32) >> 16).astype("<u2").tobytes())
+    return cfg
+
