@@ -254,7 +254,7 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
     const int* pp = device_pos ? pos_ : nullptr;
     hip_check(launch_llm_embed(ids_dev, n, H, c.vocab, embed_, bf16_ ? 1 : 0, h_, s), "embed");
     for (const Layer& L : layers_) {
-        if (n == 1) {  // decode step: norm + projection + rotation in one launch
+        if (n == 1 && H <= 8192) {  // decode step: norm + projection + rotation in one launch
             hip_check(launch_llm_qkv_rope(h_, L.ln1, c.eps, L.wqkv, bf16_ ? 1 : 0, L.bqkv, H, c.heads, c.kv_heads, d, cos_, sin_, q_,
                                           L.k_cache, L.v_cache, cache_len_, pp, s), "norm + qkv + rope");
         } else {

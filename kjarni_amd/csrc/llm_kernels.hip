@@ -339,11 +339,11 @@ __global__ __launch_bounds__(64 * NW) void llm_gemv_splitk_kernel(const float* _
     }
 }
 
-// Decode-step fusion of RMSNorm + Q|K|V projection + RoPE (decoder_attention.rs:61-97 for one new token): the
-// normalised row sits in LDS as above; a wave owns the PAIR of output columns (i, i + d/2) of one head, so it can
-// rotate them itself (rope/mod.rs:156-176) before Q goes to scratch and K to its cache row; V columns go in pairs
-// of neighbours without rotation.
-template <typename WT>
+// Decode-step fusion of RMSNorm + Q|K|V projection + RoPE (decoder_attention.rs:61-97 for one new token).  Same split-K
+// layout as llm_gemv_splitk_kernel (the four waves of a workgroup share the K dimension, the row is normalised in
+// registers); a workgroup owns the PAIR of output columns (i, i + d/2) of one head, so it rotates its own two outputs
+// (rope/mod.rs:156-176) before Q goes to scratch and K to its cache row; V columns go in pairs of neighbours, unrotated.
+template <typename WT, int CH>
 __global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
                                                            const WT* __restrict__ W, const float* __restrict__ bias, int k,
                                                            int n_heads, int n_kv_heads, int head_dim, const float* __restrict__ cos_t,
@@ -351,35 +351,14 @@ __global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restri
                                                            float* __restrict__ Kc, float* __restrict__ Vc, int pos,
                                                            const int* __restrict__ pos_ptr)
 {
-    extern __shared__ float xs[];
     __shared__ float red[4];
+    __shared__ float part[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k8 = k >> 3, half = head_dim >> 1;
-    float s = 0.0f;
-    for (int i = tid; i < k8; i += 256) {
-        const F8 x = load8(X, i);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s = fmaf(x.v[c], x.v[c], s);
-    }
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)k + eps);
-    for (int i = tid; i < k8; i += 256) {
-        F8 x = load8(X, i);
-        const F8 g = load8(gamma, i);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) x.v[c] = (x.v[c] / rms) * g.v[c];
-        *reinterpret_cast<f32x4*>(xs + i * 8) = f32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
-        *reinterpret_cast<f32x4*>(xs + i * 8 + 4) = f32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
-    }
-    __syncthreads();
-
     const int q_dim = n_heads * head_dim, kv_dim = n_kv_heads * head_dim;
-    const int q_tasks = q_dim / 2, k_tasks = kv_dim / 2, v_tasks = kv_dim / 2;
-    const int task = blockIdx.x * 4 + wave;
-    if (task >= q_tasks + k_tasks + v_tasks) return;
-    int n_a, n_b;  // the two output columns (rows of W) of this wave
+    const int q_tasks = q_dim / 2, k_tasks = kv_dim / 2;
+    const int task = blockIdx.x;
+    int n_a, n_b;  // the two output columns (rows of W) of this workgroup
     int kind;      // 0 = Q, 1 = K, 2 = V
     if (task < q_tasks + k_tasks) {
         kind = task < q_tasks ? 0 : 1;
@@ -392,38 +371,52 @@ __global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restri
         n_a = q_dim + kv_dim + 2 * (task - q_tasks - k_tasks);
         n_b = n_a + 1;
     }
-    const WT* wa = W + (int64_t)n_a * k;
-    const WT* wb = W + (int64_t)n_b * k;
-    float acc_a = 0.0f, acc_b = 0.0f;
-    for (int i0 = lane; i0 < k8; i0 += 256) {
-        F8 a[4], b[4];
+    F8 x[CH], wa[CH], wb[CH];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q * 64;
-            if (i < k8) {
-                a[q] = load8(wa, i);
-                b[q] = load8(wb, i);
-            }
+    for (int c = 0; c < CH; ++c) {
+        const int i = tid + c * 256;
+        if (i < k8) {
+            x[c] = load8(X, i);
+            wa[c] = load8(W + (int64_t)n_a * k, i);
+            wb[c] = load8(W + (int64_t)n_b * k, i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c].v[e] = wa[c].v[e] = wb[c].v[e] = 0.0f;
         }
+    }
+    float s = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q * 64;
-            if (i < k8) {
-                const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + i * 8);
-                const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + i * 8 + 4);
+    for (int c = 0; c < CH; ++c)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc_a = fmaf(xa[c], a[q].v[c], acc_a);
-                    acc_a = fmaf(xb[c], a[q].v[4 + c], acc_a);
-                    acc_b = fmaf(xa[c], b[q].v[c], acc_b);
-                    acc_b = fmaf(xb[c], b[q].v[4 + c], acc_b);
-                }
+        for (int e = 0; e < 8; ++e) s = fmaf(x[c].v[e], x[c].v[e], s);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)k + eps);
+    float acc_a = 0.0f, acc_b = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = tid + c * 256;
+        if (i < k8) {
+            const F8 g = load8(gamma, i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xn = (x[c].v[e] / rms) * g.v[e];
+                acc_a = fmaf(xn, wa[c].v[e], acc_a);
+                acc_b = fmaf(xn, wb[c].v[e], acc_b);
             }
         }
     }
-    float va = wave_sum(acc_a) + (bias ? bias[n_a] : 0.0f);
-    float vb = wave_sum(acc_b) + (bias ? bias[n_b] : 0.0f);
-    if (lane != 0) return;
+    acc_a = wave_sum(acc_a);
+    acc_b = wave_sum(acc_b);
+    if (lane == 0) {
+        part[wave][0] = acc_a;
+        part[wave][1] = acc_b;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    const float va = ((part[0][0] + part[1][0]) + (part[2][0] + part[3][0])) + (bias ? bias[n_a] : 0.0f);
+    const float vb = ((part[0][1] + part[1][1]) + (part[2][1] + part[3][1])) + (bias ? bias[n_b] : 0.0f);
     const int p = pos_ptr ? *pos_ptr : pos;
     if (kind == 2) {
         const int col = n_a - q_dim - kv_dim;
@@ -434,10 +427,9 @@ __global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restri
     const int col = kind == 0 ? n_a : n_a - q_dim;
     const int i = col % head_dim;  // < half
     const float c = cos_t[(int64_t)p * half + i], sn = sin_t[(int64_t)p * half + i];
-    const float ra = va * c - vb * sn, rb = va * sn + vb * c;
     float* out = kind == 0 ? Q : Kc + (int64_t)p * kv_dim;
-    out[col] = ra;
-    out[col + half] = rb;
+    out[col] = va * c - vb * sn;
+    out[col + half] = va * sn + vb * c;
 }
 
 // In-place rotation of `rows` rows of [n_heads * d] (rope/mod.rs:156-176): pairs (i, i + d/2), position =
@@ -919,27 +911,23 @@ hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, co
                                int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
                                float* Vc, int pos, const int* pos_ptr, hipStream_t stream)
 {
-    if ((k & 7) || k > G1_MAX_K || (head_dim & 1)) return hipErrorInvalidValue;
+    if ((k & 7) || k > 8192 || (head_dim & 1)) return hipErrorInvalidValue;
     const int tasks = (n_heads * head_dim + 2 * n_kv_heads * head_dim) / 2;
-    const dim3 grid((unsigned)((tasks + 3) / 4));
-    const size_t lds = (size_t)k * sizeof(float);
+    const dim3 grid((unsigned)tasks);
+    const int chunks = (k / 8 + 255) / 256;
+#define KJ_QKV(WT, CH)                                                                                                              \
+    hipLaunchKernelGGL((llm_qkv_rope_kernel<WT, CH>), grid, dim3(256), 0, stream, X, gamma, eps, static_cast<const WT*>(W), bias, k, \
+                       n_heads, n_kv_heads, head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr)
     if (bf16) {
-        auto kern = llm_qkv_rope_kernel<uint16_t>;
-        if (lds > 48 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, X, gamma, eps, static_cast<const uint16_t*>(W), bias, k, n_heads, n_kv_heads,
-                           head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr);
+        if (chunks <= 1) KJ_QKV(uint16_t, 1);
+        else if (chunks <= 2) KJ_QKV(uint16_t, 2);
+        else KJ_QKV(uint16_t, 4);
     } else {
-        auto kern = llm_qkv_rope_kernel<float>;
-        if (lds > 48 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, X, gamma, eps, static_cast<const float*>(W), bias, k, n_heads, n_kv_heads,
-                           head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr);
+        if (chunks <= 1) KJ_QKV(float, 1);
+        else if (chunks <= 2) KJ_QKV(float, 2);
+        else KJ_QKV(float, 4);
     }
+#undef KJ_QKV
     return hipGetLastError();
 }
 
