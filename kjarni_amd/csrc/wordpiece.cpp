@@ -1,5 +1,9 @@
 #include "wordpiece.h"
 
+#include <cstdint>
+
+#include "bpe.h"
+
 #include <exception>
 #include <thread>
 
@@ -32,6 +36,59 @@ bool is_word_char(uint32_t cp)
 
 }  // namespace
 
+void BertTokenizer::parse_post_processor(const Json& root)
+{
+    if (const Json* pp = root.find("post_processor")) {
+        if (!pp->is_null()) {
+            const std::string ppt = pp->get_string("type", "");
+            auto special_id = [&](const Json& specials, const std::string& name) -> uint32_t {
+                if (const Json* s = specials.find(name))
+                    if (const Json* ids = s->find("ids"))
+                        if (ids->is_array() && !ids->arr.empty()) return (uint32_t)ids->arr[0].as_int();
+                const int64_t id = token_to_id(name);
+                if (id < 0) throw std::runtime_error("post_processor token not in vocab: " + name);
+                return (uint32_t)id;
+            };
+            if (ppt == "TemplateProcessing") {
+                const Json empty;
+                const Json* specials = pp->find("special_tokens");
+                auto parse = [&](const Json& arr, std::vector<TemplatePiece>& out) {
+                    for (const Json& piece : arr.arr) {
+                        TemplatePiece tp;
+                        if (const Json* st = piece.find("SpecialToken")) {
+                            tp.is_special = true;
+                            tp.id = special_id(specials ? *specials : empty, st->get_string("id", ""));
+                            tp.type_id = (uint32_t)st->get_int("type_id", 0);
+                        } else if (const Json* sq = piece.find("Sequence")) {
+                            tp.sequence = sq->get_string("id", "A") == "B" ? 1 : 0;
+                            tp.type_id = (uint32_t)sq->get_int("type_id", 0);
+                        } else {
+                            throw std::runtime_error("unknown TemplateProcessing piece");
+                        }
+                        out.push_back(tp);
+                    }
+                };
+                parse(pp->at("single"), single_);
+                parse(pp->at("pair"), pair_);
+            } else if (ppt == "BertProcessing") {
+                const uint32_t sep = (uint32_t)pp->at("sep").arr.at(1).as_int();
+                const uint32_t cls = (uint32_t)pp->at("cls").arr.at(1).as_int();
+                single_ = {{true, cls, 0, 0}, {false, 0, 0, 0}, {true, sep, 0, 0}};
+                pair_ = {{true, cls, 0, 0}, {false, 0, 0, 0}, {true, sep, 0, 0}, {false, 0, 1, 1}, {true, sep, 0, 1}};
+            } else if (ppt == "RobertaProcessing") {  // <s> A </s>  |  <s> A </s></s> B </s>, every type id 0
+                const uint32_t sep = (uint32_t)pp->at("sep").arr.at(1).as_int();
+                const uint32_t cls = (uint32_t)pp->at("cls").arr.at(1).as_int();
+                single_ = {{true, cls, 0, 0}, {false, 0, 0, 0}, {true, sep, 0, 0}};
+                pair_ = {{true, cls, 0, 0}, {false, 0, 0, 0}, {true, sep, 0, 0}, {true, sep, 0, 0}, {false, 0, 1, 0}, {true, sep, 0, 0}};
+            } else {
+                throw std::runtime_error("post_processor '" + ppt + "' is not supported");
+            }
+        }
+    }
+    if (single_.empty()) single_ = {{false, 0, 0, 0}};
+    if (pair_.empty()) pair_ = {{false, 0, 0, 0}, {false, 0, 1, 1}};
+}
+
 BertTokenizer BertTokenizer::from_file(const std::string& path) { return from_json(slurp(path)); }
 
 BertTokenizer BertTokenizer::from_json(const std::string& text)
@@ -41,8 +98,17 @@ BertTokenizer BertTokenizer::from_json(const std::string& text)
 
     const Json& model = root.at("model");
     const std::string mtype = model.get_string("type", "WordPiece");
+    if (mtype == "BPE") {  // RoBERTa: byte-level BPE for the sequences, the framing below stays the same
+        auto bpe = std::make_shared<BpeTokenizer>();
+        bpe->load_json(text, "tokenizer.json");
+        t.bpe_ = bpe;
+        t.has_normalizer_ = false;
+        t.parse_post_processor(root);
+        t.pad_id_ = 0;
+        return t;
+    }
     if (mtype != "WordPiece")
-        throw std::runtime_error("tokenizer model '" + mtype + "' is not supported (WordPiece only)");
+        throw std::runtime_error("tokenizer model '" + mtype + "' is not supported (WordPiece and byte-level BPE are)");
     const Json& vocab = model.at("vocab");
     if (!vocab.is_object()) throw std::runtime_error("tokenizer.json: model.vocab must be an object");
     t.vocab_.reserve(vocab.obj.size() * 2);
@@ -91,58 +157,20 @@ BertTokenizer BertTokenizer::from_json(const std::string& text)
                 if (!at.content.empty()) t.added_.push_back(at);
             }
     }
-    // post-processor
-    if (const Json* pp = root.find("post_processor")) {
-        if (!pp->is_null()) {
-            const std::string ppt = pp->get_string("type", "");
-            auto special_id = [&](const Json& specials, const std::string& name) -> uint32_t {
-                if (const Json* s = specials.find(name))
-                    if (const Json* ids = s->find("ids"))
-                        if (ids->is_array() && !ids->arr.empty()) return (uint32_t)ids->arr[0].as_int();
-                auto it = t.vocab_.find(name);
-                if (it == t.vocab_.end()) throw std::runtime_error("post_processor token not in vocab: " + name);
-                return it->second;
-            };
-            if (ppt == "TemplateProcessing") {
-                const Json empty;
-                const Json* specials = pp->find("special_tokens");
-                auto parse = [&](const Json& arr, std::vector<TemplatePiece>& out) {
-                    for (const Json& piece : arr.arr) {
-                        TemplatePiece tp;
-                        if (const Json* st = piece.find("SpecialToken")) {
-                            tp.is_special = true;
-                            tp.id = special_id(specials ? *specials : empty, st->get_string("id", ""));
-                            tp.type_id = (uint32_t)st->get_int("type_id", 0);
-                        } else if (const Json* sq = piece.find("Sequence")) {
-                            tp.sequence = sq->get_string("id", "A") == "B" ? 1 : 0;
-                            tp.type_id = (uint32_t)sq->get_int("type_id", 0);
-                        } else {
-                            throw std::runtime_error("unknown TemplateProcessing piece");
-                        }
-                        out.push_back(tp);
-                    }
-                };
-                parse(pp->at("single"), t.single_);
-                parse(pp->at("pair"), t.pair_);
-            } else if (ppt == "BertProcessing") {
-                const uint32_t sep = (uint32_t)pp->at("sep").arr.at(1).as_int();
-                const uint32_t cls = (uint32_t)pp->at("cls").arr.at(1).as_int();
-                t.single_ = {{true, cls, 0, 0}, {false, 0, 0, 0}, {true, sep, 0, 0}};
-                t.pair_ = {{true, cls, 0, 0}, {false, 0, 0, 0}, {true, sep, 0, 0}, {false, 0, 1, 1}, {true, sep, 0, 1}};
-            } else {
-                throw std::runtime_error("post_processor '" + ppt + "' is not supported");
-            }
-        }
-    }
-    if (t.single_.empty()) t.single_ = {{false, 0, 0, 0}};
-    if (t.pair_.empty()) t.pair_ = {{false, 0, 0, 0}, {false, 0, 1, 1}};
+    t.parse_post_processor(root);
     // PaddingParams::default(): pad_id 0, pad_type_id 0 (loader.rs:112-115)
     t.pad_id_ = 0;
     return t;
 }
 
+size_t BertTokenizer::vocab_size() const { return bpe_ ? bpe_->vocab_size() : vocab_.size(); }
+
 int64_t BertTokenizer::token_to_id(const std::string& tok) const
 {
+    if (bpe_) {
+        uint32_t id = 0;
+        return bpe_->token_to_id(tok, id) ? (int64_t)id : -1;
+    }
     auto it = vocab_.find(tok);
     return it == vocab_.end() ? -1 : (int64_t)it->second;
 }
@@ -266,6 +294,11 @@ void BertTokenizer::tokenize_segment(const std::vector<uint32_t>& cps, std::vect
 // added tokens with normalized == true are cut out of the normalised text.
 void BertTokenizer::tokenize_sequence(const std::string& text, std::vector<uint32_t>& ids) const
 {
+    if (bpe_) {
+        const std::vector<uint32_t> got = bpe_->encode(text, 0);
+        ids.insert(ids.end(), got.begin(), got.end());
+        return;
+    }
     std::vector<uint32_t> cps;
     if (!unicode::decode_utf8(text.data(), text.size(), cps)) throw std::runtime_error("invalid UTF-8 in input text");
 
@@ -346,7 +379,9 @@ Encoding BertTokenizer::encode(const std::string& text_a, const std::string* tex
     // tokenizers/src/utils/truncation.rs truncate_encodings, strategy LongestFirst,
     // direction Right, stride 0; max_length is reduced by the special tokens first
     // (tokenizers/src/tokenizer/mod.rs post_process).
-    const size_t max_len = max_length_ > n_added ? max_length_ - n_added : 0;
+    // max_length - n_added is a usize subtraction in the crate: when the frame alone exceeds max_length it wraps in a
+    // release build and nothing is truncated.
+    const size_t max_len = max_length_ >= n_added ? max_length_ - n_added : SIZE_MAX;
     const size_t total = a.size() + b.size();
     if (max_len == 0) {
         a.clear();

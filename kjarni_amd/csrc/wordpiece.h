@@ -1,4 +1,5 @@
-// BERT WordPiece tokenizer reading HF tokenizer.json.
+// Encoder-side tokenizer reading HF tokenizer.json: BERT WordPiece (BERT, DistilBERT, MPNet) or byte-level BPE
+// (RoBERTa; the model itself is bpe.h), with the post-processing, truncation and padding the reference applies.
 //
 // The reference tokenises with the HF `tokenizers` crate (Tokenizer::from_file,
 // crates/kjarni-transformers/src/pipeline/encoder/loader.rs:98-115; call sites
@@ -6,7 +7,8 @@
 // .../sequence_classifier/mod.rs:272-275).  That crate is not vendored; this is
 // a restatement of its pipeline for the BERT family:
 //   added-token split -> BertNormalizer -> BertPreTokenizer -> WordPiece
-//   -> truncation (LongestFirst, right) -> TemplateProcessing / BertProcessing
+//   (or: added-token split -> ByteLevel + BPE, for a RoBERTa tokenizer.json)
+//   -> truncation (LongestFirst, right) -> TemplateProcessing / BertProcessing / RobertaProcessing
 //   -> BatchLongest right padding (pad id 0, type 0).
 // Token ids are integer work: they must be bit-exact, and are pinned against the
 // same Rust core through Python `tokenizers` in tests/test_tokenizer.py.
@@ -15,11 +17,14 @@
 // greedy longest-match core; its known-answer tests are reproduced too.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 namespace kjarni {
+
+class BpeTokenizer;
 
 struct Encoding {
     std::vector<uint32_t> ids, type_ids, attention_mask;
@@ -47,7 +52,7 @@ public:
     BatchEncoding encode_batch(const std::vector<std::string>& texts) const;
     BatchEncoding encode_batch_pairs(const std::vector<std::pair<std::string, std::string>>& pairs) const;
 
-    size_t vocab_size() const { return vocab_.size(); }
+    size_t vocab_size() const;
     int64_t token_to_id(const std::string& tok) const;
 
     // Exposed for tests: the normalised string of a plain segment.
@@ -66,12 +71,14 @@ private:
         uint32_t type_id = 0;
     };
 
+    void parse_post_processor(const class Json& root);
     void tokenize_sequence(const std::string& text, std::vector<uint32_t>& ids) const;
     void tokenize_segment(const std::vector<uint32_t>& cps, std::vector<uint32_t>& ids) const;
     void wordpiece(const std::vector<uint32_t>& word, std::vector<uint32_t>& ids) const;
     void normalize_cps(const std::vector<uint32_t>& in, std::vector<uint32_t>& out) const;
     static BatchEncoding pad_batch(std::vector<Encoding>& encs);
 
+    std::shared_ptr<const BpeTokenizer> bpe_;  // set: the sequence tokenizer is byte-level BPE (RoBERTa)
     std::unordered_map<std::string, uint32_t> vocab_;
     std::vector<AddedToken> added_;  // matched in raw text (normalized == false) or in normalised text
     std::string unk_token_ = "[UNK]";
