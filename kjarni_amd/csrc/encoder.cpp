@@ -105,6 +105,31 @@ Names bert_names(const std::string& pre)
     return n;
 }
 
+// MPNet: sentence_encoder/configs.rs:426-462 (the relative attention bias of the checkpoint is not read there either).
+Names mpnet_names()
+{
+    Names n;
+    n.emb = "embeddings.";
+    const std::string l = "encoder.layer.{}.";
+    n.q_w = l + "attention.attn.q.weight";
+    n.q_b = l + "attention.attn.q.bias";
+    n.k_w = l + "attention.attn.k.weight";
+    n.k_b = l + "attention.attn.k.bias";
+    n.v_w = l + "attention.attn.v.weight";
+    n.v_b = l + "attention.attn.v.bias";
+    n.o_w = l + "attention.attn.o.weight";
+    n.o_b = l + "attention.attn.o.bias";
+    n.ln1_g = l + "attention.LayerNorm.weight";
+    n.ln1_b = l + "attention.LayerNorm.bias";
+    n.w1 = l + "intermediate.dense.weight";
+    n.b1 = l + "intermediate.dense.bias";
+    n.w2 = l + "output.dense.weight";
+    n.b2 = l + "output.dense.bias";
+    n.ln2_g = l + "output.LayerNorm.weight";
+    n.ln2_b = l + "output.LayerNorm.bias";
+    return n;
+}
+
 Names distilbert_names(const std::string& pre)
 {
     Names n;
@@ -187,9 +212,30 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         else if (act == "relu") c.ffn_act = EPI_BIAS_RELU;
         else if (act == "swiglu") throw std::runtime_error("SwiGLU (Nomic) encoders are not supported by the HIP encoder");
         else c.ffn_act = EPI_BIAS_GELU;
+    } else if (c.model_type == "roberta" || c.model_type == "distilroberta") {
+        // sequence_classifier/configs.rs:149-280: BERT's layer layout under "roberta.", positions start at 2.
+        const std::string pre = st.contains("roberta.embeddings.word_embeddings.weight") ? "roberta." : "";
+        names = bert_names(pre);
+        c.hidden = (int)cfg.get_int("hidden_size", 0);
+        c.layers = (int)cfg.get_int("num_hidden_layers", 0);
+        c.heads = (int)cfg.get_int("num_attention_heads", 0);
+        c.inter = (int)cfg.get_int("intermediate_size", 0);
+        c.eps = (float)cfg.get_double("layer_norm_eps", 1e-5);
+        c.pos_offset = 2;  // extra_pos_embeddings (configs.rs:223)
+        const std::string act = cfg.get_string("hidden_act", "gelu");
+        c.ffn_act = act == "gelu_new" ? EPI_BIAS_GELU_NEW : (act == "relu" ? EPI_BIAS_RELU : EPI_BIAS_GELU);  // configs.rs:217-222
+    } else if (c.model_type == "mpnet") {
+        names = mpnet_names();
+        c.hidden = (int)cfg.get_int("hidden_size", 0);
+        c.layers = (int)cfg.get_int("num_hidden_layers", 0);
+        c.heads = (int)cfg.get_int("num_attention_heads", 0);
+        c.inter = (int)cfg.get_int("intermediate_size", 0);
+        c.eps = (float)cfg.get_double("layer_norm_eps", 1e-5);
+        c.pos_offset = 2;                 // sentence_encoder/configs.rs:416
+        c.ffn_act = EPI_BIAS_GELU_NEW;    // configs.rs:410: the tanh form whatever hidden_act says
     } else {
         throw std::runtime_error("unsupported model_type '" + c.model_type +
-                                 "' (the HIP encoder covers bert and distilbert)");
+                                 "' (the HIP encoder covers bert, distilbert, roberta and mpnet)");
     }
     if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads != 0)
         throw std::runtime_error("invalid encoder dimensions in config.json");
@@ -206,7 +252,8 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
     if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("position_embeddings has wrong shape");
     c.max_pos = (int)shape[0];
     m->pos_ = m->upload(buf);
-    if (c.model_type == "bert" && st.contains(names.emb + "token_type_embeddings.weight")) {
+    const bool typed_family = c.model_type == "bert" || c.model_type == "roberta" || c.model_type == "distilroberta";
+    if (typed_family && st.contains(names.emb + "token_type_embeddings.weight")) {
         shape = st.read_f32(names.emb + "token_type_embeddings.weight", buf);
         if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("token_type_embeddings has wrong shape");
         c.type_vocab = (int)shape[0];

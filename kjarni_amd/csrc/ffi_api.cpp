@@ -77,8 +77,8 @@ std::unique_ptr<Pipeline> load_pipeline(const char* cache_dir, const char* model
                 : (e->task == ModelTask::ReRanking || e->task == ModelTask::Classification);
         if (e->arch != ModelArch::Bert || !task_ok)
             throw std::runtime_error(std::string("Model '") + e->cli_name +
-                                     "' is not compatible with this component (the HIP encoder serves BERT-style "
-                                     "encoder models: bert, distilbert)");
+                                     "' is not compatible with this component (the HIP encoder serves bert, "
+                                     "distilbert, roberta and mpnet checkpoints of the matching task)");
         const std::string cache = cache_dir ? std::string(cache_dir) : default_cache_dir();
         dir = model_dir_for(*e, cache);
         if (!model_files_present(dir))

@@ -15,14 +15,14 @@ const RegistryEntry kEntries[] = {
     {"minilm-l6-v2", "sentence-transformers/all-MiniLM-L6-v2", ModelTask::Embedding, ModelArch::Bert},
     {"nomic-embed-text", "nomic-ai/nomic-embed-text-v1.5", ModelTask::Embedding, ModelArch::Other},
     {"bge-m3", "BAAI/bge-m3", ModelTask::Embedding, ModelArch::Other},
-    {"mpnet-base-v2", "sentence-transformers/all-mpnet-base-v2", ModelTask::Embedding, ModelArch::Other},
+    {"mpnet-base-v2", "sentence-transformers/all-mpnet-base-v2", ModelTask::Embedding, ModelArch::Bert},
     {"distilbert-base", "distilbert-base-cased-distilled-squad", ModelTask::Embedding, ModelArch::Bert},
     {"minilm-l6-v2-cross-encoder", "cross-encoder/ms-marco-MiniLM-L-6-v2", ModelTask::ReRanking, ModelArch::Bert},
     {"distilbert-sentiment", "distilbert/distilbert-base-uncased-finetuned-sst-2-english", ModelTask::Classification, ModelArch::Bert},
-    {"roberta-sentiment", "olafuraron/twitter-roberta-base-sentiment-latest-safetensors", ModelTask::Classification, ModelArch::Other},
+    {"roberta-sentiment", "olafuraron/twitter-roberta-base-sentiment-latest-safetensors", ModelTask::Classification, ModelArch::Bert},
     {"bert-sentiment-multilingual", "olafuraron/bert-base-multilingual-uncased-sentiment-safetensors", ModelTask::Classification, ModelArch::Bert},
-    {"roberta-emotions", "SamLowe/roberta-base-go_emotions", ModelTask::Classification, ModelArch::Other},
-    {"distilroberta-emotion", "olafuraron/emotion-english-distilroberta-base-safetensors", ModelTask::Classification, ModelArch::Other},
+    {"roberta-emotions", "SamLowe/roberta-base-go_emotions", ModelTask::Classification, ModelArch::Bert},
+    {"distilroberta-emotion", "olafuraron/emotion-english-distilroberta-base-safetensors", ModelTask::Classification, ModelArch::Bert},
     {"toxic-bert", "olafuraron/toxic-bert-safetensors", ModelTask::Classification, ModelArch::Bert},
     {"qwen2.5-0.5b-instruct", "Qwen/Qwen2.5-0.5B-Instruct", ModelTask::Other, ModelArch::Other},
     {"qwen2.5-1.5b", "Qwen/Qwen2.5-1.5B-Instruct", ModelTask::Other, ModelArch::Other},

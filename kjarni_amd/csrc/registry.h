@@ -12,7 +12,7 @@
 namespace kjarni {
 
 enum class ModelTask { Embedding, ReRanking, Classification, Other };
-enum class ModelArch { Bert, Other };
+enum class ModelArch { Bert, Other };  // Bert: an encoder family this library runs (BERT, DistilBERT, RoBERTa, MPNet)
 
 struct RegistryEntry {
     const char* cli_name;

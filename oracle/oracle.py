@@ -287,8 +287,10 @@ class OracleModel:
     """ko_model built from a {hf_tensor_name: ndarray} dict + config dict.
 
     Weight-name layouts follow kjarni-models/src/models/sentence_encoder/
-    configs.rs:218-366 (BERT: plain and "bert."-prefixed) and :638-687
-    (DistilBERT)."""
+    configs.rs:218-366 (BERT: plain and "bert."-prefixed), :393-470 (MPNet: positions
+    start at 2, tanh GELU, no token types, the relative attention bias is not read) and
+    :638-687 (DistilBERT); sequence_classifier/configs.rs:149-280 (RoBERTa: BERT's layout
+    under "roberta.", positions start at 2)."""
 
     def __init__(self, tensors: Dict[str, np.ndarray], config: dict, blocked_gemm: bool = False):
         self.config = config
@@ -326,8 +328,26 @@ class OracleModel:
                 ln2_b=f"{pre}transformer.layer.{i}.output_layer_norm.bias")
             type_name = None
             eps = 1e-12
+        elif mt == "mpnet":
+            pre = ""
+            emb = "embeddings."
+            names = lambda i: dict(
+                wq=f"encoder.layer.{i}.attention.attn.q.weight", bq=f"encoder.layer.{i}.attention.attn.q.bias",
+                wk=f"encoder.layer.{i}.attention.attn.k.weight", bk=f"encoder.layer.{i}.attention.attn.k.bias",
+                wv=f"encoder.layer.{i}.attention.attn.v.weight", bv=f"encoder.layer.{i}.attention.attn.v.bias",
+                wo=f"encoder.layer.{i}.attention.attn.o.weight", bo=f"encoder.layer.{i}.attention.attn.o.bias",
+                ln1_g=f"encoder.layer.{i}.attention.LayerNorm.weight", ln1_b=f"encoder.layer.{i}.attention.LayerNorm.bias",
+                w1=f"encoder.layer.{i}.intermediate.dense.weight", b1=f"encoder.layer.{i}.intermediate.dense.bias",
+                w2=f"encoder.layer.{i}.output.dense.weight", b2=f"encoder.layer.{i}.output.dense.bias",
+                ln2_g=f"encoder.layer.{i}.output.LayerNorm.weight", ln2_b=f"encoder.layer.{i}.output.LayerNorm.bias")
+            type_name = None
+            eps = config.get("layer_norm_eps", 1e-5)
+            act = ACT_GELU_NEW  # configs.rs:410
         else:
-            pre = "bert." if "bert.embeddings.word_embeddings.weight" in t else ""
+            if mt in ("roberta", "distilroberta"):
+                pre = "roberta." if "roberta.embeddings.word_embeddings.weight" in t else ""
+            else:
+                pre = "bert." if "bert.embeddings.word_embeddings.weight" in t else ""
             emb = pre + "embeddings."
             names = lambda i: dict(
                 wq=f"{pre}encoder.layer.{i}.attention.self.query.weight",
@@ -347,7 +367,7 @@ class OracleModel:
                 ln2_g=f"{pre}encoder.layer.{i}.output.LayerNorm.weight",
                 ln2_b=f"{pre}encoder.layer.{i}.output.LayerNorm.bias")
             type_name = emb + "token_type_embeddings.weight"
-            eps = config.get("layer_norm_eps", 1e-12)
+            eps = config.get("layer_norm_eps", 1e-5 if mt in ("roberta", "distilroberta") else 1e-12)
         for i in range(Lc):
             for field, name in names(i).items():
                 setattr(layers[i], field, _f(t[name]))
@@ -357,7 +377,7 @@ class OracleModel:
         m.vocab = t[emb + "word_embeddings.weight"].shape[0]
         m.max_pos = t[emb + "position_embeddings.weight"].shape[0]
         m.type_vocab = t[type_name].shape[0] if type_name and type_name in t else 0
-        m.pos_offset = 0
+        m.pos_offset = 2 if mt in ("roberta", "distilroberta", "mpnet") else 0  # extra_pos_embeddings
         m.act, m.prenorm, m.scale_embeddings, m.scale_qk = act, 0, 0, 1
         m.eps = eps
         m.blocked_gemm = int(blocked_gemm)
@@ -398,6 +418,10 @@ class OracleModel:
         """Classification head auto-detected from tensor names
         (cpu/encoder/classifier.rs:103-202)."""
         t = self.t
+        for stem in ("classification_head", "classifier"):  # dense + tanh + out_proj (BART / RoBERTa heads)
+            if f"{stem}.dense.weight" in t:
+                return cls_head(hidden, t[f"{stem}.dense.weight"], t.get(f"{stem}.dense.bias"), ACT_TANH,
+                                t[f"{stem}.out_proj.weight"], t.get(f"{stem}.out_proj.bias"))
         if "pre_classifier.weight" in t:
             return cls_head(hidden, t["pre_classifier.weight"], t.get("pre_classifier.bias"),
                             ACT_RELU, t["classifier.weight"], t.get("classifier.bias"))

@@ -137,6 +137,53 @@ def distilbert_sentiment(path: str, seed: int = 2, **over) -> Tuple[dict, Dict[s
     return cfg, t
 
 
+def roberta_classifier(path: str, seed: int = 3, labels=("negative", "neutral", "positive"), **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+    """RobertaForSequenceClassification layout (sequence_classifier/configs.rs:149-280): "roberta."-prefixed BERT layers,
+    514 positions (offset 2), one token type, classifier.dense + tanh + classifier.out_proj."""
+    cfg = dict(model_type="roberta", hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+               hidden_act="gelu", max_position_embeddings=514, vocab_size=640, layer_norm_eps=1e-5, type_vocab_size=1,
+               architectures=["RobertaForSequenceClassification"], id2label={str(i): l for i, l in enumerate(labels)},
+               label2id={l: i for i, l in enumerate(labels)})
+    cfg.update(over)
+    t = bert_tensors(cfg, seed, prefix="roberta.")
+    rng = np.random.default_rng(seed + 100)
+    H = cfg["hidden_size"]
+    t["classifier.dense.weight"] = (rng.standard_normal((H, H)) * 0.05).astype(np.float32)
+    t["classifier.dense.bias"] = (rng.standard_normal(H) * 0.05).astype(np.float32)
+    t["classifier.out_proj.weight"] = (rng.standard_normal((len(labels), H)) * 0.2).astype(np.float32)
+    t["classifier.out_proj.bias"] = (rng.standard_normal(len(labels)) * 0.1).astype(np.float32)
+    write_model_dir(path, cfg, t)
+    return cfg, t
+
+
+def mpnet_embedder(path: str, seed: int = 4, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+    """MPNet layout (sentence_encoder/configs.rs:393-470), including the relative-attention-bias tensor of real
+    checkpoints, which the reference never reads."""
+    cfg = dict(model_type="mpnet", hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+               hidden_act="gelu", max_position_embeddings=514, vocab_size=30527, layer_norm_eps=1e-5,
+               architectures=["MPNetModel"], relative_attention_num_buckets=32)
+    cfg.update(over)
+    rng = np.random.default_rng(seed)
+    H, L, I, V, P = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"], cfg["vocab_size"], cfg["max_position_embeddings"]
+    w = lambda *shape, s=0.02: (rng.standard_normal(shape) * s).astype(np.float32)  # noqa: E731
+    g = lambda n: (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)  # noqa: E731
+    t = {"embeddings.word_embeddings.weight": w(V, H), "embeddings.position_embeddings.weight": w(P, H),
+         "embeddings.LayerNorm.weight": g(H), "embeddings.LayerNorm.bias": w(H, s=0.05),
+         "encoder.relative_attention_bias.weight": w(32, cfg["num_attention_heads"], s=0.5),
+         "pooler.dense.weight": w(H, H), "pooler.dense.bias": w(H, s=0.05)}
+    for i in range(L):
+        p = f"encoder.layer.{i}."
+        for nm in ("q", "k", "v", "o"):
+            t[p + f"attention.attn.{nm}.weight"] = w(H, H)
+            t[p + f"attention.attn.{nm}.bias"] = w(H, s=0.05)
+        t[p + "attention.LayerNorm.weight"], t[p + "attention.LayerNorm.bias"] = g(H), w(H, s=0.05)
+        t[p + "intermediate.dense.weight"], t[p + "intermediate.dense.bias"] = w(I, H), w(I, s=0.05)
+        t[p + "output.dense.weight"], t[p + "output.dense.bias"] = w(H, I), w(H, s=0.05)
+        t[p + "output.LayerNorm.weight"], t[p + "output.LayerNorm.bias"] = g(H), w(H, s=0.05)
+    write_model_dir(path, cfg, t)
+    return cfg, t
+
+
 def synthetic_ids(n: int, seq: int, vocab: int = 30522, seed: int = 0, ragged: bool = False):
     """[CLS]=101 first, [SEP]=102 last real token, body uniform in
     1000..vocab-1; ragged=True draws lengths in 16..seq and right-pads with id 0 / mask 0."""

@@ -1,0 +1,89 @@
+"""RoBERTa (classification) and MPNet (embedding) checkpoints through the C ABI against the oracle: the two other encoder
+families the reference's SequenceClassifier / SentenceEncoder load (sequence_classifier/mod.rs:52-64,
+sentence_encoder/model.rs:41-54).  Both place positions at offset 2; RoBERTa frames with <s> </s> over byte-level BPE,
+MPNet with <s> </s> over WordPiece and uses the tanh GELU."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TEXTS = ["I love this, it's wonderful!", "meh.", "The service was slow and the food was cold, never again", "þæö 日本語 😀", "a"]
+
+
+def _tokenizer(d, name):
+    shutil.copy(os.path.join(GOLDEN, f"{name}_tokenizer.json"), os.path.join(d, "tokenizer.json"))
+    return os.path.join(d, "tokenizer.json")
+
+
+def test_roberta_classifier_matches_oracle(tmp_path):
+    import kjarni_amd
+    d = str(tmp_path / "roberta")
+    cfg, t = synth.roberta_classifier(d)
+    tok = kjarni_amd.Tokenizer(_tokenizer(d, "roberta"), cfg["max_position_embeddings"])
+    orc = O.OracleModel(t, cfg)
+    clf = kjarni_amd.Classifier(model_path=d)
+    labels = ["negative", "neutral", "positive"]
+    assert clf.num_labels == 3 and clf.labels() == labels
+    for text in TEXTS:
+        ids, mask, _ = tok.encode_batch([text])
+        assert ids[0, 0] == 0 and ids[0, int(mask[0].sum()) - 1] == 2  # <s> ... </s>
+        logits = orc.head_logits(orc.forward(ids, mask, None, O.strategy_mask_value(ids.size)))[0]
+        probs = O.softmax_rows(logits[None, :])[0]
+        got = dict(clf.classify(text))
+        for i, label in enumerate(labels):
+            assert abs(got[label] - probs[i]) < TOL, (text, label)
+    # token level: a padded batch (pad id 0 = <s>, masked) and the position offset
+    enc = kjarni_amd.HipEncoder(d)
+    ids, mask, _ = tok.encode_batch(TEXTS)
+    want = orc.forward(ids, mask, None, O.strategy_mask_value(ids.size))
+    got = enc.hidden_states(ids, mask)
+    valid = mask.astype(bool)
+    assert np.abs(got[valid] - want[valid]).max() < TOL
+    # the same weights read as plain BERT (positions from 0) must differ: the offset is really applied
+    cfg0 = dict(cfg, model_type="bert")
+    t0 = {k.replace("roberta.", "bert."): v for k, v in t.items()}
+    want0 = O.OracleModel(t0, cfg0).forward(ids, mask, None, O.strategy_mask_value(ids.size))
+    assert np.abs(want0[valid] - want[valid]).max() > 1e-2
+
+
+def test_mpnet_embedder_matches_oracle(tmp_path):
+    import kjarni_amd
+    d = str(tmp_path / "mpnet")
+    cfg, t = synth.mpnet_embedder(d)
+    tok = kjarni_amd.Tokenizer(_tokenizer(d, "mpnet"), cfg["max_position_embeddings"])
+    orc = O.OracleModel(t, cfg)
+    emb = kjarni_amd.Embedder(model_path=d)
+    assert emb.dim == cfg["hidden_size"]
+    ids, mask, _ = tok.encode_batch(TEXTS)
+    want = orc.embed_batch(ids, mask)
+    got = emb.encode_batch(TEXTS)
+    assert np.abs(got - want).max() < TOL
+    assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-5
+    one = emb.encode(TEXTS[2])
+    i1, m1, _ = tok.encode_batch([TEXTS[2]])
+    assert np.abs(one - orc.embed_batch(i1, m1)[0]).max() < TOL
+
+
+def test_registry_names_reach_the_new_families(tmp_path):
+    import kjarni_amd
+    cache = tmp_path / "cache"
+    d = str(cache / "olafuraron_twitter-roberta-base-sentiment-latest-safetensors")
+    cfg, t = synth.roberta_classifier(d)
+    _tokenizer(d, "roberta")
+    clf = kjarni_amd.Classifier("roberta-sentiment", cache_dir=str(cache))
+    assert clf.labels() == ["negative", "neutral", "positive"]
+    d2 = str(cache / "sentence-transformers_all-mpnet-base-v2")
+    synth.mpnet_embedder(d2)
+    _tokenizer(d2, "mpnet")
+    emb = kjarni_amd.Embedder("mpnet-base-v2", cache_dir=str(cache))
+    assert emb.dim == 128
+    with pytest.raises(kjarni_amd.KjarniException) as ei:  # Nomic (SwiGLU + rotary) and XLM-R stay outside
+        kjarni_amd.Embedder("nomic-embed-text", cache_dir=str(cache))
+    assert ei.value.code == kjarni_amd.KjarniError.LOAD_FAILED and "not compatible" in str(ei.value)
