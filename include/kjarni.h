@@ -345,14 +345,14 @@ size_t kjarni_indexer_chunk_size(const KjarniIndexer* indexer);                 
 
 /* ---- Chat (decoder-only LLMs): kjarni-ffi/src/chat.rs:13-758 -----------------------------------
  * model_name is a registry name ("llama3.2-1b-instruct", "qwen2.5-0.5b-instruct", ...): it selects the
- * architecture, the chat template (Llama 3 / ChatML) and the directory <cache_dir>/<org>_<repo>.  The reference
+ * architecture, the chat template (Llama 3 / ChatML / Mistral [INST]) and the directory <cache_dir>/<org>_<repo>.  The reference
  * never reads model_path (chat.rs:190-250); here a non-NULL model_path replaces that directory (config.json,
  * tokenizer.json, model.safetensors, optional generation_config.json), everything else still follows model_name.
  * Both device values run on the MI355X; KJARNI_HIP_DEVICE picks the ordinal, KJARNI_HIP_CHAT_CONTEXT the KV-cache
  * capacity in tokens (default 32768, the model's max_position_embeddings is what kjarni_chat_context_size reports).
  * Errors of kjarni_chat_new (chat.rs:126-139): unknown name / files not on disk -> MODEL_NOT_FOUND; encoder, seq2seq,
  * speech or template-less model -> INVALID_CONFIG; no GPU -> GPU_UNAVAILABLE; anything else -> LOAD_FAILED
- * (including the architectures this library does not build: Mistral, Phi-3). */
+ * (including Phi-3, which the reference cannot load either). */
 typedef struct KjarniChatConfig {      /* chat.rs:13-30 */
     KjarniDevice device;
     const char* cache_dir;     /* NULL = default cache */

@@ -2,8 +2,11 @@
 #include "bpe.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <queue>
 #include <sstream>
 #include <stdexcept>
 
@@ -212,8 +215,50 @@ void BpeTokenizer::load_json(const std::string& text, const std::string& origin)
         }
     }
 
+    // SentencePiece-style files (Llama 2 / Mistral): no ByteLevel anywhere, byte fallback in the model.
+    sp_mode_ = false;
+    {
+        const Json* model0 = j.find("model");
+        const Json* pt0 = j.find("pre_tokenizer");
+        const bool no_pt = !pt0 || pt0->is_null();
+        const bool metaspace = pt0 && !pt0->is_null() && pt0->get_string("type", "") == "Metaspace";
+        if (model0 && model0->get_bool("byte_fallback", false) && (no_pt || metaspace)) sp_mode_ = true;
+    }
+    if (sp_mode_) {
+        const std::string sp = "\xE2\x96\x81";  // U+2581
+        const Json* nz = j.find("normalizer");
+        const Json* pt0 = j.find("pre_tokenizer");
+        const bool has_nz = nz && !nz->is_null();
+        const bool has_pt = pt0 && !pt0->is_null();
+        if (has_nz) {
+            const Json* list = nz->find("normalizers");
+            if (nz->get_string("type", "") != "Sequence" || !list || list->arr.size() != 2 || list->arr[0].get_string("type", "") != "Prepend" ||
+                list->arr[0].get_string("prepend", "") != sp || list->arr[1].get_string("type", "") != "Replace")
+                fail("unsupported normalizer for a byte-fallback BPE (expected Prepend + Replace)");
+            const Json* pat = list->arr[1].find("pattern");
+            if (!pat || pat->get_string("String", "") != " " || list->arr[1].get_string("content", "") != sp)
+                fail("unsupported Replace normalizer (expected \" \" -> U+2581)");
+            if (has_pt) fail("Prepend normalizer together with a pre_tokenizer is not supported");
+            sp_prepend_ = 0;
+        } else if (has_pt) {
+            if (pt0->get_string("replacement", sp) != sp || pt0->get_bool("split", true)) fail("unsupported Metaspace pre_tokenizer (expected split = false)");
+            const std::string scheme = pt0->get_string("prepend_scheme", "always");
+            sp_prepend_ = scheme == "first" ? 1 : (scheme == "always" ? 2 : 3);
+        } else {
+            sp_prepend_ = 3;
+        }
+        const Json* dec = j.find("decoder");
+        const Json* dl = dec && !dec->is_null() ? dec->find("decoders") : nullptr;
+        const bool dec_ok = dl && dl->is_array() && dl->arr.size() == 4 && dl->arr[0].get_string("type", "") == "Replace" &&
+                            dl->arr[1].get_string("type", "") == "ByteFallback" && dl->arr[2].get_string("type", "") == "Fuse" &&
+                            dl->arr[3].get_string("type", "") == "Strip" && dl->arr[3].get_string("content", "") == " " &&
+                            dl->arr[3].get_int("start", 0) == 1 && dl->arr[3].get_int("stop", 0) == 0;
+        if (!dec_ok) fail("unsupported decoder for a byte-fallback BPE (expected Replace + ByteFallback + Fuse + Strip(\" \", 1, 0))");
+    }
+
     // normalizer
     nfc_ = false;
+    if (!sp_mode_)
     if (const Json* nz = j.find("normalizer"); nz && !nz->is_null()) {
         const std::string t = nz->get_string("type", "");
         if (t == "NFC") nfc_ = true;
@@ -245,8 +290,8 @@ void BpeTokenizer::load_json(const std::string& text, const std::string& origin)
         return Pattern::Gpt2;
     };
     const Json* pt = j.find("pre_tokenizer");
-    if (!pt || pt->is_null()) fail("no pre_tokenizer (expected ByteLevel)");
-    {
+    if (!sp_mode_ && (!pt || pt->is_null())) fail("no pre_tokenizer (expected ByteLevel)");
+    if (!sp_mode_) {
         const std::string t = pt->get_string("type", "");
         bool use_regex = true, prefix = true;
         if (t == "ByteLevel") {
@@ -270,7 +315,7 @@ void BpeTokenizer::load_json(const std::string& text, const std::string& origin)
     const Json* model = j.find("model");
     if (!model || model->get_string("type", "BPE") != "BPE") fail("model is not BPE");
     if (const Json* d = model->find("dropout"); d && !d->is_null() && d->as_double() != 0.0) fail("BPE dropout is not supported");
-    if (model->get_bool("byte_fallback", false)) fail("byte_fallback is not supported");
+    if (model->get_bool("byte_fallback", false) && !sp_mode_) fail("byte_fallback is not supported with a ByteLevel pre-tokenizer");
     for (const char* key : {"continuing_subword_prefix", "end_of_word_suffix"})
         if (const Json* v = model->find(key); v && v->is_string() && !v->as_string().empty()) fail(std::string(key) + " is not supported");
     ignore_merges_ = model->get_bool("ignore_merges", false);
@@ -306,6 +351,12 @@ void BpeTokenizer::load_json(const std::string& text, const std::string& origin)
             has_unk_ = true;
             unk_id_ = it->second;
         }
+    }
+    for (int b = 0; b < 256; ++b) {
+        char name[8];
+        std::snprintf(name, sizeof(name), "<0x%02X>", b);
+        auto it = vocab_.find(name);
+        byte_ids_[b] = it == vocab_.end() ? -1 : (int32_t)it->second;
     }
     merges_.clear();
     if (const Json* merges = model->find("merges"); merges && merges->is_array()) {
@@ -369,6 +420,7 @@ bool BpeTokenizer::token_to_id(const std::string& token, uint32_t& id) const
 
 std::string BpeTokenizer::decode(const std::vector<uint32_t>& ids, bool skip_special) const
 {
+    if (sp_mode_) return decode_sp(ids, skip_special);
     std::string bytes;
     for (uint32_t id : ids) {
         if (id >= id_to_token_.size() || !has_token_[id]) continue;
@@ -601,6 +653,135 @@ void BpeTokenizer::encode_segment(const std::string& text, std::vector<uint32_t>
     }
 }
 
+// Word::merge_all (tokenizers/src/models/bpe/word.rs): a heap of candidate merges ordered by (rank, position); stale
+// entries are dropped when popped.  Without a pre-tokenizer a whole prompt is one word, so this has to be n log n.
+void BpeTokenizer::merge_symbols(std::vector<uint32_t>& sym) const
+{
+    const int n = (int)sym.size();
+    if (n < 2) return;
+    std::vector<int> prev((size_t)n), next((size_t)n);
+    std::vector<uint8_t> alive((size_t)n, 1);
+    for (int i = 0; i < n; ++i) {
+        prev[(size_t)i] = i - 1;
+        next[(size_t)i] = i + 1 < n ? i + 1 : -1;
+    }
+    struct Cand {
+        uint32_t rank;
+        int pos;
+        uint32_t a, b, merged;
+    };
+    auto worse = [](const Cand& x, const Cand& y) { return x.rank != y.rank ? x.rank > y.rank : x.pos > y.pos; };
+    std::priority_queue<Cand, std::vector<Cand>, decltype(worse)> heap(worse);
+    auto push = [&](int pos) {
+        const int nx = next[(size_t)pos];
+        if (nx < 0) return;
+        auto it = merges_.find(((uint64_t)sym[(size_t)pos] << 32) | sym[(size_t)nx]);
+        if (it != merges_.end()) heap.push({it->second.first, pos, sym[(size_t)pos], sym[(size_t)nx], it->second.second});
+    };
+    for (int i = 0; i + 1 < n; ++i) push(i);
+    while (!heap.empty()) {
+        const Cand c = heap.top();
+        heap.pop();
+        if (!alive[(size_t)c.pos] || sym[(size_t)c.pos] != c.a) continue;
+        const int nx = next[(size_t)c.pos];
+        if (nx < 0 || sym[(size_t)nx] != c.b) continue;
+        sym[(size_t)c.pos] = c.merged;
+        alive[(size_t)nx] = 0;
+        next[(size_t)c.pos] = next[(size_t)nx];
+        if (next[(size_t)nx] >= 0) prev[(size_t)next[(size_t)nx]] = c.pos;
+        if (prev[(size_t)c.pos] >= 0) push(prev[(size_t)c.pos]);
+        push(c.pos);
+    }
+    std::vector<uint32_t> out;
+    out.reserve((size_t)n);
+    for (int i = 0; i < n; ++i)
+        if (alive[(size_t)i]) out.push_back(sym[(size_t)i]);
+    sym.swap(out);
+}
+
+// One segment between added tokens in the SentencePiece-style pipeline: spaces become U+2581, the prefix rule of the
+// normalizer / Metaspace applies, every character is a symbol (its bytes as <0xNN> tokens when it is not in the
+// vocabulary, a fused <unk> when those are missing too), then the merges.
+void BpeTokenizer::encode_segment_sp(const std::string& text, bool at_start, std::vector<uint32_t>& out) const
+{
+    if (text.empty()) return;
+    std::vector<uint32_t> cps;
+    if (!unicode::decode_utf8(text.data(), text.size(), cps)) throw std::runtime_error("tokenizer input is not valid UTF-8");
+    constexpr uint32_t kSp = 0x2581;
+    for (uint32_t& c : cps)
+        if (c == ' ') c = kSp;
+    bool prepend = false;
+    switch (sp_prepend_) {
+    case 0: prepend = true; break;                           // Prepend normalizer: every non-empty segment
+    case 1: prepend = at_start && cps[0] != kSp; break;      // Metaspace, prepend_scheme = first
+    case 2: prepend = cps[0] != kSp; break;                  // Metaspace, always
+    default: break;
+    }
+    if (prepend) cps.insert(cps.begin(), kSp);
+    std::vector<uint32_t> sym;
+    sym.reserve(cps.size());
+    bool last_unk = false;
+    std::string ch;
+    for (uint32_t c : cps) {
+        ch.clear();
+        unicode::append_utf8(ch, c);
+        auto it = vocab_.find(ch);
+        if (it != vocab_.end()) {
+            sym.push_back(it->second);
+            last_unk = false;
+            continue;
+        }
+        bool bytes_ok = true;
+        for (unsigned char b : ch)
+            if (byte_ids_[b] < 0) bytes_ok = false;
+        if (bytes_ok) {
+            for (unsigned char b : ch) sym.push_back((uint32_t)byte_ids_[b]);
+            last_unk = false;
+        } else if (has_unk_) {
+            if (!(fuse_unk_ && last_unk)) sym.push_back(unk_id_);
+            last_unk = true;
+        }
+    }
+    merge_symbols(sym);
+    out.insert(out.end(), sym.begin(), sym.end());
+}
+
+// decoders::Sequence[Replace(U+2581 -> " "), ByteFallback, Fuse, Strip(" ", 1, 0)].
+std::string BpeTokenizer::decode_sp(const std::vector<uint32_t>& ids, bool skip_special) const
+{
+    std::string fused, run;
+    auto flush = [&] {
+        if (run.empty()) return;
+        if (unicode::is_valid_utf8(run.data(), run.size())) fused += run;
+        else
+            for (size_t i = 0; i < run.size(); ++i) fused += "\xEF\xBF\xBD";  // one replacement character per byte
+        run.clear();
+    };
+    for (uint32_t id : ids) {
+        if (id >= id_to_token_.size() || !has_token_[id]) continue;
+        if (skip_special && special_[id]) continue;
+        const std::string& tok = id_to_token_[id];
+        if (tok.size() == 6 && tok.compare(0, 3, "<0x") == 0 && tok[5] == '>') {
+            char* end = nullptr;
+            const long v = std::strtol(tok.substr(3, 2).c_str(), &end, 16);
+            if (end && *end == '\0') {
+                run.push_back((char)v);
+                continue;
+            }
+        }
+        flush();
+        for (size_t i = 0; i < tok.size();) {  // U+2581 -> ' '
+            if (tok.compare(i, 3, "\xE2\x96\x81") == 0) {
+                fused += ' ';
+                i += 3;
+            } else fused += tok[i++];
+        }
+    }
+    flush();
+    if (!fused.empty() && fused[0] == ' ') fused.erase(0, 1);
+    return fused;
+}
+
 std::vector<uint32_t> BpeTokenizer::encode(const std::string& text, size_t max_length) const
 {
     std::vector<uint32_t> ids;
@@ -617,6 +798,10 @@ std::vector<uint32_t> BpeTokenizer::encode(const std::string& text, size_t max_l
             if (!unicode::decode_utf8(seg.data(), seg.size(), in)) throw std::runtime_error("tokenizer input is not valid UTF-8");
             nfc(in, o);
             seg = unicode::encode_utf8(o);
+        }
+        if (sp_mode_) {
+            encode_segment_sp(seg, s.begin == 0, ids);
+            continue;
         }
         split_on_added(seg, true, inner);
         for (const Split& t : inner) {

@@ -10,6 +10,8 @@
 //                              ByteLevel(use_regex = true) (the GPT-2 regex)
 //   model                   -> BPE (merge ranks, ignore_merges), no dropout
 //   post-processor          -> skipped (add_special_tokens = false)
+// and the SentencePiece-style shape of Llama 2 / Mistral files: Prepend + Replace normalizer (or a non-splitting Metaspace
+// pre-tokenizer), BPE with byte fallback and a fused <unk>, decoder Replace + ByteFallback + Fuse + Strip.
 // Anything else in the file is a load error rather than a silently different tokenization.
 #pragma once
 #include <cstdint>
@@ -54,6 +56,9 @@ private:
     void encode_segment(const std::string& text, std::vector<uint32_t>& out) const;
     void scan_pieces(const std::vector<uint32_t>& cps, std::vector<std::pair<size_t, size_t>>& pieces) const;
     void bpe_word(const std::string& piece_utf8, std::vector<uint32_t>& out) const;
+    void encode_segment_sp(const std::string& text, bool at_start, std::vector<uint32_t>& out) const;
+    void merge_symbols(std::vector<uint32_t>& sym) const;  // Word::merge_all with a heap: O(n log n) on long words
+    std::string decode_sp(const std::vector<uint32_t>& ids, bool skip_special) const;
 
     std::vector<std::string> id_to_token_;
     std::vector<uint8_t> has_token_, special_;
@@ -68,6 +73,10 @@ private:
     bool nfc_ = false, add_prefix_space_ = false, ignore_merges_ = false, has_unk_ = false, fuse_unk_ = false;
     uint32_t unk_id_ = 0;
     size_t max_length_ = 0;
+    // SentencePiece-style mode
+    bool sp_mode_ = false;
+    int sp_prepend_ = 0;  // 0 = Prepend normalizer (every segment), 1 = Metaspace first, 2 = Metaspace always, 3 = never
+    int32_t byte_ids_[256];
 };
 
 }  // namespace kjarni

@@ -156,7 +156,7 @@ GenerationConfig resolve_generation_config(GenerationConfig config, const Genera
 GenerationConfig model_default_generation_config(const std::string& model_type, size_t max_pos, const std::string* hf_json)
 {
     GenerationConfig c;
-    if (hf_json) {  // HFGenerationDefaults::into_generation_config; a file that does not deserialize is ignored
+    if (hf_json && model_type != "mistral") {  // HFGenerationDefaults (a file that does not deserialize is ignored); Mistral never reads it
         try {
             const Json j = Json::parse(*hf_json);
             if (!j.is_object()) throw std::runtime_error("not an object");
@@ -196,7 +196,15 @@ GenerationConfig model_default_generation_config(const std::string& model_type, 
     c.max_length = max_pos;
     c.no_repeat_ngram_size = 0;
     c.strategy = Strategy::Sample;
-    if (model_type == "qwen2") {  // qwen/model.rs:267-281
+    if (model_type == "mistral") {  // mistral/model.rs:236-252
+        c.max_new_tokens = Opt<size_t>(512);
+        c.repetition_penalty = 1.15f;
+        c.add_bos_token = true;
+        c.temperature = 0.7f;
+        c.top_k = Opt<size_t>(40);
+        c.top_p = Opt<float>(0.9f);
+        c.min_p = Opt<float>(0.05f);
+    } else if (model_type == "qwen2") {  // qwen/model.rs:267-281
         c.max_new_tokens = Opt<size_t>(512);
         c.repetition_penalty = 1.1f;
         c.add_bos_token = false;
@@ -305,11 +313,10 @@ std::unique_ptr<Chat> Chat::create(const std::string& model_name, const std::str
     if (family == "phi3") throw load_failed("Phi3 model loading not yet implemented");
     if (family == "gpt")  // loads in the reference, then fails the template check (chat/model.rs:113-116)
         throw InvalidConfig("model '" + cli + "' does not have a chat template. use Generator for raw text generation.");
-    if (family == "mistral") throw load_failed("the Mistral tokenizer (Metaspace + byte fallback) and layout are not built in this library");
 
     std::unique_ptr<Chat> chat(new Chat());
     chat->model_name_ = cli;
-    chat->template_ = family == "qwen2" ? ChatTemplateKind::ChatML : ChatTemplateKind::Llama3;
+    chat->template_ = family == "qwen2" ? ChatTemplateKind::ChatML : (family == "mistral" ? ChatTemplateKind::Mistral : ChatTemplateKind::Llama3);
     chat->mode_ = mode;
     if (system_prompt) {
         chat->has_system_ = true;

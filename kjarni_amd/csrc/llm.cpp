@@ -47,8 +47,8 @@ LlmConfig LlmConfig::from_json(const std::string& text)
         return (int)v->as_int();
     };
     c.model_type = j.get_string("model_type", "llama");
-    if (c.model_type != "llama" && c.model_type != "qwen2")
-        throw std::runtime_error("unsupported decoder model_type '" + c.model_type + "' (llama and qwen2 are)");
+    if (c.model_type != "llama" && c.model_type != "qwen2" && c.model_type != "mistral")
+        throw std::runtime_error("unsupported decoder model_type '" + c.model_type + "' (llama, qwen2 and mistral are)");
     c.hidden = req("hidden_size");
     c.layers = req("num_hidden_layers");
     c.heads = req("num_attention_heads");
@@ -57,10 +57,11 @@ LlmConfig LlmConfig::from_json(const std::string& text)
     c.vocab = req("vocab_size");
     c.max_pos = req("max_position_embeddings");
     c.head_dim = (int)j.get_int("head_dim", c.hidden / c.heads);
-    // llama/config.rs:137-152, qwen/config.rs:70-76 defaults
-    const bool llama = c.model_type == "llama";
-    c.eps = (float)j.get_double("rms_norm_eps", llama ? 1e-5 : 1e-6);
-    c.rope_theta = (float)j.get_double("rope_theta", llama ? 500000.0 : 1000000.0);
+    // llama/config.rs:137-152, qwen/config.rs:70-76, mistral/config.rs:54-56 + :168 defaults.  Mistral runs on the Llama
+    // decoder (mistral/model.rs:56-62); its sliding_window field is never read by the reference.
+    const bool llama = c.model_type == "llama", mistral = c.model_type == "mistral";
+    c.eps = (float)j.get_double("rms_norm_eps", (llama || mistral) ? 1e-5 : 1e-6);
+    c.rope_theta = (float)j.get_double("rope_theta", llama ? 500000.0 : (mistral ? 10000.0 : 1000000.0));
     c.tie_embeddings = j.get_bool("tie_word_embeddings", llama);
     if (const Json* rs = j.find("rope_scaling"); rs && rs->is_object()) {
         c.has_rope_scaling = true;

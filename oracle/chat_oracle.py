@@ -196,10 +196,13 @@ def hf_generation_defaults(text: str, max_seq_len: int) -> Optional[GenerationCo
 
 
 def model_default_generation_config(model_type: str, max_pos: int, generation_config_json: Optional[str]) -> GenerationConfig:
-    if generation_config_json is not None:
+    if generation_config_json is not None and model_type != "mistral":  # mistral/model.rs:236 never looks at the file
         c = hf_generation_defaults(generation_config_json, max_pos)
         if c is not None:
             return c
+    if model_type == "mistral":  # mistral/model.rs:236-252
+        return GenerationConfig(max_new_tokens=512, max_length=max_pos, repetition_penalty=1.15, add_bos_token=True, strategy="sample",
+                                temperature=0.7, top_k=40, top_p=0.9, min_p=0.05)
     if model_type == "qwen2":  # qwen/model.rs:267-281
         return GenerationConfig(max_new_tokens=512, max_length=max_pos, repetition_penalty=1.1, add_bos_token=False, strategy="sample",
                                 temperature=0.7, top_k=40, top_p=0.8, min_p=0.05)

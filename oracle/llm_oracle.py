@@ -130,7 +130,7 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
 
 
 class LlmOracle:
-    """Llama / Qwen2 decoder over a {hf_tensor_name: ndarray} dict + HF config dict."""
+    """Llama / Qwen2 / Mistral (= the Llama decoder, mistral/model.rs:56-62) decoder over a {hf_tensor_name: ndarray} dict + HF config dict."""
 
     def __init__(self, tensors: Dict[str, np.ndarray], config: dict):
         self.t = {k: np.ascontiguousarray(v, F32) for k, v in tensors.items()}
@@ -138,9 +138,9 @@ class LlmOracle:
         self.H, self.heads = c["hidden_size"], c["num_attention_heads"]
         self.kv_heads = c.get("num_key_value_heads", self.heads)
         self.d = c.get("head_dim") or self.H // self.heads
-        self.eps = c.get("rms_norm_eps", 1e-5 if c.get("model_type") == "llama" else 1e-6)
+        self.eps = c.get("rms_norm_eps", 1e-6 if c.get("model_type") == "qwen2" else 1e-5)
         self.L = c["num_hidden_layers"]
-        self.rope = rope_tables(self.d, c["max_position_embeddings"], c.get("rope_theta", 500000.0 if c.get("model_type") == "llama" else 10000.0),
+        self.rope = rope_tables(self.d, c["max_position_embeddings"], c.get("rope_theta", {"llama": 500000.0, "qwen2": 1000000.0}.get(c.get("model_type"), 10000.0)),
                                 c.get("rope_scaling"))
         tie = c.get("tie_word_embeddings", c.get("model_type") == "llama")
         self.lm_head = self.t["model.embed_tokens.weight"] if tie else self.t["lm_head.weight"]

@@ -121,3 +121,47 @@ def test_live_fuzz_against_tokenizers(name):
             if rng.random() < 0.1:
                 s += "'" + rng.choice(["s", "S", "t", "re", "VE", "m", "ll", "Ll", "d", "ſ", "x"])
         assert mine.encode(s) == ref.encode(s, add_special_tokens=False).ids, repr(s)
+
+
+# ---- SentencePiece-style BPE (Llama 2 / Mistral tokenizer.json): tests/golden/make_spbpe_golden.py ---------------
+
+@pytest.fixture(scope="module")
+def sp_goldens():
+    with open(os.path.join(GOLDEN, "spbpe_goldens.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["legacy", "metaspace"])
+def test_sentencepiece_style_bpe_matches_tokenizers(sp_goldens, name):
+    tok = BpeTokenizer(os.path.join(GOLDEN, f"spbpe_{name}_tokenizer.json"))
+    for case in sp_goldens[name]["cases"]:
+        if "\x00" in case["text"]:
+            continue  # NUL cannot cross a C string
+        assert tok.encode(case["text"]) == case["ids"], repr(case["text"])
+        assert tok.decode(case["ids"]) == case["decoded"], repr(case["text"])
+        assert tok.decode(case["ids"], skip_special=True) == case["decoded_skip"]
+        for i, text in zip(case["ids"][:32], case["single"]):
+            assert tok.decode([i]) == text  # single-token decode: the leading space is stripped, lone bytes become U+FFFD
+    t = sp_goldens[name]["truncated"]
+    assert tok.encode(t["text"], t["max_length"]) == t["ids"]
+
+
+@pytest.mark.parametrize("name", ["legacy", "metaspace"])
+def test_sentencepiece_style_bpe_live_fuzz(name):
+    tokenizers = pytest.importorskip("tokenizers")
+    path = os.path.join(GOLDEN, f"spbpe_{name}_tokenizer.json")
+    ref = tokenizers.Tokenizer.from_file(path)
+    mine = BpeTokenizer(path)
+    rng = random.Random(99)
+    specials = ["[INST]", "[/INST]", "<s>", "</s>", "<unk>", "[TOOL_CALLS]"]
+    for _ in range(1500):
+        s = ""
+        for _ in range(rng.randint(1, 4)):
+            pool = rng.choice(POOLS[:5] + ["   ", "▁▁ ▁"])
+            s += "".join(rng.choice(pool) for _ in range(rng.randint(1, 14)))
+            if rng.random() < 0.2:
+                s += rng.choice(specials)
+        assert mine.encode(s) == ref.encode(s, add_special_tokens=False).ids, repr(s)
+    # a whole prompt is one BPE word here: the merge loop must not be quadratic
+    long_text = "The quick brown fox jumps over the lazy dog. " * 400
+    assert mine.encode(long_text) == ref.encode(long_text, add_special_tokens=False).ids

@@ -159,7 +159,7 @@ def _to_overrides(g):
                      max_new_tokens=g.max_new_tokens, do_sample=g.do_sample)
 
 
-@pytest.mark.parametrize("model_type", ["llama", "qwen2"])
+@pytest.mark.parametrize("model_type", ["llama", "qwen2", "mistral"])
 def test_generation_resolution_matches_oracle(model_type):
     for hf in HF_FILES:
         for mode in ["default", "creative", "reasoning", None]:
@@ -180,6 +180,9 @@ def test_generation_defaults_are_the_reference_ones():
     # a greedy generation_config.json: the mode's temperature has nothing to apply to
     r = kc.generation_resolve("llama", 4096, '{"do_sample": false}', "creative")
     assert r.strategy == "greedy" and r.max_new_tokens == 1024
+    # Mistral never reads generation_config.json (mistral/model.rs:236-252)
+    r = kc.generation_resolve("mistral", 32768, '{"do_sample": false}', "default")
+    assert (r.strategy, r.top_k, r.max_new_tokens) == ("sample", 40, 512) and abs(r.repetition_penalty - 1.15) < 1e-6
     # forcing sampling on a greedy default picks SamplingParams::default()
     r = kc.generation_resolve("llama", 4096, '{"do_sample": false}', None, kc.GenerationConfig(do_sample=True))
     assert (r.strategy, r.top_k) == ("sample", 50) and abs(r.min_p - 0.1) < 1e-6 and abs(r.temperature - 0.7) < 1e-6

@@ -289,3 +289,54 @@ def test_error_codes(tmp_path, llama):
         json.dump(j, f)
     c, msg = code(lambda: Chat("llama3.2-1b-instruct", model_path=d))
     assert c == _ffi.KjarniError.LOAD_FAILED and "unsupported pre-tokenizer regex" in msg
+
+
+class _HfTokenizer:
+    """The `tokenizers` package itself as the tokenizer of the oracle chat (SentencePiece-style BPE has no Python
+    restatement in oracle/; the product tokenizer is pinned to the same package in tests/test_bpe_tokenizer.py)."""
+
+    def __init__(self, path):
+        import tokenizers
+        self.t = tokenizers.Tokenizer.from_file(path)
+
+    def encode(self, text):
+        return self.t.encode(text, add_special_tokens=False).ids
+
+    def decode(self, ids, skip_special_tokens=False):
+        return self.t.decode(list(ids), skip_special_tokens=skip_special_tokens)
+
+    def token_to_id(self, token):
+        return self.t.token_to_id(token)
+
+
+def test_mistral_chat(tmp_path):
+    pytest.importorskip("tokenizers")
+    from kjarni_amd.chat import Chat, GenerationConfig
+    from oracle.chat_oracle import ChatOracle
+    from oracle.llm_oracle import LlmOracle
+    hf = '{"do_sample": false, "max_new_tokens": 5}'  # present on disk, never read for Mistral (mistral/model.rs:236-252)
+    base = dict(synth.LLAMA_TEST, model_type="mistral", rope_theta=10000.0, tie_word_embeddings=False)
+    base.pop("rope_scaling")
+    d, cfg, tensors = _make(tmp_path, "mistral", base, "llama3", hf=hf, vocab_size=768, bos_token_id=1, eos_token_id=2)
+    shutil.copy(os.path.join(GOLDEN, "spbpe_legacy_tokenizer.json"), os.path.join(d, "tokenizer.json"))
+    tensors["lm_head.weight"] = tensors.get("lm_head.weight", tensors["model.embed_tokens.weight"])
+    chat = Chat("mistral-7b", model_path=d)
+    tok = _HfTokenizer(os.path.join(d, "tokenizer.json"))
+    o = ChatOracle(LlmOracle(tensors, cfg), tok, "mistral", "mistral", cfg["max_position_embeddings"], 1, [2], hf)
+    assert chat.model_name == "mistral-7b"
+    r = chat.resolve()
+    assert (r.strategy, r.top_k, r.max_new_tokens, r.add_bos_token) == ("sample", 40, 512, True)
+    assert abs(r.repetition_penalty - 1.15) < 1e-6 and abs(r.min_p - 0.05) < 1e-6 and abs(r.temperature - 0.7) < 1e-6
+    prompt = chat.format_prompt(None, "Hello there")
+    assert prompt == "<s>[INST] Hello there [/INST]" == o.format_prompt(o.create_conversation() + [("user", "Hello there")])
+    ids = chat.encode(prompt)
+    assert ids == o.encode(prompt, o.resolve()) and ids[0] == 1 and ids[1] != 1
+    history = [("system", "Assistant is friendly."), ("user", "Hello!"), ("assistant", "Hi there!")]
+    assert chat.format_prompt(history, "How are you?") == \
+        "<s>[INST] Assistant is friendly.\n\nHello! [/INST] Hi there!</s>[INST] How are you? [/INST]"
+    g = GenerationConfig(do_sample=False, max_new_tokens=24)
+    ov = _ov(do_sample=False, max_new_tokens=24)
+    assert chat.send("Hello there", g) == o.generate(prompt, ov)  # repetition penalty 1.15 applied on the way
+    pieces = []
+    chat.stream("Hello there", lambda t: pieces.append(t) or True, g)
+    assert pieces == [t for _, t in o.stream(prompt, ov)]
