@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int6
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkjarni_ffi.so")
+LIB_PATH = os.environ.get("KJARNI_FFI_LIB", os.path.join(_HERE, "lib", "libkjarni_ffi.so"))  # override: sanitizer builds
 
 
 class KjarniError:

@@ -762,9 +762,10 @@ std::string BpeTokenizer::decode_sp(const std::vector<uint32_t>& ids, bool skip_
         if (skip_special && special_[id]) continue;
         const std::string& tok = id_to_token_[id];
         if (tok.size() == 6 && tok.compare(0, 3, "<0x") == 0 && tok[5] == '>') {
+            const std::string hex = tok.substr(3, 2);
             char* end = nullptr;
-            const long v = std::strtol(tok.substr(3, 2).c_str(), &end, 16);
-            if (end && *end == '\0') {
+            const long v = std::strtol(hex.c_str(), &end, 16);
+            if (end == hex.c_str() + 2) {
                 run.push_back((char)v);
                 continue;
             }
