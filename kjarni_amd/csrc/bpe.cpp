@@ -328,6 +328,7 @@ void BpeTokenizer::load_json(const std::string& text, const std::string& origin)
     vocab_.clear();
     token_to_id_.clear();
     auto put = [&](uint32_t id, const std::string& tok, bool special) {
+        if (id > (1u << 24)) fail("token id " + std::to_string(id) + " is out of range");  // a corrupt file must not size the tables
         if (id >= id_to_token_.size()) {
             id_to_token_.resize(id + 1);
             has_token_.resize(id + 1, 0);

@@ -104,6 +104,7 @@ Wav parse_wav(const std::string& data)
         w.samples.resize(pcm_len / 4);
         std::memcpy(w.samples.data(), p, w.samples.size() * 4);
     } else if (tag == 1) {
+        if (bits != 8 && bits != 16 && bits != 24 && bits != 32) throw std::runtime_error("Unsupported bit depth: " + std::to_string(bits));
         const float max_value = (float)(1u << (bits - 1));  // loader.rs:136
         switch (bits) {
         case 8:

@@ -40,9 +40,14 @@ bool is_dir(const std::string& p)
 struct BinReader {
     const uint8_t* p;
     const uint8_t* end;
-    void need(size_t n) const
+    void need(uint64_t n) const
     {
-        if ((size_t)(end - p) < n) throw std::runtime_error("bincode: unexpected end of data");
+        if ((uint64_t)(end - p) < n) throw std::runtime_error("bincode: unexpected end of data");
+    }
+    // `count` records of `size` bytes must still be in the buffer (no overflow: a corrupt count must not size an allocation).
+    void need_records(uint64_t count, uint64_t size) const
+    {
+        if (size != 0 && count > (uint64_t)(end - p) / size) throw std::runtime_error("bincode: unexpected end of data");
     }
     uint64_t u64()
     {
@@ -162,7 +167,7 @@ std::vector<std::pair<size_t, float>> Bm25Index::search(const std::string& query
     if (q.empty()) return res;
     // Same result as scoring every document (bm25.rs:96-101), visiting only documents that contain
     // a query term; documents whose length slot is missing cannot be scored either way.
-    std::vector<uint8_t> seen(total_docs, 0);
+    std::vector<uint8_t> seen(std::min(total_docs, doc_lengths.size()), 0);  // d < both below; total_docs comes from the file
     for (const std::string& term : q) {
         auto it = inverted_index.find(term);
         if (it == inverted_index.end()) continue;
@@ -192,7 +197,7 @@ Bm25Index Bm25Index::from_bincode(const uint8_t* data, size_t len)
         ix.doc_frequencies[std::move(k)] = r.u64();
     }
     n = r.u64();
-    r.need(n * 8);
+    r.need_records(n, 8);
     ix.doc_lengths.resize((size_t)n);
     for (uint64_t i = 0; i < n; ++i) ix.doc_lengths[(size_t)i] = r.u64();
     ix.avg_doc_length = r.f32();
@@ -201,7 +206,7 @@ Bm25Index Bm25Index::from_bincode(const uint8_t* data, size_t len)
     for (uint64_t i = 0; i < n; ++i) {
         std::string k = r.str();
         const uint64_t m = r.u64();
-        r.need(m * 16);
+        r.need_records(m, 16);
         auto& v = ix.inverted_index[std::move(k)];
         v.reserve((size_t)m);
         for (uint64_t j = 0; j < m; ++j) {
@@ -216,7 +221,7 @@ Bm25Index Bm25Index::from_bincode(const uint8_t* data, size_t len)
     for (uint64_t i = 0; i < n; ++i) {
         (void)r.str();
         const uint64_t m = r.u64();
-        r.need(m * 8);
+        r.need_records(m, 8);
         r.p += m * 8;
     }
     ix.total_length = r.p < r.end ? r.u64() : 0;  // #[serde(default)]
@@ -503,7 +508,7 @@ std::unique_ptr<Segment> Segment::open(const std::string& dir)
     const std::string idx = slurp(dir + "/docs.idx");
     BinReader r{reinterpret_cast<const uint8_t*>(idx.data()), reinterpret_cast<const uint8_t*>(idx.data()) + idx.size()};
     const uint64_t n = r.u64();
-    r.need(n * 8);
+    r.need_records(n, 8);
     s->doc_offsets_.resize((size_t)n);
     for (uint64_t i = 0; i < n; ++i) s->doc_offsets_[(size_t)i] = r.u64();
 
@@ -531,6 +536,11 @@ std::string Segment::get_document(size_t doc_id) const
         end = (uint64_t)st.st_size - 1;
     }
     if (end < start) throw std::runtime_error("corrupt document offsets");
+    {
+        struct stat st;
+        if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot stat " + path);
+        if (end > (uint64_t)st.st_size) throw std::runtime_error("corrupt document offsets");
+    }
     std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open " + path);
     f.seekg((std::streamoff)start);

@@ -120,6 +120,7 @@ void ByteLevelVocab::load(const std::string& path)
     const Json* vocab = model ? model->find("vocab") : nullptr;
     if (!vocab || !vocab->is_object()) throw std::runtime_error(path + ": no model.vocab");
     auto put = [&](uint32_t id, const std::string& tok, bool special) {
+        if (id > (1u << 24)) throw std::runtime_error(path + ": token id " + std::to_string(id) + " is out of range");
         if (id >= id_to_token_.size()) {
             id_to_token_.resize(id + 1);
             has_token_.resize(id + 1, 0);
