@@ -308,14 +308,39 @@ struct KjarniTranscriber {
         std::vector<float> buf(chunk);
         const std::vector<uint32_t> prompt_ids = prompt();
         bool stopped = false;
-        for (size_t i = 0; i < total_chunks && !stopped; ++i) {
+        // Without a per-token callback the chunks of a long recording are decoded several at a time in lock step
+        // (WhisperModel::greedy_lanes): same tokens per chunk, one set of kernel launches per step for all of them.
+        int lanes = WhisperModel::kMaxLanes;
+        if (const char* v = std::getenv("KJARNI_HIP_WHISPER_LANES")) lanes = std::max(1, std::min(WhisperModel::kMaxLanes, std::atoi(v)));
+        const bool batched = !on_token && total_chunks > 1 && lanes > 1;
+        auto load_chunk = [&](size_t i) {
+            const size_t begin = i * chunk, n = std::min(chunk, samples.size() - begin);
+            std::fill(buf.begin(), buf.end(), 0.0f);  // chunk_audio: zero-padded to 30 s (transcriber.rs:87-119)
+            std::memcpy(buf.data(), samples.data() + begin, n * sizeof(float));
+        };
+        for (size_t i0 = 0; batched && i0 < total_chunks && !stopped; i0 += (size_t)lanes) {
+            const size_t nb = std::min((size_t)lanes, total_chunks - i0);
+            for (size_t j = 0; j < nb; ++j) {  // the reference's event order (encoding i, decoding i), chunk by chunk
+                const size_t i = i0 + j;
+                if (kjarni_cancel_token_is_cancelled(cancel)) throw TranscriberFailure(KJARNI_ERROR_CANCELLED, "Transcription cancelled");
+                const std::string msg = "Chunk " + std::to_string(i + 1) + "/" + std::to_string(total_chunks);
+                report(progress, puser, KJARNI_TRANSCRIPTION_ENCODING, i, total_chunks, &msg);
+                load_chunk(i);
+                model->encode_audio(buf.data(), (int64_t)chunk);
+                model->begin_decode_lane((int)j);
+                report(progress, puser, KJARNI_TRANSCRIPTION_DECODING, i, total_chunks, &msg);
+            }
+            const std::vector<std::vector<uint32_t>> ids =
+                model->greedy_lanes((int)nb, prompt_ids, timestamps, max_tokens, [&] { return !kjarni_cancel_token_is_cancelled(cancel); });
+            if (kjarni_cancel_token_is_cancelled(cancel)) throw TranscriberFailure(KJARNI_ERROR_CANCELLED, "Transcription cancelled");
+            for (size_t j = 0; j < nb; ++j) results.push_back(finalize_chunk(ids[j], model->vocab(), timestamps, (float)(i0 + j) * 30.0f));
+        }
+        for (size_t i = 0; !batched && i < total_chunks && !stopped; ++i) {
             if (kjarni_cancel_token_is_cancelled(cancel)) throw TranscriberFailure(KJARNI_ERROR_CANCELLED, "Transcription cancelled");
             const float offset = (float)i * 30.0f;
             const std::string msg = "Chunk " + std::to_string(i + 1) + "/" + std::to_string(total_chunks);
             report(progress, puser, KJARNI_TRANSCRIPTION_ENCODING, i, total_chunks, &msg);
-            const size_t begin = i * chunk, n = std::min(chunk, samples.size() - begin);
-            std::fill(buf.begin(), buf.end(), 0.0f);  // chunk_audio: zero-padded to 30 s (transcriber.rs:87-119)
-            std::memcpy(buf.data(), samples.data() + begin, n * sizeof(float));
+            load_chunk(i);
             model->encode_audio(buf.data(), (int64_t)chunk);
             report(progress, puser, KJARNI_TRANSCRIPTION_DECODING, i, total_chunks, &msg);
             const ByteLevelVocab& vocab = model->vocab();

@@ -700,4 +700,162 @@ std::vector<uint32_t> WhisperModel::greedy(const std::vector<uint32_t>& prompt, 
     return out;
 }
 
+// ---- lanes: several chunks decoded in lock step --------------------------------------------------------
+
+void WhisperModel::ensure_lanes()
+{
+    if (lane_logits_) return;
+    const int H = cfg_.d_model;
+    const size_t B = (size_t)kMaxLanes;
+    for (size_t l = 0; l < dec_.size(); ++l) {
+        lane_self_k_.push_back(dalloc((size_t)cache_cap_ * B * H));
+        lane_self_v_.push_back(dalloc((size_t)cache_cap_ * B * H));
+        lane_cross_kv_.push_back(dalloc(B * (size_t)max_frames_ / 2 * 2 * H));
+    }
+    lane_logits_ = dalloc(B * (size_t)cfg_.vocab);
+    lane_tokens_ = reinterpret_cast<int32_t*>(dalloc(B));
+    lane_hist_ = reinterpret_cast<int32_t*>(dalloc(B * (size_t)hist_cap_));
+    lane_counts_ = reinterpret_cast<int*>(dalloc(B));
+    drow_ = reinterpret_cast<int*>(dalloc(4));
+}
+
+void WhisperModel::begin_decode_lane(int lane)
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (lane < 0 || lane >= kMaxLanes) throw std::runtime_error("lane out of range");
+    if (enc_frames_ <= 0) throw std::runtime_error("no encoder output to decode from");
+    ensure_lanes();
+    const int H = cfg_.d_model;
+    for (size_t l = 0; l < dec_.size(); ++l)
+        hip_check(launch_gemm(hidden_, H, dec_[l].ckv, dec_[l].cbkv, nullptr, 0, lane_cross_kv_[l] + (size_t)lane * enc_frames_ * 2 * H, 2 * H,
+                              enc_frames_, 2 * H, H, EPI_BIAS, stream_), "cross kv");
+}
+
+// decoder_pass for `lanes` independent sequences at the same position: row r of every buffer is lane r.
+void WhisperModel::decoder_pass_lanes(int lanes, bool device_pos)
+{
+    hipStream_t s = stream_;
+    const int H = cfg_.d_model, heads = cfg_.heads, d = H / heads, I = cfg_.decoder_ffn, n = lanes;
+    const int* pos_ptr = device_pos ? dpos_ : nullptr;
+    const int* row_ptr = device_pos ? drow_ : nullptr;
+    hip_check(launch_decoder_embed(reinterpret_cast<const uint32_t*>(lane_tokens_), n, H, cfg_.vocab, tok_emb_, dec_pos_, cfg_.max_target_positions,
+                                   cache_len_, pos_ptr, cfg_.scale_embedding ? 1 : 0, dh_, s, 1), "decoder embed");
+    auto gemv = [&](const float* X, int64_t ldx, const float* g, const float* b, const float* W, const float* bias, const float* R,
+                    int n_out, int k, float* Y, GemmEpilogue epi, const char* what) {
+        GemvArgs a;
+        a.X = X; a.ldx = ldx; a.rows = n; a.gamma = g; a.beta = b; a.eps = 1e-5f; a.W = W; a.bias = bias; a.R = R; a.ldr = H;
+        a.n_out = n_out; a.k = k; a.Y0 = Y; a.ldy0 = n_out; a.epi = epi;
+        hip_check(launch_gemv_rows(a, s), what);
+    };
+    for (size_t l = 0; l < dec_.size(); ++l) {
+        const DecLayer& L = dec_[l];
+        {
+            GemvArgs a;  // LN1 + Q | K | V: the lanes' K / V rows are cache rows position * lanes + lane
+            a.X = dh_; a.ldx = H; a.rows = n; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.eps = 1e-5f; a.W = L.wqkv; a.bias = L.bqkv;
+            a.n_out = 3 * H; a.k = H; a.seg = H; a.Y0 = dq_; a.ldy0 = H; a.Y1 = lane_self_k_[l]; a.Y2 = lane_self_v_[l]; a.ldy12 = H;
+            a.row_off = cache_len_ * lanes; a.row_off_ptr = row_ptr; a.epi = EPI_BIAS;
+            hip_check(launch_gemv_rows(a, s), "ln1 + qkv");
+        }
+        hip_check(launch_decode_attention(dq_, H, n, lane_self_k_[l], (int64_t)lanes * H, lane_self_v_[l], (int64_t)lanes * H, cache_len_ + 1, pos_ptr,
+                                          cache_cap_, heads, d, -1, kSelfSplits, att_scratch_, dctx_, H, s, 1, H, H, 1), "self attention");
+        gemv(dctx_, H, nullptr, nullptr, L.wo, L.bo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "self out");
+        gemv(dh_, H, L.ln2_g, L.ln2_b, L.cq, L.cbq, nullptr, H, H, dq_, EPI_BIAS, "ln2 + cross q");
+        const int64_t lane_kv = (int64_t)enc_frames_ * 2 * H;
+        hip_check(launch_decode_attention(dq_, H, n, lane_cross_kv_[l], 2 * H, lane_cross_kv_[l] + H, 2 * H, enc_frames_, nullptr, enc_frames_, heads, d,
+                                          -1, kCrossSplits, att_scratch_, dctx_, H, s, 1, lane_kv, lane_kv, 1), "cross attention");
+        gemv(dctx_, H, nullptr, nullptr, L.co, L.cbo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "cross out");
+        gemv(dh_, H, L.ln3_g, L.ln3_b, L.w1, L.b1, nullptr, I, H, dmid_, EPI_BIAS_GELU, "ln3 + fc1");
+        gemv(dmid_, I, nullptr, nullptr, L.w2, L.b2, dh_, H, I, dh_, EPI_BIAS_RESIDUAL, "fc2");
+    }
+    hip_check(launch_layernorm(dh_, dec_ln_g_, dec_ln_b_, 1e-5f, n, H, dlast_, s), "final ln");
+    GemvArgs a;
+    a.X = dlast_; a.ldx = H; a.rows = n; a.W = lm_head_; a.n_out = cfg_.vocab; a.k = H; a.Y0 = lane_logits_; a.ldy0 = cfg_.vocab; a.epi = EPI_BIAS;
+    hip_check(launch_gemv_rows(a, s), "lm head");
+}
+
+hipGraphExec_t WhisperModel::lane_step_graph(bool timestamps, int lanes)
+{
+    hipGraphExec_t& exec = lane_graphs_[timestamps ? 1 : 0][lanes];
+    if (exec) return exec;
+    hipGraph_t graph = nullptr;
+    hip_check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture");
+    try {
+        decoder_pass_lanes(lanes, true);
+        hip_check(launch_pick_token(lane_logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, lane_tokens_,
+                                    lane_hist_, lane_counts_, dpos_, stream_, lanes, hist_cap_, drow_), "pick token");
+    } catch (...) {
+        (void)hipStreamEndCapture(stream_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    hip_check(hipStreamEndCapture(stream_, &graph), "end capture");
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    hip_check(e, "graph instantiate");
+    return exec;
+}
+
+std::vector<std::vector<uint32_t>> WhisperModel::greedy_lanes(int lanes, const std::vector<uint32_t>& prompt, bool timestamps, size_t max_tokens,
+                                                              const std::function<bool()>& keep_going)
+{
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (lanes < 1 || lanes > kMaxLanes) throw std::runtime_error("lanes must be 1..8");
+    if (prompt.empty() || prompt.size() > 8) throw std::runtime_error("prompt must hold 1..8 tokens");
+    if (max_tokens + 1 > (size_t)hist_cap_) throw std::runtime_error("max_tokens exceeds the decoder's capacity");
+    ensure_lanes();
+    // The prompt, one position at a time, the same token in every lane (decode_chunk feeds it as one block: same rows,
+    // same arithmetic per row).
+    cache_len_ = 0;
+    std::vector<int32_t> same((size_t)lanes);
+    for (uint32_t t : prompt) {
+        std::fill(same.begin(), same.end(), (int32_t)t);
+        hip_check(hipMemcpyAsync(lane_tokens_, same.data(), same.size() * 4, hipMemcpyHostToDevice, stream_), "H2D prompt token");
+        decoder_pass_lanes(lanes, false);
+        cache_len_ += 1;
+        hip_check(hipStreamSynchronize(stream_), "sync");
+    }
+    hip_check(hipMemsetAsync(lane_counts_, 0, (size_t)kMaxLanes * sizeof(int), stream_), "reset counts");
+    // first generated token of every lane from the last prompt position; pick advances the counters, so they are set after it
+    hip_check(launch_pick_token(lane_logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, lane_tokens_,
+                                lane_hist_, lane_counts_, dpos_, stream_, lanes, hist_cap_, drow_), "pick token");
+    const int row0 = cache_len_ * lanes;
+    hip_check(hipMemcpyAsync(dpos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
+    hip_check(hipMemcpyAsync(drow_, &row0, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D row");
+
+    std::vector<std::vector<uint32_t>> out((size_t)lanes);
+    std::vector<std::vector<int32_t>> hist((size_t)lanes, std::vector<int32_t>((size_t)hist_cap_));
+    std::vector<uint8_t> done((size_t)lanes, 0);
+    std::vector<size_t> seen((size_t)lanes, 0);
+    auto all_done = [&] { return std::all_of(done.begin(), done.end(), [](uint8_t d) { return d != 0; }); };
+    auto fetch = [&](size_t from, size_t count) {
+        for (int l = 0; l < lanes; ++l)
+            hip_check(hipMemcpyAsync(hist[(size_t)l].data() + from, lane_hist_ + (size_t)l * hist_cap_ + from, count * sizeof(int32_t),
+                                     hipMemcpyDeviceToHost, stream_), "D2H tokens");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+    };
+    auto drain = [&](size_t produced) {
+        for (int l = 0; l < lanes; ++l)
+            for (; seen[(size_t)l] < produced && !done[(size_t)l]; ++seen[(size_t)l]) {
+                const uint32_t tok = (uint32_t)hist[(size_t)l][seen[(size_t)l]];
+                out[(size_t)l].push_back(tok);
+                if (tok == eos_ || out[(size_t)l].size() == max_tokens + 1) done[(size_t)l] = 1;
+            }
+    };
+    fetch(0, 1);
+    drain(1);
+    size_t produced = 1;
+    hipGraphExec_t exec = all_done() ? nullptr : lane_step_graph(timestamps, lanes);
+    while (!all_done()) {
+        if (keep_going && !keep_going()) break;
+        const size_t steps = std::min<size_t>(16, max_tokens + 1 - produced);
+        if (steps == 0) break;
+        for (size_t i = 0; i < steps; ++i) hip_check(hipGraphLaunch(exec, stream_), "graph launch");
+        fetch(produced, steps);
+        produced += steps;
+        cache_len_ += (int)steps;
+        drain(produced);
+    }
+    return out;
+}
+
 }  // namespace kjarni

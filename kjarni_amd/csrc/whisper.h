@@ -83,6 +83,16 @@ public:
     std::vector<uint32_t> greedy(const std::vector<uint32_t>& prompt, bool timestamps, size_t max_tokens,
                                  const std::function<bool(uint32_t)>& on_token);
 
+    // Several 30-second chunks decoded in lock step ("lanes"): the chunks of a long recording are independent
+    // (transcriber.rs:85-120 cuts them up front, every chunk starts from the same prompt), and a decoder step is bound by
+    // kernel launches, not by the rows it carries -- so up to kMaxLanes chunks share each launch.  begin_decode_lane(l)
+    // projects the current encoder output into lane l's cross-attention K/V; greedy_lanes then runs all lanes to their
+    // EOS and returns, per lane, exactly what greedy() would have returned for that chunk alone.
+    static constexpr int kMaxLanes = 8;
+    void begin_decode_lane(int lane);
+    std::vector<std::vector<uint32_t>> greedy_lanes(int lanes, const std::vector<uint32_t>& prompt, bool timestamps, size_t max_tokens,
+                                                    const std::function<bool()>& keep_going);
+
 private:
     WhisperModel() = default;
     float* upload(const std::vector<float>& host);
@@ -93,6 +103,9 @@ private:
     void decoder_pass(const uint32_t* ids_dev, int n, bool device_pos);
     void enqueue_pick(bool timestamps, bool record);
     hipGraphExec_t step_graph(bool timestamps);
+    void ensure_lanes();
+    void decoder_pass_lanes(int lanes, bool device_pos);
+    hipGraphExec_t lane_step_graph(bool timestamps, int lanes);
 
     struct EncLayer {
         float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
@@ -139,6 +152,13 @@ private:
     int cache_len_ = 0, cache_cap_ = 0, last_rows_ = 0, hist_cap_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraphExec_t graphs_[2] = {nullptr, nullptr};
+    // lanes (allocated on first use): caches interleaved by lane ([position][lane][H]) so that a step's K / V rows of all
+    // lanes are consecutive cache rows, cross K/V lane-major
+    std::vector<float*> lane_self_k_, lane_self_v_, lane_cross_kv_;
+    float* lane_logits_ = nullptr;
+    int32_t *lane_tokens_ = nullptr, *lane_hist_ = nullptr;
+    int *lane_counts_ = nullptr, *drow_ = nullptr;
+    hipGraphExec_t lane_graphs_[2][kMaxLanes + 1] = {};
     static constexpr int kSelfSplits = 16, kCrossSplits = 12;
 };
 

@@ -25,7 +25,7 @@ hipError_t launch_add_rows(float* x, int64_t rows, int hidden, int period, const
 // offset_ptr (device int) overrides offset when given.
 hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int vocab, const float* word, const float* pos,
                                 int max_pos, int offset, const int* offset_ptr, int scale_embeddings, float* out,
-                                hipStream_t stream);
+                                hipStream_t stream, int lanes = 0);  // lanes: every row sits at the same position
 
 // Y = epi(LN?(X) W^T + b) (+ R) for up to 8 rows (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESIDUAL).
 //  gamma != null: X rows are layer-normalised (gamma, beta, eps) on the fly.
@@ -57,9 +57,15 @@ size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int sp
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
                                    int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
                                    int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream,
-                                   int kv_group = 1);  // grouped-query attention: kv_group query heads per KV head
+                                   int kv_group = 1,  // grouped-query attention: kv_group query heads per KV head
+                                   // lanes: the rows are independent sequences decoded in lock step; row s reads K + s * k_lane_stride
+                                   // (V alike), every row sees n_keys (or *n_keys_ptr + 1) keys and there is no causal mask.
+                                   int64_t k_lane_stride = 0, int64_t v_lane_stride = 0, int lanes = 0);
 // history/count/pos (device, may be null): append the token, advance the counters (graph-replayed steps).
 hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
-                             int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream);
+                             int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream,
+                             // lanes > 1: logits [lanes, vocab], out / count [lanes], history [lanes, hist_stride]; lane 0 advances
+                             // *pos by 1 and *row (the interleaved cache row) by `lanes`
+                             int lanes = 1, int hist_stride = 0, int* row = nullptr);
 
 }  // namespace kjarni

@@ -155,11 +155,11 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, in
 __global__ __launch_bounds__(256) void decoder_embed_kernel(const uint32_t* __restrict__ ids, int hidden, int vocab,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             int max_pos, int offset, const int* __restrict__ offset_ptr,
-                                                            float scale, float* __restrict__ out)
+                                                            int pos_step, float scale, float* __restrict__ out)
 {
     const int s = blockIdx.x;
     const uint32_t id = ids[s];
-    const int p = (offset_ptr ? *offset_ptr : offset) + s;
+    const int p = (offset_ptr ? *offset_ptr : offset) + s * pos_step;  // pos_step 0: rows are lanes at the same position
     for (int i = threadIdx.x; i < hidden; i += 256) {
         float v = 0.0f;
         if (id < (uint32_t)vocab) v = word[(int64_t)id * hidden + i] * scale;
@@ -263,10 +263,11 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 constexpr int ATT_MAX_CHUNK = 512;
 
 __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const float* __restrict__ q, int64_t ldq,
-                                                                       const float* __restrict__ K, int64_t ldk,
-                                                                       const float* __restrict__ V, int64_t ldv, int n_keys,
+                                                                       const float* __restrict__ K0, int64_t ldk,
+                                                                       const float* __restrict__ V0, int64_t ldv, int n_keys,
                                                                        const int* __restrict__ n_keys_ptr, int rows, int head_dim,
                                                                        float scale, int causal, int splits, int kv_group,
+                                                                       int64_t k_lane_stride, int64_t v_lane_stride, int lanes,
                                                                        float* __restrict__ part)
 {
     __shared__ float sc[ATT_MAX_CHUNK];
@@ -274,8 +275,12 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
     __shared__ f32x4 accs[256];
     const int h = blockIdx.x, sp = blockIdx.y, s = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int base = n_keys_ptr ? *n_keys_ptr : 0;
-    const int n = n_keys_ptr ? base + rows : n_keys;
-    const int causal_base = causal < 0 ? -1 : (n_keys_ptr ? base : causal);
+    // lanes: the rows are independent sequences in lock step -- each attends to its own cache (row s at K + s * stride),
+    // all of them hold the same number of keys (the ones before this step plus this step's own), no mask between rows.
+    const int n = n_keys_ptr ? base + (lanes ? 1 : rows) : n_keys;
+    const int causal_base = (causal < 0 || lanes) ? -1 : (n_keys_ptr ? base : causal);
+    const float* __restrict__ K = K0 + (int64_t)blockIdx.z * k_lane_stride;
+    const float* __restrict__ V = V0 + (int64_t)blockIdx.z * v_lane_stride;
     const int chunk = (n + splits - 1) / splits;
     const int t0 = sp * chunk, t1 = min(n, t0 + chunk);
     const int lpk = head_dim >> 2;          // lanes per key (16 for d = 64)
@@ -360,8 +365,18 @@ __global__ __launch_bounds__(128) void decode_attention_combine_kernel(const flo
 __global__ __launch_bounds__(1024) void pick_token_kernel(const float* __restrict__ logits, int vocab, int first_special,
                                                           int eos, int timestamp_begin, int allow_timestamps,
                                                           int32_t* __restrict__ out, int32_t* __restrict__ history,
-                                                          int* __restrict__ count, int* __restrict__ pos)
+                                                          int* __restrict__ count, int* __restrict__ pos, int hist_stride,
+                                                          int* __restrict__ row)
 {
+    // One workgroup per lane (blockIdx.x): its own logits row, output slot, history and count; lane 0 advances the
+    // shared position (and the interleaved cache row = position * lanes).
+    const int lane_id = blockIdx.x;
+    logits += (int64_t)lane_id * vocab;
+    out += lane_id;
+    if (history) {
+        history += (int64_t)lane_id * hist_stride;
+        count += lane_id;
+    }
     __shared__ float bv[16];
     __shared__ int bi[16];
     float best = -INFINITY;
@@ -400,7 +415,10 @@ __global__ __launch_bounds__(1024) void pick_token_kernel(const float* __restric
         if (history) {
             history[*count] = tok;
             *count += 1;
-            *pos += 1;
+            if (lane_id == 0) {
+                *pos += 1;
+                if (row) *row += (int)gridDim.x;
+            }
         }
     }
 }
@@ -459,11 +477,11 @@ hipError_t launch_add_rows(float* x, int64_t rows, int hidden, int period, const
 
 hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int vocab, const float* word, const float* pos,
                                 int max_pos, int offset, const int* offset_ptr, int scale_embeddings, float* out,
-                                hipStream_t stream)
+                                hipStream_t stream, int lanes)
 {
     const float scale = scale_embeddings ? sqrtf((float)hidden) : 1.0f;
     hipLaunchKernelGGL(decoder_embed_kernel, dim3((unsigned)n), dim3(256), 0, stream, ids, hidden, vocab, word, pos, max_pos,
-                       offset, offset_ptr, scale, out);
+                       offset, offset_ptr, lanes ? 0 : 1, scale, out);
     return hipGetLastError();
 }
 
@@ -508,7 +526,7 @@ size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int sp
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
                                    int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
                                    int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream,
-                                   int kv_group)
+                                   int kv_group, int64_t k_lane_stride, int64_t v_lane_stride, int lanes)
 {
     if (rows <= 0 || (n_keys <= 0 && !n_keys_ptr)) return hipSuccess;
     if (head_dim > 128 || 256 % (head_dim / 4) != 0 || (head_dim & 3) || splits < 1) return hipErrorInvalidValue;
@@ -516,17 +534,18 @@ hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const 
     if ((worst + splits - 1) / splits > ATT_MAX_CHUNK) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attention_partial_kernel, dim3((unsigned)heads, (unsigned)splits, (unsigned)rows), dim3(256), 0, stream,
                        q, ldq, K, ldk, V, ldv, n_keys, n_keys_ptr, rows, head_dim, 1.0f / sqrtf((float)head_dim), causal_base, splits,
-                       kv_group < 1 ? 1 : kv_group, scratch);
+                       kv_group < 1 ? 1 : kv_group, k_lane_stride, v_lane_stride, lanes, scratch);
     hipLaunchKernelGGL(decode_attention_combine_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(128), 0, stream, scratch, heads,
                        splits, head_dim, ctx, ldc);
     return hipGetLastError();
 }
 
 hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
-                             int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream)
+                             int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream, int lanes,
+                             int hist_stride, int* row)
 {
-    hipLaunchKernelGGL(pick_token_kernel, dim3(1), dim3(1024), 0, stream, logits, vocab, first_special, eos, timestamp_begin,
-                       allow_timestamps, out, history, count, pos);
+    hipLaunchKernelGGL(pick_token_kernel, dim3((unsigned)(lanes < 1 ? 1 : lanes)), dim3(1024), 0, stream, logits, vocab, first_special, eos,
+                       timestamp_begin, allow_timestamps, out, history, count, pos, hist_stride, row);
     return hipGetLastError();
 }
 

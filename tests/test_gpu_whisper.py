@@ -152,6 +152,37 @@ def test_transcriber_end_to_end(env, tmp_path):
     assert tr.transcribe_audio(np.zeros(0, F32), 16000).text == ""  # empty audio: no chunks
 
 
+def test_long_audio_chunks_decoded_in_lock_step(env, monkeypatch):
+    """Without a token callback the chunks of a long recording share each decoder launch (up to 8 lanes): the result must
+    be what chunk-by-chunk decoding gives -- the oracle's, and this library's own sequential path."""
+    import kjarni_amd
+    audio = synth.synthetic_audio(30.0 * 10 + 7.5, seed=12)         # 11 chunks: one full batch of 8 lanes + a batch of 3
+    for timestamps, max_tokens in ((False, 12), (True, 9)):
+        tr = kjarni_amd.Transcriber(model_path=env["dir"], timestamps=timestamps, max_tokens=max_tokens)
+        events = []
+        res = tr.transcribe_audio(audio, 16000, on_progress=lambda *a: events.append(a))
+        text, segs, dur = _oracle_transcribe(env, audio, 16000, timestamps=timestamps, max_tokens=max_tokens)
+        assert res.text == text and abs(res.duration_secs - dur) < 1e-4
+        assert [(round(s.start, 2), round(s.end, 2), s.text) for s in res.segments] == \
+            [(round(s["start"], 2), round(s["end"], 2), s["text"]) for s in segs]
+        want_events = []
+        for i in range(11):
+            want_events += [("encoding", i, 11, f"Chunk {i + 1}/11"), ("decoding", i, 11, f"Chunk {i + 1}/11")]
+        assert events == want_events + [("stitching", 0, 0, None)]
+        monkeypatch.setenv("KJARNI_HIP_WHISPER_LANES", "1")         # the sequential path
+        seq = tr.transcribe_audio(audio, 16000)
+        monkeypatch.setenv("KJARNI_HIP_WHISPER_LANES", "3")         # another lane count: 3 + 3 + 3 + 2
+        three = tr.transcribe_audio(audio, 16000)
+        monkeypatch.delenv("KJARNI_HIP_WHISPER_LANES")
+        assert seq.text == res.text == three.text
+        assert [(s.start, s.end, s.text) for s in seq.segments] == [(s.start, s.end, s.text) for s in res.segments]
+    # cancellation between steps of a batch
+    token = kjarni_amd.CancelToken()
+    token.cancel()
+    with pytest.raises(Exception):
+        tr.transcribe_audio(audio, 16000, cancel_token=token)
+
+
 def test_transcriber_timestamps_language_translate_and_stops(env):
     import kjarni_amd
     from kjarni_amd import _ffi

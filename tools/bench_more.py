@@ -255,6 +255,24 @@ def main():
                                "sample": f"oracle: log-mel {c_mel:.2f} s (vectorised DFT, not the reference's scalar O(n^2) loop), "
                                          f"encoder {c_enc:.2f} s, 16 decoder steps {c_dec16:.2f} s extrapolated to {len(ids)} tokens"}
         emit(res)
+        # A long recording through the string-level Transcriber: 16 chunks of 30 s (8 minutes), 448 tokens per chunk,
+        # chunk by chunk vs eight chunks per decoder launch (the default without a per-token callback).
+        tr = kjarni_amd.Transcriber(model_path=d, max_tokens=n_tok)
+        long_audio = np.concatenate([synth.synthetic_audio(30.0, seed=20 + i) for i in range(16)])
+        tr.transcribe_audio(long_audio[: 16000 * 45], 16000)          # warm-up (graphs for 2 lanes do not matter below)
+        rows = {}
+        for label, lanes in (("sequential", "1"), ("lock_step_8", "8")):
+            os.environ["KJARNI_HIP_WHISPER_LANES"] = lanes
+            tr.transcribe_audio(long_audio, 16000)
+            t0 = time.perf_counter()
+            out = tr.transcribe_audio(long_audio, 16000)
+            dt = time.perf_counter() - t0
+            rows[label] = {"seconds": round(dt, 3), "x_real_time": round(480.0 / dt, 1), "chars": len(out.text)}
+        os.environ.pop("KJARNI_HIP_WHISPER_LANES", None)
+        emit({"metric": "x real time, Whisper-base shaped transcribe of 8 min audio (16 chunks x 448 tokens) through kjarni_transcriber_*",
+              "value": rows["lock_step_8"]["x_real_time"], "unit": "x real time", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "whisper-base shape, random init, 480 s synthetic audio, 449 generated tokens per chunk"},
+              "runs": rows, "same_text": rows["sequential"]["chars"] == rows["lock_step_8"]["chars"]})
 
     if "llm" in which:
         d = os.path.join(tmp, "llama-1b")
