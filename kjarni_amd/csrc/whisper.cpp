@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -444,8 +445,11 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
     m->dpos_ = reinterpret_cast<int*>(m->dalloc(4));
     m->dcount_ = reinterpret_cast<int*>(m->dalloc(4));
     m->att_scratch_ = m->dalloc(decode_attention_scratch_floats(8, c.heads, d, std::max(kSelfSplits, kCrossSplits)));
+    m->dbest_ = reinterpret_cast<unsigned long long*>(m->dalloc(2 * (size_t)kMaxLanes));
+    hip_check(hipMemset(m->dbest_, 0, sizeof(unsigned long long) * kMaxLanes), "memset(pick scratch)");
     hip_check(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(load)");
+    if (const char* v = std::getenv("KJARNI_HIP_GEMV_ROWS")) set_gemv_rows_variant(std::atoi(v));  // kernel A/B measurements only
     return m;
 }
 
@@ -612,7 +616,8 @@ void WhisperModel::logits_to_host(float* out) const
 void WhisperModel::enqueue_pick(bool timestamps, bool record)
 {
     hip_check(launch_pick_token(logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, dtoken_,
-                                record ? dhist_ : nullptr, record ? dcount_ : nullptr, record ? dpos_ : nullptr, stream_),
+                                record ? dhist_ : nullptr, record ? dcount_ : nullptr, record ? dpos_ : nullptr, stream_, 1, 0, nullptr,
+                                record ? dbest_ : nullptr),
               "pick token");
 }
 
@@ -782,7 +787,7 @@ hipGraphExec_t WhisperModel::lane_step_graph(bool timestamps, int lanes)
     try {
         decoder_pass_lanes(lanes, true);
         hip_check(launch_pick_token(lane_logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, lane_tokens_,
-                                    lane_hist_, lane_counts_, dpos_, stream_, lanes, hist_cap_, drow_), "pick token");
+                                    lane_hist_, lane_counts_, dpos_, stream_, lanes, hist_cap_, drow_, dbest_), "pick token");
     } catch (...) {
         (void)hipStreamEndCapture(stream_, &graph);
         if (graph) (void)hipGraphDestroy(graph);
@@ -817,7 +822,7 @@ std::vector<std::vector<uint32_t>> WhisperModel::greedy_lanes(int lanes, const s
     hip_check(hipMemsetAsync(lane_counts_, 0, (size_t)kMaxLanes * sizeof(int), stream_), "reset counts");
     // first generated token of every lane from the last prompt position; pick advances the counters, so they are set after it
     hip_check(launch_pick_token(lane_logits_, cfg_.vocab, (int)kFirstSpecial, (int)eos_, (int)kTimestampBegin, timestamps ? 1 : 0, lane_tokens_,
-                                lane_hist_, lane_counts_, dpos_, stream_, lanes, hist_cap_, drow_), "pick token");
+                                lane_hist_, lane_counts_, dpos_, stream_, lanes, hist_cap_, drow_, dbest_), "pick token");
     const int row0 = cache_len_ * lanes;
     hip_check(hipMemcpyAsync(dpos_, &cache_len_, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D pos");
     hip_check(hipMemcpyAsync(drow_, &row0, sizeof(int), hipMemcpyHostToDevice, stream_), "H2D row");

@@ -158,6 +158,7 @@ private:
     float* lane_logits_ = nullptr;
     int32_t *lane_tokens_ = nullptr, *lane_hist_ = nullptr;
     int *lane_counts_ = nullptr, *drow_ = nullptr;
+    unsigned long long* dbest_ = nullptr;  // per-lane argmax keys of the two-stage pick
     hipGraphExec_t lane_graphs_[2][kMaxLanes + 1] = {};
     static constexpr int kSelfSplits = 16, kCrossSplits = 12;
 };

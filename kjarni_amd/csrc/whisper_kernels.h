@@ -49,6 +49,7 @@ struct GemvArgs {
     GemmEpilogue epi = EPI_BIAS;
 };
 hipError_t launch_gemv_rows(const GemvArgs& args, hipStream_t stream);
+void set_gemv_rows_variant(int variant);  // 0 = rows staged in LDS when there are several, 1 = always the per-wave kernel
 
 // Attention of `rows` query rows over cached keys/values, split over `splits` key ranges + a combine pass.
 // n_keys_ptr (device int) given: keys = *n_keys_ptr + rows and the causal base = *n_keys_ptr (max_keys bounds it);
@@ -66,6 +67,8 @@ hipError_t launch_pick_token(const float* logits, int vocab, int first_special, 
                              int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream,
                              // lanes > 1: logits [lanes, vocab], out / count [lanes], history [lanes, hist_stride]; lane 0 advances
                              // *pos by 1 and *row (the interleaved cache row) by `lanes`
-                             int lanes = 1, int hist_stride = 0, int* row = nullptr);
+                             int lanes = 1, int hist_stride = 0, int* row = nullptr,
+                             // given (>= lanes zeroed entries): the scan runs as 48 small workgroups per lane + a one-thread-per-lane finish
+                             unsigned long long* best_scratch = nullptr);
 
 }  // namespace kjarni

@@ -254,6 +254,85 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
     }
 }
 
+// The same projection for 2..8 rows (several tokens of one sequence, or the lanes of a lock-step decode): the rows are
+// (normalised and) staged in LDS once per workgroup -- wave w prepares rows w, w + 4 -- instead of being re-read and
+// re-normalised from L2 by every wave for every row.  Lane-to-chunk assignment, LayerNorm arithmetic and reduction order
+// are those of gemv_rows_kernel, so a row's result is bit-identical whichever kernel computes it.
+template <int EPI, bool LN>
+__global__ __launch_bounds__(256) void gemv_rows_lds_kernel(const float* __restrict__ X, int64_t ldx, int rows,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            const float* __restrict__ R, int64_t ldr, int n_out, int k, int seg,
+                                                            float* __restrict__ Y0, int64_t ldy0, float* __restrict__ Y1,
+                                                            float* __restrict__ Y2, int64_t ldy12, int row_off,
+                                                            const int* __restrict__ row_off_ptr)
+{
+    extern __shared__ __attribute__((aligned(16))) float gx[];  // [rows][k]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k4 = k >> 2;
+    for (int r = wave; r < rows; r += 4) {
+        float mu = 0.0f, rs = 1.0f;
+        if (LN) {
+            float s = 0.0f;
+            for (int i = lane; i < k4; i += 64) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+                s += (x[0] + x[1]) + (x[2] + x[3]);
+            }
+            mu = wave_sum(s) / (float)k;
+            float v = 0.0f;
+            for (int i = lane; i < k4; i += 64) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v = fmaf(x[c] - mu, x[c] - mu, v);
+            }
+            rs = 1.0f / sqrtf(wave_sum(v) / (float)k + eps);
+        }
+        for (int i = lane; i < k4; i += 64) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + i * 4);
+            if (LN) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 4);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + i * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = (x[c] - mu) * rs * g[c] + bt[c];
+            }
+            *reinterpret_cast<f32x4*>(gx + (int64_t)r * k + i * 4) = x;
+        }
+    }
+    __syncthreads();
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    if (n >= n_out) return;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + n * (int64_t)k);
+    float acc[GEMV_MAX_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) acc[r] = 0.0f;
+    for (int i = lane; i < k4; i += 64) {
+        const f32x4 w = w4[i];
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+            if (r < rows) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (int64_t)r * k + i * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r] = fmaf(x[c], w[c], acc[r]);
+            }
+        }
+    }
+    const float b = bias ? bias[n] : 0.0f;
+    const int which = seg > 0 ? (int)(n / seg) : 0;
+    const int64_t col = seg > 0 ? n - (int64_t)which * seg : n;
+    float* Y = which == 0 ? Y0 : (which == 1 ? Y1 : Y2);
+    const int64_t ldy = which == 0 ? ldy0 : ldy12;
+    const int64_t r0 = which == 0 ? 0 : (row_off_ptr ? *row_off_ptr : row_off);
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+        if (r < rows) {
+            float v = wave_sum(acc[r]) + b;
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            if (EPI == EPI_BIAS_RESIDUAL) v += R[r * ldr + n];
+            if (lane == 0) Y[(r0 + r) * ldy + col] = v;
+        }
+    }
+}
+
 // Cached attention for a few query rows, split over the keys ("flash decoding"): workgroup (head, split, row)
 // reduces its key range to (max, sum of exp, sum of exp * V); decode_attention_combine_kernel merges the
 // splits.  K rows are ldk floats apart with head h at columns [h*d, h*d+d); same for V.  The number of keys
@@ -423,6 +502,60 @@ __global__ __launch_bounds__(1024) void pick_token_kernel(const float* __restric
     }
 }
 
+// The same choice in two small launches, for the replayed greedy step: the 1024-thread scan above takes ~22 us of a
+// 430 us step.  Keys are (orderable logit << 32 | id): atomicMax keeps the largest logit and, among equals, the largest
+// id -- the last maximum, as above.  Key 0 = nothing producible seen (a real key is never 0: the sign flip sets a bit).
+__global__ __launch_bounds__(256) void pick_partial_kernel(const float* __restrict__ logits, int vocab, int first_special, int eos,
+                                                           int timestamp_begin, int allow_timestamps,
+                                                           unsigned long long* __restrict__ best)
+{
+    __shared__ unsigned long long red[4];
+    const int lane_id = blockIdx.y;
+    logits += (int64_t)lane_id * vocab;
+    unsigned long long key = 0ull;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vocab; i += gridDim.x * 256) {
+        const bool ok = i < first_special || i == eos || (allow_timestamps && i >= timestamp_begin);
+        if (!ok) continue;
+        const float v = logits[i];
+        uint32_t u = __float_as_uint(v);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        if (v != v) u = 1u;  // NaN below every number, above "nothing seen"
+        const unsigned long long k = ((unsigned long long)u << 32) | (uint32_t)i;
+        key = k > key ? k : key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, kWave);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) key = red[w] > key ? red[w] : key;
+        if (key) atomicMax(best + lane_id, key);
+    }
+}
+
+__global__ void pick_finalize_kernel(unsigned long long* __restrict__ best, int eos, int32_t* __restrict__ out,
+                                     int32_t* __restrict__ history, int* __restrict__ count, int* __restrict__ pos, int hist_stride,
+                                     int* __restrict__ row, int lanes)
+{
+    const int lane_id = threadIdx.x;
+    if (lane_id >= lanes) return;
+    const unsigned long long key = best[lane_id];
+    best[lane_id] = 0ull;
+    const int tok = key ? (int)(uint32_t)(key & 0xFFFFFFFFull) : eos;
+    out[lane_id] = tok;
+    if (history) {
+        history[(int64_t)lane_id * hist_stride + count[lane_id]] = tok;
+        count[lane_id] += 1;
+        if (lane_id == 0) {
+            *pos += 1;
+            if (row) *row += lanes;
+        }
+    }
+}
+
 }  // namespace
 
 // ---- launchers --------------------------------------------------------------------------------------
@@ -485,6 +618,9 @@ hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int voca
     return hipGetLastError();
 }
 
+int g_gemv_rows_variant = 0;  // 1 = never stage the rows in LDS (measurements)
+void set_gemv_rows_variant(int v) { g_gemv_rows_variant = v; }
+
 hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
 {
     if (a.rows <= 0 || a.n_out <= 0) return hipSuccess;
@@ -495,9 +631,25 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
         return launch_gemm(a.X, a.ldx, a.W, a.bias, a.R, a.ldr, a.Y0, a.ldy0, a.rows, a.n_out, a.k, a.epi, stream);
     }
     const dim3 grid((unsigned)((a.n_out + 3) / 4));
-#define KJ_GEMV(EPI, LN)                                                                                                      \
-    hipLaunchKernelGGL((gemv_rows_kernel<EPI, LN>), grid, dim3(256), 0, stream, a.X, a.ldx, a.rows, a.gamma, a.beta, a.eps, a.W, \
-                       a.bias, a.R, a.ldr, a.n_out, a.k, a.seg, a.Y0, a.ldy0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr)
+    const size_t lds = (size_t)a.rows * a.k * sizeof(float);
+    const bool staged = a.rows >= 2 && lds <= 64 * 1024 && g_gemv_rows_variant == 0;
+#define KJ_GEMV(EPI, LN)                                                                                                         \
+    do {                                                                                                                         \
+        if (staged) {                                                                                                            \
+            auto kern = gemv_rows_lds_kernel<EPI, LN>;                                                                           \
+            if (lds > 48 * 1024) {                                                                                               \
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+                if (e != hipSuccess) return e;                                                                                   \
+            }                                                                                                                    \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a.X, a.ldx, a.rows, a.gamma, a.beta, a.eps, a.W, a.bias, a.R, \
+                               a.ldr, a.n_out, a.k, a.seg, a.Y0, a.ldy0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr);        \
+        } else {                                                                                                                 \
+            hipLaunchKernelGGL((gemv_rows_kernel<EPI, LN>), grid, dim3(256), 0, stream, a.X, a.ldx, a.rows, a.gamma, a.beta,     \
+                               a.eps, a.W, a.bias, a.R, a.ldr, a.n_out, a.k, a.seg, a.Y0, a.ldy0, a.Y1, a.Y2, a.ldy12,           \
+                               a.row_off, a.row_off_ptr);                                                                        \
+        }                                                                                                                        \
+    } while (0)
     const bool ln = a.gamma != nullptr;
     switch (a.epi) {
     case EPI_BIAS:
@@ -542,10 +694,17 @@ hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const 
 
 hipError_t launch_pick_token(const float* logits, int vocab, int first_special, int eos, int timestamp_begin,
                              int allow_timestamps, int32_t* out, int32_t* history, int* count, int* pos, hipStream_t stream, int lanes,
-                             int hist_stride, int* row)
+                             int hist_stride, int* row, unsigned long long* best_scratch)
 {
-    hipLaunchKernelGGL(pick_token_kernel, dim3((unsigned)(lanes < 1 ? 1 : lanes)), dim3(1024), 0, stream, logits, vocab, first_special, eos,
-                       timestamp_begin, allow_timestamps, out, history, count, pos, hist_stride, row);
+    const int n = lanes < 1 ? 1 : lanes;
+    if (best_scratch) {  // two-stage: many small workgroups + one thread per lane
+        hipLaunchKernelGGL(pick_partial_kernel, dim3(48, (unsigned)n), dim3(256), 0, stream, logits, vocab, first_special, eos,
+                           timestamp_begin, allow_timestamps, best_scratch);
+        hipLaunchKernelGGL(pick_finalize_kernel, dim3(1), dim3(64), 0, stream, best_scratch, eos, out, history, count, pos, hist_stride, row, n);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(pick_token_kernel, dim3((unsigned)n), dim3(1024), 0, stream, logits, vocab, first_special, eos, timestamp_begin,
+                       allow_timestamps, out, history, count, pos, hist_stride, row);
     return hipGetLastError();
 }
 
