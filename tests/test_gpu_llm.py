@@ -125,3 +125,46 @@ def test_bf16_weights(tmp_path):
     ids = rng.integers(4, cfg2["vocab_size"], 6).tolist()
     h, logits = g.forward(ids)
     assert np.abs(h - orc2.forward(ids, cache)[0]).max() < TOL
+
+
+def _close(got, want):
+    """1e-4 absolute on O(1) values; a 4096-term f32 dot product with |logit| ~ 15 carries ~1e-5 relative rounding of its own."""
+    return np.allclose(got, want, atol=TOL, rtol=1e-5)
+
+
+GEOMETRIES = {
+    # head_dim 64 and 128 (the production sizes), GQA groups of 2 and 4, hidden sizes that take 1 and 2 K-chunks per lane
+    "d64-gqa2": dict(synth.LLAMA_TEST, hidden_size=256, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512, head_dim=64),
+    "d128-gqa4": dict(synth.LLAMA_TEST, hidden_size=512, num_attention_heads=4, num_key_value_heads=1, intermediate_size=1024, head_dim=128,
+                      num_hidden_layers=1),
+    "d32-wide": dict(synth.QWEN_TEST, hidden_size=4096, num_attention_heads=128, num_key_value_heads=8, intermediate_size=8192 + 32 * 8, head_dim=32,
+                     num_hidden_layers=1, vocab_size=320),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GEOMETRIES))
+def test_production_head_sizes_prefill_and_decode(tmp_path, name):
+    """The matrix-core prefill (64 x 64 GEMM tiles, flash-style causal attention with 16 / 32 / 64 / 128-wide heads), the
+    split-K decode GEMVs (1, 2 and 16-wave variants: k = 256 ... 8448) and the fused norm + QKV + RoPE step."""
+    base = GEOMETRIES[name]
+    orc, gpu, cfg = _pair(tmp_path, base, seed=9)
+    rng = np.random.default_rng(2)
+    ids = rng.integers(4, cfg["vocab_size"], 70).tolist()   # >= 24 rows: the GEMM route, two 32-query attention blocks + a tail
+    cache = orc.new_cache()
+    ref_h = orc.forward(ids, cache)[0]
+    h, logits = gpu.forward(ids)
+    k = (len(ids) - 1) % 8 + 1
+    assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL
+    assert _close(logits, orc.logits(ref_h[-1]))
+    for _ in range(3):                                        # single-token steps on top of the GEMM-filled cache
+        t = [int(rng.integers(4, cfg["vocab_size"]))]
+        ref_h = orc.forward(t, cache)[0]
+        h, logits = gpu.forward(t)
+        assert np.abs(h[-1] - ref_h[-1]).max() < TOL and _close(logits, orc.logits(ref_h[-1]))
+    more = rng.integers(4, cfg["vocab_size"], 40).tolist()  # a second long block: attention over old + new keys
+    ref_h = orc.forward(more, cache)[0]
+    h, logits = gpu.forward(more)
+    assert _close(logits, orc.logits(ref_h[-1]))
+    gpu.reset()
+    exp = orc.generate(ids[:30], 6)
+    assert gpu.generate(ids[:30], 6) == exp
