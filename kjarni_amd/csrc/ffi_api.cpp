@@ -146,7 +146,11 @@ namespace kjarni {
 // (get_hidden_states_batch_from_ids: embed_tokens(ids, None, 0), traits.rs:79).
 std::vector<float> embed_texts(Pipeline& p, const std::vector<std::string>& texts, PoolMode pool, bool normalize)
 {
-    const BatchEncoding be = p.tokenizer.encode_batch(texts);
+    return embed_encoding(p, p.tokenizer.encode_batch(texts), pool, normalize);
+}
+
+std::vector<float> embed_encoding(Pipeline& p, const BatchEncoding& be, PoolMode pool, bool normalize)
+{
     const size_t H = (size_t)p.model->config().hidden;
     std::vector<float> out(be.batch * H);
     if (be.batch == 0 || be.seq == 0) return out;

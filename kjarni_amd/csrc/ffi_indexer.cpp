@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
+#include <memory>
 #include <numeric>
 
 #include "ffi_common.h"
@@ -141,7 +143,41 @@ struct KjarniIndexer {
             return count;
         }
 
+        // One device batch is in flight on a worker thread (tokenise -> GPU -> writer) while the caller keeps loading and
+        // splitting files; inside the batch the next length group is tokenised while the GPU works on the current one.
+        std::future<void> pending;
+
+        void wait()
+        {
+            if (pending.valid()) pending.get();  // rethrows what the batch threw
+        }
+
         void drain()
+        {
+            wait();
+            if (texts.empty()) return;
+            auto job_texts = std::make_shared<std::vector<std::string>>(std::move(texts));
+            auto job_metas = std::make_shared<std::vector<Metadata>>(std::move(metas));
+            texts.clear();
+            metas.clear();
+            pending = std::async(std::launch::async, [this, job_texts, job_metas] { process(*job_texts, *job_metas); });
+        }
+
+        void finish()  // everything handed over so far is on disk when this returns
+        {
+            drain();
+            wait();
+        }
+
+        ~Sink()
+        {
+            try {
+                wait();
+            } catch (...) {
+            }
+        }
+
+        void process(std::vector<std::string>& texts, std::vector<Metadata>& metas)
         {
             const size_t n = texts.size();
             if (n == 0) return;
@@ -152,16 +188,22 @@ struct KjarniIndexer {
             std::iota(order.begin(), order.end(), (size_t)0);
             std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return texts[a].size() < texts[b].size(); });
             const size_t group = 256;
-            std::vector<std::string> g;
+            auto tokenize = [&](size_t s) {
+                std::vector<std::string> g;
+                for (size_t i = s, e = std::min(n, s + group); i < e; ++i) g.push_back(texts[order[i]]);
+                return ix.embedder->tokenizer.encode_batch(g);
+            };
+            std::future<BatchEncoding> next = std::async(std::launch::async, tokenize, (size_t)0);
             for (size_t s = 0; s < n; s += group) {
                 const size_t e = std::min(n, s + group);
-                g.clear();
-                for (size_t i = s; i < e; ++i) g.push_back(texts[order[i]]);
                 std::vector<float> out;
                 try {
+                    const BatchEncoding be = next.get();
+                    if (e < n) next = std::async(std::launch::async, tokenize, e);
                     // Embedder::embed_batch: mean pool, L2-normalised (crates/kjarni/src/embedder/model.rs:142-160)
-                    out = embed_texts(*ix.embedder, g, POOL_MEAN, true);
+                    out = embed_encoding(*ix.embedder, be, POOL_MEAN, true);
                 } catch (const std::exception& ex) {
+                    if (next.valid()) next.wait();
                     throw IndexerFailure(KJARNI_ERROR_INFERENCE_FAILED, std::string("Failed to load embedder: ") + ex.what());
                 }
                 for (size_t i = s; i < e; ++i) std::memcpy(&emb[order[i] * H], &out[(i - s) * H], H * sizeof(float));
@@ -171,8 +213,6 @@ struct KjarniIndexer {
             } catch (const std::exception& ex) {
                 throw indexing_failed(ex.what());
             }
-            texts.clear();
-            metas.clear();
         }
     };
 
@@ -191,7 +231,7 @@ struct KjarniIndexer {
         if (is_cancelled()) throw cancelled();
 
         const DocumentLoader doc_loader(loader);
-        Sink sink{*this, writer, std::max(device_batch_chunks(), std::max<size_t>(batch_size, 1)), {}, {}};
+        Sink sink{*this, writer, std::max(device_batch_chunks(), std::max<size_t>(batch_size, 1)), {}, {}, {}};
         std::vector<std::string> batch_texts;
         std::vector<Metadata> batch_metas;
 
@@ -222,7 +262,7 @@ struct KjarniIndexer {
             report(KJARNI_PROGRESS_EMBEDDING, total_docs, 0, nullptr);
             total_docs += sink.accept(batch_texts, batch_metas);
         }
-        sink.drain();
+        sink.finish();
         report(KJARNI_PROGRESS_COMMITTING, total_docs, total_docs, commit_msg);
         try {
             writer.commit();

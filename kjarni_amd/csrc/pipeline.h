@@ -27,6 +27,8 @@ std::unique_ptr<Pipeline> load_pipeline(const char* cache_dir, const char* model
                                         const char* default_name, Want want);
 // texts -> [n, H] embeddings (tokenise on the host, encode + pool on the GPU).
 std::vector<float> embed_texts(Pipeline& p, const std::vector<std::string>& texts, PoolMode pool, bool normalize);
+// The GPU half of embed_texts for a batch that is already tokenised (the indexer tokenises ahead of the GPU).
+std::vector<float> embed_encoding(Pipeline& p, const BatchEncoding& be, PoolMode pool, bool normalize);
 // (query, doc_i) pairs -> scores (logit column 0).
 std::vector<float> rerank_scores(Pipeline& p, const std::string& query, const std::vector<std::string>& docs);
 
