@@ -48,9 +48,10 @@ constexpr float kNegInf = -std::numeric_limits<float>::infinity();
 
 // ---- full-vocabulary passes --------------------------------------------------------------------------
 // The reference runs softmax_inplace over the whole vocabulary up to three times per token (scalar exp, running sum).
-// Here the whole-vocabulary work is one max pass and one exp pass, 8 lanes wide when the CPU has AVX2 (expf by range
-// reduction + degree-6 polynomial, < 2 ulp), followed by the reference's own running sum in index order: top-p / min-p
-// cut-offs hang on the rounding of that 10^5-term f32 sum, so its order is kept.
+// Here the whole-vocabulary work is one max pass and one exp + sum pass, 8 lanes wide when the CPU has AVX2 (expf by
+// range reduction + degree-6 polynomial, < 2 ulp; 8 interleaved partial sums).  A top-p cut-off hangs on the rounding of
+// that 10^5-term f32 sum, so whenever the crossing is within rounding of p the sum is redone in the reference's index
+// order and the decision repeated.
 
 float max_scalar(const float* v, size_t n)
 {
@@ -98,12 +99,24 @@ __attribute__((target("avx2,fma"))) inline __m256 exp_avx2(__m256 x)
     return _mm256_andnot_ps(under, _mm256_mul_ps(p, _mm256_castsi256_ps(e)));
 }
 
-__attribute__((target("avx2,fma"))) void exp_all_avx2(const float* v, size_t n, float mx, float inv_temp, float* out)
+__attribute__((target("avx2,fma"))) float exp_all_avx2(const float* v, size_t n, float mx, float inv_temp, float* out)
 {
     const __m256 vm = _mm256_set1_ps(mx), vt = _mm256_set1_ps(inv_temp);
+    __m256 acc = _mm256_setzero_ps();
     size_t i = 0;
-    for (; i + 8 <= n; i += 8) _mm256_storeu_ps(out + i, exp_avx2(_mm256_mul_ps(_mm256_sub_ps(_mm256_loadu_ps(v + i), vm), vt)));
-    for (; i < n; ++i) out[i] = std::exp((v[i] - mx) * inv_temp);
+    for (; i + 8 <= n; i += 8) {
+        const __m256 e = exp_avx2(_mm256_mul_ps(_mm256_sub_ps(_mm256_loadu_ps(v + i), vm), vt));
+        _mm256_storeu_ps(out + i, e);
+        acc = _mm256_add_ps(acc, e);
+    }
+    float lanes[8];
+    _mm256_storeu_ps(lanes, acc);
+    float sum = ((lanes[0] + lanes[1]) + (lanes[2] + lanes[3])) + ((lanes[4] + lanes[5]) + (lanes[6] + lanes[7]));
+    for (; i < n; ++i) {
+        out[i] = std::exp((v[i] - mx) * inv_temp);
+        sum += out[i];
+    }
+    return sum;
 }
 
 const bool kHaveAvx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
@@ -121,17 +134,27 @@ float vec_max(const float* v, size_t n)
     return max_scalar(v, n);
 }
 
-// out[i] = exp((v[i] - mx) * inv_temp); returns their running sum in index order.
-float vec_sum_exp(const float* v, size_t n, float mx, float inv_temp, float* out)
+float running_sum(const float* e, size_t n)  // the reference's summation order
+{
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; ++i) sum += e[i];
+    return sum;
+}
+
+// out[i] = exp((v[i] - mx) * inv_temp).  Returns the sum of out: `exact` tells whether it is the running sum in index order
+// (scalar path) or 8 interleaved partial sums (AVX2 path; differs from the running sum by rounding order, ~1e-5 relative
+// on a 10^5-term sum -- callers that compare a cumulative mass with a threshold re-sum in order when the decision is close).
+float vec_exp_sum(const float* v, size_t n, float mx, float inv_temp, float* out, bool& exact)
 {
 #if defined(__x86_64__)
-    if (kHaveAvx2 && n >= kVectorFrom) exp_all_avx2(v, n, mx, inv_temp, out);
-    else
+    if (kHaveAvx2 && n >= kVectorFrom) {
+        exact = false;
+        return exp_all_avx2(v, n, mx, inv_temp, out);
+    }
 #endif
-        exp_scalar(v, n, mx, inv_temp, out);
-    float sum = 0.0f;
-    for (size_t i = 0; i < n; ++i) sum += out[i];
-    return sum;
+    exp_scalar(v, n, mx, inv_temp, out);
+    exact = true;
+    return running_sum(out, n);
 }
 
 // softmax_inplace over a (small) survivor list, summed in ascending id order exactly as the reference does.
@@ -219,6 +242,7 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
 {
     // Survivors: everything (`all`, values read straight from `logits`) until a filter shrinks the set to (ids, vals).
     bool all = true, have_exps = false;
+    float exps_sum = 0.0f;
     std::vector<float> vals, exps;
     ids.clear();
     probs.clear();
@@ -255,24 +279,51 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
         bool found = false;
         if (all) {
             exps.resize(vocab);
-            const float sum = vec_sum_exp(logits, vocab, mx_all, 1.0f, exps.data());
+            bool exact = false;
+            float sum = vec_exp_sum(logits, vocab, mx_all, 1.0f, exps.data(), exact);
             have_exps = true;
-            const float scale = sum > 0.0f ? 1.0f / sum : 1.0f;
-            auto scan = [&](const std::vector<uint32_t>& c) {
-                float cumulative = 0.0f;
-                for (size_t i = 0; i < c.size(); ++i) {
-                    cumulative += exps[c[i]] * scale;
-                    if (cumulative > p.top_p) {
-                        cut = i;
-                        found = true;
-                        return true;
+            exps_sum = sum;
+            std::vector<uint32_t> order;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                const float scale = sum > 0.0f ? 1.0f / sum : 1.0f;
+                bool ambiguous = false;
+                found = false;
+                auto scan = [&](const std::vector<uint32_t>& c) {
+                    float cumulative = 0.0f;
+                    for (size_t i = 0; i < c.size(); ++i) {
+                        const float before = cumulative;
+                        cumulative += exps[c[i]] * scale;
+                        if (cumulative > p.top_p) {
+                            cut = i;
+                            found = true;
+                            // with an out-of-order sum the crossing is only trusted when it is not within rounding of p
+                            const float eps = 2e-4f * cumulative;
+                            if (!exact && (cumulative - p.top_p <= eps || p.top_p - before <= eps)) ambiguous = true;
+                            return true;
+                        }
+                    }
+                    return false;
+                };
+                if (attempt == 1) {
+                    scan(order);  // the same sorted candidates, now against the in-order sum
+                } else {
+                    // a peaked distribution crosses p within a few units of the maximum: one cheap threshold pass; otherwise
+                    // the histogram picks the threshold
+                    order = sorted_prefix(logits, vocab, mx_all, 6.0f, [&](const std::vector<uint32_t>& c) { return scan(c) || true; });
+                }
+                if (!found) {
+                    const float tau0 = tau_for_mass(logits, exps.data(), vocab, mx_all, (double)p.top_p * (double)sum);
+                    order = sorted_prefix(logits, vocab, mx_all, tau0, scan);
+                    if (!found) {
+                        scan(order);
+                        if (!found && !exact && order.size() == vocab) ambiguous = true;  // total mass within rounding of p
                     }
                 }
-                return false;
-            };
-            const float tau0 = tau_for_mass(logits, exps.data(), vocab, mx_all, (double)p.top_p * (double)sum);
-            std::vector<uint32_t> order = sorted_prefix(logits, vocab, mx_all, tau0, scan);
-            if (!found) scan(order);
+                if (!ambiguous) break;
+                sum = running_sum(exps.data(), vocab);
+                exps_sum = sum;
+                exact = true;
+            }
             if (found) {
                 order.resize(cut + 1);
                 shrink_from_all(order);
@@ -303,12 +354,11 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
     }
     if (p.min_p >= 0.0f) {  // min_p_filtering
         if (all) {
-            float sum = 0.0f;
-            if (have_exps) {
-                for (size_t i = 0; i < vocab; ++i) sum += exps[i];
-            } else {
+            float sum = exps_sum;
+            if (!have_exps) {
                 exps.resize(vocab);
-                sum = vec_sum_exp(logits, vocab, mx_all, 1.0f, exps.data());
+                bool exact = false;
+                sum = vec_exp_sum(logits, vocab, mx_all, 1.0f, exps.data(), exact);
             }
             const float scale = sum > 0.0f ? 1.0f / sum : 1.0f;
             const float max_prob = std::max(0.0f, 1.0f * scale);  // exp(0) * scale
@@ -336,7 +386,8 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
         for (size_t i = 0; i < vocab; ++i) ids[i] = (uint32_t)i;
         probs.resize(vocab);
         // (x / t) - max(x / t) == (x - max) / t for t > 0 up to rounding
-        const float sum = vec_sum_exp(logits, vocab, mx_all, 1.0f / temp, probs.data());
+        bool exact = false;
+        const float sum = vec_exp_sum(logits, vocab, mx_all, 1.0f / temp, probs.data(), exact);
         if (sum > 0.0f) {
             const float scale = 1.0f / sum;
             for (float& q : probs) q *= scale;
