@@ -392,6 +392,35 @@ def main():
             rows[label] = {"tokens": len(pieces), "ms_to_first_token": round(first[0] * 1e3, 2) if first else None,
                            "tokens_per_s_after_first": round((len(pieces) - 1) / (dt - first[0]), 1) if len(pieces) > 1 else None,
                            "ms_total": round(dt * 1e3, 1)}
+        # Random weights give a nearly flat next-token distribution (top-p 0.9 keeps thousands of tokens: the sampler's worst
+        # case).  A trained model's is peaked; the same checkpoint with its final norm scaled 8x stands in for that.
+        from safetensors.torch import load_file, save_file
+        d2 = os.path.join(tmp, "llama-1b-chat-peaked")
+        os.makedirs(d2)
+        for name in ("config.json", "tokenizer.json"):
+            shutil.copy(os.path.join(d, name), os.path.join(d2, name))
+        tensors = load_file(os.path.join(d, "model.safetensors"))
+        tensors["model.norm.weight"] = tensors["model.norm.weight"] * 8.0
+        save_file(tensors, os.path.join(d2, "model.safetensors"))
+        del tensors
+        chat2 = Chat("llama3.2-1b-instruct", model_path=d2)
+        chat2.seed(1)
+        chat2.send(message, GenerationConfig(max_new_tokens=8))
+        pieces, first = [], []
+        t0 = time.perf_counter()
+
+        def on_token2(text):
+            if not pieces:
+                first.append(time.perf_counter() - t0)
+            pieces.append(text)
+            return True
+
+        chat2.stream(message, on_token2, GenerationConfig(max_new_tokens=n_new))
+        dt = time.perf_counter() - t0
+        rows["sample_default_peaked_logits"] = {"tokens": len(pieces), "ms_to_first_token": round(first[0] * 1e3, 2),
+                                                "tokens_per_s_after_first": round((len(pieces) - 1) / (dt - first[0]), 1),
+                                                "ms_total": round(dt * 1e3, 1)}
+        del chat2
         t0 = time.perf_counter()
         for _ in range(20):
             chat.encode(chat.format_prompt(None, message))
