@@ -468,6 +468,33 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     for (int i = lane; i < hidden; i += 64) out[(int64_t)r * hidden + i] = (row[i] / rms) * gamma[i];
 }
 
+// The same for a handful of rows (the decode step's final norm): one 256-thread workgroup per row, 16-byte loads.
+__global__ __launch_bounds__(256) void rmsnorm_block_kernel(const float* __restrict__ x, const float* __restrict__ gamma, float eps,
+                                                            int hidden, float* __restrict__ out)
+{
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = x + (int64_t)blockIdx.x * hidden;
+    const int h4 = hidden >> 2;
+    float s = 0.0f;
+    for (int i = tid; i < h4; i += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + i * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s = fmaf(v[c], v[c], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)hidden + eps);
+    for (int i = tid; i < h4; i += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(row + i * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (v[c] / rms) * g[c];
+        *reinterpret_cast<f32x4*>(out + (int64_t)blockIdx.x * hidden + i * 4) = v;
+    }
+}
+
 template <typename WT>
 __global__ __launch_bounds__(256) void llm_embed_kernel(const uint32_t* __restrict__ ids, int hidden, int vocab,
                                                         const WT* __restrict__ table, float* __restrict__ out)
@@ -953,6 +980,10 @@ hipError_t launch_rope(float* x, int64_t ldx, int rows, int n_heads, int head_di
 hipError_t launch_rmsnorm(const float* x, const float* gamma, float eps, int rows, int hidden, float* out, hipStream_t stream)
 {
     if (rows <= 0) return hipSuccess;
+    if (rows <= 16 && (hidden & 3) == 0) {
+        hipLaunchKernelGGL(rmsnorm_block_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, gamma, eps, hidden, out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, eps, rows, hidden, out);
     return hipGetLastError();
 }
