@@ -1,4 +1,5 @@
 // Byte-level BPE tokenizer (see bpe.h for the pipeline being restated).
+#include "host_util.h"
 #include "bpe.h"
 
 #include <algorithm>
@@ -77,15 +78,6 @@ size_t contraction(const std::vector<uint32_t>& cps, size_t i, bool fold)
     if (a == 'l' && b == 'l') return 3;
     if (a == 'd') return 2;
     return 0;
-}
-
-std::string slurp(const std::string& path)
-{
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
 }
 
 // String::from_utf8_lossy: every maximal invalid subpart becomes U+FFFD.

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <numeric>
 
+#include "host_util.h"
 #include "../../include/kjarni_hip.h"
 #include "ffi_common.h"
 #include "json.h"
@@ -25,20 +26,6 @@ using namespace kjarni;
 namespace {
 
 constexpr float kNegInf = -std::numeric_limits<float>::infinity();
-
-bool valid_utf8(const char* s) { return unicode::is_valid_utf8(s, std::strlen(s)); }
-
-char* dup_cstr(const std::string& s)
-{
-    // CString::new(label).unwrap_or_default(): an interior NUL yields "".
-    const bool has_nul = s.find('\0') != std::string::npos;
-    const std::string& src = has_nul ? std::string() : s;
-    char* p = static_cast<char*>(std::malloc(src.size() + 1));
-    if (!p) throw std::bad_alloc();
-    std::memcpy(p, src.data(), src.size());
-    p[src.size()] = '\0';
-    return p;
-}
 
 bool is_dir(const std::string& p)
 {

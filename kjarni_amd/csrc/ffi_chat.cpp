@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "host_util.h"
 #include "../../include/kjarni_hip.h"
 #include "bpe.h"
 #include "chat.h"
@@ -28,8 +29,6 @@ struct KjarniBpeTokenizer {
 };
 
 namespace {
-
-bool valid_utf8(const char* s) { return unicode::is_valid_utf8(s, std::strlen(s)); }
 
 // CString::new(response): an interior NUL is an error here, not an empty string (chat.rs:303-313).
 char* response_cstr(const std::string& s)

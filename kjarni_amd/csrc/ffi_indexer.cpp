@@ -18,6 +18,7 @@
 #include <memory>
 #include <numeric>
 
+#include "host_util.h"
 #include "ffi_common.h"
 #include "index.h"
 #include "index_writer.h"
@@ -48,19 +49,6 @@ KJARNI_EXPORT void kjarni_cancel_token_reset(KjarniCancelToken* t)
 KJARNI_EXPORT void kjarni_cancel_token_free(KjarniCancelToken* t) { delete t; }
 
 namespace {
-
-bool valid_utf8(const char* s) { return unicode::is_valid_utf8(s, std::strlen(s)); }
-
-char* dup_cstr(const std::string& s)
-{
-    const bool has_nul = s.find('\0') != std::string::npos;  // CString::new(..).unwrap_or_default()
-    const size_t n = has_nul ? 0 : s.size();
-    char* p = static_cast<char*>(std::malloc(n + 1));
-    if (!p) throw std::bad_alloc();
-    std::memcpy(p, s.data(), n);
-    p[n] = '\0';
-    return p;
-}
 
 std::string trim(const std::string& s)  // str::trim (ASCII + Unicode White_Space; the lists here are ASCII)
 {

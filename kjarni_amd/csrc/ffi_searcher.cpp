@@ -15,6 +15,7 @@
 #include <map>
 #include <numeric>
 
+#include "host_util.h"
 #include "ffi_common.h"
 #include "index.h"
 #include "pipeline.h"
@@ -23,19 +24,6 @@
 using namespace kjarni;
 
 namespace {
-
-bool valid_utf8(const char* s) { return unicode::is_valid_utf8(s, std::strlen(s)); }
-
-char* dup_cstr(const std::string& s)
-{
-    const bool has_nul = s.find('\0') != std::string::npos;  // CString::new(..).unwrap_or_default()
-    const std::string& src = has_nul ? std::string() : s;
-    char* p = static_cast<char*>(std::malloc(src.size() + 1));
-    if (!p) throw std::bad_alloc();
-    std::memcpy(p, src.data(), src.size());
-    p[src.size()] = '\0';
-    return p;
-}
 
 struct DeviceSegment {
     float* vectors = nullptr;

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <sstream>
 
+#include "host_util.h"
 #include "../../include/kjarni_hip.h"
 #include "ffi_common.h"
 #include "registry.h"
@@ -29,19 +30,6 @@
 using namespace kjarni;
 
 namespace {
-
-bool valid_utf8(const char* s) { return unicode::is_valid_utf8(s, std::strlen(s)); }
-
-char* dup_cstr(const std::string& s)
-{
-    const bool has_nul = s.find('\0') != std::string::npos;
-    const size_t n = has_nul ? 0 : s.size();
-    char* p = static_cast<char*>(std::malloc(n + 1));
-    if (!p) throw std::bad_alloc();
-    std::memcpy(p, s.data(), n);
-    p[n] = '\0';
-    return p;
-}
 
 std::string lower_ascii(std::string s)
 {

@@ -1,3 +1,4 @@
+#include "host_util.h"
 #include "index.h"
 
 #include <dirent.h>
@@ -20,15 +21,6 @@
 namespace kjarni {
 
 namespace {
-
-std::string slurp(const std::string& path)
-{
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
-}
 
 bool is_dir(const std::string& p)
 {

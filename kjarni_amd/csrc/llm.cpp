@@ -1,3 +1,4 @@
+#include "host_util.h"
 #include "llm.h"
 
 #include <algorithm>
@@ -16,15 +17,6 @@
 namespace kjarni {
 
 namespace {
-
-std::string slurp_file(const std::string& path)
-{
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
-}
 
 uint16_t f32_to_bf16(float v)  // round to nearest even
 {
@@ -129,7 +121,7 @@ std::unique_ptr<LlmModel> LlmModel::load(const std::string& dir, int device, int
     std::unique_ptr<LlmModel> m(new LlmModel());
     m->device_ = device;
     hip_check(hipSetDevice(device), "hipSetDevice");
-    m->cfg_ = LlmConfig::from_json(slurp_file(dir + "/config.json"));
+    m->cfg_ = LlmConfig::from_json(slurp(dir + "/config.json"));
     const LlmConfig& c = m->cfg_;
     const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d;
     if ((d & 3) || d > 128 || 256 % (d / 4) != 0 || (H & 7) || (c.inter & 7)) throw std::runtime_error("unsupported decoder geometry");

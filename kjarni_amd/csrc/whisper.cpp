@@ -1,3 +1,4 @@
+#include "host_util.h"
 #include "whisper.h"
 
 #include <algorithm>
@@ -15,15 +16,6 @@
 namespace kjarni {
 
 namespace {
-
-std::string slurp_file(const std::string& path)
-{
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
-}
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -116,7 +108,7 @@ WhisperConfig WhisperConfig::from_json(const std::string& text)
 
 void ByteLevelVocab::load(const std::string& path)
 {
-    const Json j = Json::parse(slurp_file(path));
+    const Json j = Json::parse(slurp(path));
     const Json* model = j.find("model");
     const Json* vocab = model ? model->find("vocab") : nullptr;
     if (!vocab || !vocab->is_object()) throw std::runtime_error(path + ": no model.vocab");
@@ -209,7 +201,7 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
     std::unique_ptr<WhisperModel> m(new WhisperModel());
     m->device_ = device;
     hip_check(hipSetDevice(device), "hipSetDevice");
-    m->cfg_ = WhisperConfig::from_json(slurp_file(dir + "/config.json"));
+    m->cfg_ = WhisperConfig::from_json(slurp(dir + "/config.json"));
     const WhisperConfig& c = m->cfg_;
     const int H = c.d_model, d = H / c.heads;
     if ((d & 3) || 256 % d != 0) throw std::runtime_error("unsupported head dimension " + std::to_string(d));

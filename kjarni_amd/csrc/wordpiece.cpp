@@ -1,3 +1,4 @@
+#include "host_util.h"
 #include "wordpiece.h"
 
 #include <cstdint>
@@ -18,15 +19,6 @@
 namespace kjarni {
 
 namespace {
-
-std::string slurp(const std::string& path)
-{
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
-}
 
 bool is_word_char(uint32_t cp)
 {
