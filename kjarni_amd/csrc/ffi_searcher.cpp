@@ -76,41 +76,63 @@ public:
         if (work_) (void)hipFree(work_);
     }
 
-    std::vector<std::pair<size_t, float>> scan(const Segment& seg, const float* query, size_t query_dim, size_t limit)
+    // One query against every segment: the kernels of all segments are enqueued back to back and the host waits once.
+    std::vector<SegmentHits> scan(const std::vector<const Segment*>& segs, const float* query, size_t query_dim, size_t limit)
     {
-        std::vector<std::pair<size_t, float>> out;
-        const size_t n = seg.doc_count(), dim = seg.dimension();
-        if (n == 0 || limit == 0 || dim == 0) return out;
-        if (dim != query_dim) return out;                               // query.len() != dimension -> empty
-        if (seg.vectors_bytes() < n * dim * sizeof(float)) return out;  // get_embedding() would return None
+        std::vector<SegmentHits> out(segs.size());
+        if (limit == 0 || query_dim == 0) return out;
         float qn = 0.0f;
-        for (size_t i = 0; i < dim; ++i) qn += query[i] * query[i];
+        for (size_t i = 0; i < query_dim; ++i) qn += query[i] * query[i];
         if (std::sqrt(qn) < 1e-9f) return out;                          // segment.rs:315-317
 
         std::lock_guard<std::mutex> lock(mu_);
         hip_check(hipSetDevice(device_), "hipSetDevice");
-        struct stat st;
-        const std::string vpath = seg.dir() + "/vectors.bin";
-        if (::stat(vpath.c_str(), &st) != 0) return out;
-        const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
-        DeviceSegment& ds = cache_[vpath];
-        const size_t bytes = n * dim * sizeof(float);
-        if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt) {
-            if (ds.vectors) {
-                hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-                (void)hipFree(ds.vectors);
-                ds.vectors = nullptr;
-            }
-            hip_check(hipMalloc((void**)&ds.vectors, bytes), "hipMalloc(segment vectors)");
-            hip_check(hipMemcpy(ds.vectors, seg.vectors(), bytes, hipMemcpyHostToDevice), "H2D segment vectors");
-            ds.bytes = bytes;
-            ds.mtime_ns = mt;
-        }
-        const int k = (int)std::min(limit, n);
-        const size_t ws_bytes = cosine_topk_workspace_bytes(1, (int64_t)n, k);
         auto pad = [](size_t b) { return 256 * ((b + 255) / 256); };
-        const size_t s_off = pad(dim * 4), w_off = s_off + pad(n * 4), i_off = w_off + pad(ws_bytes);
-        const size_t o_off = i_off + pad((size_t)k * 8), total = o_off + pad((size_t)k * 4);
+        struct Plan {
+            size_t seg, n;
+            int k;
+            DeviceSegment* ds;
+            size_t s_off, w_off, r_off;  // scores, top-k workspace, slot in the result arrays
+        };
+        std::vector<Plan> plans;
+        size_t cursor = pad(query_dim * 4), slots = 0;
+        for (size_t si = 0; si < segs.size(); ++si) {
+            const Segment& seg = *segs[si];
+            const size_t n = seg.doc_count(), dim = seg.dimension();
+            if (n == 0 || dim != query_dim) continue;                        // query.len() != dimension -> empty
+            if (seg.vectors_bytes() < n * dim * sizeof(float)) continue;     // get_embedding() would return None
+            struct stat st;
+            const std::string vpath = seg.dir() + "/vectors.bin";
+            if (::stat(vpath.c_str(), &st) != 0) continue;
+            const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+            DeviceSegment& ds = cache_[vpath];
+            const size_t bytes = n * dim * sizeof(float);
+            if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt) {
+                if (ds.vectors) {
+                    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+                    (void)hipFree(ds.vectors);
+                    ds.vectors = nullptr;
+                }
+                hip_check(hipMalloc((void**)&ds.vectors, bytes), "hipMalloc(segment vectors)");
+                hip_check(hipMemcpy(ds.vectors, seg.vectors(), bytes, hipMemcpyHostToDevice), "H2D segment vectors");
+                ds.bytes = bytes;
+                ds.mtime_ns = mt;
+            }
+            Plan p;
+            p.seg = si;
+            p.n = n;
+            p.k = (int)std::min(limit, n);
+            p.ds = &ds;
+            p.s_off = cursor;
+            cursor += pad(n * 4);
+            p.w_off = cursor;
+            cursor += pad(cosine_topk_workspace_bytes(1, (int64_t)n, p.k));
+            p.r_off = slots;
+            slots += (size_t)p.k;
+            plans.push_back(p);
+        }
+        if (plans.empty()) return out;
+        const size_t i_off = cursor, o_off = i_off + pad(slots * 8), total = o_off + pad(slots * 4);
         if (total > work_bytes_) {
             if (work_) {
                 hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
@@ -122,20 +144,24 @@ public:
             work_bytes_ = total;
         }
         float* q_d = reinterpret_cast<float*>(work_);
-        float* s_d = reinterpret_cast<float*>(work_ + s_off);
         int64_t* i_d = reinterpret_cast<int64_t*>(work_ + i_off);
         float* o_d = reinterpret_cast<float*>(work_ + o_off);
-        hip_check(hipMemcpyAsync(q_d, query, dim * 4, hipMemcpyHostToDevice, nullptr), "H2D query");
-        hip_check(launch_cosine_scores(q_d, 1, ds.vectors, (int64_t)n, (int)dim, /*segment mode*/ 1, s_d, nullptr),
-                  "cosine_scores");
-        hip_check(launch_cosine_topk(s_d, 1, (int64_t)n, k, work_ + w_off, i_d, o_d, nullptr), "cosine_topk");
-        std::vector<int64_t> idx((size_t)k);
-        std::vector<float> sc((size_t)k);
-        hip_check(hipMemcpyAsync(idx.data(), i_d, (size_t)k * 8, hipMemcpyDeviceToHost, nullptr), "D2H idx");
-        hip_check(hipMemcpyAsync(sc.data(), o_d, (size_t)k * 4, hipMemcpyDeviceToHost, nullptr), "D2H scores");
+        hip_check(hipMemcpyAsync(q_d, query, query_dim * 4, hipMemcpyHostToDevice, nullptr), "H2D query");
+        for (const Plan& p : plans) {
+            float* s_d = reinterpret_cast<float*>(work_ + p.s_off);
+            hip_check(launch_cosine_scores(q_d, 1, p.ds->vectors, (int64_t)p.n, (int)query_dim, /*segment mode*/ 1, s_d, nullptr),
+                      "cosine_scores");
+            hip_check(launch_cosine_topk(s_d, 1, (int64_t)p.n, p.k, work_ + p.w_off, i_d + p.r_off, o_d + p.r_off, nullptr),
+                      "cosine_topk");
+        }
+        std::vector<int64_t> idx(slots);
+        std::vector<float> sc(slots);
+        hip_check(hipMemcpyAsync(idx.data(), i_d, slots * 8, hipMemcpyDeviceToHost, nullptr), "D2H idx");
+        hip_check(hipMemcpyAsync(sc.data(), o_d, slots * 4, hipMemcpyDeviceToHost, nullptr), "D2H scores");
         hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
-        for (int i = 0; i < k; ++i)
-            if (idx[(size_t)i] >= 0) out.emplace_back((size_t)idx[(size_t)i], sc[(size_t)i]);
+        for (const Plan& p : plans)
+            for (int i = 0; i < p.k; ++i)
+                if (idx[p.r_off + (size_t)i] >= 0) out[p.seg].emplace_back((size_t)idx[p.r_off + (size_t)i], sc[p.r_off + (size_t)i]);
         return out;
     }
 
@@ -302,8 +328,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
                                 ") doesn't match model dimension (" + std::to_string(model_dim) + ")");
         const bool rerank = o.use_reranker && s->reranker;
         const size_t fetch_k = rerank ? o.top_k * 5 : o.top_k;
-        const SegmentScanFn scan = [&](const Segment& seg, const float* q, size_t limit) {
-            return s->scanner->scan(seg, q, model_dim, limit);
+        const SegmentScanFn scan = [&](const std::vector<const Segment*>& segs, const float* q, size_t limit) {
+            return s->scanner->scan(segs, q, model_dim, limit);
         };
         std::vector<float> q;
         if (o.mode != KJARNI_SEARCH_KEYWORD)  // embedder.embed(query): mean pool, normalised (embedder/model.rs:118-140)
@@ -455,7 +481,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, co
                                 ") doesn't match query dimension (" + std::to_string(dim) + ")");
         static std::mutex mu;
         static std::unique_ptr<SegmentScanner> scanner;
-        const SegmentScanFn scan = [&](const Segment& seg, const float* q, size_t limit) {
+        const SegmentScanFn scan = [&](const std::vector<const Segment*>& segs, const float* q, size_t limit) {
             {
                 std::lock_guard<std::mutex> lock(mu);
                 if (!scanner) {
@@ -464,7 +490,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, co
                     scanner = std::make_unique<SegmentScanner>(0);
                 }
             }
-            return scanner->scan(seg, q, dim, limit);
+            return scanner->scan(segs, q, dim, limit);
         };
         std::vector<SearchHit> results =
             retrieve(*reader, o.mode, text_query ? text_query : "", query_emb, o.top_k, o.filter, scan);

@@ -157,25 +157,43 @@ std::vector<std::pair<size_t, float>> Bm25Index::search(const std::string& query
     if (total_docs == 0) return res;
     const std::vector<std::string> q = tokenize(query);
     if (q.empty()) return res;
-    // Same result as scoring every document (bm25.rs:96-101), visiting only documents that contain
-    // a query term; documents whose length slot is missing cannot be scored either way.
-    std::vector<uint8_t> seen(std::min(total_docs, doc_lengths.size()), 0);  // d < both below; total_docs comes from the file
-    for (const std::string& term : q) {
-        auto it = inverted_index.find(term);
+    // Same result as scoring every document with score() (bm25.rs:96-101): each document's sum is accumulated term by
+    // term in query order, so the f32 additions happen in the order score() makes them, but every posting list is
+    // walked once instead of once per (document, term).  Documents without a length slot cannot be scored either way.
+    const size_t n = std::min(total_docs, doc_lengths.size());  // total_docs comes from the file
+    std::vector<float> acc(n, 0.0f);
+    std::vector<uint32_t> term_seen(n, 0);  // term_frequency() takes the first posting of a document
+    std::vector<size_t> touched;
+    for (size_t t = 0; t < q.size(); ++t) {
+        auto it = inverted_index.find(q[t]);
         if (it == inverted_index.end()) continue;
+        auto dit = doc_frequencies.find(q[t]);
+        const float df = dit == doc_frequencies.end() ? 0.0f : (float)dit->second;
+        const float idf = std::log(((float)total_docs - df + 0.5f) / (df + 0.5f) + 1.0f);
         for (const auto& p : it->second) {
             const size_t d = (size_t)p.first;
-            if (d >= total_docs || d >= doc_lengths.size() || seen[d]) continue;
-            seen[d] = 1;
-            const float s = score(q, d);
-            if (s > 0.0f) res.emplace_back(d, s);
+            if (d >= n) continue;
+            if (term_seen[d] == 0) touched.push_back(d);
+            if (term_seen[d] == t + 1) continue;
+            term_seen[d] = (uint32_t)(t + 1);
+            const float tf = (float)(size_t)p.second;
+            if (tf == 0.0f || df == 0.0f) continue;
+            const float length_norm = 1.0f - b + b * ((float)doc_lengths[d] / avg_doc_length);
+            acc[d] += idf * ((tf * (k1 + 1.0f)) / (tf + k1 * length_norm));
         }
     }
-    std::stable_sort(res.begin(), res.end(), [](const auto& x, const auto& y) {
+    for (size_t d : touched)
+        if (acc[d] > 0.0f) res.emplace_back(d, acc[d]);
+    const auto better = [](const auto& x, const auto& y) {
         if (x.second != y.second) return x.second > y.second;
         return x.first < y.first;
-    });
-    if (res.size() > limit) res.resize(limit);
+    };
+    if (res.size() > limit) {  // a total order on (score, id): the best `limit` are the head of the full sort
+        std::partial_sort(res.begin(), res.begin() + (std::ptrdiff_t)limit, res.end(), better);
+        res.resize(limit);
+    } else {
+        std::sort(res.begin(), res.end(), better);
+    }
     return res;
 }
 
@@ -509,6 +527,62 @@ std::unique_ptr<Segment> Segment::open(const std::string& dir)
     return s;
 }
 
+namespace {
+// (size, mtime, ctime, inode) of each file a parsed Segment depends on; a rewritten or replaced file changes one.
+struct SegmentStamp {
+    uint64_t v[24] = {};
+    bool operator==(const SegmentStamp& o) const { return std::memcmp(v, o.v, sizeof v) == 0; }
+};
+bool stamp_of(const std::string& dir, SegmentStamp& out)
+{
+    static const char* const kFiles[6] = {"segment.json", "vectors.bin", "docs.idx", "bm25.bin", "docs.bin", "metadata.jsonl"};
+    for (int i = 0; i < 6; ++i) {
+        struct stat st;
+        if (::stat((dir + "/" + kFiles[i]).c_str(), &st) != 0) {
+            if (i < 4) return false;  // Segment::open would throw
+            continue;
+        }
+        out.v[4 * i] = (uint64_t)st.st_size;
+        out.v[4 * i + 1] = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+        out.v[4 * i + 2] = (uint64_t)st.st_ctim.tv_sec * 1000000000ull + (uint64_t)st.st_ctim.tv_nsec;
+        out.v[4 * i + 3] = (uint64_t)st.st_ino;
+    }
+    return true;
+}
+struct CachedSegment {
+    SegmentStamp stamp;
+    std::shared_ptr<const Segment> seg;
+};
+std::mutex g_segment_mu;
+std::unordered_map<std::string, CachedSegment> g_segments;
+}  // namespace
+
+std::shared_ptr<const Segment> Segment::open_shared(const std::string& dir)
+{
+    SegmentStamp stamp;
+    if (!stamp_of(dir, stamp)) return std::shared_ptr<const Segment>(open(dir).release());  // throws the open error
+    {
+        std::lock_guard<std::mutex> lock(g_segment_mu);
+        auto it = g_segments.find(dir);
+        if (it != g_segments.end() && it->second.stamp == stamp) return it->second.seg;
+    }
+    std::shared_ptr<const Segment> seg(open(dir).release());
+    std::lock_guard<std::mutex> lock(g_segment_mu);
+    if (g_segments.size() >= 4096) {  // drop what no reader holds (deleted or superseded indexes)
+        for (auto it = g_segments.begin(); it != g_segments.end();)
+            it = it->second.seg.use_count() == 1 ? g_segments.erase(it) : std::next(it);
+    }
+    g_segments[dir] = CachedSegment{stamp, seg};
+    return seg;
+}
+
+void Segment::forget_under(const std::string& root)
+{
+    std::lock_guard<std::mutex> lock(g_segment_mu);
+    for (auto it = g_segments.begin(); it != g_segments.end();)
+        it = it->first.compare(0, root.size(), root) == 0 ? g_segments.erase(it) : std::next(it);
+}
+
 Segment::~Segment()
 {
     if (map_) munmap(map_, map_len_);
@@ -545,11 +619,21 @@ std::string Segment::get_document(size_t doc_id) const
 
 Metadata Segment::get_metadata(size_t doc_id) const
 {
-    std::ifstream f(dir_ + "/metadata.jsonl");
+    std::ifstream f(dir_ + "/metadata.jsonl", std::ios::binary);
     if (!f) throw std::runtime_error("cannot open metadata.jsonl");
+    std::call_once(meta_once_, [&] {  // one pass for the line starts; later lookups seek
+        std::string l;
+        uint64_t off = 0;
+        while (std::getline(f, l)) {
+            meta_offsets_.push_back(off);
+            off += l.size() + (f.eof() ? 0 : 1);
+        }
+        f.clear();
+    });
+    if (doc_id >= meta_offsets_.size()) throw std::runtime_error("Document ID out of range");
+    f.seekg((std::streamoff)meta_offsets_[doc_id]);
     std::string line;
-    for (size_t i = 0; std::getline(f, line); ++i) {
-        if (i != doc_id) continue;
+    if (std::getline(f, line)) {
         const Json j = Json::parse(line);
         if (!j.is_object()) throw std::runtime_error("Invalid JSON: metadata is not an object");
         Metadata md;
@@ -583,7 +667,7 @@ std::unique_ptr<IndexReader> IndexReader::open(const std::string& root)
         std::sort(names.begin(), names.end());  // entries.sort_by_key(file_name)
         for (const std::string& n : names) {
             try {
-                r->segments_.push_back(Segment::open(segdir + "/" + n));
+                r->segments_.push_back(Segment::open_shared(segdir + "/" + n));
             } catch (const std::exception&) {
                 // index_reader.rs:178-181: a segment that fails to load is skipped with a warning
             }
@@ -641,8 +725,11 @@ static void sort_desc_truncate(std::vector<std::tuple<size_t, size_t, float>>& a
 std::vector<SearchHit> IndexReader::search_semantic(const float* query, size_t limit, const SegmentScanFn& scan) const
 {
     std::vector<std::tuple<size_t, size_t, float>> all;
-    for (size_t si = 0; si < segments_.size(); ++si)
-        for (const auto& r : scan(*segments_[si], query, limit)) all.emplace_back(si, r.first, r.second);
+    std::vector<const Segment*> segs;
+    for (const auto& s : segments_) segs.push_back(s.get());
+    const std::vector<SegmentHits> per_segment = scan(segs, query, limit);
+    for (size_t si = 0; si < per_segment.size() && si < segments_.size(); ++si)
+        for (const auto& r : per_segment[si]) all.emplace_back(si, r.first, r.second);
     sort_desc_truncate(all, limit);
     return convert(all);
 }

@@ -18,6 +18,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -77,6 +78,10 @@ struct SearchHit {
 class Segment {
 public:
     static std::unique_ptr<Segment> open(const std::string& dir);
+    // Same segment, parsed once per process: queries re-open the index (Searcher::search does), so the parsed
+    // BM25 postings / offsets / mmap are kept and revalidated by every file's (size, mtime) before reuse.
+    static std::shared_ptr<const Segment> open_shared(const std::string& dir);
+    static void forget_under(const std::string& root);  // the index at `root` is being removed
     ~Segment();
     size_t doc_count() const { return doc_count_; }
     size_t dimension() const { return dimension_; }
@@ -99,12 +104,17 @@ private:
     size_t map_len_ = 0;
     std::vector<uint64_t> doc_offsets_;
     Bm25Index bm25_;
+    // byte offset of every metadata.jsonl line, built on the first get_metadata
+    mutable std::once_flag meta_once_;
+    mutable std::vector<uint64_t> meta_offsets_;
 };
 
-// Scans one segment for the query: returns up to `limit` (local doc id, score), score
-// descending (Segment::search_vectors, segment.rs:307-337).  Supplied by the GPU side.
-using SegmentScanFn = std::function<std::vector<std::pair<size_t, float>>(const Segment&, const float* query,
-                                                                          size_t limit)>;
+// Scans every segment for the query: per segment, up to `limit` (local doc id, score), score descending
+// (Segment::search_vectors, segment.rs:307-337).  Supplied by the GPU side, which takes the whole list so that
+// all segments of a query are enqueued before the one synchronisation.
+using SegmentHits = std::vector<std::pair<size_t, float>>;
+using SegmentScanFn = std::function<std::vector<SegmentHits>(const std::vector<const Segment*>& segments,
+                                                             const float* query, size_t limit)>;
 
 // crates/kjarni-rag/src/index_reader.rs:104-347
 class IndexReader {
@@ -128,7 +138,7 @@ private:
     std::vector<SearchHit> convert(const std::vector<std::tuple<size_t, size_t, float>>& r) const;
 
     size_t dimension_ = 0, total_docs_ = 0;
-    std::vector<std::unique_ptr<Segment>> segments_;
+    std::vector<std::shared_ptr<const Segment>> segments_;
 };
 
 std::string metadata_to_json(const Metadata& md);  // serde_json::to_string(&HashMap), keys sorted

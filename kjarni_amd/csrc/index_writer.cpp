@@ -7,6 +7,7 @@
 #include <fstream>
 #include <system_error>
 
+#include "index.h"
 #include "json.h"
 #include "unicode.h"
 
@@ -499,6 +500,7 @@ uint64_t directory_size(const std::string& path)
 
 void remove_dir_all(const std::string& path)
 {
+    Segment::forget_under(path);  // parsed segments of this index must not outlive it
     std::error_code ec;
     fs::remove_all(path, ec);
     if (ec) throw std::runtime_error("cannot remove " + path + ": " + ec.message());

@@ -168,6 +168,34 @@ def test_keywords_match_oracle_bit_exact(small_index, big_index):
             _same(search_keywords(root, q, k), orc.search_keywords(q, k))
 
 
+def test_keywords_repeated_terms_and_dense_matches_bit_exact(tmp_path):
+    # The posting-list accumulation must add in the order score() does (bm25.rs:70-94): repeated query terms count
+    # again, and a query that matches most of a segment is still ranked exactly.
+    rng = np.random.default_rng(17)
+    words = ["glacier", "fjord", "basalt", "wool", "geyser", "harbour", "lights", "river"]
+    docs = [(" ".join(rng.choice(words, int(rng.integers(1, 14)))) + f" d{i}", rng.standard_normal(4).astype(np.float32),
+             {"source": f"f{i % 7}.txt"}) for i in range(1500)]
+    root = str(tmp_path / "dense")
+    SO.write_index(root, 4, docs, max_docs_per_segment=400)
+    orc = SO.IndexOracle(docs, 400)
+    for q in ["glacier fjord basalt", "fjord fjord glacier fjord", "wool wool", "river d17 lights", "d3 d3 d4"]:
+        for k in (1, 10, 2000):
+            _same(search_keywords(root, q, k), orc.search_keywords(q, k))
+
+
+def test_rewritten_index_is_not_served_from_the_segment_cache(tmp_path):
+    # parsed segments are kept across queries, keyed by directory and revalidated by each file's stat()
+    import shutil
+    root = str(tmp_path / "again")
+    for docs in (DOCS, [(t.replace("rust", "zig"), v, m) for t, v, m in DOCS], DOCS[:4]):
+        SO.write_index(root, 4, docs, max_docs_per_segment=3)
+        orc = SO.IndexOracle(docs, 3)
+        for q in ("rust", "zig", "is"):
+            _same(search_keywords(root, q, 10), orc.search_keywords(q, 10))
+            _same(search_keywords(root, q, 10), orc.search_keywords(q, 10))   # second query: cached segments
+        shutil.rmtree(root)
+
+
 def test_index_search_keyword_mode_and_filters(small_index, big_index):
     # keyword mode of the retrieval hook needs no GPU
     orc = SO.IndexOracle(DOCS, 3)
