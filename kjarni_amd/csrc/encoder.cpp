@@ -69,6 +69,9 @@ namespace {
 
 struct Names {
     std::string emb, q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b, ln1_g, ln1_b, w1, b1, w2, b2, ln2_g, ln2_b;
+    std::string qkv_w;              // one fused [3H,H] tensor instead of q_w / k_w / v_w
+    std::string wg;                 // SwiGLU gate
+    std::string emb_ln_g, emb_ln_b; // embedding LayerNorm when it is not <emb>LayerNorm.*
 };
 
 std::string fmt_layer(const std::string& pattern, int i)
@@ -154,6 +157,26 @@ Names distilbert_names(const std::string& pre)
     return n;
 }
 
+// Nomic (sentence_encoder/configs.rs:219-275): fused Wqkv, no biases anywhere, SwiGLU with fc11 = gate and fc12 = up.
+Names nomic_names()
+{
+    Names n;
+    n.emb = "embeddings.";
+    n.emb_ln_g = "emb_ln.weight";
+    n.emb_ln_b = "emb_ln.bias";
+    const std::string l = "encoder.layers.{}.";
+    n.qkv_w = l + "attn.Wqkv.weight";
+    n.o_w = l + "attn.out_proj.weight";
+    n.ln1_g = l + "norm1.weight";
+    n.ln1_b = l + "norm1.bias";
+    n.wg = l + "mlp.fc11.weight";
+    n.w1 = l + "mlp.fc12.weight";
+    n.w2 = l + "mlp.fc2.weight";
+    n.ln2_g = l + "norm2.weight";
+    n.ln2_b = l + "norm2.bias";
+    return n;
+}
+
 void expect_shape(const std::vector<int64_t>& got, std::initializer_list<int64_t> want,
                   const std::string& name)
 {
@@ -210,7 +233,7 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         std::string act = cfg.get_string("hidden_act", cfg.get_string("activation_function", "gelu"));
         if (act == "gelu_new") c.ffn_act = EPI_BIAS_GELU_NEW;
         else if (act == "relu") c.ffn_act = EPI_BIAS_RELU;
-        else if (act == "swiglu") throw std::runtime_error("SwiGLU (Nomic) encoders are not supported by the HIP encoder");
+        else if (act == "swiglu") throw std::runtime_error("activation 'swiglu' needs model_type 'nomic_bert' (a gate weight)");
         else c.ffn_act = EPI_BIAS_GELU;
     } else if (c.model_type == "roberta" || c.model_type == "distilroberta") {
         // sequence_classifier/configs.rs:149-280: BERT's layer layout under "roberta.", positions start at 2.
@@ -233,9 +256,28 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         c.eps = (float)cfg.get_double("layer_norm_eps", 1e-5);
         c.pos_offset = 2;                 // sentence_encoder/configs.rs:416
         c.ffn_act = EPI_BIAS_GELU_NEW;    // configs.rs:410: the tanh form whatever hidden_act says
+    } else if (c.model_type == "nomic_bert") {
+        // BertConfig with its serde aliases (sentence_encoder/configs.rs:15-27, 43-44, 140-149)
+        auto key = [&](const char* a, const char* b) { return (int)cfg.get_int(a, cfg.get_int(b, 0)); };
+        names = nomic_names();
+        c.hidden = key("hidden_size", "n_embd");
+        c.layers = key("num_hidden_layers", "n_layer");
+        c.heads = key("num_attention_heads", "n_head");
+        c.inter = key("intermediate_size", "n_inner");
+        if (c.inter <= 0) c.inter = 4 * c.hidden;
+        if (!cfg.find("layer_norm_eps") && !cfg.find("layer_norm_epsilon"))
+            throw std::runtime_error("config.json: missing field `layer_norm_eps`");
+        c.eps = (float)cfg.get_double("layer_norm_eps", cfg.get_double("layer_norm_epsilon", 1e-12));
+        c.gated_ffn = true;  // the layout always names a gate (configs.rs:243-246)
+        c.max_pos = key("n_positions", "max_position_embeddings");
+        if (c.max_pos <= 0) c.max_pos = 512;
+        // configs.rs:175-183: either rotary key switches RoPE on; theta defaults to 10000
+        if (cfg.find("rotary_emb_fraction") || cfg.find("rotary_emb_base") || cfg.find("rotary_embedding_fraction") ||
+            cfg.find("rotary_embedding_base"))
+            c.rope_theta = (float)cfg.get_double("rotary_emb_base", cfg.get_double("rotary_embedding_base", 10000.0));
     } else {
         throw std::runtime_error("unsupported model_type '" + c.model_type +
-                                 "' (the HIP encoder covers bert, distilbert, roberta and mpnet)");
+                                 "' (the HIP encoder covers bert, distilbert, roberta, mpnet and nomic_bert)");
     }
     if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads != 0)
         throw std::runtime_error("invalid encoder dimensions in config.json");
@@ -248,20 +290,41 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
     if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("word_embeddings has wrong shape");
     c.vocab = (int)shape[0];
     m->word_ = m->upload(buf);
-    shape = st.read_f32(names.emb + "position_embeddings.weight", buf);
-    if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("position_embeddings has wrong shape");
-    c.max_pos = (int)shape[0];
-    m->pos_ = m->upload(buf);
-    const bool typed_family = c.model_type == "bert" || c.model_type == "roberta" || c.model_type == "distilroberta";
+    if (c.model_type != "nomic_bert") {  // Nomic's layout has position_embedding: None (configs.rs:254)
+        shape = st.read_f32(names.emb + "position_embeddings.weight", buf);
+        if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("position_embeddings has wrong shape");
+        c.max_pos = (int)shape[0];
+        m->pos_ = m->upload(buf);
+    }
+    if (c.rope_theta > 0.0f) {
+        // RoPE::new(head_dim, max_seq_len, theta): rope/mod.rs:57-62 (inverse frequencies), :96-116 (caches)
+        const int d = H / c.heads, half = d / 2;
+        if (d % 2) throw std::runtime_error("RoPE needs an even head dimension");
+        std::vector<float> inv((size_t)half), cs((size_t)c.max_pos * d), sn((size_t)c.max_pos * d);
+        for (int i = 0; i < half; ++i) inv[(size_t)i] = 1.0f / std::pow(c.rope_theta, (float)(2 * i) / (float)d);
+        for (int p = 0; p < c.max_pos; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float angle = (float)p * inv[(size_t)i];
+                const float cv = std::cos(angle), sv = std::sin(angle);
+                cs[(size_t)p * d + i] = cs[(size_t)p * d + i + half] = cv;
+                sn[(size_t)p * d + i] = sn[(size_t)p * d + i + half] = sv;
+            }
+        m->rope_cos_ = m->upload(cs);
+        m->rope_sin_ = m->upload(sn);
+    }
+    const bool typed_family = c.model_type == "bert" || c.model_type == "roberta" || c.model_type == "distilroberta" ||
+                              c.model_type == "nomic_bert";
     if (typed_family && st.contains(names.emb + "token_type_embeddings.weight")) {
         shape = st.read_f32(names.emb + "token_type_embeddings.weight", buf);
         if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("token_type_embeddings has wrong shape");
         c.type_vocab = (int)shape[0];
         m->type_ = m->upload(buf);
     }
-    expect_shape(st.read_f32(names.emb + "LayerNorm.weight", buf), {H}, "embeddings.LayerNorm.weight");
+    const std::string eg = names.emb_ln_g.empty() ? names.emb + "LayerNorm.weight" : names.emb_ln_g;
+    const std::string eb = names.emb_ln_b.empty() ? names.emb + "LayerNorm.bias" : names.emb_ln_b;
+    expect_shape(st.read_f32(eg, buf), {H}, eg);
     m->emb_ln_g_ = m->upload(buf);
-    expect_shape(st.read_f32(names.emb + "LayerNorm.bias", buf), {H}, "embeddings.LayerNorm.bias");
+    expect_shape(st.read_f32(eb, buf), {H}, eb);
     m->emb_ln_b_ = m->upload(buf);
 
     m->layers_.resize(c.layers);
@@ -271,7 +334,12 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         std::vector<float> wqkv((size_t)3 * H * H), bqkv((size_t)3 * H);
         const std::string* wn[3] = {&names.q_w, &names.k_w, &names.v_w};
         const std::string* bn[3] = {&names.q_b, &names.k_b, &names.v_b};
-        for (int p = 0; p < 3; ++p) {
+        if (!names.qkv_w.empty()) {
+            // the checkpoint already holds Q | K | V rows in one tensor (transformer_encoder.rs:75-83); no bias
+            const std::string w_name = fmt_layer(names.qkv_w, i);
+            expect_shape(st.read_f32(w_name, wqkv), {3 * H, H}, w_name);
+        }
+        for (int p = 0; p < 3 && names.qkv_w.empty(); ++p) {
             const std::string w_name = fmt_layer(*wn[p], i), b_name = fmt_layer(*bn[p], i);
             expect_shape(st.read_f32(w_name, buf), {H, H}, w_name);
             std::memcpy(wqkv.data() + (size_t)p * H * H, buf.data(), sizeof(float) * H * H);
@@ -283,13 +351,14 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
             }
         }
         L.wqkv = m->upload(wqkv);
-        L.bqkv = m->upload(bqkv);
+        L.bqkv = names.qkv_w.empty() ? m->upload(bqkv) : nullptr;
         auto up = [&](const std::string& pattern, std::initializer_list<int64_t> want) {
             const std::string name = fmt_layer(pattern, i);
             expect_shape(st.read_f32(name, buf), want, name);
             return m->upload(buf);
         };
-        auto up_bias = [&](const std::string& pattern, int n) {
+        auto up_bias = [&](const std::string& pattern, int n) -> float* {
+            if (pattern.empty()) return nullptr;  // the layout has no such bias
             const std::string name = fmt_layer(pattern, i);
             if (!st.contains(name)) {
                 buf.assign((size_t)n, 0.0f);
@@ -302,6 +371,7 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         L.bo = up_bias(names.o_b, H);
         L.ln1_g = up(names.ln1_g, {H});
         L.ln1_b = up(names.ln1_b, {H});
+        if (!names.wg.empty()) L.wg = up(names.wg, {I, H});
         L.w1 = up(names.w1, {I, H});
         L.b1 = up_bias(names.b1, I);
         L.w2 = up(names.w2, {H, I});
@@ -413,7 +483,7 @@ void* EncoderModel::scratch2(size_t bytes)
 
 namespace {
 const char* const kKindNames[KK_COUNT] = {"embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm",
-                                          "gemm_fc1", "gemm_fc2", "pool", "head"};
+                                          "gemm_fc1", "gemm_fc2", "pool", "head", "rope"};
 }
 
 void EncoderModel::profile_begin(uint32_t kinds_mask)
@@ -431,7 +501,7 @@ void EncoderModel::profile_begin(uint32_t kinds_mask)
                                                               : "gemm_nt_f32_mfma<EPI_BIAS_RELU>";
     const char* syms[KK_COUNT] = {"embed_layernorm_kernel", "gemm_nt_f32_mfma<EPI_BIAS>", "attention_kernel",
                                   "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "layernorm_kernel", act_sym,
-                                  "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "pool_kernel", "head"};
+                                  "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "pool_kernel", "head", "rope_qk_kernel"};
     for (int k = 0; k < KK_COUNT; ++k) {
         prof_stats_[k] = KernelStat();
         prof_stats_[k].kind = kKindNames[k];
@@ -517,6 +587,11 @@ void EncoderModel::forward_chunk(const uint32_t* ids, const uint32_t* mask, cons
                               stream),
                   "gemm(qkv)");
         prof_stop(stream);
+        if (rope_cos_) {
+            prof_start(KK_ROPE, stream, 0.0, 4.0 * (4 * Td * Hd));
+            hip_check(launch_rope_qk(ws_qkv_, rope_cos_, rope_sin_, T, seq, cfg_.heads, H / cfg_.heads, stream), "rope");
+            prof_stop(stream);
+        }
         prof_start(KK_ATTENTION, stream, f_att, b_att);
         hip_check(launch_attention(ws_qkv_, mask, batch, seq, cfg_.heads, H / cfg_.heads, mask_value,
                                    ws_ctx_, stream),
@@ -531,10 +606,22 @@ void EncoderModel::forward_chunk(const uint32_t* ids, const uint32_t* mask, cons
         prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
         hip_check(launch_layernorm(hidden, L.ln1_g, L.ln1_b, cfg_.eps, T, H, hidden, stream), "layernorm1");
         prof_stop(stream);
-        prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
-        hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws_mid_, I, T, I, H, cfg_.ffn_act, stream),
-                  "gemm(fc1)");
-        prof_stop(stream);
+        if (L.wg) {
+            // SwiGLU (cpu/feedforward/swiglu.rs:40-50): the gate projection lands in ws_mid, the up projection's
+            // epilogue multiplies it by silu(gate) in place (read then written by the same thread).
+            prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
+            hip_check(launch_gemm(hidden, H, L.wg, nullptr, nullptr, 0, ws_mid_, I, T, I, H, EPI_BIAS, stream), "gemm(gate)");
+            prof_stop(stream);
+            prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1 + 4.0 * Td * Id);
+            hip_check(launch_gemm(hidden, H, L.w1, L.b1, ws_mid_, I, ws_mid_, I, T, I, H, EPI_BIAS_MUL_SILU, stream),
+                      "gemm(up * silu(gate))");
+            prof_stop(stream);
+        } else {
+            prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
+            hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws_mid_, I, T, I, H, cfg_.ffn_act, stream),
+                      "gemm(fc1)");
+            prof_stop(stream);
+        }
         prof_start(KK_GEMM_FC2, stream, f_fc2, b_fc2);
         hip_check(launch_gemm(ws_mid_, I, L.w2, L.b2, hidden, H, hidden, H, T, H, I, EPI_BIAS_RESIDUAL,
                               stream),

@@ -27,11 +27,13 @@ void hip_check(hipError_t e, const char* what);
 int visible_device_count();  // 0 when no HIP device / runtime is usable
 
 struct EncoderConfig {
-    std::string model_type;  // "bert" | "distilbert"
+    std::string model_type;  // "bert" | "distilbert" | "roberta" | "distilroberta" | "mpnet" | "nomic_bert"
     int hidden = 0, layers = 0, heads = 0, inter = 0, vocab = 0, max_pos = 0, type_vocab = 0;
     int pos_offset = 0;
     float eps = 1e-12f;
     GemmEpilogue ffn_act = EPI_BIAS_GELU;
+    bool gated_ffn = false;   // SwiGLU: down(silu(gate(x)) * up(x)) (transformer_encoder.rs:163-172)
+    float rope_theta = 0.0f;  // > 0: no position table, Q / K rotated instead (transformer_encoder.rs:222-227)
     // classification head (cpu/encoder/classifier.rs:103-202), 0 = none
     int num_labels = 0;
     int head_kind = 0;  // 0 none, 1 dense+tanh (bert.pooler / classifier.dense), 2 dense+relu (pre_classifier), 3 classifier only
@@ -43,6 +45,7 @@ struct DeviceLayer {
     float *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *bo = nullptr, *ln1_g = nullptr,
           *ln1_b = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr,
           *ln2_g = nullptr, *ln2_b = nullptr;
+    float* wg = nullptr;  // SwiGLU gate [inter, hidden]; w1 is then the up projection
 };
 
 // Per-kernel HIP-event timing on the launch stream (bench.py's roofline leg).
@@ -50,7 +53,7 @@ struct DeviceLayer {
 // events that are resolved at profile_end().
 enum KernelKind : int {
     KK_EMBED_LN = 0, KK_GEMM_QKV, KK_ATTENTION, KK_GEMM_OUT, KK_LAYERNORM, KK_GEMM_FC1, KK_GEMM_FC2,
-    KK_POOL, KK_HEAD, KK_COUNT
+    KK_POOL, KK_HEAD, KK_ROPE, KK_COUNT
 };
 
 struct KernelStat {
@@ -131,6 +134,7 @@ private:
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,
           *emb_ln_b_ = nullptr;
+    float *rope_cos_ = nullptr, *rope_sin_ = nullptr;  // [max_pos, head_dim]
     std::vector<DeviceLayer> layers_;
     float *head_dense_w_ = nullptr, *head_dense_b_ = nullptr, *head_cls_w_ = nullptr,
           *head_cls_b_ = nullptr;

@@ -50,7 +50,7 @@ namespace {
 // epilogue, 9 diagnostic build without an epilogue (micro-benchmark upper bound).
 int g_gemm_variant = 0;
 
-constexpr int EPI_GELU_LIBM = 6;
+constexpr int EPI_GELU_LIBM = 100;
 constexpr int BM = 128, BN = 128;
 constexpr int EPI_STRIDE = 68;  // floats per staged output row (64 + 4: conflict-light b128 reads)
 
@@ -69,6 +69,14 @@ struct Tile {
     static constexpr int EPI_ROWS = (LDS_BYTES >= 4 * 64 * EPI_STRIDE * 4) ? 64 : 32;
     static constexpr int WAVES_PER_SIMD = BKT == 16 ? 3 : 2;
 };
+
+// silu_scalar, activations.rs:74-82
+__device__ __forceinline__ float silu_ref(float x)
+{
+    if (x <= -20.0f) return 0.0f;
+    if (x >= 20.0f) return x;
+    return x / (1.0f + expf(-x));
+}
 
 template <int EPI>
 __device__ __forceinline__ float epilogue(float v)
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
         // Fully unrolled: all residual loads of the round are issued back to back (the accumulator
         // registers are free once the tile sits in LDS), instead of a few exposed round trips.
         f32x4 res[EROWS / 4];
-        if (EPI == EPI_BIAS_RESIDUAL) {
+        if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_MUL_SILU) {
 #pragma unroll
             for (int it = 0; it < EROWS / 4; ++it) {
                 int64_t m = m_base + it * 4;
@@ -287,6 +295,10 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
             f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
             v += bv;
             if (EPI == EPI_BIAS_RESIDUAL) v += res[it];
+            if (EPI == EPI_BIAS_MUL_SILU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= silu_ref(res[it][c]);
+            }
             if (EPI == EPI_BIAS_GELU) {
                 const f32x2 lo = gelu_erf_fast2(f32x2{v[0], v[1]}), hi = gelu_erf_fast2(f32x2{v[2], v[3]});
                 v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -341,6 +353,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_generic(const float* __restri
             if (m < M) {
                 float v = acc[i] + bv;
                 if (EPI == EPI_BIAS_RESIDUAL) v += R[m * ldr + n];
+                if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[m * ldr + n]);
                 Y[m * ldy + n] = epilogue<EPI>(v);
             }
         }
@@ -417,6 +430,7 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
     case EPI_BIAS_RELU: return launch_epi<EPI_BIAS_RELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     case EPI_BIAS_TANH: return launch_epi<EPI_BIAS_TANH>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     case EPI_BIAS_RESIDUAL: return launch_epi<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_MUL_SILU: return launch_epi<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
     return hipErrorInvalidValue;
 }

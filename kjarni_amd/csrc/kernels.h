@@ -18,6 +18,8 @@ enum GemmEpilogue : int {
     EPI_BIAS_RELU = 3,
     EPI_BIAS_TANH = 4,
     EPI_BIAS_RESIDUAL = 5,  // y = acc + b + R   (encoder_layer.rs:129-136, 155-163)
+    EPI_BIAS_MUL_SILU = 6,  // y = silu(R) * (acc + b): the up projection of a SwiGLU FFN over the gate's output R
+                            // (cpu/feedforward/swiglu.rs:40-50, activations.rs:74-82)
 };
 
 enum PoolMode : int { POOL_MEAN = 0, POOL_CLS = 1, POOL_MAX = 2, POOL_LAST = 3 };
@@ -51,6 +53,12 @@ void set_cosine_variant(int variant);     // 0 = default, 1 = streaming passes o
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq,
                             int heads, int head_dim, float mask_value, float* ctx,
                             hipStream_t stream);
+
+// RoPE on the Q and K thirds of qkv [tokens, 3*hidden] in place, position = token index within its sentence
+// (RoPE::apply_3d with offset 0, cpu/rope/mod.rs:118-170, 210-245; encoder_self_attention.rs:81-85).
+// cos / sin are the reference's caches [>= seq, head_dim].
+hipError_t launch_rope_qk(float* qkv, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
+                          int head_dim, hipStream_t stream);
 
 // R11: pooling (+ optional L2 normalisation) of [batch, seq, hidden].
 hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t batch, int seq,

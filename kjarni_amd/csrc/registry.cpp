@@ -13,7 +13,7 @@ namespace {
 // registry.rs:226-275 (cli_name) with the repo ids of :318-708.
 const RegistryEntry kEntries[] = {
     {"minilm-l6-v2", "sentence-transformers/all-MiniLM-L6-v2", ModelTask::Embedding, ModelArch::Bert},
-    {"nomic-embed-text", "nomic-ai/nomic-embed-text-v1.5", ModelTask::Embedding, ModelArch::Other},
+    {"nomic-embed-text", "nomic-ai/nomic-embed-text-v1.5", ModelTask::Embedding, ModelArch::Bert},
     {"bge-m3", "BAAI/bge-m3", ModelTask::Embedding, ModelArch::Other},
     {"mpnet-base-v2", "sentence-transformers/all-mpnet-base-v2", ModelTask::Embedding, ModelArch::Bert},
     {"distilbert-base", "distilbert-base-cased-distilled-squad", ModelTask::Embedding, ModelArch::Bert},

@@ -3,6 +3,9 @@
 // softmax / sigmoid.  One wave64 per row, 16-byte loads, wave-shuffle
 // reductions; rows stay in registers between the statistics and the affine
 // pass so every byte is read once.
+#include <algorithm>
+#include <cstdint>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -318,9 +321,64 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
     }
 }
 
+// RoPE over the Q and K thirds of [tokens, 3*hidden] (rope/mod.rs:148-170): V = 4 rotates four neighbouring pairs per
+// thread with 16-byte accesses, V = 1 is the any-shape form.
+template <int V>
+__global__ __launch_bounds__(256) void rope_qk_kernel(float* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                      const float* __restrict__ sin_t, int64_t tokens, int seq, int heads,
+                                                      int head_dim)
+{
+    const int half = head_dim >> 1, hv = half / V, hidden = heads * head_dim;
+    const int64_t per_tok = (int64_t)2 * heads * hv, total = tokens * per_tok;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / per_tok;
+        int item = (int)(idx - t * per_tok);
+        const int part = item / (heads * hv);
+        item -= part * heads * hv;
+        const int h = item / hv, i = (item - h * hv) * V;
+        const int s = (int)(t % seq);
+        float* r = qkv + t * 3 * hidden + part * hidden + h * head_dim + i;
+        const float* c = cos_t + (int64_t)s * head_dim + i;
+        const float* sn = sin_t + (int64_t)s * head_dim + i;
+        if (V == 4) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(r), x1 = *reinterpret_cast<const f32x4*>(r + half);
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(c), sv = *reinterpret_cast<const f32x4*>(sn);
+            f32x4 y0, y1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // two roundings per product-difference, as the scalar reference
+                y0[k] = __fsub_rn(__fmul_rn(x0[k], cv[k]), __fmul_rn(x1[k], sv[k]));
+                y1[k] = __fadd_rn(__fmul_rn(x0[k], sv[k]), __fmul_rn(x1[k], cv[k]));
+            }
+            *reinterpret_cast<f32x4*>(r) = y0;
+            *reinterpret_cast<f32x4*>(r + half) = y1;
+        } else {
+            const float x0 = r[0], x1 = r[half];
+            r[0] = __fsub_rn(__fmul_rn(x0, c[0]), __fmul_rn(x1, sn[0]));
+            r[half] = __fadd_rn(__fmul_rn(x0, sn[0]), __fmul_rn(x1, c[0]));
+        }
+    }
+}
+
 inline unsigned rows_to_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 
 }  // namespace
+
+hipError_t launch_rope_qk(float* qkv, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
+                          int head_dim, hipStream_t stream)
+{
+    if (tokens <= 0) return hipSuccess;
+    if (head_dim < 2 || (head_dim & 1) || seq <= 0) return hipErrorInvalidValue;
+    const int half = head_dim / 2;
+    const bool vec = (half % 4 == 0) && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(cos_t) & 15) == 0) && ((reinterpret_cast<uintptr_t>(sin_t) & 15) == 0);
+    const int64_t total = tokens * 2 * heads * (vec ? half / 4 : half);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(rope_qk_kernel<4>, dim3(grid), dim3(256), 0, stream, qkv, cos_t, sin_t, tokens, seq, heads, head_dim);
+    else
+        hipLaunchKernelGGL(rope_qk_kernel<1>, dim3(grid), dim3(256), 0, stream, qkv, cos_t, sin_t, tokens, seq, heads, head_dim);
+    return hipGetLastError();
+}
 
 hipError_t launch_embed_layernorm(const uint32_t* ids, const uint32_t* type_ids, const float* word,
                                   const float* pos, const float* type, const float* gamma,

@@ -64,7 +64,7 @@ class HipEncoder:
         check_error(lib().kjarni_hip_encoder_set_chunk_tokens(self._h, int(tokens)))
 
     KINDS = ("embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm", "gemm_fc1", "gemm_fc2",
-             "pool", "head")
+             "pool", "head", "rope")
 
     def profile_begin(self, kinds=None):
         """Bracket kernel launches with HIP events on their stream until profile_end().

@@ -328,6 +328,7 @@ typedef struct {
     const float *ln1_g, *ln1_b;
     const float *w1, *b1, *w2, *b2;
     const float *ln2_g, *ln2_b;
+    const float *wg; /* SwiGLU gate weight [inter, hidden] (Nomic: mlp.fc11); NULL: FC2(act(FC1(x))) */
 } ko_layer;
 
 typedef struct {
@@ -337,7 +338,38 @@ typedef struct {
     int32_t blocked_gemm; /* 1: use the reference's 64-row / 4x3 AVX2 blocking (timed baseline) */
     const float *word, *pos, *type, *emb_ln_g, *emb_ln_b;
     const ko_layer *L;
+    /* RoPE caches [rope_len, head_dim] (cpu/rope/mod.rs:96-116), NULL when the model has position embeddings */
+    const float *rope_cos, *rope_sin;
+    int32_t rope_len;
 } ko_model;
+
+/* silu_scalar, activations.rs:74-82 */
+static inline float ko_silu(float x)
+{
+    if (x <= -20.0f) return 0.0f;
+    if (x >= 20.0f) return x;
+    return x / (1.0f + expf(-x));
+}
+
+/* RoPE::apply_3d -> rotate_4d_in_place (cpu/rope/mod.rs:118-170, 210-245) on [batch*seq, heads*head_dim]:
+ * (x0, x1) = (x[i], x[i + half]) -> (x0*cos - x1*sin, x0*sin + x1*cos) with the caches' row `s` (offset 0). */
+static void ko_rope_rows(const ko_model *m, float *x, int64_t batch, int seq, int heads, int head_dim)
+{
+    const int half = head_dim / 2;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < batch * seq; ++t) {
+        const int s = (int)(t % seq);
+        const float *c = m->rope_cos + (int64_t)s * head_dim, *sn = m->rope_sin + (int64_t)s * head_dim;
+        for (int h = 0; h < heads; ++h) {
+            float *r = x + (t * heads + h) * head_dim;
+            for (int i = 0; i < half; ++i) {
+                const float x0 = r[i], x1 = r[i + half];
+                r[i] = x0 * c[i] - x1 * sn[i];
+                r[i + half] = x0 * sn[i] + x1 * c[i];
+            }
+        }
+    }
+}
 
 static void ko_lin(const ko_model *m, const float *x, const float *w, const float *b, int64_t rows,
                    int k, int n, float *y)
@@ -353,7 +385,9 @@ static void ko_lin(const ko_model *m, const float *x, const float *w, const floa
  * the same values):
  *   post: h1 = LN1(x + Attn(x)); y = LN2(h1 + FFN(h1))
  *   pre : h1 = x + Attn(LN1(x)); y = h1 + FFN(LN2(h1))
- * FFN = cpu/feedforward/standard_new.rs:29-82: FC2(act(FC1(x))).
+ * FFN = cpu/feedforward/standard_new.rs:29-82: FC2(act(FC1(x))); with a gate weight,
+ * cpu/feedforward/swiglu.rs:33-57: down(silu(gate(x)) * up(x)) (transformer_encoder.rs:163-172).
+ * With RoPE caches Q and K are rotated after the projections (encoder_self_attention.rs:81-85).
  * hidden is updated in place.  tokens = batch*seq. */
 KO_API void ko_encoder_layer(const ko_model *m, const ko_layer *L, float *hidden, const float *mask,
                              const float *position_bias, int64_t batch, int seq, float mask_value)
@@ -378,6 +412,10 @@ KO_API void ko_encoder_layer(const ko_model *m, const ko_layer *L, float *hidden
     ko_lin(m, attn_in, L->wq, L->bq, T, H, H, q);
     ko_lin(m, attn_in, L->wk, L->bk, T, H, H, k);
     ko_lin(m, attn_in, L->wv, L->bv, T, H, H, v);
+    if (m->rope_cos) {
+        ko_rope_rows(m, q, batch, seq, m->heads, H / m->heads);
+        ko_rope_rows(m, k, batch, seq, m->heads, H / m->heads);
+    }
     ko_attention(q, k, v, mask, position_bias, batch, seq, m->heads, H / m->heads, m->scale_qk,
                  mask_value, ctx);
     ko_lin(m, ctx, L->wo, L->bo, T, H, H, attn);
@@ -393,9 +431,18 @@ KO_API void ko_encoder_layer(const ko_model *m, const ko_layer *L, float *hidden
         memcpy(hidden, normed, sizeof(float) * T * H);
         ffn_in = hidden;
     }
-    ko_lin(m, ffn_in, L->w1, L->b1, T, H, I, mid);
+    if (L->wg) {
+        float *up = (float *)malloc(sizeof(float) * T * I);
+        ko_lin(m, ffn_in, L->wg, NULL, T, H, I, mid);
+        ko_lin(m, ffn_in, L->w1, L->b1, T, H, I, up);
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < T * I; ++i) mid[i] = ko_act(mid[i], m->act);
+        for (int64_t i = 0; i < T * I; ++i) mid[i] = ko_silu(mid[i]) * up[i];
+        free(up);
+    } else {
+        ko_lin(m, ffn_in, L->w1, L->b1, T, H, I, mid);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < T * I; ++i) mid[i] = ko_act(mid[i], m->act);
+    }
     ko_lin(m, mid, L->w2, L->b2, T, I, H, attn);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < T * H; ++i) hidden[i] += attn[i];

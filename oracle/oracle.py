@@ -36,7 +36,7 @@ def build(force: bool = False) -> str:
 class KoLayer(C.Structure):
     _fields_ = [(n, _f32p) for n in (
         "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b",
-        "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+        "w1", "b1", "w2", "b2", "ln2_g", "ln2_b", "wg")]
 
 
 class KoModel(C.Structure):
@@ -48,6 +48,7 @@ class KoModel(C.Structure):
         ("blocked_gemm", C.c_int32),
         ("word", _f32p), ("pos", _f32p), ("type", _f32p), ("emb_ln_g", _f32p), ("emb_ln_b", _f32p),
         ("L", C.POINTER(KoLayer)),
+        ("rope_cos", _f32p), ("rope_sin", _f32p), ("rope_len", C.c_int32),
     ]
 
 
@@ -290,7 +291,9 @@ class OracleModel:
     configs.rs:218-366 (BERT: plain and "bert."-prefixed), :393-470 (MPNet: positions
     start at 2, tanh GELU, no token types, the relative attention bias is not read) and
     :638-687 (DistilBERT); sequence_classifier/configs.rs:149-280 (RoBERTa: BERT's layout
-    under "roberta.", positions start at 2)."""
+    under "roberta.", positions start at 2); sentence_encoder/configs.rs:140-275 (Nomic: `model_type` "nomic_bert",
+    fused `attn.Wqkv`, no biases, no position table but RoPE with `rotary_emb_base`, SwiGLU with gate = `mlp.fc11` and
+    up = `mlp.fc12`, `emb_ln`; BertConfig's serde aliases n_embd / n_layer / n_head / n_inner / layer_norm_epsilon)."""
 
     def __init__(self, tensors: Dict[str, np.ndarray], config: dict, blocked_gemm: bool = False):
         self.config = config
@@ -298,15 +301,35 @@ class OracleModel:
         t = self.t
         mt = config.get("model_type", "bert")
         self.keep = []
-        H = config.get("hidden_size", config.get("dim"))
-        Lc = config.get("num_hidden_layers", config.get("n_layers"))
-        heads = config.get("num_attention_heads", config.get("n_heads"))
-        inter = config.get("intermediate_size", config.get("hidden_dim", 4 * H))
+        H = config.get("hidden_size", config.get("dim", config.get("n_embd")))
+        Lc = config.get("num_hidden_layers", config.get("n_layers", config.get("n_layer")))
+        heads = config.get("num_attention_heads", config.get("n_heads", config.get("n_head")))
+        inter = config.get("intermediate_size", config.get("hidden_dim", config.get("n_inner"))) or 4 * H
         act_s = config.get("hidden_act", config.get("activation", "gelu"))
         # configs.rs:194-200: "gelu" -> erf GELU, "gelu_new" -> tanh, "relu"
         act = {"gelu": ACT_GELU, "gelu_new": ACT_GELU_NEW, "relu": ACT_RELU}.get(act_s, ACT_GELU)
         layers = (KoLayer * Lc)()
-        if mt == "distilbert":
+        emb_ln = None
+        rope = None
+        if mt == "nomic_bert":
+            pre = ""
+            emb = "embeddings."
+            emb_ln = ("emb_ln.weight", "emb_ln.bias")
+
+            def names(i):
+                l = f"encoder.layers.{i}."
+                w = t[l + "attn.Wqkv.weight"]  # transformer_encoder.rs:75-83: rows [0,H) / [H,2H) / [2H,3H)
+                parts = [f32(w[p * H:(p + 1) * H]) for p in range(3)]
+                self.keep.extend(parts)
+                return dict(wq=parts[0], wk=parts[1], wv=parts[2], bq=None, bk=None, bv=None,
+                            wo=l + "attn.out_proj.weight", bo=None, ln1_g=l + "norm1.weight", ln1_b=l + "norm1.bias",
+                            wg=l + "mlp.fc11.weight", w1=l + "mlp.fc12.weight", b1=None, w2=l + "mlp.fc2.weight", b2=None,
+                            ln2_g=l + "norm2.weight", ln2_b=l + "norm2.bias")
+            type_name = emb + "token_type_embeddings.weight"
+            eps = config.get("layer_norm_eps", config.get("layer_norm_epsilon"))
+            if config.get("rotary_emb_fraction") is not None or config.get("rotary_emb_base") is not None:
+                rope = float(config.get("rotary_emb_base") or 10000.0)  # configs.rs:175-183
+        elif mt == "distilbert":
             pre = "distilbert." if "distilbert.embeddings.word_embeddings.weight" in t else ""
             emb = pre + "embeddings."
             names = lambda i: dict(
@@ -370,23 +393,31 @@ class OracleModel:
             eps = config.get("layer_norm_eps", 1e-5 if mt in ("roberta", "distilroberta") else 1e-12)
         for i in range(Lc):
             for field, name in names(i).items():
-                setattr(layers[i], field, _f(t[name]))
+                setattr(layers[i], field, _f(t[name] if isinstance(name, str) else name))
         self.layers = layers
         m = KoModel()
         m.hidden, m.layers, m.heads, m.inter = H, Lc, heads, inter
         m.vocab = t[emb + "word_embeddings.weight"].shape[0]
-        m.max_pos = t[emb + "position_embeddings.weight"].shape[0]
+        has_pos = emb + "position_embeddings.weight" in t
+        # get_max_seq_len (configs.rs:145-149) when there is no position table
+        m.max_pos = (t[emb + "position_embeddings.weight"].shape[0] if has_pos else
+                     config.get("n_positions") or config.get("max_position_embeddings") or 512)
         m.type_vocab = t[type_name].shape[0] if type_name and type_name in t else 0
         m.pos_offset = 2 if mt in ("roberta", "distilroberta", "mpnet") else 0  # extra_pos_embeddings
         m.act, m.prenorm, m.scale_embeddings, m.scale_qk = act, 0, 0, 1
         m.eps = eps
         m.blocked_gemm = int(blocked_gemm)
         m.word = _f(t[emb + "word_embeddings.weight"])
-        m.pos = _f(t[emb + "position_embeddings.weight"])
+        m.pos = _f(t[emb + "position_embeddings.weight"]) if has_pos else None
         m.type = _f(t[type_name]) if m.type_vocab else None
-        m.emb_ln_g = _f(t[emb + "LayerNorm.weight"])
-        m.emb_ln_b = _f(t[emb + "LayerNorm.bias"])
+        m.emb_ln_g = _f(t[emb_ln[0] if emb_ln else emb + "LayerNorm.weight"])
+        m.emb_ln_b = _f(t[emb_ln[1] if emb_ln else emb + "LayerNorm.bias"])
         m.L = C.cast(layers, C.POINTER(KoLayer))
+        if rope is not None:  # RoPE::new(head_dim, max_seq_len, theta), transformer_encoder.rs:222-227
+            from oracle.llm_oracle import rope_tables
+            cos, sin = rope_tables(H // heads, int(m.max_pos), rope)
+            self.rope_cos, self.rope_sin = f32(cos), f32(sin)
+            m.rope_cos, m.rope_sin, m.rope_len = _f(self.rope_cos), _f(self.rope_sin), int(m.max_pos)
         self.m = m
         self.hidden = H
         self.prefix = pre

@@ -184,6 +184,31 @@ def mpnet_embedder(path: str, seed: int = 4, **over) -> Tuple[dict, Dict[str, np
     return cfg, t
 
 
+def nomic_embedder(path: str, seed: int = 6, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+    """nomic-embed-text layout (sentence_encoder/configs.rs:218-275): config.json with the GPT-style key names, fused
+    Wqkv, no biases, SwiGLU (fc11 = gate, fc12 = up), RoPE instead of a position table."""
+    cfg = dict(model_type="nomic_bert", n_embd=128, n_layer=2, n_head=4, n_inner=256, activation_function="swiglu",
+               n_positions=256, vocab_size=30528, layer_norm_epsilon=1e-12, type_vocab_size=2, rotary_emb_fraction=1.0,
+               rotary_emb_base=1000, qkv_proj_bias=False, mlp_fc1_bias=False, mlp_fc2_bias=False,
+               architectures=["NomicBertModel"])
+    cfg.update(over)
+    rng = np.random.default_rng(seed)
+    H, L, I, V = cfg["n_embd"], cfg["n_layer"], cfg["n_inner"], cfg["vocab_size"]
+    w = lambda *shape, s=0.02: (rng.standard_normal(shape) * s).astype(np.float32)  # noqa: E731
+    g = lambda n: (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)  # noqa: E731
+    t = {"embeddings.word_embeddings.weight": w(V, H), "embeddings.token_type_embeddings.weight": w(2, H),
+         "emb_ln.weight": g(H), "emb_ln.bias": w(H, s=0.05)}
+    for i in range(L):
+        p = f"encoder.layers.{i}."
+        t[p + "attn.Wqkv.weight"] = w(3 * H, H, s=0.08)
+        t[p + "attn.out_proj.weight"] = w(H, H)
+        t[p + "norm1.weight"], t[p + "norm1.bias"] = g(H), w(H, s=0.05)
+        t[p + "mlp.fc11.weight"], t[p + "mlp.fc12.weight"], t[p + "mlp.fc2.weight"] = w(I, H, s=0.08), w(I, H, s=0.08), w(H, I)
+        t[p + "norm2.weight"], t[p + "norm2.bias"] = g(H), w(H, s=0.05)
+    write_model_dir(path, cfg, t)
+    return cfg, t
+
+
 def synthetic_ids(n: int, seq: int, vocab: int = 30522, seed: int = 0, ragged: bool = False):
     """[CLS]=101 first, [SEP]=102 last real token, body uniform in
     1000..vocab-1; ragged=True draws lengths in 16..seq and right-pads with id 0 / mask 0."""

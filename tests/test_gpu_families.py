@@ -1,6 +1,6 @@
-"""RoBERTa (classification) and MPNet (embedding) checkpoints through the C ABI against the oracle: the two other encoder
+"""RoBERTa (classification), MPNet and Nomic (embedding) checkpoints through the C ABI against the oracle: the other encoder
 families the reference's SequenceClassifier / SentenceEncoder load (sequence_classifier/mod.rs:52-64,
-sentence_encoder/model.rs:41-54).  Both place positions at offset 2; RoBERTa frames with <s> </s> over byte-level BPE,
+sentence_encoder/model.rs:41-54; Nomic is BertConfig with model_type "nomic_bert", sentence_encoder/configs.rs:140-275).  Both place positions at offset 2; RoBERTa frames with <s> </s> over byte-level BPE,
 MPNet with <s> </s> over WordPiece and uses the tanh GELU."""
 import os
 import shutil
@@ -71,6 +71,53 @@ def test_mpnet_embedder_matches_oracle(tmp_path):
     assert np.abs(one - orc.embed_batch(i1, m1)[0]).max() < TOL
 
 
+@pytest.mark.parametrize("over", [{}, dict(n_embd=256, n_head=4, n_inner=512), dict(n_embd=40, n_head=4, n_inner=72)],
+                         ids=["d32", "d64", "d10-generic"])
+def test_nomic_embedder_matches_oracle(tmp_path, over):
+    """RoPE on Q / K, SwiGLU through the GEMM epilogue, fused Wqkv, no biases, no position table."""
+    import kjarni_amd
+    d = str(tmp_path / "nomic")
+    cfg, t = synth.nomic_embedder(d, **over)
+    synth.add_tokenizer(d)
+    tok = kjarni_amd.Tokenizer(os.path.join(d, "tokenizer.json"), cfg["n_positions"])
+    orc = O.OracleModel(t, cfg)
+    emb = kjarni_amd.Embedder(model_path=d)
+    assert emb.dim == cfg["n_embd"]
+    texts = ["the quick brown fox", "a", "rust is fast and the kernel is faster " * 6, "hello world, hello gpu"]
+    ids, mask, _ = tok.encode_batch(texts)
+    got = emb.encode_batch(texts)
+    assert np.abs(got - orc.embed_batch(ids, mask)).max() < TOL
+    # token level, ragged batch, both mask conventions; 1 200 tokens take the no-alloc (-inf) strategy
+    enc = kjarni_amd.HipEncoder(d)
+    assert enc.max_seq_len == cfg["n_positions"]
+    for n, seq in ((3, 17), (12, 100)):
+        ids, mask = synth.synthetic_ids(n, seq, vocab=cfg["vocab_size"], seed=n, ragged=True)
+        mv = O.strategy_mask_value(ids.size)
+        want = orc.forward(ids, mask, None, mv)
+        got = enc.hidden_states(ids, mask)
+        valid = mask.astype(bool)
+        assert np.abs(got[valid] - want[valid]).max() < TOL, (n, seq)
+    # position matters only through the rotation: the same sentence shifted right by padding on the LEFT is not
+    # something the tokenizer produces, but reversing the token order must change the pooled vector
+    ids, mask = synth.synthetic_ids(1, 24, vocab=cfg["vocab_size"], seed=9)
+    a = enc.embed(ids, mask)
+    b = enc.embed(np.ascontiguousarray(ids[:, ::-1]), mask)
+    assert np.abs(a - b).max() > 5e-5  # without the rotation mean pooling would be order-blind (differences ~1e-7)
+
+
+def test_nomic_long_sequence(tmp_path):
+    """2 048 tokens in one sentence: RoPE rows far from 0 and the tiled attention path."""
+    import kjarni_amd
+    d = str(tmp_path / "nomic")
+    cfg, t = synth.nomic_embedder(d, n_positions=2048, n_layer=1)
+    orc = O.OracleModel(t, cfg)
+    enc = kjarni_amd.HipEncoder(d)
+    ids, mask = synth.synthetic_ids(1, 2048, vocab=cfg["vocab_size"], seed=2)
+    want = orc.forward(ids, mask, None, O.strategy_mask_value(ids.size))
+    got = enc.hidden_states(ids, mask)
+    assert np.abs(got - want).max() < TOL
+
+
 def test_registry_names_reach_the_new_families(tmp_path):
     import kjarni_amd
     cache = tmp_path / "cache"
@@ -84,6 +131,10 @@ def test_registry_names_reach_the_new_families(tmp_path):
     _tokenizer(d2, "mpnet")
     emb = kjarni_amd.Embedder("mpnet-base-v2", cache_dir=str(cache))
     assert emb.dim == 128
-    with pytest.raises(kjarni_amd.KjarniException) as ei:  # Nomic (SwiGLU + rotary) and XLM-R stay outside
-        kjarni_amd.Embedder("nomic-embed-text", cache_dir=str(cache))
+    d3 = str(cache / "nomic-ai_nomic-embed-text-v1.5")
+    synth.nomic_embedder(d3)
+    synth.add_tokenizer(d3)
+    assert kjarni_amd.Embedder("nomic-embed-text", cache_dir=str(cache)).dim == 128
+    with pytest.raises(kjarni_amd.KjarniException) as ei:  # XLM-R (Unigram tokenizer) stays outside
+        kjarni_amd.Embedder("bge-m3", cache_dir=str(cache))
     assert ei.value.code == kjarni_amd.KjarniError.LOAD_FAILED and "not compatible" in str(ei.value)

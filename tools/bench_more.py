@@ -50,7 +50,7 @@ def timed(fn, sync, steps, warmup):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "indexer", "search", "whisper", "llm", "chat"}  # "llm8b" only on request (writes 16 GB)
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "families", "indexer", "search", "whisper", "llm", "chat"}  # "llm8b" only on request (writes 16 GB)
     import numpy as np
     import torch
 
@@ -89,6 +89,39 @@ def main():
               "e2e_tflops": round(N / dt * fl / 1e12, 2),
               "e2e_frac_fp32_mfma_peak": round(N / dt * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
         del enc, t_ids, t_mask, t_types, out
+
+    if "families" in which:
+        # The other registry embedders at their real shapes (random weights): nomic-embed-text-v1.5 (RoPE + SwiGLU, 768 x 12
+        # layers, inner 3072) and all-mpnet-base-v2 (BERT-base shape).  Same token-level entry point as the headline.
+        for name, make, over, gated in (
+                ("nomic-embed-text", synth.nomic_embedder, dict(n_embd=768, n_layer=12, n_head=12, n_inner=3072, n_positions=8192), True),
+                ("mpnet-base-v2", synth.mpnet_embedder, dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                                                             intermediate_size=3072), False)):
+            d = os.path.join(tmp, name)
+            cfg_f, _ = make(d, **over)
+            enc = kjarni_amd.HipEncoder(d, 0)
+            H, Lf, If = 768, 12, 3072
+            for N, seq in ((16384, 128), (1024, 2048) if gated else (4096, 512)):
+                ids, mask = synth.synthetic_ids(N, seq, vocab=cfg_f["vocab_size"], seed=0)
+                t_ids, t_mask = (torch.from_numpy(a.view(np.int32)).to(dev) for a in (ids, mask))
+                out = torch.empty((N, H), dtype=torch.float32, device=dev)
+                run = lambda: enc.embed_dev(t_ids.data_ptr(), t_mask.data_ptr(), N, seq, out.data_ptr(), stream=stream())  # noqa: E731
+                dt = timed(run, sync, steps=2, warmup=1)
+                enc.profile_begin()
+                run()
+                stats = [k for k in enc.profile_end() if k["launches"]]
+                ffn = (3 if gated else 2) * 2 * seq * H * If
+                fl = Lf * (2 * seq * H * 3 * H + 4 * seq * seq * H + 2 * seq * H * H + ffn)
+                emit({"metric": f"sentences/sec {name} batch encode (seq={seq})", "value": round(N / dt, 1), "unit": "sentences/s",
+                      "n_gpus": 1, "ms_per_step": round(dt * 1e3, 2), "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"{N} sentences x {seq} tokens, ids/mask in HBM, mean pool + L2"},
+                      "tokens_per_s": round(N * seq / dt, 0), "e2e_tflops": round(N / dt * fl / 1e12, 2),
+                      "e2e_frac_fp32_mfma_peak": round(N / dt * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                      "kernels": [{"kind": k["kind"], "launches": k["launches"], "ms": round(k["total_ms"], 2),
+                                   "tflops": round(k["flops"] / k["total_ms"] / 1e9, 1) if k["flops"] else None,
+                                   "gbs": round(k["bytes"] / k["total_ms"] / 1e6, 0)} for k in stats]})
+                del t_ids, t_mask, out
+            del enc
 
     if "ragged" in which or "host" in which:
         enc = kjarni_amd.HipEncoder(emb_dir, 0)
