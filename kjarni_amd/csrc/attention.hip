@@ -47,8 +47,10 @@ struct AttnSmem {
     static constexpr int BYTES = (K_FLOATS + VT_FLOATS + KCHUNK) * 4;
 };
 
+// Two workgroups per CU (<= 256 VGPRs): one stages its next K / V chunk and runs its softmax while the other's MFMAs
+// occupy the matrix pipe.  Left to itself the compiler took 276 registers for D = 64, i.e. one wave per SIMD and no overlap.
 template <int D>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv,
                                                         const uint32_t* __restrict__ mask, int seq,
                                                         int heads, float scale, float mask_value,
                                                         float* __restrict__ ctx)
