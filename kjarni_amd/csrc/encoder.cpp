@@ -220,21 +220,6 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         c.inter = (int)cfg.get_int("hidden_dim", 4 * c.hidden);
         c.eps = 1e-12f;                // configs.rs:620 (DistilBERT norm_eps is fixed)
         c.ffn_act = EPI_BIAS_GELU;     // configs.rs:621
-    } else if (c.model_type == "bert") {
-        const std::string pre = st.contains("bert.embeddings.word_embeddings.weight") ? "bert." : "";
-        names = bert_names(pre);
-        c.hidden = (int)cfg.get_int("hidden_size", 0);
-        c.layers = (int)cfg.get_int("num_hidden_layers", 0);
-        c.heads = (int)cfg.get_int("num_attention_heads", 0);
-        c.inter = (int)cfg.get_int("intermediate_size", 0);
-        if (c.inter <= 0) c.inter = 4 * c.hidden;  // configs.rs:160-167
-        c.eps = (float)cfg.get_double("layer_norm_eps", 1e-12);
-        // configs.rs:194-200: "gelu" -> erf GELU, "gelu_new" -> tanh GELU, "relu"; anything else erf GELU
-        std::string act = cfg.get_string("hidden_act", cfg.get_string("activation_function", "gelu"));
-        if (act == "gelu_new") c.ffn_act = EPI_BIAS_GELU_NEW;
-        else if (act == "relu") c.ffn_act = EPI_BIAS_RELU;
-        else if (act == "swiglu") throw std::runtime_error("activation 'swiglu' needs model_type 'nomic_bert' (a gate weight)");
-        else c.ffn_act = EPI_BIAS_GELU;
     } else if (c.model_type == "roberta" || c.model_type == "distilroberta") {
         // sequence_classifier/configs.rs:149-280: BERT's layer layout under "roberta.", positions start at 2.
         const std::string pre = st.contains("roberta.embeddings.word_embeddings.weight") ? "roberta." : "";
@@ -276,8 +261,23 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
             cfg.find("rotary_embedding_base"))
             c.rope_theta = (float)cfg.get_double("rotary_emb_base", cfg.get_double("rotary_embedding_base", 10000.0));
     } else {
-        throw std::runtime_error("unsupported model_type '" + c.model_type +
-                                 "' (the HIP encoder covers bert, distilbert, roberta, mpnet and nomic_bert)");
+        // "Default to BertConfig for BERT-like models" (sentence_encoder/model.rs:50-53, sequence_classifier/mod.rs:60-63):
+        // plain BERT and every other model_type with BERT's tensor names, e.g. bge-m3's "xlm-roberta" (positions from 0 here,
+        // as the reference reads it).
+        const std::string pre = st.contains("bert.embeddings.word_embeddings.weight") ? "bert." : "";
+        names = bert_names(pre);
+        c.hidden = (int)cfg.get_int("hidden_size", 0);
+        c.layers = (int)cfg.get_int("num_hidden_layers", 0);
+        c.heads = (int)cfg.get_int("num_attention_heads", 0);
+        c.inter = (int)cfg.get_int("intermediate_size", 0);
+        if (c.inter <= 0) c.inter = 4 * c.hidden;  // configs.rs:160-167
+        c.eps = (float)cfg.get_double("layer_norm_eps", 1e-12);
+        // configs.rs:194-200: "gelu" -> erf GELU, "gelu_new" -> tanh GELU, "relu"; anything else erf GELU
+        std::string act = cfg.get_string("hidden_act", cfg.get_string("activation_function", "gelu"));
+        if (act == "gelu_new") c.ffn_act = EPI_BIAS_GELU_NEW;
+        else if (act == "relu") c.ffn_act = EPI_BIAS_RELU;
+        else if (act == "swiglu") throw std::runtime_error("activation 'swiglu' needs model_type 'nomic_bert' (a gate weight)");
+        else c.ffn_act = EPI_BIAS_GELU;
     }
     if (c.hidden <= 0 || c.layers <= 0 || c.heads <= 0 || c.hidden % c.heads != 0)
         throw std::runtime_error("invalid encoder dimensions in config.json");
@@ -312,8 +312,7 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
         m->rope_cos_ = m->upload(cs);
         m->rope_sin_ = m->upload(sn);
     }
-    const bool typed_family = c.model_type == "bert" || c.model_type == "roberta" || c.model_type == "distilroberta" ||
-                              c.model_type == "nomic_bert";
+    const bool typed_family = c.model_type != "distilbert" && c.model_type != "mpnet";
     if (typed_family && st.contains(names.emb + "token_type_embeddings.weight")) {
         shape = st.read_f32(names.emb + "token_type_embeddings.weight", buf);
         if (shape.size() != 2 || shape[1] != H) throw std::runtime_error("token_type_embeddings has wrong shape");

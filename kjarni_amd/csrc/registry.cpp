@@ -14,7 +14,7 @@ namespace {
 const RegistryEntry kEntries[] = {
     {"minilm-l6-v2", "sentence-transformers/all-MiniLM-L6-v2", ModelTask::Embedding, ModelArch::Bert},
     {"nomic-embed-text", "nomic-ai/nomic-embed-text-v1.5", ModelTask::Embedding, ModelArch::Bert},
-    {"bge-m3", "BAAI/bge-m3", ModelTask::Embedding, ModelArch::Other},
+    {"bge-m3", "BAAI/bge-m3", ModelTask::Embedding, ModelArch::Bert},
     {"mpnet-base-v2", "sentence-transformers/all-mpnet-base-v2", ModelTask::Embedding, ModelArch::Bert},
     {"distilbert-base", "distilbert-base-cased-distilled-squad", ModelTask::Embedding, ModelArch::Bert},
     {"minilm-l6-v2-cross-encoder", "cross-encoder/ms-marco-MiniLM-L-6-v2", ModelTask::ReRanking, ModelArch::Bert},

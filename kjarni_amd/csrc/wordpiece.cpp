@@ -4,6 +4,7 @@
 #include <cstdint>
 
 #include "bpe.h"
+#include "unigram.h"
 
 #include <exception>
 #include <thread>
@@ -99,8 +100,17 @@ BertTokenizer BertTokenizer::from_json(const std::string& text)
         t.pad_id_ = 0;
         return t;
     }
+    if (mtype == "Unigram") {  // XLM-R (bge-m3): SentencePiece Unigram for the sequences, TemplateProcessing framing
+        auto uni = std::make_shared<UnigramTokenizer>();
+        uni->load_json(text, "tokenizer.json");
+        t.unigram_ = uni;
+        t.has_normalizer_ = false;
+        t.parse_post_processor(root);
+        t.pad_id_ = 0;  // PaddingParams::default() (loader.rs:112-115), not the checkpoint's <pad>
+        return t;
+    }
     if (mtype != "WordPiece")
-        throw std::runtime_error("tokenizer model '" + mtype + "' is not supported (WordPiece and byte-level BPE are)");
+        throw std::runtime_error("tokenizer model '" + mtype + "' is not supported (WordPiece, byte-level BPE and Unigram are)");
     const Json& vocab = model.at("vocab");
     if (!vocab.is_object()) throw std::runtime_error("tokenizer.json: model.vocab must be an object");
     t.vocab_.reserve(vocab.obj.size() * 2);
@@ -155,13 +165,20 @@ BertTokenizer BertTokenizer::from_json(const std::string& text)
     return t;
 }
 
-size_t BertTokenizer::vocab_size() const { return bpe_ ? bpe_->vocab_size() : vocab_.size(); }
+size_t BertTokenizer::vocab_size() const
+{
+    return bpe_ ? bpe_->vocab_size() : unigram_ ? unigram_->vocab_size() : vocab_.size();
+}
 
 int64_t BertTokenizer::token_to_id(const std::string& tok) const
 {
     if (bpe_) {
         uint32_t id = 0;
         return bpe_->token_to_id(tok, id) ? (int64_t)id : -1;
+    }
+    if (unigram_) {
+        uint32_t id = 0;
+        return unigram_->token_to_id(tok, id) ? (int64_t)id : -1;
     }
     auto it = vocab_.find(tok);
     return it == vocab_.end() ? -1 : (int64_t)it->second;
@@ -288,6 +305,11 @@ void BertTokenizer::tokenize_sequence(const std::string& text, std::vector<uint3
 {
     if (bpe_) {
         const std::vector<uint32_t> got = bpe_->encode(text, 0);
+        ids.insert(ids.end(), got.begin(), got.end());
+        return;
+    }
+    if (unigram_) {
+        const std::vector<uint32_t> got = unigram_->encode(text);
         ids.insert(ids.end(), got.begin(), got.end());
         return;
     }

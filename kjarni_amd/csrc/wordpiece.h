@@ -25,6 +25,7 @@
 namespace kjarni {
 
 class BpeTokenizer;
+class UnigramTokenizer;
 
 struct Encoding {
     std::vector<uint32_t> ids, type_ids, attention_mask;
@@ -79,6 +80,7 @@ private:
     static BatchEncoding pad_batch(std::vector<Encoding>& encs);
 
     std::shared_ptr<const BpeTokenizer> bpe_;  // set: the sequence tokenizer is byte-level BPE (RoBERTa)
+    std::shared_ptr<const UnigramTokenizer> unigram_;  // set: SentencePiece Unigram (XLM-R / bge-m3)
     std::unordered_map<std::string, uint32_t> vocab_;
     std::vector<AddedToken> added_;  // matched in raw text (normalized == false) or in normalised text
     std::string unk_token_ = "[UNK]";

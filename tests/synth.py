@@ -209,6 +209,19 @@ def nomic_embedder(path: str, seed: int = 6, **over) -> Tuple[dict, Dict[str, np
     return cfg, t
 
 
+def xlmr_embedder(path: str, seed: int = 8, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+    """bge-m3's layout: config.json says "xlm-roberta", which the reference's factories read as plain BertConfig
+    (sentence_encoder/model.rs:50-53): BERT tensor names without a prefix, positions from 0, one token type."""
+    cfg = dict(model_type="xlm-roberta", hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+               hidden_act="gelu", layer_norm_eps=1e-5, vocab_size=1024, max_position_embeddings=130, type_vocab_size=1,
+               architectures=["XLMRobertaModel"], pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    cfg.update(over)
+    t = bert_tensors(cfg, seed)
+    t["pooler.dense.weight"] = np.zeros((cfg["hidden_size"], cfg["hidden_size"]), np.float32)  # present in the checkpoint, never read
+    write_model_dir(path, cfg, t)
+    return cfg, t
+
+
 def synthetic_ids(n: int, seq: int, vocab: int = 30522, seed: int = 0, ragged: bool = False):
     """[CLS]=101 first, [SEP]=102 last real token, body uniform in
     1000..vocab-1; ragged=True draws lengths in 16..seq and right-pads with id 0 / mask 0."""

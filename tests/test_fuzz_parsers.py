@@ -53,7 +53,7 @@ def _tolerant(fn):
 
 
 @pytest.mark.parametrize("name", ["bpe_llama3_tokenizer.json", "bpe_qwen2_tokenizer.json", "spbpe_legacy_tokenizer.json", "roberta_tokenizer.json",
-                                  "tokenizer_small.json", "mpnet_tokenizer.json"])
+                                  "tokenizer_small.json", "mpnet_tokenizer.json", "unigram_tokenizer.json"])
 def test_corrupt_tokenizer_json(tmp_path, name):
     data = open(os.path.join(GOLDEN, name), "rb").read()
     rng = random.Random(len(name))
@@ -67,7 +67,7 @@ def test_corrupt_tokenizer_json(tmp_path, name):
             t.decode(t.encode("Hello [INST] wörld <|eot_id|> 12345\n"))
 
         def enc():
-            Tokenizer(p, 32).encode_batch(["Hello wörld", "x" * 300], ["pair", ""])
+            Tokenizer(p, 32).encode_batch(["Hello wörld ﬁ e\u0301 \r\n <mask>", "x" * 300], ["pair", ""])
 
         _tolerant(bpe)
         _tolerant(enc)

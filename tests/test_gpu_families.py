@@ -105,6 +105,31 @@ def test_nomic_embedder_matches_oracle(tmp_path, over):
     assert np.abs(a - b).max() > 5e-5  # without the rotation mean pooling would be order-blind (differences ~1e-7)
 
 
+def test_bge_m3_layout_matches_oracle(tmp_path):
+    """config.json says "xlm-roberta": read as plain BertConfig (positions from 0, one token type), SentencePiece-Unigram
+    tokenizer.json with '<s> $A </s>' framing; ids are pinned against the `tokenizers` goldens in test_unigram_tokenizer.py."""
+    import json
+    import kjarni_amd
+    d = str(tmp_path / "bge")
+    cfg, t = synth.xlmr_embedder(d)
+    tok = kjarni_amd.Tokenizer(_tokenizer(d, "unigram"), cfg["max_position_embeddings"])
+    orc = O.OracleModel(t, cfg)
+    emb = kjarni_amd.Embedder(model_path=d)
+    texts = ["hello world", "Ísland er fallegt land með fjörðum", "日本語のテキストを東京で 🙂", "café naïve ﬁnance № ① ｆｕｌｌ ½ x² Ⅷ",
+             "the quick brown fox jumps over the lazy dog " * 30]
+    ids, mask, _ = tok.encode_batch(texts)
+    assert ids.shape[1] == cfg["max_position_embeddings"] and ids[4, -1] == 2          # truncated to max_seq_len, </s> kept
+    with open(os.path.join(GOLDEN, "unigram_goldens.json")) as f:
+        by_text = {c["text"]: c["ids"] for c in json.load(f)["cases"]}
+    for i in (0, 1, 3):
+        assert ids[i, :int(mask[i].sum())].tolist() == by_text[texts[i]]
+    got = emb.encode_batch(texts)
+    assert np.abs(got - orc.embed_batch(ids, mask)).max() < TOL
+    one = emb.encode(texts[2])
+    i1, m1, _ = tok.encode_batch([texts[2]])
+    assert np.abs(one - orc.embed_batch(i1, m1)[0]).max() < TOL
+
+
 def test_nomic_long_sequence(tmp_path):
     """2 048 tokens in one sentence: RoPE rows far from 0 and the tiled attention path."""
     import kjarni_amd
@@ -135,6 +160,10 @@ def test_registry_names_reach_the_new_families(tmp_path):
     synth.nomic_embedder(d3)
     synth.add_tokenizer(d3)
     assert kjarni_amd.Embedder("nomic-embed-text", cache_dir=str(cache)).dim == 128
-    with pytest.raises(kjarni_amd.KjarniException) as ei:  # XLM-R (Unigram tokenizer) stays outside
-        kjarni_amd.Embedder("bge-m3", cache_dir=str(cache))
+    d4 = str(cache / "BAAI_bge-m3")
+    synth.xlmr_embedder(d4)
+    _tokenizer(d4, "unigram")
+    assert kjarni_amd.Embedder("bge-m3", cache_dir=str(cache)).dim == 128
+    with pytest.raises(kjarni_amd.KjarniException) as ei:  # a seq2seq model is not an embedder
+        kjarni_amd.Embedder("flan-t5-base", cache_dir=str(cache))
     assert ei.value.code == kjarni_amd.KjarniError.LOAD_FAILED and "not compatible" in str(ei.value)
