@@ -207,7 +207,7 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
     c.config_json = read_file(dir + "/config.json");
     Json cfg = Json::parse(c.config_json);
     SafeTensors st;
-    st.open(dir + "/model.safetensors");
+    st.open_dir(dir);
 
     c.model_type = cfg.get_string("model_type", "bert");
     Names names;

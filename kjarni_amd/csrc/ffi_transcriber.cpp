@@ -483,7 +483,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_transcriber_new(const KjarniTranscriberConf
         }
         struct stat sb;
         for (const char* f : {"config.json", "tokenizer.json", "model.safetensors"})
-            if (::stat((dir + "/" + f).c_str(), &sb) != 0)
+            if (::stat((dir + "/" + f).c_str(), &sb) != 0 &&
+                !(std::string(f) == "model.safetensors" && ::stat((dir + "/model.safetensors.index.json").c_str(), &sb) == 0))
                 throw ModelNotFound("Model load failed: " + dir + "/" + f + " is missing (models are not downloaded)");
         int device = 0;
         if (const char* e = std::getenv("KJARNI_HIP_DEVICE")) device = std::atoi(e);

@@ -85,7 +85,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_load(const char* model_dir, int
     *out = nullptr;
     return guarded(KJARNI_ERROR_LOAD_FAILED, [&] {
         const std::string dir(model_dir);
-        if (!file_exists(dir + "/config.json") || !file_exists(dir + "/model.safetensors"))
+        if (!file_exists(dir + "/config.json") ||
+            !(file_exists(dir + "/model.safetensors") || file_exists(dir + "/model.safetensors.index.json")))
             throw ModelNotFound("model files not found in '" + dir +
                                 "' (need config.json and model.safetensors)");
         auto h = std::make_unique<KjarniHipEncoder>();

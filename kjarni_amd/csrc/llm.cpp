@@ -126,7 +126,7 @@ std::unique_ptr<LlmModel> LlmModel::load(const std::string& dir, int device, int
     const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d;
     if ((d & 3) || d > 128 || 256 % (d / 4) != 0 || (H & 7) || (c.inter & 7)) throw std::runtime_error("unsupported decoder geometry");
     SafeTensors st;
-    st.open(dir + "/model.safetensors");
+    st.open_dir(dir);
     m->bf16_ = weights == 2 || (weights == 0 && st.get("model.layers.0.self_attn.q_proj.weight").dtype == "BF16");
     std::vector<float> buf, tmp;
     auto get = [&](const std::string& name, std::vector<int64_t> want) {

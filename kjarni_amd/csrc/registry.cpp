@@ -169,7 +169,9 @@ std::string model_dir_for(const RegistryEntry& e, const std::string& cache_dir)
 
 bool model_files_present(const std::string& dir)
 {
-    return is_file(dir + "/config.json") && is_file(dir + "/tokenizer.json") && is_file(dir + "/model.safetensors");
+    // model_weights.rs:51-53: one file or an index over shards
+    return is_file(dir + "/config.json") && is_file(dir + "/tokenizer.json") &&
+           (is_file(dir + "/model.safetensors") || is_file(dir + "/model.safetensors.index.json"));
 }
 
 }  // namespace kjarni

@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 
@@ -14,11 +15,53 @@ namespace kjarni {
 
 SafeTensors::~SafeTensors()
 {
-    if (map_) munmap(map_, map_len_);
+    for (const auto& m : maps_) munmap(m.first, m.second);
 }
 
-void SafeTensors::open(const std::string& path)
+void SafeTensors::open(const std::string& path) { map_file(path, tensors_); }
+
+void SafeTensors::open_dir(const std::string& dir)
 {
+    const std::string index_path = dir + "/model.safetensors.index.json";
+    struct stat ist;
+    if (::stat(index_path.c_str(), &ist) != 0) {
+        open(dir + "/model.safetensors");
+        return;
+    }
+    std::string text;
+    {
+        FILE* f = std::fopen(index_path.c_str(), "rb");
+        if (!f) throw std::runtime_error("failed to read index file: " + index_path);
+        char buf[65536];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+        std::fclose(f);
+    }
+    const Json index = Json::parse(text);
+    const Json* wm = index.find("weight_map");
+    if (!wm || !wm->is_object()) throw std::runtime_error("invalid index.json: missing 'weight_map' object");
+    std::map<std::string, std::map<std::string, TensorView>> shards;  // file name -> its tensors (sorted, deduplicated)
+    for (const auto& kv : wm->obj)
+        if (kv.second.is_string()) {
+            const std::string& file = kv.second.str;
+            if (file.empty() || file.find('/') != std::string::npos || file.find("..") != std::string::npos)
+                throw std::runtime_error("invalid index.json: shard name '" + file + "'");
+            shards[file];
+        }
+    for (auto& sh : shards) map_file(dir + "/" + sh.first, sh.second);
+    for (const auto& kv : wm->obj) {
+        if (!kv.second.is_string()) continue;
+        const auto& shard = shards[kv.second.str];
+        auto it = shard.find(kv.first);
+        if (it == shard.end()) throw std::runtime_error("tensor '" + kv.first + "' is not in the shard the index maps it to (" + kv.second.str + ")");
+        tensors_[kv.first] = it->second;
+    }
+}
+
+void SafeTensors::map_file(const std::string& path, std::map<std::string, TensorView>& tensors_)
+{
+    void* map_ = nullptr;
+    size_t map_len_ = 0;
     int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open " + path);
     struct stat st;
@@ -29,10 +72,8 @@ void SafeTensors::open(const std::string& path)
     map_len_ = (size_t)st.st_size;
     map_ = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
-    if (map_ == MAP_FAILED) {
-        map_ = nullptr;
-        throw std::runtime_error("mmap failed: " + path);
-    }
+    if (map_ == MAP_FAILED) throw std::runtime_error("mmap failed: " + path);
+    maps_.emplace_back(map_, map_len_);
     const uint8_t* base = static_cast<const uint8_t*>(map_);
     uint64_t hlen = 0;
     std::memcpy(&hlen, base, 8);  // little-endian host

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace kjarni {
@@ -33,6 +34,11 @@ public:
 
     // Throws std::runtime_error with a readable message on any format problem.
     void open(const std::string& path);
+    // A model directory (weights/safetensors_loader.rs:46-129): `model.safetensors.index.json` + the shards its
+    // weight_map names when the index exists, else the single `model.safetensors`.  A sharded model exposes the tensors the
+    // weight_map lists, each read from the shard it is mapped to.
+    void open_dir(const std::string& dir);
+    size_t shard_count() const { return maps_.size(); }
     bool contains(const std::string& name) const { return tensors_.count(name) != 0; }
     const TensorView& get(const std::string& name) const;
     // Copies the tensor as f32 into out (resized); returns its shape.
@@ -40,8 +46,9 @@ public:
     const std::map<std::string, TensorView>& tensors() const { return tensors_; }
 
 private:
-    void* map_ = nullptr;
-    size_t map_len_ = 0;
+    void map_file(const std::string& path, std::map<std::string, TensorView>& into);
+
+    std::vector<std::pair<void*, size_t>> maps_;
     std::map<std::string, TensorView> tensors_;
 };
 

@@ -223,7 +223,7 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
         }
     }
     SafeTensors st;
-    st.open(dir + "/model.safetensors");
+    st.open_dir(dir);
     std::vector<float> buf;
     auto get = [&](const std::string& name, std::vector<int64_t> want) {
         const std::vector<int64_t> shape = st.read_f32(name, buf);

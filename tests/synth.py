@@ -107,6 +107,29 @@ def write_model_dir(path: str, config: dict, tensors: Dict[str, np.ndarray]) -> 
     return path
 
 
+def shard_model_dir(path: str, n_shards: int = 3) -> Dict[str, str]:
+    """Rewrites <path>/model.safetensors as model-0000i-of-0000n.safetensors + model.safetensors.index.json, the layout of
+    the registry's larger checkpoints (weights/safetensors_loader.rs:84-129).  Returns the weight_map."""
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    single = os.path.join(path, "model.safetensors")
+    with safe_open(single, framework="pt") as f:
+        names = list(f.keys())
+        tensors = {k: f.get_tensor(k) for k in names}
+    weight_map, total = {}, 0
+    for i in range(n_shards):
+        part = names[i::n_shards]   # interleaved, so neighbouring tensors of a layer live in different files
+        fname = f"model-{i + 1:05d}-of-{n_shards:05d}.safetensors"
+        save_file({k: tensors[k].contiguous() for k in part}, os.path.join(path, fname))
+        for k in part:
+            weight_map[k] = fname
+            total += tensors[k].numel() * tensors[k].element_size()
+    with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
+        json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
+    os.remove(single)
+    return weight_map
+
+
 def minilm_embedder(path: str, seed: int = 0, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
     cfg = dict(MINILM, model_type="bert", hidden_act="gelu", layer_norm_eps=1e-12,
                architectures=["BertModel"])
