@@ -139,6 +139,12 @@ GEOMETRIES = {
                       num_hidden_layers=1),
     "d32-wide": dict(synth.QWEN_TEST, hidden_size=4096, num_attention_heads=128, num_key_value_heads=8, intermediate_size=8192 + 32 * 8, head_dim=32,
                      num_hidden_layers=1, vocab_size=320),
+    # the registry's odd head counts: Qwen2.5-0.5B (14 query heads over 2 KV heads, hidden 896, inner 4864, biases, tied
+    # embeddings) and Llama-3.2-3B (24 heads over 8, hidden 3072)
+    "qwen0.5b-heads14-kv2": dict(synth.QWEN_TEST, hidden_size=896, num_attention_heads=14, num_key_value_heads=2, intermediate_size=4864,
+                                 head_dim=64, num_hidden_layers=1, vocab_size=512, tie_word_embeddings=True),
+    "llama3b-heads24-kv8": dict(synth.LLAMA_TEST, hidden_size=3072, num_attention_heads=24, num_key_value_heads=8, intermediate_size=8192,
+                                head_dim=128, num_hidden_layers=1, vocab_size=320),
 }
 
 
