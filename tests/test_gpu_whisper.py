@@ -213,6 +213,31 @@ def test_transcriber_timestamps_language_translate_and_stops(env):
         tr3.transcribe_file("/nonexistent/audio.wav")
 
 
+def test_large_v3_style_geometry(tmp_path):
+    """whisper-large-v3's differences from base at a small size: 128 mel bins (model.rs:144), 64-wide heads, one more
+    vocabulary entry (51 866)."""
+    import kjarni_amd
+    d = str(tmp_path / "openai_whisper-large-v3")
+    cfg, t = synth.whisper_model(d, seed=13, num_mel_bins=128, d_model=128, encoder_attention_heads=2, decoder_attention_heads=2,
+                                 encoder_ffn_dim=256, decoder_ffn_dim=256, vocab_size=51866)
+    g = kjarni_amd.HipWhisper(d)
+    m = W.WhisperOracle(t, cfg)
+    audio = synth.synthetic_audio(30.0, seed=14)
+    mel = W.log_mel(audio, n_mels=128)
+    got_mel = g.log_mel(audio)
+    assert got_mel.shape == (128, 3000) and np.abs(got_mel - mel).max() < 2e-4
+    enc = m.encode_mel(mel)
+    assert np.abs(g.encode_mel(mel) - enc[0]).max() < TOL
+    g.decode_begin()
+    cross = m.precompute_cross_kv(enc)
+    cache = [None] * len(m.dec_layers)
+    for ids in ([W.SOT_TOKEN, 50259, W.TRANSCRIBE_TOKEN, W.NO_TIMESTAMPS_TOKEN], [1234], [51865]):
+        ref_h = m.decoder_forward(np.asarray([ids], np.uint32), enc, cache, cross)[0]
+        h, logits = g.decode_forward(ids)
+        assert np.abs(h - ref_h).max() < TOL
+        assert np.abs(logits - m.logits(ref_h[None, -1:, :])[0, 0]).max() < TOL
+
+
 def test_full_size_whisper_base_shape(tmp_path):
     """BASELINE.json configs[3] shape (d_model 512, 6 + 6 layers, 8 heads, ffn 2048): encoder output and the first
     decoder steps against the oracle, then properties the oracle would take too long for: greedy decoding is
