@@ -200,6 +200,14 @@ void UnigramTokenizer::load_json(const std::string& text, const std::string& ori
         else sorted_[w++] = sorted_[i];
     }
     sorted_.resize(w);
+    {
+        size_t i = 0;
+        for (int b = 0; b < 256; ++b) {
+            while (i < sorted_.size() && (sorted_[i].first.empty() || (uint8_t)sorted_[i].first[0] < b)) ++i;
+            first_[b] = (uint32_t)i;
+        }
+        first_[256] = (uint32_t)sorted_.size();
+    }
 
     if (const Json* n = root.find("normalizer"); n && !n->is_null()) parse_normalizer(*n);
     if (const Json* p = root.find("pre_tokenizer"); p && !p->is_null()) parse_pre_tokenizer(*p);
@@ -435,8 +443,11 @@ std::vector<std::string> UnigramTokenizer::pre_tokenize(const std::string& s) co
 template <typename F>
 void UnigramTokenizer::common_prefixes(const std::string& s, size_t pos, F&& f) const
 {
-    size_t lo = 0, hi = sorted_.size();
-    for (size_t d = 0; pos + d < s.size() && lo < hi; ++d) {
+    if (pos >= s.size()) return;
+    // depth 0 from the first-byte table, then binary search inside the shrinking range
+    size_t lo = first_[(uint8_t)s[pos]], hi = first_[(uint8_t)s[pos] + 1];
+    if (lo < hi && sorted_[lo].first.size() == 1) f(1, sorted_[lo].second);
+    for (size_t d = 1; pos + d < s.size() && lo < hi; ++d) {
         const uint8_t c = (uint8_t)s[pos + d];
         // entries of length <= d sort first inside the range and cannot continue
         auto key = [&](size_t idx) -> int { return sorted_[idx].first.size() > d ? (int)(uint8_t)sorted_[idx].first[d] : -1; };

@@ -55,6 +55,7 @@ private:
 
     std::vector<std::pair<std::string, double>> pieces_;            // id -> (piece, score)
     std::vector<std::pair<std::string, uint32_t>> sorted_;          // piece -> id (last id wins), byte-wise sorted
+    uint32_t first_[257] = {};                                       // sorted_ range of every first byte
     double min_score_ = 0.0;
     bool has_unk_ = false, byte_fallback_ = false, fuse_unk_ = true;
     uint32_t unk_id_ = 0;
