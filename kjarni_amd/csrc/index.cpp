@@ -588,62 +588,89 @@ Segment::~Segment()
     if (map_) munmap(map_, map_len_);
 }
 
+namespace {
+void pread_all(int fd, char* dst, size_t n, uint64_t off, const std::string& what)
+{
+    size_t done = 0;
+    while (done < n) {
+        const ssize_t r = ::pread(fd, dst + done, n - done, (off_t)(off + done));
+        if (r <= 0) throw std::runtime_error("short read in " + what);
+        done += (size_t)r;
+    }
+}
+}  // namespace
+
+namespace {
+struct ScopedFd {
+    int fd;
+    explicit ScopedFd(const std::string& path) : fd(::open(path.c_str(), O_RDONLY | O_CLOEXEC)) {}
+    ~ScopedFd()
+    {
+        if (fd >= 0) ::close(fd);
+    }
+    ScopedFd(const ScopedFd&) = delete;
+    ScopedFd& operator=(const ScopedFd&) = delete;
+};
+uint64_t fd_size(int fd)
+{
+    struct stat st;
+    return fstat(fd, &st) == 0 ? (uint64_t)st.st_size : 0;
+}
+}  // namespace
+
 std::string Segment::get_document(size_t doc_id) const
 {
     if (doc_id >= doc_count_ || doc_id >= doc_offsets_.size()) throw std::runtime_error("Document ID out of range");
     const std::string path = dir_ + "/docs.bin";
+    const ScopedFd f(path);
+    if (f.fd < 0) throw std::runtime_error("cannot open " + path);
+    const int fd = f.fd;
+    std::call_once(docs_once_, [&] { docs_size_ = fd_size(fd); });
     const uint64_t start = doc_offsets_[doc_id];
-    uint64_t end;
-    if (doc_id + 1 < doc_offsets_.size()) {
-        end = doc_offsets_[doc_id + 1] - 1;  // -1 for the newline
-    } else {
-        struct stat st;
-        if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot stat " + path);
-        end = (uint64_t)st.st_size - 1;
-    }
-    if (end < start) throw std::runtime_error("corrupt document offsets");
-    {
-        struct stat st;
-        if (::stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot stat " + path);
-        if (end > (uint64_t)st.st_size) throw std::runtime_error("corrupt document offsets");
-    }
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    f.seekg((std::streamoff)start);
+    // the next document's offset, or the file's end; -1 for the newline
+    const uint64_t next = doc_id + 1 < doc_offsets_.size() ? doc_offsets_[doc_id + 1] : docs_size_;
+    if (next == 0 || next - 1 < start || next - 1 > docs_size_) throw std::runtime_error("corrupt document offsets");
+    const uint64_t end = next - 1;
     std::string buf((size_t)(end - start), '\0');
-    f.read(&buf[0], (std::streamsize)buf.size());
-    if ((uint64_t)f.gcount() != end - start) throw std::runtime_error("short read in " + path);
+    if (!buf.empty()) pread_all(fd, &buf[0], buf.size(), start, dir_ + "/docs.bin");
     if (!unicode::is_valid_utf8(buf.data(), buf.size())) throw std::runtime_error("Invalid UTF-8 in document");
     return buf;
 }
 
 Metadata Segment::get_metadata(size_t doc_id) const
 {
-    std::ifstream f(dir_ + "/metadata.jsonl", std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open metadata.jsonl");
-    std::call_once(meta_once_, [&] {  // one pass for the line starts; later lookups seek
-        std::string l;
+    const ScopedFd f(dir_ + "/metadata.jsonl");
+    if (f.fd < 0) throw std::runtime_error("cannot open metadata.jsonl");
+    const int fd = f.fd;
+    std::call_once(meta_once_, [&] {  // one pass for the line starts; later lookups read one line
+        meta_size_ = fd_size(fd);
+        std::vector<char> chunk(1 << 16);
         uint64_t off = 0;
-        while (std::getline(f, l)) {
-            meta_offsets_.push_back(off);
-            off += l.size() + (f.eof() ? 0 : 1);
+        bool at_line_start = true;
+        while (off < meta_size_) {
+            const size_t want = (size_t)std::min<uint64_t>(chunk.size(), meta_size_ - off);
+            pread_all(fd, chunk.data(), want, off, "metadata.jsonl");
+            for (size_t i = 0; i < want; ++i) {
+                if (at_line_start) meta_offsets_.push_back(off + i);
+                at_line_start = chunk[i] == '\n';
+            }
+            off += want;
         }
-        f.clear();
     });
     if (doc_id >= meta_offsets_.size()) throw std::runtime_error("Document ID out of range");
-    f.seekg((std::streamoff)meta_offsets_[doc_id]);
-    std::string line;
-    if (std::getline(f, line)) {
-        const Json j = Json::parse(line);
-        if (!j.is_object()) throw std::runtime_error("Invalid JSON: metadata is not an object");
-        Metadata md;
-        for (const auto& kv : j.obj) {
-            if (!kv.second.is_string()) throw std::runtime_error("Invalid JSON: metadata values must be strings");
-            md[kv.first] = kv.second.str;
-        }
-        return md;
+    const uint64_t start = meta_offsets_[doc_id];
+    uint64_t end = doc_id + 1 < meta_offsets_.size() ? meta_offsets_[doc_id + 1] : meta_size_;
+    std::string line((size_t)(end - start), '\0');
+    if (!line.empty()) pread_all(fd, &line[0], line.size(), start, "metadata.jsonl");
+    while (!line.empty() && line.back() == '\n') line.pop_back();
+    const Json j = Json::parse(line);
+    if (!j.is_object()) throw std::runtime_error("Invalid JSON: metadata is not an object");
+    Metadata md;
+    for (const auto& kv : j.obj) {
+        if (!kv.second.is_string()) throw std::runtime_error("Invalid JSON: metadata values must be strings");
+        md[kv.first] = kv.second.str;
     }
-    throw std::runtime_error("Document ID out of range");
+    return md;
 }
 
 // ---------------------------------------------------------------------------------- IndexReader

@@ -104,8 +104,11 @@ private:
     size_t map_len_ = 0;
     std::vector<uint64_t> doc_offsets_;
     Bm25Index bm25_;
-    // byte offset of every metadata.jsonl line, built on the first get_metadata
-    mutable std::once_flag meta_once_;
+    // Hits are read with open + pread + close (no descriptor is held: an index may have thousands of segments).  The
+    // file sizes and the byte offset of every metadata.jsonl line are taken once per parsed segment (a changed file makes a
+    // new Segment, see open_shared).
+    mutable std::once_flag docs_once_, meta_once_;
+    mutable uint64_t docs_size_ = 0, meta_size_ = 0;
     mutable std::vector<uint64_t> meta_offsets_;
 };
 
