@@ -115,13 +115,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c) sVt[(c4 * 4 + c) * SM::VT_STRIDE + r] = vv[c];
         }
+        int plain = 1;
         if (tid < KCHUNK) {
             const int key = key0 + tid;
             float mv = -1.0f;
             if (key < seq) mv = (mask == nullptr || mask[b * seq + key] != 0u) ? 1.0f : 0.0f;
             sMask[tid] = mv;
+            plain = mv == 1.0f;
         }
-        __syncthreads();
+        // also the staging barrier; all_plain: every key of the chunk exists and is kept, so the mask pass can be skipped
+        const int all_plain = __syncthreads_and(plain);
 
         // S^T tiles: 4 key tiles x 32 queries, K = D.
         f32x16 s[4];
@@ -139,36 +142,50 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
             }
         }
 
-        // scale -> mask overwrite; keys beyond seq contribute exact zeros.
+        // scale -> mask overwrite; keys beyond seq contribute exact zeros.  The softmax runs in the exp2 domain as in the
+        // pipelined kernel: t = score * (scale * log2 e), p = exp2(t - max t), one v_exp_f32 per element (libm's expf is
+        // eight instructions; the VALU work of this phase is what the matrix pipe waits for).
+        const float c1 = scale * 1.4426950408889634f;
+        const float masked_t = mask_value * 1.4426950408889634f;  // -1e9 -> -1.44e9, -inf -> -inf
         float cmax = -INFINITY;
+        if (all_plain) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float mk = sMask[kt * 32 + acc_row(r, half)];
-                float v = s[kt][r] * scale;
-                v = (mk == 0.0f) ? mask_value : v;
-                v = (mk < 0.0f) ? -INFINITY : v;
-                s[kt][r] = v;
-                cmax = fmaxf(cmax, v);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    s[kt][r] *= c1;
+                    cmax = fmaxf(cmax, s[kt][r]);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mk = sMask[kt * 32 + acc_row(r, half)];
+                    float v = s[kt][r] * c1;
+                    v = (mk == 0.0f) ? masked_t : v;
+                    v = (mk < 0.0f) ? -INFINITY : v;
+                    s[kt][r] = v;
+                    cmax = fmaxf(cmax, v);
+                }
+        }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, kWave));
 
         float alpha = 1.0f;
         float new_max = cmax;
         if (n_chunks > 1) {
             new_max = fmaxf(run_max, cmax);
-            // exp(-inf - finite) = 0 on the first chunk; guard -inf - -inf.
-            alpha = (run_max == -INFINITY) ? 0.0f : expf(run_max - new_max);
+            // exp2(-inf - finite) = 0 on the first chunk; guard -inf - -inf.
+            alpha = (run_max == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(run_max - new_max);
         }
         float csum = 0.0f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // One chunk: literal reference order; a row that is entirely -inf gives NaN like the
+                // One chunk: max, exp, sum, scale as the reference; a row that is entirely -inf gives NaN like the
                 // reference's no-alloc path.  Several chunks: a chunk that is entirely -inf adds zeros.
-                float e = expf(s[kt][r] - new_max);
+                float e = __builtin_amdgcn_exp2f(s[kt][r] - new_max);
                 if (n_chunks > 1 && new_max == -INFINITY) e = 0.0f;
                 s[kt][r] = e;
                 csum += e;
