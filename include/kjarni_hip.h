@@ -121,6 +121,8 @@ typedef enum KjarniHipEpilogue {
     KJARNI_HIP_EPI_BIAS_RELU = 3,
     KJARNI_HIP_EPI_BIAS_TANH = 4,
     KJARNI_HIP_EPI_BIAS_RESIDUAL = 5,
+    KJARNI_HIP_EPI_BIAS_MUL_SILU = 6, /* y = silu(residual) * (x . w^T + bias): the up projection of SwiGluFeedForward over the
+                                       * gate projection's output (cpu/feedforward/swiglu.rs:40-50) */
 } KjarniHipEpilogue;
 
 /* y[m,n] = epilogue(x[m,k] . w[n,k]^T + bias[n] (+ residual[m,n])); bias / residual may be NULL. */

@@ -299,7 +299,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* 
     if (!x || !w || !y) return KJARNI_ERROR_NULL_POINTER;
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
         if (m < 0 || k <= 0 || n <= 0) throw InvalidConfig("invalid GEMM dimensions");
-        if (epilogue == KJARNI_HIP_EPI_BIAS_RESIDUAL && !residual) throw InvalidConfig("residual epilogue without residual");
+        if ((epilogue == KJARNI_HIP_EPI_BIAS_RESIDUAL || epilogue == KJARNI_HIP_EPI_BIAS_MUL_SILU) && !residual)
+            throw InvalidConfig("residual epilogue without residual");
         use_device(device);
         if (m == 0) return;
         const size_t xb = (size_t)m * k * 4, wb = (size_t)n * k * 4, yb = (size_t)m * n * 4;

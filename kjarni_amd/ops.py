@@ -11,7 +11,7 @@ import numpy as np
 from . import _ffi
 from ._ffi import check_error, lib
 
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_NEW, EPI_BIAS_RELU, EPI_BIAS_TANH, EPI_BIAS_RESIDUAL = range(6)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_NEW, EPI_BIAS_RELU, EPI_BIAS_TANH, EPI_BIAS_RESIDUAL, EPI_BIAS_MUL_SILU = range(7)
 
 
 def _f(a):

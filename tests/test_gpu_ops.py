@@ -7,6 +7,12 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _silu(x):
+    x = x.astype(np.float32)
+    y = x / (np.float32(1.0) + np.exp(-x, dtype=np.float32))
+    return np.where(x <= -20, np.float32(0), np.where(x >= 20, x, y)).astype(np.float32)
+
+
 @pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (127, 384, 1152), (128, 384, 1536), (300, 1536, 384),
                                    (1000, 768, 768), (77, 100, 7), (5, 17, 4), (257, 64, 128), (130, 32, 128)])
@@ -26,7 +32,9 @@ def test_linear_all_epilogues(m, k, n, variant):
              (ops.EPI_BIAS_GELU_NEW, None, np.vectorize(O.gelu_new, otypes=[np.float32])(base)),
              (ops.EPI_BIAS_RELU, None, np.maximum(base, 0)),
              (ops.EPI_BIAS_TANH, None, np.tanh(base)),
-             (ops.EPI_BIAS_RESIDUAL, r, base + r)]
+             (ops.EPI_BIAS_RESIDUAL, r, base + r),
+             # SwiGLU: silu(gate) * up, silu_scalar's cut-offs at +-20 included (activations.rs:74-82)
+             (ops.EPI_BIAS_MUL_SILU, r * 12, _silu(r * 12) * base)]
     for epi, res, ref in cases:
         got, _ = ops.linear(x, w, b, res, epi)
         assert np.abs(got - ref).max() < tol, (epi, float(np.abs(got - ref).max()))
