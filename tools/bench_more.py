@@ -92,16 +92,22 @@ def main():
 
     if "families" in which:
         # The other registry embedders at their real shapes (random weights): nomic-embed-text-v1.5 (RoPE + SwiGLU, 768 x 12
-        # layers, inner 3072) and all-mpnet-base-v2 (BERT-base shape).  Same token-level entry point as the headline.
+        # layers, inner 3072), all-mpnet-base-v2 (BERT-base shape) and bge-m3 (XLM-R large: 1024 x 24 layers, inner 4096,
+        # 250 002-row embedding table, up to 8 192 tokens).  Same token-level entry point as the headline.
         for name, make, over, gated in (
                 ("nomic-embed-text", synth.nomic_embedder, dict(n_embd=768, n_layer=12, n_head=12, n_inner=3072, n_positions=8192), True),
                 ("mpnet-base-v2", synth.mpnet_embedder, dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
-                                                             intermediate_size=3072), False)):
+                                                             intermediate_size=3072), False),
+                ("bge-m3", synth.xlmr_embedder, dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                                                     vocab_size=250002, max_position_embeddings=8194), False)):
             d = os.path.join(tmp, name)
             cfg_f, _ = make(d, **over)
             enc = kjarni_amd.HipEncoder(d, 0)
-            H, Lf, If = 768, 12, 3072
-            for N, seq in ((16384, 128), (1024, 2048) if gated else (4096, 512)):
+            H = cfg_f.get("hidden_size", cfg_f.get("n_embd"))
+            Lf = cfg_f.get("num_hidden_layers", cfg_f.get("n_layer"))
+            If = cfg_f.get("intermediate_size", cfg_f.get("n_inner"))
+            shapes = ((16384, 128), (1024, 2048)) if gated else ((8192, 128), (256, 8192)) if name == "bge-m3" else ((16384, 128), (4096, 512))
+            for N, seq in shapes:
                 ids, mask = synth.synthetic_ids(N, seq, vocab=cfg_f["vocab_size"], seed=0)
                 t_ids, t_mask = (torch.from_numpy(a.view(np.int32)).to(dev) for a in (ids, mask))
                 out = torch.empty((N, H), dtype=torch.float32, device=dev)
