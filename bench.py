@@ -1,26 +1,38 @@
 #!/usr/bin/env python3
 """Headline benchmark: sentences/s, minilm-l6-v2 batch encode (seq 128, fp32).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload embed|rerank]
 
-One process per GPU (the driver launches N > 1 through torch.distributed.run).
-A "step" is one pass of the hot path over the whole synthetic workload of this
-rank: BASELINE.json configs[1] = 65 536 sentences x 128 tokens through
-ids -> embeddings+LN -> 6 encoder layers -> mean-pool -> L2 (the token-level
-boundary get_hidden_states_batch_from_ids + encode_batch_flat), inputs already
-resident in HBM.  With N > 1 every rank encodes its own 65 536-sentence shard
-(weak scaling) and the step ends with the RCCL all-gather of the [65 536, 384]
-output slabs, so each rank holds all N*65 536 vectors.
+One process per GPU.  The driver launches N > 1 through torch.distributed.run; a plain
+`python bench.py --gpus N` spawns its N ranks itself (the parent never touches the GPU).
+
+--workload embed (default; BASELINE.json configs[1], weak scaling): a "step" is one pass of
+the hot path over this rank's 65 536 sentences x 128 tokens -- ids -> embeddings+LN -> 6
+encoder layers -> mean-pool -> L2 (get_hidden_states_batch_from_ids + encode_batch_flat),
+inputs resident in HBM -- followed, when N > 1, by the RCCL all-gather of the [65 536, 384]
+slabs (kjarni_amd.distributed.sharded_embed), so every rank holds all N*65 536 vectors.
+
+--workload rerank (BASELINE.json configs[2], STRONG scaling): 100 000 pre-tokenised
+(query, doc) pairs x 128 tokens in total, balanced row blocks per rank through the
+cross-encoder (kjarni_amd.distributed.sharded_rerank_scores), all-gather of the [100 000]
+scores, and the host's stable descending sort (cross_encoder/model.rs:251-252) -- all
+inside the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel, timed live with HIP events on its launch
-                  stream over the timed region (libkjarni_ffi's profiler)
-  cpu_baseline -- the CPU restatement of the reference path (oracle/, with the
-                  reference's GEMM blocking) timed on this host, N = 1 only.
+  roofline      the dominant kernel, timed live with HIP events on its launch stream over
+                the timed region (libkjarni_ffi's profiler)
+  cpu_baseline  (N = 1, embed) the port of the reference's CPU path (oracle/
+                kjarni_cpu_baseline.c) timed on this host: calls of 32 and of 256, with the
+                reference's serial row loops and with them parallelised
+  value_host_ptrs / value_ragged  (N = 1, embed) the same workload through host pointers
+                (H2D of ids/mask + D2H of the embeddings inside the timed region) and with
+                ragged lengths U{16..128}.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -30,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SENTENCES_PER_GPU = 65536
+RERANK_PAIRS = 100000
 SEQ = 128
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
@@ -41,33 +54,137 @@ def flops_per_sentence(H=384, L=6, I=1536, S=128):
     return L * per_layer
 
 
-def cpu_baseline(cfg, tensors, budget_s=15.0):
-    """CPU restatement of the reference path (oracle, blocked AVX2 GEMM as in
-    cpu/ops/matmul.rs:571-686), B = 32 sentences per call (the Indexer default,
-    kjarni-ffi/src/indexer.rs:132), one thread per physical core."""
-    import numpy as np
-    from oracle import oracle as O
-    from tests import synth
+def host_description():
+    """lscpu model, physical cores and SMT state of the box the CPU leg runs on."""
+    info = {"logical_cpus": os.cpu_count()}
     try:
         import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+        info["physical_cores"] = psutil.cpu_count(logical=False)
     except Exception:
-        cores = os.cpu_count() or 1
-    O.lib().ko_set_num_threads(int(cores))
-    model = O.OracleModel(tensors, cfg, blocked_gemm=True)
-    B = 32
-    ids, mask = synth.synthetic_ids(B * 64, SEQ, seed=0)
-    model.embed_batch(ids[:B], mask[:B])  # warm-up (page in weights, spin up threads)
-    done, t0 = 0, time.perf_counter()
-    while done < ids.shape[0]:
-        model.embed_batch(ids[done:done + B], mask[done:done + B])
-        done += B
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 2), "unit": "sentences/s", "cores": int(cores), "kind": "port",
-            "sample": f"{done} sentences x {SEQ} tokens in calls of {B} ({dt:.1f} s), "
-                      "oracle/kjarni_oracle.c with the reference's 64-row / 4x3 AVX2 GEMM blocking"}
+        pass
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                info["model"] = v
+            elif k == "Thread(s) per core":
+                info["threads_per_core"] = int(v)
+            elif k == "Socket(s)":
+                info["sockets"] = int(v)
+    except Exception:
+        pass
+    try:
+        with open("/sys/devices/system/cpu/smt/active") as f:
+            info["smt_active"] = f.read().strip() == "1"
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(cfg, tensors, budget_s=36.0, cap_sentences=4096):
+    """The reference's CPU path as oracle/kjarni_cpu_baseline.c ports it (fused QKV, 64-row / 4x3 AVX2 GEMM
+    blocks, per-(b,h) attention GEMMs, persistent buffers), one thread per physical core (the reference pins its
+    rayon pool that way, kjarni-ffi/src/lib.rs:37-40).  Four figures: calls of 32 (the
+    Indexer default, kjarni-ffi/src/indexer.rs:132) and of 256 sentences, with the reference's serial row loops
+    (softmax, LayerNorm, mask, residual) and with those loops parallelised.  Each figure: one warm-up call, then
+    the median of 3 passes over up to `cap_sentences` sentences, passes bounded so the whole leg stays near
+    `budget_s`."""
+    import numpy as np
+    from oracle import cpu_baseline as CB
+    from tests import synth
+    host = host_description()
+    cores = int(host.get("physical_cores") or os.cpu_count() or 1)
+    CB.lib().kb_set_num_threads(cores)
+    model = CB.BaselineModel(tensors, cfg, max_batch=256, max_seq=SEQ)
+    ids, mask = synth.synthetic_ids(cap_sentences, SEQ, seed=0)
+    per_pass = budget_s / (4 * 3.5)
+    variants = []
+    for B in (32, 256):
+        for par in (False, True):
+            t0 = time.perf_counter()
+            model.embed_batch(ids[:B], mask[:B], par)  # warm-up: pages in the weights, spins up the threads
+            est = max(time.perf_counter() - t0, 1e-4) / B
+            n = int(min(cap_sentences, max(B, (per_pass / est) // B * B)))
+            rates = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for s in range(0, n, B):
+                    model.embed_batch(ids[s:s + B], mask[s:s + B], par)
+                rates.append(n / (time.perf_counter() - t0))
+            variants.append({"call_size": B, "row_loops": "parallel" if par else "serial (as the reference)",
+                             "sentences_per_pass": n, "value": round(float(np.median(rates)), 2),
+                             "passes": [round(r, 2) for r in rates]})
+    head = variants[0]
+    return {"value": head["value"], "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": f"calls of {head['call_size']} sentences x {SEQ} tokens, {head['sentences_per_pass']} sentences "
+                      "per pass, median of 3 passes after 1 warm-up; oracle/kjarni_cpu_baseline.c = the reference's "
+                      "no-alloc path (fused QKV, 64-row / 4x3 AVX2 GEMM blocks, per-(b,h) attention GEMMs, serial "
+                      "softmax / LayerNorm loops)",
+            "variants": variants, "host": host}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children.  Nothing in this process has
+    touched torch.cuda or HIP, and it never execs."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # a dead rank would leave the others waiting in the collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+class HostStubEncoder:
+    """--dry-run-cpu only: stands in for HipEncoder so the launcher / sharding / collective / JSON plumbing can be
+    exercised on a box without a GPU (gloo).  Its line is marked data = "dry-run" and carries no roofline."""
+    hidden_size, num_labels, num_layers = 384, 1, 6
+
+    @staticmethod
+    def _view(ptr, rows, cols, ctype, dtype):
+        import ctypes as C
+
+        import numpy as np
+        return np.ctypeslib.as_array((ctype * (rows * cols)).from_address(ptr)).reshape(rows, cols).view(dtype)
+
+    def embed_dev(self, ids_ptr, mask_ptr, batch, seq, out_ptr, type_ptr=0, pooling=0, normalize=True, fill=0,
+                  stream=0):
+        import ctypes as C
+
+        import numpy as np
+        ids = self._view(ids_ptr, batch, seq, C.c_uint32, np.uint32).astype(np.float64)
+        out = self._view(out_ptr, batch, self.hidden_size, C.c_float, np.float32)
+        x = np.sin(ids.sum(1, keepdims=True) * 1e-4 + np.arange(self.hidden_size)[None, :])
+        out[:] = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+    def logits_dev(self, ids_ptr, mask_ptr, type_ptr, batch, seq, out_ptr, fill=0, stream=0):
+        import ctypes as C
+
+        import numpy as np
+        ids = self._view(ids_ptr, batch, seq, C.c_uint32, np.uint32).astype(np.float64)
+        self._view(out_ptr, batch, 1, C.c_float, np.float32)[:, 0] = np.cos(ids.sum(1) * 1e-4)
 
 
 def main():
@@ -75,71 +192,103 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sentences", type=int, default=SENTENCES_PER_GPU, help="sentences per GPU per step")
+    ap.add_argument("--workload", choices=("embed", "rerank"), default="embed")
+    ap.add_argument("--sentences", type=int, default=SENTENCES_PER_GPU, help="embed: sentences per GPU per step")
+    ap.add_argument("--pairs", type=int, default=RERANK_PAIRS, help="rerank: pairs per step over ALL GPUs")
     ap.add_argument("--chunk-tokens", type=int, default=0, help="override the encoder's chunk size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer and ragged legs")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="plumbing self-test without a GPU: gloo + a host stub instead of the HIP encoder")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch  # imported before libkjarni_ffi.so so both share torch's HIP runtime
     import torch.distributed as dist
 
-    import kjarni_amd
+    from kjarni_amd import distributed as D
     from tests import synth
 
-    if not torch.cuda.is_available() or kjarni_amd.device_count() < 1:
-        print("bench.py needs an AMD GPU (there is no CPU fallback for the product path)", file=sys.stderr)
-        sys.exit(1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    dry = args.dry_run_cpu
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        import kjarni_amd
+        if not torch.cuda.is_available() or kjarni_amd.device_count() < 1:
+            print("bench.py needs an AMD GPU (there is no CPU fallback for the product path)", file=sys.stderr)
+            sys.exit(1)
+        if torch.cuda.device_count() <= local_rank:
+            print(f"bench.py: rank {rank} wants GPU {local_rank}, {torch.cuda.device_count()} visible", file=sys.stderr)
+            sys.exit(1)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
 
-    N, S = args.sentences, SEQ
+    S = SEQ
+    rerank = args.workload == "rerank"
     with tempfile.TemporaryDirectory(prefix=f"kjarni_bench_r{rank}_") as tmp:
-        cfg, tensors = synth.minilm_embedder(tmp, seed=0)  # random-init MiniLM-L6-v2 shaped weights
-        enc = kjarni_amd.HipEncoder(tmp, local_rank)
-    if args.chunk_tokens:
+        # random-init weights of the named architecture (no network for checkpoints)
+        cfg, tensors = (synth.minilm_cross_encoder if rerank else synth.minilm_embedder)(tmp, seed=1 if rerank else 0)
+        enc = HostStubEncoder() if dry else kjarni_amd.HipEncoder(tmp, local_rank)
+    if args.chunk_tokens and not dry:
         enc.set_chunk_tokens(args.chunk_tokens)
     H = enc.hidden_size
 
-    ids_np, mask_np = synth.synthetic_ids(N, S, seed=rank)
-    ids = torch.from_numpy(ids_np.view(np.int32)).to(dev)
-    mask = torch.from_numpy(mask_np.view(np.int32)).to(dev)
-    out = torch.empty((N, H), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * N, H), dtype=torch.float32, device=dev) if world > 1 else None
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+
+    if rerank:
+        n_total = args.pairs
+        start, n_local = D.shard_rows(n_total, world, rank)
+        ids_np, mask_np, types_np = synth.synthetic_pairs(n_total, S, seed=1)  # the same 100 000 pairs on every rank
+        ids, mask, types = (to_dev(a[start:start + n_local]) for a in (ids_np, mask_np, types_np))
+        del ids_np, mask_np, types_np
+    else:
+        n_local = args.sentences
+        n_total = world * n_local
+        ids_np, mask_np = synth.synthetic_ids(n_local, S, seed=rank)
+        ids, mask = to_dev(ids_np), to_dev(mask_np)
+    result_holder = {}
 
     def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        enc.embed_dev(ids.data_ptr(), mask.data_ptr(), N, S, out.data_ptr(), stream=stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+        if rerank:
+            scores = D.sharded_rerank_scores(enc, ids, mask, types, n_total=n_total)
+            result_holder["order"] = D.rerank_order_arrays(scores)  # D2H + stable descending sort on the host
+            result_holder["scores"] = scores
+        else:
+            result_holder["emb"] = D.sharded_embed(enc, ids, mask, n_total=n_total)
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     sync()
     # The matrix-core GEMMs hold ~85 % of the time, so the dominant kernel is one of them: only
     # their launches are bracketed by HIP events inside the timed region (events on every one of
-    # the 44 launches per chunk cost ~2.5 % throughput).  The full per-kernel table comes from one
+    # the launches of a chunk cost ~2.5 % throughput).  The full per-kernel table comes from one
     # extra, untimed step below.
     GEMM_KINDS = ("gemm_qkv", "gemm_out_proj", "gemm_fc1", "gemm_fc2")
-    if not args.no_profile:
+    profile = not args.no_profile and not dry
+    if profile:
         enc.profile_begin(GEMM_KINDS)
     sync()
     t0 = time.perf_counter()
@@ -147,9 +296,9 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    stats = enc.profile_end() if not args.no_profile else []
+    stats = enc.profile_end() if profile else []
     all_stats = []
-    if not args.no_profile and rank == 0 and world == 1:
+    if profile and rank == 0 and world == 1:
         enc.profile_begin()
         step()
         all_stats = enc.profile_end()
@@ -158,34 +307,77 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity: outputs are unit vectors
-    norms = torch.linalg.vector_norm(out[:1024], dim=1)
-    assert torch.allclose(norms, torch.ones_like(norms), atol=1e-4), "embeddings are not L2-normalised"
+    # sanity on what the step produced
+    if rerank:
+        sc, order = result_holder["scores"], result_holder["order"]
+        assert sc.shape == (n_total,) and bool(torch.isfinite(sc).all()), "rerank scores are not finite"
+        assert order[0].shape == (n_total,) and bool((order[1][:-1] >= order[1][1:]).all()), "order is not descending"
+        assert bool(torch.equal(torch.sort(order[0]).values, torch.arange(n_total))), "order is not a permutation"
+    else:
+        emb = result_holder["emb"]
+        assert emb.shape == (n_total, H)
+        norms = torch.linalg.vector_norm(emb[:: max(1, n_total // 4096)], dim=1)
+        assert torch.allclose(norms, torch.ones_like(norms), atol=1e-4), "embeddings are not L2-normalised"
+
+    extras = {}
+    if rank == 0 and world == 1 and not rerank and not dry and not args.no_extras:
+        # PCIe-inclusive rate: the same 65 536 x 128 workload through host pointers (kjarni_hip_encoder_embed_host:
+        # H2D of ids/mask, D2H of the [N,384] embeddings inside the timed region); and ragged lengths U{16..128}.
+        enc.embed(ids_np[:1024], mask_np[:1024])
+        t1 = time.perf_counter()
+        for _ in range(2):
+            enc.embed(ids_np, mask_np)
+        extras["value_host_ptrs"] = round(2 * n_local / (time.perf_counter() - t1), 1)
+        rid, rmask = synth.synthetic_ids(n_local, S, seed=7, ragged=True)
+        rid_d, rmask_d = to_dev(rid), to_dev(rmask)
+        out = torch.empty((n_local, H), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), 1024, S, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), n_local, S, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        extras["value_ragged"] = round(2 * n_local / (time.perf_counter() - t1), 1)
+        extras["extras_note"] = ("value_host_ptrs: ids/mask handed over as host buffers, embeddings returned to the "
+                                 "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128; 2 steps each")
 
     if rank == 0:
-        total = world * N * args.steps
+        total = n_total * args.steps
         value = total / elapsed
         fps = flops_per_sentence(H, enc.num_layers, cfg["intermediate_size"], S)
+        if rerank:
+            fps += 2 * H * H + 2 * H  # pooler + classifier
+            metric, unit = "pairs/sec minilm-l6-v2-cross-encoder rerank (seq=128)", "pairs/s"
+            workload = (f"minilm-l6-v2-cross-encoder Reranker over {n_total} synthetic query-doc pairs, seq_len=128, fp32, "
+                        f"batch-sharded across {world} GPU(s) with an all-gather of the scores and the host's stable "
+                        "descending sort inside the timed region (BASELINE.json configs[2]); random-init weights of that "
+                        "architecture")
+            shard = f"rows x{world}" + (" + RCCL all-gather of [N] scores" if world > 1 else "")
+        else:
+            metric, unit = "sentences/sec minilm-l6-v2 batch encode (seq=128)", "sentences/s"
+            workload = ("minilm-l6-v2 Embedder: 65 536 synthetic sentences per GPU, seq_len=128, fp32 "
+                        "(BASELINE.json configs[1]); random-init weights of that architecture")
+            shard = f"rows x{world}" + (" + RCCL all-gather of [N,384] outputs" if world > 1 else "")
         result = {
-            "metric": "sentences/sec minilm-l6-v2 batch encode (seq=128)",
+            "metric": metric,
             "value": round(value, 1),
-            "unit": "sentences/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if rerank else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "minilm-l6-v2 Embedder: 65 536 synthetic sentences per GPU, seq_len=128, fp32 "
-                                   "(BASELINE.json configs[1]); random-init weights of that architecture",
-                       "sentences_per_gpu": N, "seq_len": S, "sharding": f"rows x{world}" +
-                       (" + RCCL all-gather of [N,384] outputs" if world > 1 else "")},
-            "e2e_tflops": round(value * fps / 1e12, 2),
-            "e2e_frac_fp32_mfma_peak": round(value * fps / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            "data": "dry-run" if dry else "synthetic",
+            "config": {"workload": workload, "rows_per_step": n_total, "rows_per_gpu": n_local, "seq_len": S,
+                       "sharding": shard},
         }
+        if not dry:
+            result["e2e_tflops"] = round(value * fps / 1e12, 2)
+            result["e2e_frac_fp32_mfma_peak"] = round(value * fps / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)
         if stats:
             by_symbol = {}
             for s in stats:
@@ -219,10 +411,11 @@ def main():
                                 "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2) if s["flops"] else None,
                                 "gbs": round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)}
                     for s in all_stats if s["launches"]}
-        if world == 1 and not args.no_cpu_baseline:
+        result.update(extras)
+        if world == 1 and not rerank and not dry and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, tensors)
             result["speedup_vs_cpu_baseline"] = round(value / result["cpu_baseline"]["value"], 1)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
 The reference is single-process (no communication layer at
 all); this is the MI355X-side addition the north star asks for: every sentence /
 query-document pair is independent (no cross-row reduction anywhere on the path),
-so rows are split into contiguous blocks of ceil(N/G), one process per GPU, weights
+so rows are split into balanced contiguous blocks (floor(N/G) or one more), one process per GPU, weights
 replicated, and ONE collective at the end -- an RCCL all-gather of the [N/G, H]
 embedding slab (or [N/G] rerank scores) -- leaves the full result on every rank.
 xGMI is point-to-point, so the single large all-gather (12.6 MB/rank for the
@@ -22,28 +22,43 @@ import torch.distributed as dist
 
 
 def shard_rows(n: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous block partition: rank r owns rows [start, start+count) with
-    count = ceil(n/world) except for the tail ranks (possibly 0)."""
-    per = -(-n // world) if world > 0 else n
-    start = min(rank * per, n)
-    return start, max(0, min(per, n - start))
+    """Balanced contiguous partition: every rank owns floor(n/world) rows and the
+    first n % world ranks one more, so no rank idles while another holds two rows'
+    worth (n = 9, world = 8 gives 2,1,1,1,1,1,1,1 -- not 2,2,2,2,1,0,0,0)."""
+    if world <= 0:
+        return 0, n
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
 
 
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Gathers row blocks produced under shard_rows() into the full [n_total, ...]
-    tensor on every rank.  Uneven tails are padded to the common block size for
-    the collective and trimmed afterwards."""
+    tensor on every rank.  Blocks differ by at most one row: they are padded to the
+    common size for the ONE collective and compacted afterwards."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local
-    per = -(-n_total // world)
-    tail = local.shape[1:]
+    base, rem = divmod(n_total, world)
+    per = base + (1 if rem else 0)
+    tail = tuple(local.shape[1:])
     if local.shape[0] < per:
-        pad = torch.zeros((per - local.shape[0],) + tuple(tail), dtype=local.dtype, device=local.device)
+        pad = torch.zeros((per - local.shape[0],) + tail, dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
-    out = torch.empty((world * per,) + tuple(tail), dtype=local.dtype, device=local.device)
+    out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out[:n_total]
+    if rem == 0:
+        return out
+    # ranks < rem hold `per` rows back to back; the others have one row of padding each
+    head = out[:rem * per]
+    rest = out[rem * per:].reshape((world - rem, per) + tail)[:, :base].reshape((-1,) + tail)
+    return torch.cat([head, rest], dim=0)
+
+
+def _stream_of(t: torch.Tensor) -> int:
+    """Raw HIP stream the encoder should enqueue on: torch's current stream of the tensor's device, so the
+    collective that follows (same stream) is ordered behind the kernels; 0 for host tensors (gloo tests)."""
+    return int(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else 0
 
 
 def sharded_map(fn: Callable[[int, int], torch.Tensor], n_total: int, group=None) -> torch.Tensor:
@@ -54,49 +69,65 @@ def sharded_map(fn: Callable[[int, int], torch.Tensor], n_total: int, group=None
     return all_gather_rows(fn(start, count), n_total, group)
 
 
-def rerank_order(scores: torch.Tensor, top_k: Optional[int] = None) -> List[Tuple[int, float]]:
-    """Host-side ordering of gathered rerank scores: stable sort by score
-    descending (CrossEncoder::rerank, crates/kjarni-models/src/models/cross_encoder/
-    model.rs:251-252), optional truncation (kjarni/src/reranker/model.rs:270-273)."""
+def rerank_order_arrays(scores: torch.Tensor, top_k: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host-side ordering of gathered rerank scores: stable sort by score descending
+    (CrossEncoder::rerank, crates/kjarni-models/src/models/cross_encoder/model.rs:251-252),
+    optional truncation (kjarni/src/reranker/model.rs:270-273).  Returns (index int64 [k],
+    score f32 [k]) host tensors: `index` = position in the input, as KjarniRerankResult.index."""
     s = scores.detach().to("cpu", torch.float32)
-    order = torch.sort(s, descending=True, stable=True).indices.tolist()
+    order = torch.sort(s, descending=True, stable=True).indices
     if top_k is not None:
         order = order[:top_k]
-    return [(i, float(s[i])) for i in order]
+    return order, s[order]
 
 
-def sharded_embed(enc, ids: torch.Tensor, mask: torch.Tensor, group=None) -> torch.Tensor:
-    """ids/mask: int32 [N, S] device tensors holding the FULL batch on every rank
-    (or at least this rank's rows).  Returns [N, H] embeddings on every rank."""
-    n, s = ids.shape
-    h = enc.hidden_size
-
-    def run(start, count):
-        out = torch.empty((count, h), dtype=torch.float32, device=ids.device)
-        if count:
-            stream = torch.cuda.current_stream().cuda_stream
-            enc.embed_dev(ids[start:start + count].data_ptr(), mask[start:start + count].data_ptr(), count, s,
-                          out.data_ptr(), stream=stream)
-        return out
-
-    return sharded_map(run, n, group)
+def rerank_order(scores: torch.Tensor, top_k: Optional[int] = None) -> List[Tuple[int, float]]:
+    """rerank_order_arrays as a list of (index, score) pairs."""
+    idx, sc = rerank_order_arrays(scores, top_k)
+    return list(zip(idx.tolist(), sc.tolist()))
 
 
-def sharded_rerank_scores(enc, ids: torch.Tensor, mask: torch.Tensor, types: torch.Tensor, group=None
-                          ) -> torch.Tensor:
-    """Pre-tokenised (query, doc) pairs [N, S] -> scores [N] (logit column 0) on every rank."""
-    n, s = ids.shape
-    labels = enc.num_labels
+def _local_view(t: torch.Tensor, n_total: Optional[int], group) -> Tuple[torch.Tensor, int]:
+    """(this rank's rows of t, n_total).  n_total None: t holds the full batch and is sliced; otherwise t IS this
+    rank's shard of a batch of n_total rows (weak scaling: no rank ever materialises the other ranks' inputs)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if n_total is None:
+        start, count = shard_rows(t.shape[0], world, rank)
+        return t[start:start + count], t.shape[0]
+    _, count = shard_rows(n_total, world, rank)
+    if t.shape[0] != count:
+        raise ValueError(f"rank {rank} holds {t.shape[0]} rows, its shard of {n_total} rows over {world} ranks is {count}")
+    return t, n_total
 
-    def run(start, count):
-        out = torch.empty((count, labels), dtype=torch.float32, device=ids.device)
-        if count:
-            stream = torch.cuda.current_stream().cuda_stream
-            enc.logits_dev(ids[start:start + count].data_ptr(), mask[start:start + count].data_ptr(),
-                           types[start:start + count].data_ptr(), count, s, out.data_ptr(), stream=stream)
-        return out[:, 0].contiguous()
 
-    return sharded_map(run, n, group)
+def sharded_embed(enc, ids: torch.Tensor, mask: torch.Tensor, group=None, n_total: Optional[int] = None
+                  ) -> torch.Tensor:
+    """ids/mask: int32 [N, S] tensors holding the full batch on every rank, or (with n_total) this rank's shard.
+    Every rank encodes its row block (SentenceEncoder::encode_batch_flat semantics: mean pool + L2) and ONE
+    all-gather leaves the [N, H] embeddings on every rank."""
+    ids_l, n = _local_view(ids, n_total, group)
+    mask_l, _ = _local_view(mask, n_total, group)
+    count, s = ids_l.shape
+    out = torch.empty((count, enc.hidden_size), dtype=torch.float32, device=ids.device)
+    if count:
+        enc.embed_dev(ids_l.data_ptr(), mask_l.data_ptr(), count, s, out.data_ptr(), stream=_stream_of(ids))
+    return all_gather_rows(out, n, group)
+
+
+def sharded_rerank_scores(enc, ids: torch.Tensor, mask: torch.Tensor, types: torch.Tensor, group=None,
+                          n_total: Optional[int] = None) -> torch.Tensor:
+    """Pre-tokenised (query, doc) pairs [N, S] -> scores [N] (logit column 0, CrossEncoder::predict_pairs,
+    cross_encoder/model.rs:170-240) on every rank; the caller orders them with rerank_order()."""
+    ids_l, n = _local_view(ids, n_total, group)
+    mask_l, _ = _local_view(mask, n_total, group)
+    types_l, _ = _local_view(types, n_total, group)
+    count, s = ids_l.shape
+    out = torch.empty((count, enc.num_labels), dtype=torch.float32, device=ids.device)
+    if count:
+        enc.logits_dev(ids_l.data_ptr(), mask_l.data_ptr(), types_l.data_ptr(), count, s, out.data_ptr(),
+                       stream=_stream_of(ids))
+    return all_gather_rows(out[:, 0].contiguous(), n, group)
 
 
 def sharded_cosine_topk(local_idx: torch.Tensor, local_score: torch.Tensor, row_offset: int, k: int, group=None

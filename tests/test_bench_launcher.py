@@ -1,0 +1,48 @@
+"""bench.py's own launcher: `python bench.py --gpus 2` (no torchrun) must spawn its ranks, run the sharded
+workloads through kjarni_amd.distributed and print exactly one JSON line.  Exercised on the CPU with --dry-run-cpu
+(gloo + a host stub in place of the HIP encoder); the GPU path differs only in the encoder object and the backend."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, launcher=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,extra", [("rerank", ["--pairs", "257"]), ("embed", ["--sentences", "65"])])
+def test_plain_invocation_spawns_its_ranks(workload, extra):
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--dry-run-cpu", *extra])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["data"] == "dry-run"
+    if workload == "rerank":
+        assert r["scaling"] == "strong" and r["config"]["rows_per_step"] == 257 and r["config"]["rows_per_gpu"] == 129
+        assert r["unit"] == "pairs/s"
+    else:
+        assert r["scaling"] == "weak" and r["config"]["rows_per_step"] == 130 and r["unit"] == "sentences/s"
+    assert r["value"] > 0 and r["higher_is_better"] is True and r["vs_baseline"] is None
+
+
+def test_under_torchrun():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "rerank", "--pairs", "100", "--dry-run-cpu"],
+             launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", "29533"))
+    assert r["n_gpus"] == 2 and r["config"]["rows_per_gpu"] == 50
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr

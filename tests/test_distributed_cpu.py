@@ -1,7 +1,10 @@
 """N > 1 path on CPU: world_size-2 gloo processes exercise the row partition,
 the (uneven) all-gather, the rerank ordering and the sharded top-k merge with a
-deterministic stand-in for the per-row compute (the HIP encoder itself needs a
-GPU; its parity is covered by the -m gpu tests)."""
+deterministic stand-in for the per-row compute, and drive sharded_embed /
+sharded_rerank_scores themselves through a host stub with HipEncoder's
+interface (the HIP encoder needs a GPU: tests/test_gpu_distributed.py runs the
+same functions through it against the oracle)."""
+import ctypes as C
 import os
 import socket
 
@@ -23,9 +26,10 @@ def test_shard_rows_partition():
             for s, c in blocks:
                 assert s == min(pos, n)
                 pos += c
-            per = -(-n // world)
-            assert all(c <= per for _, c in blocks)
+            counts = [c for _, c in blocks]
+            assert max(counts) - min(counts) <= 1 and counts == sorted(counts, reverse=True)
     assert D.shard_rows(100000, 8, 7) == (87500, 12500)
+    assert [D.shard_rows(9, 8, r)[1] for r in range(8)] == [2, 1, 1, 1, 1, 1, 1, 1]  # no idle rank
 
 
 def test_rerank_order_is_stable_descending():
@@ -46,6 +50,48 @@ def _fake_rows(start, count, width):
     return torch.stack([torch.sin(r * (j + 1)) for j in range(width)], dim=1) if width else r
 
 
+def _host_u32(ptr, rows, seq):
+    return np.ctypeslib.as_array((C.c_uint32 * (rows * seq)).from_address(ptr)).reshape(rows, seq)
+
+
+class StubEncoder:
+    """Stands in for kjarni_amd.HipEncoder on the host (same embed_dev / logits_dev / hidden_size / num_labels):
+    raw pointers in, row r of the output depends only on row r of the inputs, so any mis-sharded, mis-ordered or
+    dropped row shows up in the gathered result."""
+    hidden_size, num_labels = 6, 2
+
+    def embed_dev(self, ids_ptr, mask_ptr, batch, seq, out_ptr, type_ptr=0, pooling=0, normalize=True, fill=0,
+                  stream=0):
+        assert stream == 0
+        ids, mask = _host_u32(ids_ptr, batch, seq), _host_u32(mask_ptr, batch, seq)
+        out = np.ctypeslib.as_array((C.c_float * (batch * self.hidden_size)).from_address(out_ptr))
+        out.reshape(batch, self.hidden_size)[:] = self.embed_rows(ids, mask)
+
+    def logits_dev(self, ids_ptr, mask_ptr, type_ptr, batch, seq, out_ptr, fill=0, stream=0):
+        ids, mask, types = (_host_u32(p, batch, seq) for p in (ids_ptr, mask_ptr, type_ptr))
+        out = np.ctypeslib.as_array((C.c_float * (batch * self.num_labels)).from_address(out_ptr))
+        out.reshape(batch, self.num_labels)[:] = self.logit_rows(ids, mask, types)
+
+    @classmethod
+    def embed_rows(cls, ids, mask):
+        x = (ids.astype(np.float64) * mask).sum(1)
+        return np.stack([np.sin(x * (j + 1) * 1e-3) for j in range(cls.hidden_size)], 1).astype(np.float32)
+
+    @classmethod
+    def logit_rows(cls, ids, mask, types):
+        x = (ids.astype(np.float64) * mask * (1 + types)).sum(1)
+        return np.stack([np.cos(x * 1e-3), np.sin(x * 1e-3)], 1).astype(np.float32)
+
+
+def _token_batch(n, seq=8):
+    rng = np.random.default_rng(n)
+    ids = rng.integers(1, 30000, (n, seq), dtype=np.int64).astype(np.uint32)
+    mask = (rng.random((n, seq)) < 0.8).astype(np.uint32)
+    types = (rng.random((n, seq)) < 0.5).astype(np.uint32)
+    t = lambda a: torch.from_numpy(a.view(np.int32))  # noqa: E731
+    return (ids, mask, types), (t(ids), t(mask), t(types))
+
+
 def _worker(rank, world, port, n_list, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,6 +106,23 @@ def _worker(rank, world, port, n_list, q):
             ref = (_fake_rows(0, n, 0) * 0.37).cos()
             ok &= bool(torch.equal(sc, ref))
             ok &= D.rerank_order(sc, 5) == D.rerank_order(ref, 5)
+            # the product entry points themselves, full batch on every rank ...
+            enc = StubEncoder()
+            (ids, mask, types), (tids, tmask, ttypes) = _token_batch(n)
+            want_e = torch.from_numpy(enc.embed_rows(ids, mask)) if n else torch.zeros((0, enc.hidden_size))
+            want_s = torch.from_numpy(enc.logit_rows(ids, mask, types)[:, 0]) if n else torch.zeros((0,))
+            got_e = D.sharded_embed(enc, tids, tmask)
+            got_s = D.sharded_rerank_scores(enc, tids, tmask, ttypes)
+            ok &= got_e.shape == want_e.shape and bool(torch.equal(got_e, want_e))
+            ok &= got_s.shape == want_s.shape and bool(torch.equal(got_s, want_s))
+            # ... and with every rank holding only its own shard (the weak-scaling bench's form)
+            st, cnt = D.shard_rows(n, world, rank)
+            sl = slice(st, st + cnt)
+            got_e = D.sharded_embed(enc, tids[sl].contiguous(), tmask[sl].contiguous(), n_total=n)
+            got_s = D.sharded_rerank_scores(enc, tids[sl].contiguous(), tmask[sl].contiguous(),
+                                            ttypes[sl].contiguous(), n_total=n)
+            ok &= bool(torch.equal(got_e, want_e)) and bool(torch.equal(got_s, want_s))
+            ok &= D.rerank_order(got_s) == D.rerank_order(want_s)
         # sharded cosine top-k merge: corpus rows split, local top-k, global merge
         rng = np.random.default_rng(0)
         scores = torch.from_numpy(rng.standard_normal(1001).astype(np.float32))
