@@ -80,13 +80,27 @@ def host_description():
             info["smt_active"] = f.read().strip() == "1"
     except Exception:
         pass
+    # What this process may actually use: the affinity mask and the cgroup CPU quota (a container on a 128-core
+    # host is typically given a fraction of it; threads beyond the quota only fight each other for time slices).
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info["affinity_cpus"] = usable
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            info["cgroup_cpu_quota"] = round(int(quota) / int(period), 2)
+            usable = min(usable, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    info["usable_cpus"] = usable
     return info
 
 
 def cpu_baseline(cfg, tensors, budget_s=36.0, cap_sentences=4096):
     """The reference's CPU path as oracle/kjarni_cpu_baseline.c ports it (fused QKV, 64-row / 4x3 AVX2 GEMM
     blocks, per-(b,h) attention GEMMs, persistent buffers), one thread per physical core (the reference pins its
-    rayon pool that way, kjarni-ffi/src/lib.rs:37-40).  Four figures: calls of 32 (the
+    rayon pool that way, kjarni-ffi/src/lib.rs:37-40) -- of the cores this process is allowed to use: the GPU
+    box runs under a cgroup CPU quota, and 128 threads on a 16-CPU quota measured 10x slower than 16.  Four figures: calls of 32 (the
     Indexer default, kjarni-ffi/src/indexer.rs:132) and of 256 sentences, with the reference's serial row loops
     (softmax, LayerNorm, mask, residual) and with those loops parallelised.  Each figure: one warm-up call, then
     the median of 3 passes over up to `cap_sentences` sentences, passes bounded so the whole leg stays near
@@ -95,7 +109,7 @@ def cpu_baseline(cfg, tensors, budget_s=36.0, cap_sentences=4096):
     from oracle import cpu_baseline as CB
     from tests import synth
     host = host_description()
-    cores = int(host.get("physical_cores") or os.cpu_count() or 1)
+    cores = int(min(host.get("physical_cores") or os.cpu_count() or 1, host["usable_cpus"]))
     CB.lib().kb_set_num_threads(cores)
     model = CB.BaselineModel(tensors, cfg, max_batch=256, max_seq=SEQ)
     ids, mask = synth.synthetic_ids(cap_sentences, SEQ, seed=0)

@@ -73,7 +73,15 @@ int32_t kjarni_hip_encoder_device(const KjarniHipEncoder* enc);
 /* Tokens processed per internal chunk (workspace size); 0 keeps the default. */
 KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64_t tokens);
 
-/* hidden_out_dev: f32 [batch, seq, hidden].  type_ids_dev may be NULL (token
+/* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
+ * calls may be made concurrently from any number of host threads and on any streams, as on the reference's
+ * handles (its model types are Send + Sync, crates/kjarni-ffi/src/lib.rs:25-32).  The weights are immutable; each
+ * call leases one of up to 4 activation workspaces of the handle (a fifth concurrent call waits for a lease),
+ * and a workspace that moves from one stream to another is ordered by an event.  Device-pointer forms only
+ * ENQUEUE on `stream` (NULL = the legacy default stream); host-pointer forms run on a stream of their own and
+ * return when the result is in the caller's buffer.  The profiler (profile_begin / _end) is single-caller.
+ *
+ * hidden_out_dev: f32 [batch, seq, hidden].  type_ids_dev may be NULL (token
  * type row 0 is added to every token, cpu/embeddings/mod.rs:216-223). */
 KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
                                                  const uint32_t* mask_dev, const uint32_t* type_ids_dev,
@@ -107,6 +115,48 @@ KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* enc, const uint
                                                int64_t batch, int32_t seq, KjarniHipMaskFill fill,
                                                float* logits_out);
 
+/* ---- several devices in one process ---------------------------------------------------
+ * A group holds one replica of the model per listed device (weights replicated, ~90 MB for MiniLM).  Rows are
+ * independent on this path, so a batch is cut into balanced contiguous row blocks -- floor(rows / n) each, the first
+ * rows % n one more (kjarni_hip_group_shard) -- one host thread + one stream per device, no exchange inside the
+ * layer loop.  This is what the string-level handles (kjarni_embedder_*, kjarni_reranker_*, kjarni_classifier_*)
+ * use internally with the devices of KJARNI_HIP_DEVICES="0,1,..." (default: every visible device; a device may be
+ * listed twice); n_devices = 0 here means the same list.  A batch smaller than 8 rows per device uses fewer
+ * devices, chosen in rotation. */
+typedef struct KjarniHipEncoderGroup KjarniHipEncoderGroup;
+KjarniErrorCode kjarni_hip_group_load(const char* model_dir, const int32_t* devices, size_t n_devices,
+                                      KjarniHipEncoderGroup** out);
+void kjarni_hip_group_free(KjarniHipEncoderGroup* group);
+size_t kjarni_hip_group_size(const KjarniHipEncoderGroup* group);
+int32_t kjarni_hip_group_device(const KjarniHipEncoderGroup* group, size_t i);
+int32_t kjarni_hip_group_hidden_size(const KjarniHipEncoderGroup* group);
+int32_t kjarni_hip_group_num_labels(const KjarniHipEncoderGroup* group);
+/* Row block [*start_out, *start_out + *count_out) of `rows` rows that replica i owns. */
+KjarniErrorCode kjarni_hip_group_shard(const KjarniHipEncoderGroup* group, int64_t rows, size_t i, int64_t* start_out,
+                                       int64_t* count_out);
+/* Host pointers: every device stages, encodes and returns its block straight into `out` ([batch, hidden] /
+ * [batch, num_labels]); the mask fill follows the size of the whole call. */
+KjarniErrorCode kjarni_hip_group_embed_host(KjarniHipEncoderGroup* group, const uint32_t* ids, const uint32_t* mask,
+                                            const uint32_t* type_ids, int64_t batch, int32_t seq, KjarniHipPooling pooling,
+                                            int32_t normalize, KjarniHipMaskFill fill, float* out);
+KjarniErrorCode kjarni_hip_group_logits_host(KjarniHipEncoderGroup* group, const uint32_t* ids, const uint32_t* mask,
+                                             const uint32_t* type_ids, int64_t batch, int32_t seq, KjarniHipMaskFill fill,
+                                             float* logits_out);
+/* Device-resident: ids_dev[i] / mask_dev[i] / type_ids_dev[i] point at replica i's row block ON device i, out_dev[i]
+ * at a full [batch_total, hidden] (or [batch_total, num_labels]) buffer on device i.  Every replica computes its block
+ * in place, then ONE collective leaves the whole output in every buffer: ncclAllGather over xGMI (grouped
+ * ncclBroadcast when the blocks differ by a row) when the devices are distinct, peer copies otherwise.  Returns when
+ * the collective has completed.  type_ids_dev may be NULL.  kjarni_hip_group_transport: "rccl" or "memcpy". */
+KjarniErrorCode kjarni_hip_group_embed_allgather(KjarniHipEncoderGroup* group, const uint32_t* const* ids_dev,
+                                                 const uint32_t* const* mask_dev, const uint32_t* const* type_ids_dev,
+                                                 int64_t batch_total, int32_t seq, KjarniHipPooling pooling,
+                                                 int32_t normalize, KjarniHipMaskFill fill, float* const* out_dev);
+KjarniErrorCode kjarni_hip_group_logits_allgather(KjarniHipEncoderGroup* group, const uint32_t* const* ids_dev,
+                                                  const uint32_t* const* mask_dev, const uint32_t* const* type_ids_dev,
+                                                  int64_t batch_total, int32_t seq, KjarniHipMaskFill fill,
+                                                  float* const* logits_out_dev);
+const char* kjarni_hip_group_transport(KjarniHipEncoderGroup* group);
+
 /* ---- single operators (host pointers) ---------------------------------------------
  * The kernels of the forward pass, one at a time, at the granularity of the
  * reference's own operator types: LinearLayer::matmul (+ fused epilogue),
@@ -136,14 +186,12 @@ KjarniErrorCode kjarni_hip_op_attention(int32_t device, const float* qkv, const 
 KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const float* gamma, const float* beta,
                                          float eps, int64_t rows, int32_t hidden, float* y, int32_t iters,
                                          float* ms_out);
-/* Tuning hook: selects the projection-GEMM tiling variant for subsequent launches in this
- * process (0 = default).  Every variant computes the same function. */
-void kjarni_hip_set_gemm_variant(int32_t variant);
-/* Same for the attention kernel (0 = default persistent kernel for seq <= 128, 1 = one workgroup per item). */
-void kjarni_hip_set_attention_variant(int32_t variant);
-/* Cosine scan (0 = default: from 20 queries on the dot products go through the matrix-core GEMM;
- * 1 = always one streaming pass per 4 queries). */
-void kjarni_hip_set_cosine_variant(int32_t variant);
+/* y = LayerNorm(x . w^T + bias + residual) * gamma + beta -- the post-norm layer's residual projection with the
+ * LayerNorm folded into the GEMM epilogue where the kernel covers the row width n (384, 256), otherwise GEMM + LayerNorm
+ * (encoder_layer.rs:129-147, 155-176; layer_norm.rs:37-131). */
+KjarniErrorCode kjarni_hip_op_linear_layer_norm(int32_t device, const float* x, const float* w, const float* bias,
+                                                const float* residual, const float* gamma, const float* beta, float eps,
+                                                int64_t m, int32_t k, int32_t n, float* y, int32_t iters, float* ms_out);
 
 /* ---- per-kernel timing (HIP events on the launch stream) -------------------------
  * profile_begin() switches the encoder into timed mode: every kernel launch of the

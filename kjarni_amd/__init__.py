@@ -6,7 +6,7 @@ kjarni_amd/lib/libkjarni_ffi.so (hand-written gfx950 HIP kernels + C++ host).
 """
 from ._ffi import KjarniDevice, KjarniError, KjarniException, lib  # noqa: F401
 from .encoder import (COSINE_SEGMENT, COSINE_VECTOR_STORE, MASK_AUTO, MASK_NEG_1E9, MASK_NEG_INF,  # noqa: F401
-                      POOL_CLS, POOL_LAST_TOKEN, POOL_MAX, POOL_MEAN, HipEncoder, cosine_search,
+                      POOL_CLS, POOL_LAST_TOKEN, POOL_MAX, POOL_MEAN, HipEncoder, HipEncoderGroup, cosine_search,
                       device_count)
 
 from .classifier import Classifier  # noqa: F401,E402

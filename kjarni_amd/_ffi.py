@@ -430,9 +430,23 @@ SIGNATURES = {
                                           _f32p, c_int32, _f32p]),
     "kjarni_hip_op_layer_norm": (c_int32, [c_int32, _f32p, _f32p, _f32p, c_float, c_int64, c_int32, _f32p,
                                            c_int32, _f32p]),
-    "kjarni_hip_set_gemm_variant": (None, [c_int32]),
-    "kjarni_hip_set_attention_variant": (None, [c_int32]),
-    "kjarni_hip_set_cosine_variant": (None, [c_int32]),
+    "kjarni_hip_op_linear_layer_norm": (c_int32, [c_int32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, c_float, c_int64,
+                                                  c_int32, c_int32, _f32p, c_int32, _f32p]),
+    "kjarni_hip_group_load": (c_int32, [c_char_p, POINTER(c_int32), c_size_t, POINTER(c_void_p)]),
+    "kjarni_hip_group_free": (None, [c_void_p]),
+    "kjarni_hip_group_size": (c_size_t, [c_void_p]),
+    "kjarni_hip_group_device": (c_int32, [c_void_p, c_size_t]),
+    "kjarni_hip_group_hidden_size": (c_int32, [c_void_p]),
+    "kjarni_hip_group_num_labels": (c_int32, [c_void_p]),
+    "kjarni_hip_group_shard": (c_int32, [c_void_p, c_int64, c_size_t, POINTER(c_int64), POINTER(c_int64)]),
+    "kjarni_hip_group_embed_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                              _f32p]),
+    "kjarni_hip_group_logits_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32, _f32p]),
+    "kjarni_hip_group_embed_allgather": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                   c_int64, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "kjarni_hip_group_logits_allgather": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                    c_int64, c_int32, c_int32, POINTER(c_void_p)]),
+    "kjarni_hip_group_transport": (c_char_p, [c_void_p]),
     "kjarni_hip_encoder_profile_begin": (c_int32, [c_void_p]),
     "kjarni_hip_encoder_profile_begin_kinds": (c_int32, [c_void_p, C.c_uint32]),
     "kjarni_hip_encoder_profile_end": (c_int32, [c_void_p, POINTER(KjarniHipKernelStat), c_size_t,

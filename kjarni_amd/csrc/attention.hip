@@ -26,6 +26,8 @@
 // One chunk (seq <= 128) follows the reference's op order exactly
 // (max, exp(x-max), sum, p = e * (1/sum), then PV).  Longer sequences use the
 // online-softmax recurrence over chunks and normalise at the end.
+#include <atomic>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -33,7 +35,11 @@ namespace kjarni {
 
 namespace {
 
-int g_attention_variant = 0;  // 0: persistent pipelined kernel for seq <= 128 (default), 1: plain kernel
+#ifdef KJARNI_TUNING
+std::atomic<int> g_attention_variant{0};  // 0: persistent pipelined kernel for seq <= 128 (default), 1: plain kernel -- tuning build only
+#else
+constexpr int g_attention_variant = 0;
+#endif
 
 constexpr int QBLK = 128;   // queries per workgroup
 constexpr int KCHUNK = 128; // keys per LDS chunk
@@ -541,7 +547,9 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
 
 }  // namespace
 
+#ifdef KJARNI_TUNING
 void set_attention_variant(int v) { g_attention_variant = v; }
+#endif
 
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads,
                             int head_dim, float mask_value, float* ctx, hipStream_t stream)

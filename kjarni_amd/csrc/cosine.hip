@@ -16,6 +16,8 @@
 // (orderable score bits << 32 | ~index) with LDS bitonic networks: each block
 // reduces a segment of 2048..16384 candidates to its best KPAD, levels repeat until
 // one block is left.
+#include <atomic>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -23,7 +25,11 @@ namespace kjarni {
 
 namespace {
 
-int g_scan_variant = 0;          // 1 = never take the GEMM route (tests / measurements)
+#ifdef KJARNI_TUNING
+std::atomic<int> g_scan_variant{0};  // 1 = never take the GEMM route -- tuning build only
+#else
+constexpr int g_scan_variant = 0;
+#endif
 constexpr int SCAN_NQ = 4;       // queries held in registers per pass
 constexpr int SCAN_MAX_V4 = 4;   // dim <= 1024 on the float4 path
 
@@ -590,7 +596,9 @@ hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_
 
 }  // namespace
 
+#ifdef KJARNI_TUNING
 void set_cosine_variant(int variant) { g_scan_variant = variant; }
+#endif
 
 // Workspace: two ping-pong key buffers sized for the first level's output, plus
 // one `upper` key per query.

@@ -43,15 +43,19 @@ static std::string read_file(const std::string& path)
 EncoderModel::~EncoderModel()
 {
     (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
     for (void* p : allocs_) (void)hipFree(p);
     for (hipEvent_t e : prof_pool_) (void)hipEventDestroy(e);
     for (const PendingEvent& pe : prof_pending_) {
         (void)hipEventDestroy(pe.start);
         (void)hipEventDestroy(pe.stop);
     }
-    for (void* p : {(void*)ws_hidden_, (void*)ws_qkv_, (void*)ws_ctx_, (void*)ws_mid_, (void*)ws_feat_,
-                    scratch_, scratch2_})
-        if (p) (void)hipFree(p);
+    for (auto& w : ws_all_) {
+        for (void* p : {(void*)w->hidden, (void*)w->qkv, (void*)w->ctx, (void*)w->mid, (void*)w->feat, w->stage})
+            if (p) (void)hipFree(p);
+        if (w->done) (void)hipEventDestroy(w->done);
+        if (w->stream) (void)hipStreamDestroy(w->stream);
+    }
 }
 
 float* EncoderModel::upload(const std::vector<float>& host)
@@ -434,50 +438,101 @@ int64_t EncoderModel::sentences_per_chunk(int seq) const
     return n < 1 ? 1 : n;
 }
 
-void EncoderModel::ensure_workspace(int64_t tokens, int64_t sentences)
+// ---- workspace pool ---------------------------------------------------------------------------------
+
+EncoderModel::Lease::Lease(EncoderModel& m, hipStream_t stream, bool own_stream) : m_(m), ws_(nullptr), stream_(stream)
 {
-    if (tokens <= ws_tokens_ && sentences <= ws_sentences_) return;
-    tokens = std::max(tokens, ws_tokens_);
-    sentences = std::max(sentences, ws_sentences_);
-    // The workspace may still be in use by earlier launches.
-    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(workspace)");
-    for (float** p : {&ws_hidden_, &ws_qkv_, &ws_ctx_, &ws_mid_, &ws_feat_})
+    hip_check(hipSetDevice(m.device_), "hipSetDevice");
+    {
+        std::unique_lock<std::mutex> lock(m.ws_mu_);
+        for (;;) {
+            if (!m.ws_free_.empty()) {
+                ws_ = m.ws_free_.back();
+                m.ws_free_.pop_back();
+                break;
+            }
+            if ((int)m.ws_all_.size() < kMaxWorkspaces) {
+                m.ws_all_.push_back(std::make_unique<Workspace>());
+                ws_ = m.ws_all_.back().get();
+                break;
+            }
+            m.ws_cv_.wait(lock);
+        }
+    }
+    try {
+        if (!ws_->stream) hip_check(hipStreamCreateWithFlags(&ws_->stream, hipStreamNonBlocking), "hipStreamCreate");
+        if (!ws_->done) hip_check(hipEventCreateWithFlags(&ws_->done, hipEventDisableTiming), "hipEventCreate");
+        if (own_stream) stream_ = ws_->stream;
+        // The previous user's launches may still be running on another stream: order this stream behind them.
+        if (ws_->done_pending && ws_->done_stream != stream_)
+            hip_check(hipStreamWaitEvent(stream_, ws_->done, 0), "hipStreamWaitEvent");
+    } catch (...) {
+        std::lock_guard<std::mutex> lock(m_.ws_mu_);
+        m_.ws_free_.push_back(ws_);
+        m_.ws_cv_.notify_one();
+        throw;
+    }
+}
+
+EncoderModel::Lease::~Lease()
+{
+    if (hipEventRecord(ws_->done, stream_) == hipSuccess) {
+        ws_->done_pending = true;
+        ws_->done_stream = stream_;
+    } else {
+        // Cannot order the next user behind this call's launches: drain them here instead.
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream_);
+        ws_->done_pending = false;
+    }
+    std::lock_guard<std::mutex> lock(m_.ws_mu_);
+    m_.ws_free_.push_back(ws_);
+    m_.ws_cv_.notify_one();
+}
+
+// Grows the activation buffers.  The recorded capacity drops to 0 BEFORE anything is freed, so a failed
+// hipMalloc (an oversized batch) leaves a workspace that the next, smaller call re-allocates instead of
+// launching kernels on null buffers.
+void EncoderModel::reserve(Workspace& ws, int64_t tokens, int64_t sentences)
+{
+    if (tokens <= ws.tokens && sentences <= ws.sentences) return;
+    tokens = std::max(tokens, ws.tokens);
+    sentences = std::max(sentences, ws.sentences);
+    // Earlier launches on this workspace may still be reading the buffers.
+    if (ws.done_pending) {
+        hip_check(hipEventSynchronize(ws.done), "hipEventSynchronize(workspace)");
+        ws.done_pending = false;
+    }
+    ws.tokens = ws.sentences = 0;
+    for (float** p : {&ws.hidden, &ws.qkv, &ws.ctx, &ws.mid, &ws.feat})
         if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
         }
     const size_t H = (size_t)cfg_.hidden, I = (size_t)cfg_.inter, T = (size_t)tokens;
-    hip_check(hipMalloc((void**)&ws_hidden_, T * H * 4), "hipMalloc(ws_hidden)");
-    hip_check(hipMalloc((void**)&ws_qkv_, T * 3 * H * 4), "hipMalloc(ws_qkv)");
-    hip_check(hipMalloc((void**)&ws_ctx_, T * H * 4), "hipMalloc(ws_ctx)");
-    hip_check(hipMalloc((void**)&ws_mid_, T * I * 4), "hipMalloc(ws_mid)");
-    hip_check(hipMalloc((void**)&ws_feat_, (size_t)sentences * H * 4), "hipMalloc(ws_feat)");
-    ws_tokens_ = tokens;
-    ws_sentences_ = sentences;
+    hip_check(hipMalloc((void**)&ws.hidden, T * H * 4), "hipMalloc(ws_hidden)");
+    hip_check(hipMalloc((void**)&ws.qkv, T * 3 * H * 4), "hipMalloc(ws_qkv)");
+    hip_check(hipMalloc((void**)&ws.ctx, T * H * 4), "hipMalloc(ws_ctx)");
+    hip_check(hipMalloc((void**)&ws.mid, T * I * 4), "hipMalloc(ws_mid)");
+    hip_check(hipMalloc((void**)&ws.feat, (size_t)sentences * H * 4), "hipMalloc(ws_feat)");
+    ws.tokens = tokens;
+    ws.sentences = sentences;
 }
 
-static void* grow(void*& p, size_t& have, size_t want)
+void* EncoderModel::reserve_stage(Workspace& ws, size_t bytes)
 {
-    if (want > have) {
-        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(scratch)");
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        hip_check(hipMalloc(&p, want), "hipMalloc(scratch)");
-        have = want;
+    if (bytes > ws.stage_bytes) {
+        if (ws.done_pending) {
+            hip_check(hipEventSynchronize(ws.done), "hipEventSynchronize(stage)");
+            ws.done_pending = false;
+        }
+        ws.stage_bytes = 0;
+        if (ws.stage) (void)hipFree(ws.stage);
+        ws.stage = nullptr;
+        hip_check(hipMalloc(&ws.stage, bytes), "hipMalloc(stage)");
+        ws.stage_bytes = bytes;
     }
-    return p;
-}
-
-void* EncoderModel::scratch(size_t bytes)
-{
-    hip_check(hipSetDevice(device_), "hipSetDevice");
-    return grow(scratch_, scratch_bytes_, bytes);
-}
-
-void* EncoderModel::scratch2(size_t bytes)
-{
-    hip_check(hipSetDevice(device_), "hipSetDevice");
-    return grow(scratch2_, scratch2_bytes_, bytes);
+    return ws.stage;
 }
 
 namespace {
@@ -487,9 +542,10 @@ const char* const kKindNames[KK_COUNT] = {"embed_layernorm", "gemm_qkv", "attent
 
 void EncoderModel::profile_begin(uint32_t kinds_mask)
 {
-    prof_mask_ = kinds_mask;
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    std::lock_guard<std::mutex> lock(prof_mu_);
+    prof_mask_ = kinds_mask;
     for (const PendingEvent& pe : prof_pending_) {
         prof_pool_.push_back(pe.start);
         prof_pool_.push_back(pe.stop);
@@ -498,9 +554,10 @@ void EncoderModel::profile_begin(uint32_t kinds_mask)
     const char* act_sym = cfg_.ffn_act == EPI_BIAS_GELU ? "gemm_nt_f32_mfma<EPI_BIAS_GELU>"
                           : cfg_.ffn_act == EPI_BIAS_GELU_NEW ? "gemm_nt_f32_mfma<EPI_BIAS_GELU_NEW>"
                                                               : "gemm_nt_f32_mfma<EPI_BIAS_RELU>";
+    const char* res_sym = fuse_layernorm() ? "gemm_nt_f32_mfma_ln" : "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>";
     const char* syms[KK_COUNT] = {"embed_layernorm_kernel", "gemm_nt_f32_mfma<EPI_BIAS>", "attention_kernel",
-                                  "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "layernorm_kernel", act_sym,
-                                  "gemm_nt_f32_mfma<EPI_BIAS_RESIDUAL>", "pool_kernel", "head", "rope_qk_kernel"};
+                                  res_sym, "layernorm_kernel", act_sym, res_sym, "pool_kernel", "head",
+                                  "rope_qk_kernel"};
     for (int k = 0; k < KK_COUNT; ++k) {
         prof_stats_[k] = KernelStat();
         prof_stats_[k].kind = kKindNames[k];
@@ -509,10 +566,11 @@ void EncoderModel::profile_begin(uint32_t kinds_mask)
     prof_on_ = true;
 }
 
-void EncoderModel::prof_start(int kind, hipStream_t stream, double flops, double bytes)
+hipEvent_t EncoderModel::prof_start(int kind, hipStream_t stream, double flops, double bytes)
 {
-    prof_cur_active_ = prof_on_ && ((prof_mask_ >> kind) & 1u);
-    if (!prof_cur_active_) return;
+    if (!prof_on_) return nullptr;  // racy read is fine: the profiler is a single-caller tool
+    std::lock_guard<std::mutex> lock(prof_mu_);
+    if (!prof_on_ || !((prof_mask_ >> kind) & 1u)) return nullptr;
     auto get = [&]() {
         hipEvent_t e;
         if (!prof_pool_.empty()) {
@@ -525,23 +583,23 @@ void EncoderModel::prof_start(int kind, hipStream_t stream, double flops, double
     };
     PendingEvent pe{kind, get(), get()};
     hip_check(hipEventRecord(pe.start, stream), "hipEventRecord");
-    prof_cur_stop_ = pe.stop;
     prof_pending_.push_back(pe);
     prof_stats_[kind].launches += 1;
     prof_stats_[kind].flops += flops;
     prof_stats_[kind].bytes += bytes;
+    return pe.stop;
 }
 
-void EncoderModel::prof_stop(hipStream_t stream)
+void EncoderModel::prof_stop(hipEvent_t stop, hipStream_t stream)
 {
-    if (!prof_cur_active_) return;
-    hip_check(hipEventRecord(prof_cur_stop_, stream), "hipEventRecord");
+    if (stop) hip_check(hipEventRecord(stop, stream), "hipEventRecord");
 }
 
 std::vector<KernelStat> EncoderModel::profile_end()
 {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    std::lock_guard<std::mutex> lock(prof_mu_);
     for (const PendingEvent& pe : prof_pending_) {
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, pe.start, pe.stop), "hipEventElapsedTime");
@@ -558,7 +616,7 @@ std::vector<KernelStat> EncoderModel::profile_end()
 //   h1 = LN1(x + Attn(x)); y = LN2(h1 + FFN(h1))
 // (cpu/encoder/encoder_layer.rs:113-179 / 216-232, transformer_encoder.rs:335-368;
 // no final norm, :300-302).  `hidden` is both the residual stream and the output.
-void EncoderModel::forward_chunk(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                                  int64_t batch, int seq, float mask_value, float* hidden,
                                  hipStream_t stream)
 {
@@ -573,76 +631,133 @@ void EncoderModel::forward_chunk(const uint32_t* ids, const uint32_t* mask, cons
     const double f_fc1 = 2.0 * Td * Hd * Id, b_fc1 = 4.0 * (Td * Hd + Hd * Id + Td * Id);
     const double f_fc2 = 2.0 * Td * Hd * Id, b_fc2 = 4.0 * (Td * Id + Hd * Id + 2 * Td * Hd);
     const double b_ln = 8.0 * Td * Hd;
+    const bool fused_ln = fuse_layernorm();
 
-    prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
+    hipEvent_t pe = prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
     hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,
                                      seq, H, cfg_.vocab, cfg_.max_pos, cfg_.type_vocab, cfg_.pos_offset,
                                      0, hidden, stream),
               "embed_layernorm");
-    prof_stop(stream);
+    prof_stop(pe, stream);
+    // hidden = LN(A W^T + b + hidden), in place: a workgroup owns whole rows, reads its residual rows before it
+    // writes them, and no other workgroup touches those rows.
+    auto residual_ln = [&](int kind, const float* A, int K, const float* W, const float* b, const float* g,
+                           const float* beta, double flops, double bytes, const char* what) {
+        if (fused_ln) {
+            hipEvent_t e = prof_start(kind, stream, flops, bytes);
+            hip_check(launch_gemm_residual_layernorm(A, K, W, b, hidden, H, g, beta, cfg_.eps, hidden, H, T, H, K,
+                                                     stream), what);
+            prof_stop(e, stream);
+            return;
+        }
+        hipEvent_t e = prof_start(kind, stream, flops, bytes);
+        hip_check(launch_gemm(A, K, W, b, hidden, H, hidden, H, T, H, K, EPI_BIAS_RESIDUAL, stream), what);
+        prof_stop(e, stream);
+        e = prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
+        hip_check(launch_layernorm(hidden, g, beta, cfg_.eps, T, H, hidden, stream), "layernorm");
+        prof_stop(e, stream);
+    };
     for (const DeviceLayer& L : layers_) {
-        prof_start(KK_GEMM_QKV, stream, f_qkv, b_qkv);
-        hip_check(launch_gemm(hidden, H, L.wqkv, L.bqkv, nullptr, 0, ws_qkv_, 3 * H, T, 3 * H, H, EPI_BIAS,
+        pe = prof_start(KK_GEMM_QKV, stream, f_qkv, b_qkv);
+        hip_check(launch_gemm(hidden, H, L.wqkv, L.bqkv, nullptr, 0, ws.qkv, 3 * H, T, 3 * H, H, EPI_BIAS,
                               stream),
                   "gemm(qkv)");
-        prof_stop(stream);
+        prof_stop(pe, stream);
         if (rope_cos_) {
-            prof_start(KK_ROPE, stream, 0.0, 4.0 * (4 * Td * Hd));
-            hip_check(launch_rope_qk(ws_qkv_, rope_cos_, rope_sin_, T, seq, cfg_.heads, H / cfg_.heads, stream), "rope");
-            prof_stop(stream);
+            pe = prof_start(KK_ROPE, stream, 0.0, 4.0 * (4 * Td * Hd));
+            hip_check(launch_rope_qk(ws.qkv, rope_cos_, rope_sin_, T, seq, cfg_.heads, H / cfg_.heads, stream), "rope");
+            prof_stop(pe, stream);
         }
-        prof_start(KK_ATTENTION, stream, f_att, b_att);
-        hip_check(launch_attention(ws_qkv_, mask, batch, seq, cfg_.heads, H / cfg_.heads, mask_value,
-                                   ws_ctx_, stream),
+        pe = prof_start(KK_ATTENTION, stream, f_att, b_att);
+        hip_check(launch_attention(ws.qkv, mask, batch, seq, cfg_.heads, H / cfg_.heads, mask_value,
+                                   ws.ctx, stream),
                   "attention");
-        prof_stop(stream);
-        // hidden = ctx Wo^T + bo + hidden  (in place: each element is read then written by one thread)
-        prof_start(KK_GEMM_OUT, stream, f_out, b_out);
-        hip_check(launch_gemm(ws_ctx_, H, L.wo, L.bo, hidden, H, hidden, H, T, H, H, EPI_BIAS_RESIDUAL,
-                              stream),
-                  "gemm(out_proj)");
-        prof_stop(stream);
-        prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
-        hip_check(launch_layernorm(hidden, L.ln1_g, L.ln1_b, cfg_.eps, T, H, hidden, stream), "layernorm1");
-        prof_stop(stream);
+        prof_stop(pe, stream);
+        residual_ln(KK_GEMM_OUT, ws.ctx, H, L.wo, L.bo, L.ln1_g, L.ln1_b, f_out, b_out, "gemm(out_proj)");
         if (L.wg) {
-            // SwiGLU (cpu/feedforward/swiglu.rs:40-50): the gate projection lands in ws_mid, the up projection's
+            // SwiGLU (cpu/feedforward/swiglu.rs:40-50): the gate projection lands in ws.mid, the up projection's
             // epilogue multiplies it by silu(gate) in place (read then written by the same thread).
-            prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
-            hip_check(launch_gemm(hidden, H, L.wg, nullptr, nullptr, 0, ws_mid_, I, T, I, H, EPI_BIAS, stream), "gemm(gate)");
-            prof_stop(stream);
-            prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1 + 4.0 * Td * Id);
-            hip_check(launch_gemm(hidden, H, L.w1, L.b1, ws_mid_, I, ws_mid_, I, T, I, H, EPI_BIAS_MUL_SILU, stream),
+            pe = prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
+            hip_check(launch_gemm(hidden, H, L.wg, nullptr, nullptr, 0, ws.mid, I, T, I, H, EPI_BIAS, stream), "gemm(gate)");
+            prof_stop(pe, stream);
+            pe = prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1 + 4.0 * Td * Id);
+            hip_check(launch_gemm(hidden, H, L.w1, L.b1, ws.mid, I, ws.mid, I, T, I, H, EPI_BIAS_MUL_SILU, stream),
                       "gemm(up * silu(gate))");
-            prof_stop(stream);
+            prof_stop(pe, stream);
         } else {
-            prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
-            hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws_mid_, I, T, I, H, cfg_.ffn_act, stream),
+            pe = prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
+            hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws.mid, I, T, I, H, cfg_.ffn_act, stream),
                       "gemm(fc1)");
-            prof_stop(stream);
+            prof_stop(pe, stream);
         }
-        prof_start(KK_GEMM_FC2, stream, f_fc2, b_fc2);
-        hip_check(launch_gemm(ws_mid_, I, L.w2, L.b2, hidden, H, hidden, H, T, H, I, EPI_BIAS_RESIDUAL,
-                              stream),
-                  "gemm(fc2)");
-        prof_stop(stream);
-        prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
-        hip_check(launch_layernorm(hidden, L.ln2_g, L.ln2_b, cfg_.eps, T, H, hidden, stream), "layernorm2");
-        prof_stop(stream);
+        residual_ln(KK_GEMM_FC2, ws.mid, I, L.w2, L.b2, L.ln2_g, L.ln2_b, f_fc2, b_fc2, "gemm(fc2)");
     }
+}
+
+bool EncoderModel::fuse_layernorm() const
+{
+    return gemm_residual_layernorm_supported(cfg_.hidden, cfg_.hidden) &&
+           gemm_residual_layernorm_supported(cfg_.hidden, cfg_.inter);
 }
 
 void EncoderModel::hidden_states(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                                  int64_t batch, int seq, float mask_value, float* out, hipStream_t stream)
 {
     if (batch <= 0 || seq <= 0) return;
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    Lease lease(*this, stream, false);
     const int64_t per = sentences_per_chunk(seq);
-    ensure_workspace(std::min(per, batch) * seq, std::min(per, batch));
+    reserve(lease.ws(), std::min(per, batch) * seq, std::min(per, batch));
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
         const int64_t nb = std::min(per, batch - b0);
-        forward_chunk(ids + b0 * seq, mask ? mask + b0 * seq : nullptr, type_ids ? type_ids + b0 * seq : nullptr,
-                      nb, seq, mask_value, out + b0 * seq * (int64_t)cfg_.hidden, stream);
+        forward_chunk(lease.ws(), ids + b0 * seq, mask ? mask + b0 * seq : nullptr,
+                      type_ids ? type_ids + b0 * seq : nullptr, nb, seq, mask_value,
+                      out + b0 * seq * (int64_t)cfg_.hidden, stream);
+    }
+}
+
+void EncoderModel::embed_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+                            int64_t batch, int seq, PoolMode pool, bool normalize, float mask_value, float* out,
+                            hipStream_t stream)
+{
+    const int64_t per = sentences_per_chunk(seq);
+    reserve(ws, std::min(per, batch) * seq, std::min(per, batch));
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+        const int64_t nb = std::min(per, batch - b0);
+        const uint32_t* m = mask ? mask + b0 * seq : nullptr;
+        forward_chunk(ws, ids + b0 * seq, m, type_ids ? type_ids + b0 * seq : nullptr, nb, seq, mask_value,
+                      ws.hidden, stream);
+        hipEvent_t pe = prof_start(KK_POOL, stream, 0.0, 4.0 * ((double)nb * seq * cfg_.hidden + (double)nb * cfg_.hidden));
+        hip_check(launch_pool(ws.hidden, m, nb, seq, cfg_.hidden, pool, normalize ? 1 : 0,
+                              out + b0 * (int64_t)cfg_.hidden, stream),
+                  "pool");
+        prof_stop(pe, stream);
+    }
+}
+
+void EncoderModel::logits_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+                             int64_t batch, int seq, float mask_value, float* out, hipStream_t stream)
+{
+    if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
+    const int H = cfg_.hidden;
+    const int64_t per = sentences_per_chunk(seq);
+    reserve(ws, std::min(per, batch) * seq, std::min(per, batch));
+    for (int64_t b0 = 0; b0 < batch; b0 += per) {
+        const int64_t nb = std::min(per, batch - b0);
+        forward_chunk(ws, ids + b0 * seq, mask ? mask + b0 * seq : nullptr, type_ids ? type_ids + b0 * seq : nullptr,
+                      nb, seq, mask_value, ws.hidden, stream);
+        // CLS rows are read in place: row stride seq*H (cpu/encoder/classifier.rs:219).
+        const float* feat = ws.hidden;
+        int64_t ld = (int64_t)seq * H;
+        if (cfg_.head_kind == 1 || cfg_.head_kind == 2) {
+            hip_check(launch_gemm(ws.hidden, ld, head_dense_w_, head_dense_b_, nullptr, 0, ws.feat, H, nb, H, H,
+                                  cfg_.head_kind == 1 ? EPI_BIAS_TANH : EPI_BIAS_RELU, stream),
+                      "gemm(head dense)");
+            feat = ws.feat;
+            ld = H;
+        }
+        hip_check(launch_small_linear(feat, ld, head_cls_w_, head_cls_b_, nb, H, cfg_.num_labels,
+                                      out + b0 * cfg_.num_labels, stream),
+                  "classifier");
     }
 }
 
@@ -651,49 +766,77 @@ void EncoderModel::embed(const uint32_t* ids, const uint32_t* mask, const uint32
                          hipStream_t stream)
 {
     if (batch <= 0 || seq <= 0) return;
-    hip_check(hipSetDevice(device_), "hipSetDevice");
-    const int64_t per = sentences_per_chunk(seq);
-    ensure_workspace(std::min(per, batch) * seq, std::min(per, batch));
-    for (int64_t b0 = 0; b0 < batch; b0 += per) {
-        const int64_t nb = std::min(per, batch - b0);
-        const uint32_t* m = mask ? mask + b0 * seq : nullptr;
-        forward_chunk(ids + b0 * seq, m, type_ids ? type_ids + b0 * seq : nullptr, nb, seq, mask_value,
-                      ws_hidden_, stream);
-        prof_start(KK_POOL, stream, 0.0, 4.0 * ((double)nb * seq * cfg_.hidden + (double)nb * cfg_.hidden));
-        hip_check(launch_pool(ws_hidden_, m, nb, seq, cfg_.hidden, pool, normalize ? 1 : 0,
-                              out + b0 * (int64_t)cfg_.hidden, stream),
-                  "pool");
-        prof_stop(stream);
-    }
+    Lease lease(*this, stream, false);
+    embed_on(lease.ws(), ids, mask, type_ids, batch, seq, pool, normalize, mask_value, out, stream);
 }
 
 void EncoderModel::logits(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
                           int seq, float mask_value, float* out, hipStream_t stream)
 {
     if (batch <= 0 || seq <= 0) return;
+    Lease lease(*this, stream, false);
+    logits_on(lease.ws(), ids, mask, type_ids, batch, seq, mask_value, out, stream);
+}
+
+// ---- host-pointer entry points ------------------------------------------------------------------------
+// One lease covers staging, compute and the copy back, all on the workspace's own stream; only that stream
+// is synchronised, so calls from other host threads (other workspaces, other streams) keep running.
+template <class F>
+void EncoderModel::run_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                            int seq, size_t out_floats, float* out, F&& body)
+{
+    if (batch <= 0 || seq <= 0) return;
+    Lease lease(*this, nullptr, true);
+    Workspace& ws = lease.ws();
+    hipStream_t st = lease.stream();
+    const size_t tok_bytes = (size_t)batch * (size_t)seq * sizeof(uint32_t);
+    const size_t in_bytes = tok_bytes * (type_ids ? 3 : 2);
+    const size_t out_off = (in_bytes + 255) & ~(size_t)255;
+    uint8_t* base = static_cast<uint8_t*>(reserve_stage(ws, out_off + out_floats * sizeof(float)));
+    uint32_t* ids_d = reinterpret_cast<uint32_t*>(base);
+    uint32_t* mask_d = reinterpret_cast<uint32_t*>(base + tok_bytes);
+    uint32_t* type_d = type_ids ? reinterpret_cast<uint32_t*>(base + 2 * tok_bytes) : nullptr;
+    float* out_d = reinterpret_cast<float*>(base + out_off);
+    hip_check(hipMemcpyAsync(ids_d, ids, tok_bytes, hipMemcpyHostToDevice, st), "H2D ids");
+    hip_check(hipMemcpyAsync(mask_d, mask, tok_bytes, hipMemcpyHostToDevice, st), "H2D mask");
+    if (type_ids) hip_check(hipMemcpyAsync(type_d, type_ids, tok_bytes, hipMemcpyHostToDevice, st), "H2D type ids");
+    body(ws, ids_d, mask_d, type_d, out_d, st);
+    hip_check(hipMemcpyAsync(out, out_d, out_floats * sizeof(float), hipMemcpyDeviceToHost, st), "D2H output");
+    hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+}
+
+void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+                                      int64_t batch, int seq, float mask_value, float* out)
+{
+    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * seq * cfg_.hidden, out,
+             [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
+                 const int64_t per = sentences_per_chunk(seq);
+                 reserve(ws, std::min(per, batch) * seq, std::min(per, batch));
+                 for (int64_t b0 = 0; b0 < batch; b0 += per) {
+                     const int64_t nb = std::min(per, batch - b0);
+                     forward_chunk(ws, i + b0 * seq, k + b0 * seq, t ? t + b0 * seq : nullptr, nb, seq, mask_value,
+                                   o + b0 * seq * (int64_t)cfg_.hidden, st);
+                 }
+             });
+}
+
+void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                              int seq, PoolMode pool, bool normalize, float mask_value, float* out)
+{
+    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.hidden, out,
+             [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
+                 embed_on(ws, i, k, t, batch, seq, pool, normalize, mask_value, o, st);
+             });
+}
+
+void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                               int seq, float mask_value, float* out)
+{
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
-    hip_check(hipSetDevice(device_), "hipSetDevice");
-    const int H = cfg_.hidden;
-    const int64_t per = sentences_per_chunk(seq);
-    ensure_workspace(std::min(per, batch) * seq, std::min(per, batch));
-    for (int64_t b0 = 0; b0 < batch; b0 += per) {
-        const int64_t nb = std::min(per, batch - b0);
-        forward_chunk(ids + b0 * seq, mask ? mask + b0 * seq : nullptr, type_ids ? type_ids + b0 * seq : nullptr,
-                      nb, seq, mask_value, ws_hidden_, stream);
-        // CLS rows are read in place: row stride seq*H (cpu/encoder/classifier.rs:219).
-        const float* feat = ws_hidden_;
-        int64_t ld = (int64_t)seq * H;
-        if (cfg_.head_kind == 1 || cfg_.head_kind == 2) {
-            hip_check(launch_gemm(ws_hidden_, ld, head_dense_w_, head_dense_b_, nullptr, 0, ws_feat_, H, nb, H, H,
-                                  cfg_.head_kind == 1 ? EPI_BIAS_TANH : EPI_BIAS_RELU, stream),
-                      "gemm(head dense)");
-            feat = ws_feat_;
-            ld = H;
-        }
-        hip_check(launch_small_linear(feat, ld, head_cls_w_, head_cls_b_, nb, H, cfg_.num_labels,
-                                      out + b0 * cfg_.num_labels, stream),
-                  "classifier");
-    }
+    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.num_labels, out,
+             [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
+                 logits_on(ws, i, k, t, batch, seq, mask_value, o, st);
+             });
 }
 
 }  // namespace kjarni

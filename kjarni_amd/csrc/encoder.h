@@ -6,8 +6,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -20,6 +23,9 @@ struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 struct GpuUnavailable : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct InvalidDeviceList : std::runtime_error {  // KJARNI_HIP_DEVICES / an explicit device list that cannot be used
     using std::runtime_error::runtime_error;
 };
 
@@ -65,6 +71,21 @@ struct KernelStat {
     double bytes = 0.0;  // algorithmic bytes (operands read once + outputs written once)
 };
 
+// Activations + staging area of ONE call in flight.  A model owns a small pool of these: the weights are
+// immutable after load, so calls on one handle from several host threads run concurrently, each on its own
+// workspace (the reference's model types are Send + Sync and nothing serialises calls on a handle,
+// crates/kjarni-ffi/src/lib.rs:25-32, kjarni-transformers/src/traits.rs:33).
+struct Workspace {
+    int64_t tokens = 0, sentences = 0;  // capacity of the activation buffers (0 whenever they are not all allocated)
+    float *hidden = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *feat = nullptr;
+    void* stage = nullptr;  // ids / mask / types in, outputs back, for the host-pointer entry points
+    size_t stage_bytes = 0;
+    hipStream_t stream = nullptr;  // this workspace's own stream (host-pointer entry points run on it)
+    hipEvent_t done = nullptr;     // recorded behind the last launch that used the buffers
+    hipStream_t done_stream = nullptr;
+    bool done_pending = false;
+};
+
 class EncoderModel {
 public:
     // Loads <dir>/config.json + <dir>/model.safetensors onto `device`.
@@ -76,7 +97,7 @@ public:
     const EncoderConfig& config() const { return cfg_; }
     int device() const { return device_; }
     size_t weight_bytes() const { return weight_bytes_; }
-    void set_chunk_tokens(int64_t t) { chunk_tokens_ = t > 0 ? t : chunk_tokens_; }
+    void set_chunk_tokens(int64_t t) { if (t > 0) chunk_tokens_ = t; }
     int64_t chunk_tokens() const { return chunk_tokens_; }
 
     // All pointers are DEVICE pointers on this model's device; work is enqueued
@@ -99,37 +120,72 @@ public:
     // Synchronises the device, resolves the events; returns KK_COUNT entries.
     std::vector<KernelStat> profile_end();
 
-    // Scratch on this model's device (grown on demand, reused between calls).
-    void* scratch(size_t bytes);
-    void* scratch2(size_t bytes);
+    // The same three on HOST pointers: ids / mask / type_ids are staged on the leased workspace's own stream,
+    // the result is copied back and that stream (only) is synchronised before returning.
+    void hidden_states_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                            int seq, float mask_value, float* out);
+    void embed_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq,
+                    PoolMode pool, bool normalize, float mask_value, float* out);
+    void logits_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq,
+                     float mask_value, float* out);
+
+    // Thread safety: every entry point above may be called concurrently from any number of host threads and on
+    // any streams.  A call leases one workspace for its launches; when the pool (kMaxWorkspaces) is exhausted
+    // the call waits for a lease.  A workspace handed from one stream to another is ordered by an event, so
+    // two streams never see each other's activations.  The profiler is a single-caller tool.
+    static constexpr int kMaxWorkspaces = 4;
 
 private:
     EncoderModel() = default;
     float* upload(const std::vector<float>& host);
-    void ensure_workspace(int64_t tokens, int64_t sentences);
+
+    class Lease {
+    public:
+        Lease(EncoderModel& m, hipStream_t stream, bool own_stream);
+        ~Lease();
+        Lease(const Lease&) = delete;
+        Lease& operator=(const Lease&) = delete;
+        Workspace& ws() { return *ws_; }
+        hipStream_t stream() const { return stream_; }
+
+    private:
+        EncoderModel& m_;
+        Workspace* ws_;
+        hipStream_t stream_;
+    };
+    void reserve(Workspace& ws, int64_t tokens, int64_t sentences);
+    void* reserve_stage(Workspace& ws, size_t bytes);
+    template <class F>
+    void run_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq,
+                  size_t out_floats, float* out, F&& body);
     // Runs embeddings + all layers for `batch` sentences into hidden (device, [batch*seq, H]).
-    void forward_chunk(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
+    void forward_chunk(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                        int64_t batch, int seq, float mask_value, float* hidden, hipStream_t stream);
+    void embed_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                  int seq, PoolMode pool, bool normalize, float mask_value, float* out, hipStream_t stream);
+    void logits_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                   int seq, float mask_value, float* out, hipStream_t stream);
     int64_t sentences_per_chunk(int seq) const;
+    // LayerNorm folded into the residual GEMMs' epilogue when the kernel covers this model's row width.
+    bool fuse_layernorm() const;
 
     struct PendingEvent {
         int kind;
         hipEvent_t start, stop;
     };
-    void prof_start(int kind, hipStream_t stream, double flops, double bytes);
-    void prof_stop(hipStream_t stream);
+    hipEvent_t prof_start(int kind, hipStream_t stream, double flops, double bytes);  // null: not timed
+    void prof_stop(hipEvent_t stop, hipStream_t stream);
+    std::mutex prof_mu_;
     bool prof_on_ = false;
     uint32_t prof_mask_ = 0xFFFFFFFFu;
-    bool prof_cur_active_ = false;
     std::vector<PendingEvent> prof_pending_;
     std::vector<hipEvent_t> prof_pool_;
     KernelStat prof_stats_[KK_COUNT];
-    hipEvent_t prof_cur_stop_ = nullptr;
 
     EncoderConfig cfg_;
     int device_ = 0;
     size_t weight_bytes_ = 0;
-    int64_t chunk_tokens_ = 131072;
+    std::atomic<int64_t> chunk_tokens_{131072};
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,
@@ -139,14 +195,11 @@ private:
     float *head_dense_w_ = nullptr, *head_dense_b_ = nullptr, *head_cls_w_ = nullptr,
           *head_cls_b_ = nullptr;
 
-    // workspace
-    int64_t ws_tokens_ = 0, ws_sentences_ = 0;
-    float *ws_hidden_ = nullptr, *ws_qkv_ = nullptr, *ws_ctx_ = nullptr, *ws_mid_ = nullptr,
-          *ws_feat_ = nullptr;
-    void* scratch_ = nullptr;
-    size_t scratch_bytes_ = 0;
-    void* scratch2_ = nullptr;
-    size_t scratch2_bytes_ = 0;
+    // workspace pool
+    std::mutex ws_mu_;
+    std::condition_variable ws_cv_;
+    std::vector<std::unique_ptr<Workspace>> ws_all_;
+    std::vector<Workspace*> ws_free_;  // LIFO: a single-threaded caller keeps getting the same (warm) workspace
 };
 
 }  // namespace kjarni

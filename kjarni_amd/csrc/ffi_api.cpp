@@ -76,14 +76,12 @@ std::unique_ptr<Pipeline> load_pipeline(const char* cache_dir, const char* model
     }
     auto p = std::make_unique<Pipeline>();
     p->model_name = name;
-    // One GPU per process; KJARNI_HIP_DEVICE picks it (default 0).
-    int device = 0;
-    if (const char* dv = std::getenv("KJARNI_HIP_DEVICE")) device = std::atoi(dv);
-    p->model = EncoderModel::load(dir, device);
+    // One replica per device of KJARNI_HIP_DEVICES (default: every visible GPU); batches are cut into row blocks.
+    p->group = EncoderGroup::load(dir, devices_from_env());
     p->tokenizer = BertTokenizer::from_file(dir + "/tokenizer.json");
     // loader.rs:108-111: truncation max_length = max_seq_len
-    p->tokenizer.set_max_length((size_t)p->model->config().max_pos);
-    if (want != Want::Embedding && p->model->config().head_kind == 0)
+    p->tokenizer.set_max_length((size_t)p->config().max_pos);
+    if (want != Want::Embedding && p->config().head_kind == 0)
         throw std::runtime_error("Model '" + name + "' has no classification head");
     return p;
 }
@@ -94,36 +92,6 @@ namespace {
 
 // cpu/strategy.rs:43-44
 float embed_mask_value(size_t tokens) { return (tokens <= 1 || tokens >= 1000) ? kNegInf : -1e9f; }
-
-struct DeviceTokens {
-    uint32_t *ids, *mask, *types;
-    float* out;
-};
-
-// Uploads a BatchEncoding into the model's scratch and returns device views + an output area.
-DeviceTokens stage(EncoderModel& m, const BatchEncoding& be, bool with_types, size_t out_floats)
-{
-    const size_t n = be.batch * be.seq;
-    const size_t tb = n * sizeof(uint32_t);
-    const size_t in_bytes = tb * (with_types ? 3 : 2);
-    const size_t out_off = (in_bytes + 255) & ~(size_t)255;
-    uint8_t* base = static_cast<uint8_t*>(m.scratch(out_off + out_floats * sizeof(float)));
-    DeviceTokens d;
-    d.ids = reinterpret_cast<uint32_t*>(base);
-    d.mask = reinterpret_cast<uint32_t*>(base + tb);
-    d.types = with_types ? reinterpret_cast<uint32_t*>(base + 2 * tb) : nullptr;
-    d.out = reinterpret_cast<float*>(base + out_off);
-    hip_check(hipMemcpyAsync(d.ids, be.ids.data(), tb, hipMemcpyHostToDevice, nullptr), "H2D ids");
-    hip_check(hipMemcpyAsync(d.mask, be.attention_mask.data(), tb, hipMemcpyHostToDevice, nullptr), "H2D mask");
-    if (with_types) hip_check(hipMemcpyAsync(d.types, be.type_ids.data(), tb, hipMemcpyHostToDevice, nullptr), "H2D types");
-    return d;
-}
-
-void fetch(float* host, const float* dev, size_t floats)
-{
-    hip_check(hipMemcpyAsync(host, dev, floats * sizeof(float), hipMemcpyDeviceToHost, nullptr), "D2H");
-    hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
-}
 
 }  // namespace
 
@@ -138,27 +106,23 @@ std::vector<float> embed_texts(Pipeline& p, const std::vector<std::string>& text
 
 std::vector<float> embed_encoding(Pipeline& p, const BatchEncoding& be, PoolMode pool, bool normalize)
 {
-    const size_t H = (size_t)p.model->config().hidden;
+    const size_t H = (size_t)p.config().hidden;
     std::vector<float> out(be.batch * H);
     if (be.batch == 0 || be.seq == 0) return out;
-    std::lock_guard<std::mutex> lock(p.mu);
-    DeviceTokens d = stage(*p.model, be, false, out.size());
-    p.model->embed(d.ids, d.mask, nullptr, (int64_t)be.batch, (int)be.seq, pool, normalize,
-                   embed_mask_value(be.batch * be.seq), d.out, nullptr);
-    fetch(out.data(), d.out, out.size());
+    // The mask fill follows the size of the WHOLE call, as in the reference, however the rows are spread.
+    p.group->embed_host(be.ids.data(), be.attention_mask.data(), nullptr, (int64_t)be.batch, (int)be.seq, pool, normalize,
+                        embed_mask_value(be.batch * be.seq), out.data());
     return out;
 }
 
 // pairs -> logits [n, num_labels]; forward_tokens always takes the alloc path (mask -1e9).
 std::vector<float> pair_logits(Pipeline& p, const BatchEncoding& be)
 {
-    const size_t L = (size_t)p.model->config().num_labels;
+    const size_t L = (size_t)p.config().num_labels;
     std::vector<float> out(be.batch * L);
     if (be.batch == 0 || be.seq == 0) return out;
-    std::lock_guard<std::mutex> lock(p.mu);
-    DeviceTokens d = stage(*p.model, be, true, out.size());
-    p.model->logits(d.ids, d.mask, d.types, (int64_t)be.batch, (int)be.seq, -1e9f, d.out, nullptr);
-    fetch(out.data(), d.out, out.size());
+    p.group->logits_host(be.ids.data(), be.attention_mask.data(), be.type_ids.data(), (int64_t)be.batch, (int)be.seq, -1e9f,
+                         out.data());
     return out;
 }
 
@@ -288,7 +252,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_embedder_encode_batch(KjarniEmbedder* e, co
         std::memcpy(d, r.data(), r.size() * sizeof(float));
         out->data = d;
         out->rows = num_texts;
-        out->cols = (size_t)e->p->model->config().hidden;
+        out->cols = (size_t)e->p->config().hidden;
     });
 }
 
@@ -300,12 +264,12 @@ KJARNI_EXPORT KjarniErrorCode kjarni_embedder_similarity(KjarniEmbedder* e, cons
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
         // Embedder::similarity: embed_batch([t1,t2]) (mean, config normalize) -> cosine (model.rs:178-181)
         std::vector<float> r = embed_texts(*e->p, {std::string(t1), std::string(t2)}, POOL_MEAN, e->normalize);
-        const size_t H = (size_t)e->p->model->config().hidden;
+        const size_t H = (size_t)e->p->config().hidden;
         *out = cosine_k(r.data(), r.data() + H, H);
     });
 }
 
-KJARNI_EXPORT size_t kjarni_embedder_dim(const KjarniEmbedder* e) { return e ? (size_t)e->p->model->config().hidden : 0; }
+KJARNI_EXPORT size_t kjarni_embedder_dim(const KjarniEmbedder* e) { return e ? (size_t)e->p->config().hidden : 0; }
 
 // ---- Reranker ----------------------------------------------------------------
 
@@ -356,7 +320,7 @@ std::vector<float> rerank_scores(Pipeline& p, const std::string& query, const st
     for (const std::string& d : docs) pairs.emplace_back(query, d);
     const BatchEncoding be = p.tokenizer.encode_batch_pairs(pairs);
     const std::vector<float> logits = pair_logits(p, be);
-    const size_t L = (size_t)p.model->config().num_labels;
+    const size_t L = (size_t)p.config().num_labels;
     std::vector<float> scores(docs.size());
     for (size_t i = 0; i < docs.size(); ++i) scores[i] = logits[i * L];
     return scores;
@@ -479,7 +443,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_classifier_new(const KjarniClassifierConfig
         // Default name "sentiment" (kjarni-ffi/src/classifier.rs:133) is not a registry name in the
         // reference either: it resolves to "Unknown model 'sentiment'. Did you mean: ...".
         h->p = load_pipeline(c.cache_dir, c.model_name, c.model_path, "sentiment", Want::Classification);
-        const EncoderConfig& mc = h->p->model->config();
+        const EncoderConfig& mc = h->p->config();
         h->labels = mc.labels;
         if (h->labels.empty())
             for (int i = 0; i < mc.num_labels; ++i) h->labels.push_back("LABEL_" + std::to_string(i));

@@ -39,6 +39,9 @@ KjarniErrorCode guarded(KjarniErrorCode fallback, F&& fn)
     } catch (const InvalidConfig& e) {
         set_last_error(e.what());
         return KJARNI_ERROR_INVALID_CONFIG;
+    } catch (const InvalidDeviceList& e) {
+        set_last_error(e.what());
+        return KJARNI_ERROR_INVALID_CONFIG;
     } catch (const std::exception& e) {
         set_last_error(e.what());
         return fallback;

@@ -169,7 +169,7 @@ struct KjarniIndexer {
         {
             const size_t n = texts.size();
             if (n == 0) return;
-            const size_t H = (size_t)ix.embedder->model->config().hidden;
+            const size_t H = (size_t)ix.embedder->config().hidden;
             std::vector<float> emb(n * H);
             // length-sorted groups: every group is padded to ITS longest member only
             std::vector<size_t> order(n);
@@ -274,7 +274,7 @@ struct KjarniIndexer {
             }
         }
         const auto start = std::chrono::steady_clock::now();
-        const size_t dimension = (size_t)embedder->model->config().hidden;
+        const size_t dimension = (size_t)embedder->config().hidden;
         IndexConfig config;
         config.dimension = dimension;
         config.max_docs_per_segment = max_docs_per_segment;
@@ -307,7 +307,7 @@ struct KjarniIndexer {
         } catch (const std::exception& e) {
             throw indexing_failed(e.what());
         }
-        const size_t model_dim = (size_t)embedder->model->config().hidden;
+        const size_t model_dim = (size_t)embedder->config().hidden;
         if (writer->dimension() != model_dim)
             throw IndexerFailure(KJARNI_ERROR_INVALID_CONFIG, "Dimension mismatch: index has " + std::to_string(writer->dimension()) +
                                                                   ", model produces " + std::to_string(model_dim));
@@ -540,6 +540,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_index_delete(const char* index_path)
     if (!valid_utf8(index_path)) return KJARNI_ERROR_INVALID_UTF8;
     try {
         if (!path_exists(index_path)) throw std::runtime_error(std::string("Index not found at ") + index_path);
+        forget_device_segments_under(index_path);  // HBM copies of its vectors.bin in live Searchers
         try {
             remove_dir_all(index_path);
         } catch (const std::exception& e) {
@@ -566,7 +567,7 @@ KJARNI_EXPORT size_t kjarni_indexer_model_name(const KjarniIndexer* indexer, cha
 
 KJARNI_EXPORT size_t kjarni_indexer_dimension(const KjarniIndexer* indexer)
 {
-    return indexer ? (size_t)indexer->embedder->model->config().hidden : 0;
+    return indexer ? (size_t)indexer->embedder->config().hidden : 0;
 }
 
 KJARNI_EXPORT size_t kjarni_indexer_chunk_size(const KjarniIndexer* indexer) { return indexer ? indexer->chunk_size : 0; }

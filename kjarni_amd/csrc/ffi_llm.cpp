@@ -23,7 +23,9 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_decoder_load(const char* model_dir, int
     if (!model_dir || !out) return KJARNI_ERROR_NULL_POINTER;
     if (weights_dtype < 0 || weights_dtype > 2) return KJARNI_ERROR_INVALID_CONFIG;
     return guarded(KJARNI_ERROR_LOAD_FAILED, [&] {
-        if (const char* v = std::getenv("KJARNI_HIP_LLM_GEMV")) set_llm_gemv_variant(std::atoi(v));  // kernel A/B measurements only
+#ifdef KJARNI_TUNING
+        if (const char* v = std::getenv("KJARNI_HIP_LLM_GEMV")) set_llm_gemv_variant(std::atoi(v));  // kernel A/B measurements
+#endif
         auto h = std::make_unique<KjarniHipDecoder>();
         h->model = LlmModel::load(model_dir, device, weights_dtype, max_context);
         *out = h.release();

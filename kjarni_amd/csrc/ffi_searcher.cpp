@@ -25,10 +25,14 @@ using namespace kjarni;
 
 namespace {
 
+// Device copy of one segment's vectors.bin, revalidated on every scan by the file's identity
+// (size, mtime, ctime, inode -- a segment re-created under the same name is a different file).
 struct DeviceSegment {
     float* vectors = nullptr;
     size_t bytes = 0;
-    int64_t mtime_ns = 0;
+    int64_t mtime_ns = 0, ctime_ns = 0;
+    uint64_t inode = 0;
+    uint64_t last_used = 0;  // scan counter: least-recently-used copies go first when the budget is exceeded
 };
 
 void fill_results(const std::vector<SearchHit>& hits, KjarniSearchResults* out)
@@ -61,15 +65,38 @@ std::unique_ptr<IndexReader> open_index(const std::string& path)
     }
 }
 
+class SegmentScanner;
+std::mutex g_scanners_mu;
+std::vector<SegmentScanner*> g_scanners;  // live scanners, so that kjarni_index_delete can drop their device copies
+
 // Segment::search_vectors (kjarni-rag/src/segment.rs:307-337) on the GPU, with the device copies of
 // the segments it has seen.
 class SegmentScanner {
 public:
-    explicit SegmentScanner(int device) : device_(device) {}
+    explicit SegmentScanner(int device) : device_(device)
+    {
+        {
+            std::lock_guard<std::mutex> lock(g_scanners_mu);
+            g_scanners.push_back(this);
+        }
+        // The copies may take half of the device's memory; past that, copies no scan has touched longest are dropped
+        // (a long-lived searcher that walks many indexes must not grow until hipMalloc fails).
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(device_) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
+            budget_bytes_ = total_b / 2;
+        else
+            (void)hipGetLastError();
+    }
+    void set_budget(size_t bytes) { budget_bytes_ = bytes; }
+    size_t cached_bytes() const { return cached_bytes_; }
     SegmentScanner(const SegmentScanner&) = delete;
     SegmentScanner& operator=(const SegmentScanner&) = delete;
     ~SegmentScanner()
     {
+        {
+            std::lock_guard<std::mutex> lock(g_scanners_mu);
+            g_scanners.erase(std::remove(g_scanners.begin(), g_scanners.end(), this), g_scanners.end());
+        }
         (void)hipSetDevice(device_);
         for (auto& kv : cache_)
             if (kv.second.vectors) (void)hipFree(kv.second.vectors);
@@ -87,6 +114,7 @@ public:
 
         std::lock_guard<std::mutex> lock(mu_);
         hip_check(hipSetDevice(device_), "hipSetDevice");
+        const uint64_t tick = ++tick_;
         auto pad = [](size_t b) { return 256 * ((b + 255) / 256); };
         struct Plan {
             size_t seg, n;
@@ -105,19 +133,21 @@ public:
             const std::string vpath = seg.dir() + "/vectors.bin";
             if (::stat(vpath.c_str(), &st) != 0) continue;
             const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+            const int64_t ct = (int64_t)st.st_ctim.tv_sec * 1000000000ll + st.st_ctim.tv_nsec;
             DeviceSegment& ds = cache_[vpath];
             const size_t bytes = n * dim * sizeof(float);
-            if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt) {
-                if (ds.vectors) {
-                    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-                    (void)hipFree(ds.vectors);
-                    ds.vectors = nullptr;
-                }
+            if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt || ds.ctime_ns != ct || ds.inode != (uint64_t)st.st_ino) {
+                drop(ds);
+                make_room(bytes, tick);
                 hip_check(hipMalloc((void**)&ds.vectors, bytes), "hipMalloc(segment vectors)");
-                hip_check(hipMemcpy(ds.vectors, seg.vectors(), bytes, hipMemcpyHostToDevice), "H2D segment vectors");
                 ds.bytes = bytes;
+                cached_bytes_ += bytes;
+                hip_check(hipMemcpy(ds.vectors, seg.vectors(), bytes, hipMemcpyHostToDevice), "H2D segment vectors");
                 ds.mtime_ns = mt;
+                ds.ctime_ns = ct;
+                ds.inode = (uint64_t)st.st_ino;
             }
+            ds.last_used = tick;
             Plan p;
             p.seg = si;
             p.n = n;
@@ -165,10 +195,51 @@ public:
         return out;
     }
 
+    // Drops the copies of every segment under `root` (the index there is being deleted or rebuilt).
+    void forget_under(const std::string& root)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        (void)hipSetDevice(device_);
+        const std::string prefix = root.empty() || root.back() == '/' ? root : root + "/";
+        for (auto it = cache_.begin(); it != cache_.end();)
+            if (it->first.compare(0, prefix.size(), prefix) == 0) {
+                drop(it->second);
+                it = cache_.erase(it);
+            } else {
+                ++it;
+            }
+    }
+
 private:
+    void drop(DeviceSegment& ds)
+    {
+        if (!ds.vectors) return;
+        (void)hipDeviceSynchronize();  // earlier scans may still be reading it
+        (void)hipFree(ds.vectors);
+        ds.vectors = nullptr;
+        cached_bytes_ -= ds.bytes;
+        ds.bytes = 0;
+    }
+    // Evicts least-recently-used copies that the current scan (tick) has not touched until `incoming` more bytes fit.
+    void make_room(size_t incoming, uint64_t tick)
+    {
+        while (budget_bytes_ && cached_bytes_ + incoming > budget_bytes_) {
+            auto victim = cache_.end();
+            for (auto it = cache_.begin(); it != cache_.end(); ++it)
+                if (it->second.vectors && it->second.last_used != tick &&
+                    (victim == cache_.end() || it->second.last_used < victim->second.last_used))
+                    victim = it;
+            if (victim == cache_.end()) return;  // everything resident belongs to this scan
+            drop(victim->second);
+            cache_.erase(victim);
+        }
+    }
+
     int device_;
     std::mutex mu_;
     std::map<std::string, DeviceSegment> cache_;
+    size_t cached_bytes_ = 0, budget_bytes_ = 0;
+    uint64_t tick_ = 0;
     uint8_t* work_ = nullptr;
     size_t work_bytes_ = 0;
 };
@@ -236,6 +307,14 @@ void apply_threshold_and_limit(std::vector<SearchHit>& results, const ResolvedOp
 
 }  // namespace
 
+namespace kjarni {
+void forget_device_segments_under(const std::string& root)
+{
+    std::lock_guard<std::mutex> lock(g_scanners_mu);
+    for (SegmentScanner* sc : g_scanners) sc->forget_under(root);
+}
+}  // namespace kjarni
+
 struct KjarniSearcher {
     std::unique_ptr<Pipeline> embedder;
     std::unique_ptr<Pipeline> reranker;  // optional
@@ -290,7 +369,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_new(const KjarniSearcherConfig* co
         auto h = std::make_unique<KjarniSearcher>();
         h->embedder = load_pipeline(c.cache_dir, c.model_name, nullptr, "minilm-l6-v2", Want::Embedding);
         if (c.rerank_model) h->reranker = load_pipeline(c.cache_dir, c.rerank_model, nullptr, "", Want::Reranking);
-        h->scanner = std::make_unique<SegmentScanner>(h->embedder->model->device());
+        h->scanner = std::make_unique<SegmentScanner>(h->embedder->model().device());
         h->default_mode = c.default_mode;
         if (c.default_top_k > 0) h->default_top_k = c.default_top_k;
         *out = h.release();
@@ -322,7 +401,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
 
         // Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:96-187)
         std::unique_ptr<IndexReader> reader = open_index(index_path);
-        const size_t model_dim = (size_t)s->embedder->model->config().hidden;
+        const size_t model_dim = (size_t)s->embedder->config().hidden;
         if (reader->dimension() != model_dim)
             throw InvalidConfig("Index dimension (" + std::to_string(reader->dimension()) +
                                 ") doesn't match model dimension (" + std::to_string(model_dim) + ")");

@@ -36,6 +36,7 @@
 //
 // Workgroup order: XCD-aware (every XCD walks one contiguous run of tiles, N
 // fastest) so the tiles that share an X row panel hit the same L2.
+#include <atomic>
 #include <type_traits>
 
 #include "device_utils.h"
@@ -45,10 +46,15 @@ namespace kjarni {
 
 namespace {
 
-// Tuning hook (kjarni_hip_set_gemm_variant): 0 default, 1 BK=32 (2 workgroups/CU),
-// 2 BK=16 (3 workgroups/CU), 3 default tiling with the libm-grade erff in the GELU
-// epilogue, 9 diagnostic build without an epilogue (micro-benchmark upper bound).
-int g_gemm_variant = 0;
+// Tuning hook, -DKJARNI_TUNING builds only (tools/kernel_bench.py; the shipped library has neither the
+// switch nor the extra kernels): 0 default, 2 BK=16 (3 workgroups/CU), 3 default tiling with the libm-grade
+// erff in the GELU epilogue, 4 residual GEMMs without the fused LayerNorm, 9 diagnostic build without an
+// epilogue (micro-benchmark upper bound).
+#ifdef KJARNI_TUNING
+std::atomic<int> g_gemm_variant{0};
+#else
+[[maybe_unused]] constexpr int g_gemm_variant = 0;
+#endif
 
 constexpr int EPI_GELU_LIBM = 100;
 constexpr int BM = 128, BN = 128;
@@ -116,8 +122,9 @@ __device__ __forceinline__ void mfma16(f32x16 (&acc)[2][2], const Frag& f)
 template <int EPI, int BKT, int DIAG>
 __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mfma(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
-    const float* __restrict__ R, int64_t ldr, float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K,
-    int n_tiles)
+    const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int n_tiles)
+// R and Y are NOT __restrict__: the encoder's residual GEMMs run in place (R == Y, encoder.cpp); every
+// element is read by the one lane that later stores it, and all of a round's residual loads precede its stores.
 {
     using T = Tile<BKT>;
     constexpr int BK = T::BK, NKK = T::NKK, STRIDE = T::STRIDE, TILE_FLOATS = T::TILE_FLOATS;
@@ -311,14 +318,252 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Residual GEMM with the LayerNorm folded into its epilogue:
+//     Y = LayerNorm(A W^T + bias + R) * gamma + beta          (R == Y allowed)
+// replaces out-proj / FC2 + residual add + LayerNorm of the post-norm layer
+// (cpu/encoder/encoder_layer.rs:129-147, 155-176; cpu/normalization/layer_norm.rs:37-131): one launch and
+// one pass over the [T, H] residual stream instead of two launches and two passes.
+//
+// LayerNorm needs whole rows, so a workgroup owns BM = 64 complete rows: block tile 64 x N with
+// N = 128 * NT (NT = 3: the 384-wide MiniLM rows), 4 waves side by side, each 64 rows x (32 * NT) columns =
+// 2 x NT accumulator tiles.  BK = 16 keeps the double-buffered operand tiles at (64 + N) * 20 * 4 * 2 bytes
+// = 70 KiB for N = 384, i.e. two workgroups per CU, so one workgroup's epilogue (no MFMA work) runs under the
+// other's K-loop.  Row stride BK + 4 = 20 floats: the 16 lanes of a ds_read_b128 group cover all 16 16-byte
+// slots of the 256-byte bank row.  Same software pipeline as gemm_nt_f32_mfma (2 phases of 8 * NT MFMAs per
+// K-step, tile t+1 written to LDS and tile t+2 requested under the first phase's MFMAs).
+//
+// Epilogue, two rounds of 32 rows: the four waves drop their accumulators into one [32][N + 32] LDS tile (row
+// stride = 8 sixteen-byte slots mod 16: conflict-free 16-byte reads for the 8-lanes-per-row pattern below),
+// then 8 lanes own a row: v = acc + bias + R, two-pass statistics in registers (sum, then sum of squared
+// deviations; 3 butterfly steps across the 8 lanes), normalise, 16-byte stores.  Population variance, eps
+// inside the sqrt, as the reference.
+template <int NT>
+struct LnTile {
+    static constexpr int BM = 64, BK = 16, NKK = 2, STRIDE = BK + 4;
+    static constexpr int BN = 128 * NT;
+    static constexpr int STAGE_FLOATS = (BM + BN) * STRIDE;
+    static constexpr int OUT_STRIDE = BN + 32;
+    static constexpr int OUT_FLOATS = 32 * OUT_STRIDE;
+    static constexpr int LDS_FLOATS = 2 * STAGE_FLOATS > OUT_FLOATS ? 2 * STAGE_FLOATS : OUT_FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int B_LOADS = BN * (BK / 4) / 256;  // 16-byte loads per thread per K-step for W (A: one)
+    static constexpr int V4_PER_THREAD = BN / 4 / 8;     // epilogue: 8 lanes per row
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* R, int64_t ldr, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float* Y, int64_t ldy, int64_t M, int K)
+{
+    using T = LnTile<NT>;
+    constexpr int BM = T::BM, BK = T::BK, STRIDE = T::STRIDE, BN = T::BN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int64_t nwg = gridDim.x;
+    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int64_t q8 = nwg / 8, r8 = nwg % 8;
+    const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int64_t m0 = bid * BM;
+
+    // staging: thread -> (row, 16-byte column) of the [rows][BK] operand tiles
+    const int ld_row = tid >> 2, ld_c4 = tid & 3;
+    int64_t am = m0 + ld_row;
+    am = am < M ? am : M - 1;
+    const float* ga_ptr = A + am * lda + ld_c4 * 4;
+    const float* gb_ptr = W + (int64_t)ld_row * K + ld_c4 * 4;
+    const int64_t gb_step = (int64_t)64 * K;  // 64 rows of W between a thread's loads
+    f32x4 ga, gb[T::B_LOADS];
+    auto load_tiles = [&](int k0) {
+        ga = *reinterpret_cast<const f32x4*>(ga_ptr + k0);
+#pragma unroll
+        for (int i = 0; i < T::B_LOADS; ++i) gb[i] = *reinterpret_cast<const f32x4*>(gb_ptr + i * gb_step + k0);
+    };
+    const int st_off = ld_row * STRIDE + ld_c4 * 4;
+    auto store_tiles = [&](int stage) {
+        float* base = smem + stage * T::STAGE_FLOATS;
+        *reinterpret_cast<f32x4*>(base + st_off) = ga;
+#pragma unroll
+        for (int i = 0; i < T::B_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(base + BM * STRIDE + st_off + 64 * i * STRIDE) = gb[i];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    struct LnFrag {
+        f32x4 a[2], b[NT];
+    };
+    const int a_off = l31 * STRIDE + half * 4;
+    const int b_off = BM * STRIDE + (wid * 32 * NT + l31) * STRIDE + half * 4;
+    auto read_frag = [&](LnFrag& f, int stage, int kk) {
+        const float* base = smem + stage * T::STAGE_FLOATS + kk * 8;
+        f.a[0] = *reinterpret_cast<const f32x4*>(base + a_off);
+        f.a[1] = *reinterpret_cast<const f32x4*>(base + a_off + 32 * STRIDE);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(base + b_off + j * 32 * STRIDE);
+    };
+    auto mfma_phase = [&](const LnFrag& f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][c], f.b[j][c], acc[i][j], 0, 0, 0);
+    };
+
+    const int nk = K / BK;
+    load_tiles(0);
+    store_tiles(0);
+    if (nk > 1) load_tiles(BK);
+    __syncthreads();
+    LnFrag fr[2];
+    read_frag(fr[0], 0, 0);
+
+    auto step = [&](auto store_tag, auto load_tag, int kt) {
+        constexpr bool STORE = decltype(store_tag)::value;
+        constexpr bool LOAD = decltype(load_tag)::value;
+        const int cur = kt & 1;
+        // phase 0: fragments kk = 1 | MFMAs kk = 0, with the next tiles' memory traffic one per MFMA
+        read_frag(fr[1], cur, 1);
+        if (STORE) store_tiles(cur ^ 1);
+        if (LOAD) load_tiles((kt + 2) * BK);
+        mfma_phase(fr[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // DS reads first
+        if (STORE) {
+#pragma unroll
+            for (int i = 0; i < 1 + T::B_LOADS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            }
+        }
+        if (LOAD) {
+#pragma unroll
+            for (int i = 0; i < 1 + T::B_LOADS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 1: everyone has read LDS[cur] and written LDS[cur^1]: barrier, fetch the next tile's first
+        // fragments, then the last MFMAs of this tile from registers
+        __syncthreads();
+        if (STORE) read_frag(fr[0], cur ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase(fr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(TT{}, TT{}, kt);
+    if (kt + 1 < nk) step(TT{}, FF{}, kt++);
+    step(FF{}, FF{}, kt);
+
+    // ---- epilogue ----
+    constexpr int OS = T::OUT_STRIDE, NV = T::V4_PER_THREAD;
+    const int e_row = tid >> 3, e_t8 = tid & 7;
+    f32x4 res[2][NV];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t m = m0 + i * 32 + e_row;
+        m = m < M ? m : M - 1;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) res[i][q] = *reinterpret_cast<const f32x4*>(R + m * ldr + (e_t8 + 8 * q) * 4);
+    }
+    const float inv_n = 1.0f / (float)BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();  // round 0: the operand tiles are dead; round 1: round 0's reads are done
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                smem[acc_row(r, half) * OS + wid * 32 * NT + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        f32x4 x[NV];
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int c = (e_t8 + 8 * q) * 4;
+            x[q] = *reinterpret_cast<const f32x4*>(smem + e_row * OS + c);
+            if (bias) x[q] += *reinterpret_cast<const f32x4*>(bias + c);
+            x[q] += res[i][q];
+            s += (x[q][0] + x[q][1]) + (x[q][2] + x[q][3]);
+        }
+        s += __shfl_xor(s, 1, kWave);
+        s += __shfl_xor(s, 2, kWave);
+        s += __shfl_xor(s, 4, kWave);
+        const float mean = s * inv_n;
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d = x[q][c] - mean;
+                v = fmaf(d, d, v);
+            }
+        v += __shfl_xor(v, 1, kWave);
+        v += __shfl_xor(v, 2, kWave);
+        v += __shfl_xor(v, 4, kWave);
+        const float inv_std = 1.0f / sqrtf(v * inv_n + eps);
+        const int64_t m = m0 + i * 32 + e_row;
+        if (m < M) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int c = (e_t8 + 8 * q) * 4;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (x[q][e] - mean) * inv_std * g[e] + b[e];
+                *reinterpret_cast<f32x4*>(Y + m * ldy + c) = o;
+            }
+        }
+    }
+}
+
+template <int NT>
+hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr,
+                           const float* gamma, const float* beta, float eps, float* Y, int64_t ldy, int64_t M, int K,
+                           hipStream_t stream)
+{
+    using T = LnTile<NT>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (T::LDS_BYTES > 64 * 1024 && !attr_set[dev & 63]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma_ln<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    dim3 grid((unsigned)((M + T::BM - 1) / T::BM));
+    hipLaunchKernelGGL((gemm_nt_f32_mfma_ln<NT>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias, R, ldr,
+                       gamma, beta, eps, Y, ldy, M, K);
+    return hipGetLastError();
+}
+
 // Any-shape fallback (odd hidden sizes in tests, tiny heads): 32x32 LDS tiles,
 // plain FMA.  Not on the MiniLM/BERT hot path.
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_f32_generic(const float* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ W,
                                                            const float* __restrict__ bias,
-                                                           const float* __restrict__ R, int64_t ldr,
-                                                           float* __restrict__ Y, int64_t ldy,
+                                                           const float* R, int64_t ldr, float* Y, int64_t ldy,
                                                            int64_t M, int N, int K)
 {
     __shared__ float sA[32][33];
@@ -398,12 +643,14 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
                          (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (R == nullptr || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(R) & 15) == 0));
     if (aligned) {
+#ifdef KJARNI_TUNING
         switch (g_gemm_variant) {
-        case 1: return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
         case 2: return launch_tiled<EPI, 16, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
         case 9: return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-        default: return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        default: break;
         }
+#endif
+        return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
     hipLaunchKernelGGL(gemm_nt_f32_generic<EPI>, grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N,
@@ -413,8 +660,31 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
 
 }  // namespace
 
+#ifdef KJARNI_TUNING
 void set_gemm_variant(int variant) { g_gemm_variant = variant; }
 int gemm_variant() { return g_gemm_variant; }
+#endif
+
+bool gemm_residual_layernorm_supported(int N, int K)
+{
+#ifdef KJARNI_TUNING
+    if (g_gemm_variant == 4) return false;
+#endif
+    return (N == 384 || N == 256) && K >= 16 && K % 16 == 0;
+}
+
+hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
+                                          const float* R, int64_t ldr, const float* gamma, const float* beta, float eps,
+                                          float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
+{
+    if (M <= 0) return hipSuccess;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!gemm_residual_layernorm_supported(N, K) || !R || !gamma || !beta || lda % 4 || ldr % 4 || ldy % 4 ||
+        !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y))
+        return hipErrorInvalidValue;
+    if (N == 384) return launch_ln_tiled<3>(A, lda, W, bias, R, ldr, gamma, beta, eps, Y, ldy, M, K, stream);
+    return launch_ln_tiled<2>(A, lda, W, bias, R, ldr, gamma, beta, eps, Y, ldy, M, K, stream);
+}
 
 hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
                        int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi,
@@ -424,7 +694,9 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
     switch (epi) {
     case EPI_BIAS: return launch_epi<EPI_BIAS>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     case EPI_BIAS_GELU:
+#ifdef KJARNI_TUNING
         if (g_gemm_variant == 3) return launch_epi<EPI_GELU_LIBM>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+#endif
         return launch_epi<EPI_BIAS_GELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     case EPI_BIAS_GELU_NEW: return launch_epi<EPI_BIAS_GELU_NEW>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     case EPI_BIAS_RELU: return launch_epi<EPI_BIAS_RELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);

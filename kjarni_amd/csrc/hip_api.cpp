@@ -7,6 +7,7 @@
 
 #include "../../include/kjarni_hip.h"
 #include "ffi_common.h"
+#include "group.h"
 
 using namespace kjarni;
 
@@ -153,36 +154,6 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_logits(KjarniHipEncoder* enc, c
     });
 }
 
-namespace {
-
-// Shared body of the *_host variants: stage ids/mask/type on the device, run
-// `body(ids_dev, mask_dev, type_dev, out_dev)`, copy `out_floats` back.
-template <class F>
-void run_host(EncoderModel& m, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
-              int64_t batch, int32_t seq, size_t out_floats, float* out, F&& body)
-{
-    check_shape(m, batch, seq);
-    if (batch == 0 || seq == 0) return;
-    hip_check(hipSetDevice(m.device()), "hipSetDevice");
-    const size_t n = (size_t)batch * (size_t)seq;
-    const size_t tok_bytes = n * sizeof(uint32_t);
-    const size_t in_bytes = tok_bytes * (type_ids ? 3 : 2);
-    const size_t out_off = (in_bytes + 255) & ~(size_t)255;
-    uint8_t* base = static_cast<uint8_t*>(m.scratch(out_off + out_floats * sizeof(float)));
-    uint32_t* ids_d = reinterpret_cast<uint32_t*>(base);
-    uint32_t* mask_d = reinterpret_cast<uint32_t*>(base + tok_bytes);
-    uint32_t* type_d = type_ids ? reinterpret_cast<uint32_t*>(base + 2 * tok_bytes) : nullptr;
-    float* out_d = reinterpret_cast<float*>(base + out_off);
-    hip_check(hipMemcpyAsync(ids_d, ids, tok_bytes, hipMemcpyHostToDevice, nullptr), "H2D ids");
-    hip_check(hipMemcpyAsync(mask_d, mask, tok_bytes, hipMemcpyHostToDevice, nullptr), "H2D mask");
-    if (type_ids) hip_check(hipMemcpyAsync(type_d, type_ids, tok_bytes, hipMemcpyHostToDevice, nullptr), "H2D type ids");
-    body(ids_d, mask_d, type_d, out_d);
-    hip_check(hipMemcpyAsync(out, out_d, out_floats * sizeof(float), hipMemcpyDeviceToHost, nullptr), "D2H output");
-    hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
-}
-
-}  // namespace
-
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states_host(KjarniHipEncoder* enc, const uint32_t* ids,
                                                                     const uint32_t* mask,
                                                                     const uint32_t* type_ids, int64_t batch,
@@ -191,11 +162,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states_host(KjarniHipEnc
 {
     if (!enc || !ids || !mask || !hidden_out) return KJARNI_ERROR_NULL_POINTER;
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
-        EncoderModel& m = *enc->model;
-        run_host(m, ids, mask, type_ids, batch, seq, (size_t)batch * seq * m.config().hidden, hidden_out,
-                 [&](uint32_t* i, uint32_t* k, uint32_t* t, float* o) {
-                     m.hidden_states(i, k, t, batch, seq, resolve_fill(fill, batch * seq, false), o, nullptr);
-                 });
+        check_shape(*enc->model, batch, seq);
+        enc->model->hidden_states_host(ids, mask, type_ids, batch, seq, resolve_fill(fill, batch * seq, false), hidden_out);
     });
 }
 
@@ -206,13 +174,9 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_embed_host(KjarniHipEncoder* en
 {
     if (!enc || !ids || !mask || !out) return KJARNI_ERROR_NULL_POINTER;
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
-        EncoderModel& m = *enc->model;
-        const PoolMode pm = pool_mode(pooling);
-        run_host(m, ids, mask, type_ids, batch, seq, (size_t)batch * m.config().hidden, out,
-                 [&](uint32_t* i, uint32_t* k, uint32_t* t, float* o) {
-                     m.embed(i, k, t, batch, seq, pm, normalize != 0, resolve_fill(fill, batch * seq, false), o,
-                             nullptr);
-                 });
+        check_shape(*enc->model, batch, seq);
+        enc->model->embed_host(ids, mask, type_ids, batch, seq, pool_mode(pooling), normalize != 0,
+                               resolve_fill(fill, batch * seq, false), out);
     });
 }
 
@@ -223,11 +187,114 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* e
 {
     if (!enc || !ids || !mask || !logits_out) return KJARNI_ERROR_NULL_POINTER;
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
-        EncoderModel& m = *enc->model;
-        run_host(m, ids, mask, type_ids, batch, seq, (size_t)batch * m.config().num_labels, logits_out,
-                 [&](uint32_t* i, uint32_t* k, uint32_t* t, float* o) {
-                     m.logits(i, k, t, batch, seq, resolve_fill(fill, batch * seq, true), o, nullptr);
-                 });
+        check_shape(*enc->model, batch, seq);
+        enc->model->logits_host(ids, mask, type_ids, batch, seq, resolve_fill(fill, batch * seq, true), logits_out);
+    });
+}
+
+// ---- several devices in one process (group.h) ----------------------------------------------------------
+
+struct KjarniHipEncoderGroup {
+    std::unique_ptr<EncoderGroup> group;
+};
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_load(const char* model_dir, const int32_t* devices, size_t n_devices,
+                                                    KjarniHipEncoderGroup** out)
+{
+    if (!model_dir || !out || (n_devices > 0 && !devices)) return KJARNI_ERROR_NULL_POINTER;
+    *out = nullptr;
+    return guarded(KJARNI_ERROR_LOAD_FAILED, [&] {
+        const std::string dir(model_dir);
+        if (!file_exists(dir + "/config.json") ||
+            !(file_exists(dir + "/model.safetensors") || file_exists(dir + "/model.safetensors.index.json")))
+            throw ModelNotFound("model files not found in '" + dir + "' (need config.json and model.safetensors)");
+        std::vector<int> devs(devices, devices + n_devices);
+        if (devs.empty()) devs = devices_from_env();
+        auto h = std::make_unique<KjarniHipEncoderGroup>();
+        h->group = EncoderGroup::load(dir, devs);
+        *out = h.release();
+    });
+}
+
+KJARNI_EXPORT void kjarni_hip_group_free(KjarniHipEncoderGroup* g) { delete g; }
+KJARNI_EXPORT size_t kjarni_hip_group_size(const KjarniHipEncoderGroup* g) { return g ? g->group->size() : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_group_device(const KjarniHipEncoderGroup* g, size_t i)
+{
+    return (g && i < g->group->size()) ? g->group->device(i) : -1;
+}
+KJARNI_EXPORT int32_t kjarni_hip_group_hidden_size(const KjarniHipEncoderGroup* g) { return g ? g->group->config().hidden : 0; }
+KJARNI_EXPORT int32_t kjarni_hip_group_num_labels(const KjarniHipEncoderGroup* g) { return g ? g->group->config().num_labels : 0; }
+KJARNI_EXPORT const char* kjarni_hip_group_transport(KjarniHipEncoderGroup* g)
+{
+    if (!g) return "";
+    const char* t = "";
+    (void)guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] { t = g->group->transport(); });
+    return t;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_shard(const KjarniHipEncoderGroup* g, int64_t rows, size_t i, int64_t* start_out,
+                                                     int64_t* count_out)
+{
+    if (!g || !start_out || !count_out) return KJARNI_ERROR_NULL_POINTER;
+    if (i >= g->group->size() || rows < 0) return KJARNI_ERROR_INVALID_CONFIG;
+    EncoderGroup::shard(rows, g->group->size(), i, start_out, count_out);
+    return KJARNI_OK;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_embed_host(KjarniHipEncoderGroup* g, const uint32_t* ids, const uint32_t* mask,
+                                                          const uint32_t* type_ids, int64_t batch, int32_t seq,
+                                                          KjarniHipPooling pooling, int32_t normalize, KjarniHipMaskFill fill,
+                                                          float* out)
+{
+    if (!g || !ids || !mask || !out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(g->group->replica(0), batch, seq);
+        g->group->embed_host(ids, mask, type_ids, batch, seq, pool_mode(pooling), normalize != 0,
+                             resolve_fill(fill, batch * seq, false), out);
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_logits_host(KjarniHipEncoderGroup* g, const uint32_t* ids, const uint32_t* mask,
+                                                           const uint32_t* type_ids, int64_t batch, int32_t seq,
+                                                           KjarniHipMaskFill fill, float* logits_out)
+{
+    if (!g || !ids || !mask || !logits_out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(g->group->replica(0), batch, seq);
+        if (g->group->config().head_kind == 0) throw InvalidConfig("model has no classification head");
+        g->group->logits_host(ids, mask, type_ids, batch, seq, resolve_fill(fill, batch * seq, true), logits_out);
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_embed_allgather(KjarniHipEncoderGroup* g, const uint32_t* const* ids_dev,
+                                                               const uint32_t* const* mask_dev,
+                                                               const uint32_t* const* type_ids_dev, int64_t batch_total,
+                                                               int32_t seq, KjarniHipPooling pooling, int32_t normalize,
+                                                               KjarniHipMaskFill fill, float* const* out_dev)
+{
+    if (!g || !ids_dev || !mask_dev || !out_dev) return KJARNI_ERROR_NULL_POINTER;
+    for (size_t i = 0; i < g->group->size(); ++i)
+        if (!ids_dev[i] || !mask_dev[i] || !out_dev[i]) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(g->group->replica(0), batch_total, seq);
+        g->group->allgather_embed(ids_dev, mask_dev, type_ids_dev, batch_total, seq, pool_mode(pooling), normalize != 0,
+                                  resolve_fill(fill, batch_total * seq, false), out_dev);
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_logits_allgather(KjarniHipEncoderGroup* g, const uint32_t* const* ids_dev,
+                                                                const uint32_t* const* mask_dev,
+                                                                const uint32_t* const* type_ids_dev, int64_t batch_total,
+                                                                int32_t seq, KjarniHipMaskFill fill, float* const* logits_out_dev)
+{
+    if (!g || !ids_dev || !mask_dev || !logits_out_dev) return KJARNI_ERROR_NULL_POINTER;
+    for (size_t i = 0; i < g->group->size(); ++i)
+        if (!ids_dev[i] || !mask_dev[i] || !logits_out_dev[i]) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        check_shape(g->group->replica(0), batch_total, seq);
+        if (g->group->config().head_kind == 0) throw InvalidConfig("model has no classification head");
+        g->group->allgather_logits(ids_dev, mask_dev, type_ids_dev, batch_total, seq, resolve_fill(fill, batch_total * seq, true),
+                                   logits_out_dev);
     });
 }
 
@@ -364,9 +431,51 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const flo
     });
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear_layer_norm(int32_t device, const float* x, const float* w,
+                                                              const float* bias, const float* residual, const float* gamma,
+                                                              const float* beta, float eps, int64_t m, int32_t k, int32_t n,
+                                                              float* y, int32_t iters, float* ms_out)
+{
+    if (!x || !w || !residual || !gamma || !beta || !y) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (m < 0 || k <= 0 || n <= 0) throw InvalidConfig("invalid GEMM dimensions");
+        use_device(device);
+        if (m == 0) return;
+        const size_t xb = (size_t)m * k * 4, wb = (size_t)n * k * 4, yb = (size_t)m * n * 4, nb = (size_t)n * 4;
+        DeviceBuf xd(xb), wd(wb), bd(nb), rd(yb), gd(nb), ed(nb), yd(yb);
+        hip_check(hipMemcpy(xd.p, x, xb, hipMemcpyHostToDevice), "H2D x");
+        hip_check(hipMemcpy(wd.p, w, wb, hipMemcpyHostToDevice), "H2D w");
+        if (bias) hip_check(hipMemcpy(bd.p, bias, nb, hipMemcpyHostToDevice), "H2D bias");
+        const float* bias_d = bias ? (const float*)bd.p : nullptr;
+        hip_check(hipMemcpy(rd.p, residual, yb, hipMemcpyHostToDevice), "H2D residual");
+        hip_check(hipMemcpy(gd.p, gamma, nb, hipMemcpyHostToDevice), "H2D gamma");
+        hip_check(hipMemcpy(ed.p, beta, nb, hipMemcpyHostToDevice), "H2D beta");
+        const bool fused = gemm_residual_layernorm_supported(n, k);
+        time_launches(iters, ms_out, [&] {
+            if (fused) {
+                hip_check(launch_gemm_residual_layernorm((const float*)xd.p, k, (const float*)wd.p, bias_d,
+                                                         (const float*)rd.p, n, (const float*)gd.p, (const float*)ed.p, eps,
+                                                         (float*)yd.p, n, m, n, k, nullptr),
+                          "gemm + layernorm");
+            } else {
+                hip_check(launch_gemm((const float*)xd.p, k, (const float*)wd.p, bias_d, (const float*)rd.p, n,
+                                      (float*)yd.p, n, m, n, k, EPI_BIAS_RESIDUAL, nullptr),
+                          "gemm");
+                hip_check(launch_layernorm((const float*)yd.p, (const float*)gd.p, (const float*)ed.p, eps, m, n, (float*)yd.p,
+                                           nullptr),
+                          "layernorm");
+            }
+        });
+        hip_check(hipMemcpy(y, yd.p, yb, hipMemcpyDeviceToHost), "D2H y");
+    });
+}
+
+#ifdef KJARNI_TUNING
+// Kernel A/B switches: exported by the tuning build only (kjarni_amd/lib/libkjarni_ffi_tuning.so, tools/).
 KJARNI_EXPORT void kjarni_hip_set_gemm_variant(int32_t variant) { set_gemm_variant(variant); }
 KJARNI_EXPORT void kjarni_hip_set_attention_variant(int32_t variant) { set_attention_variant(variant); }
 KJARNI_EXPORT void kjarni_hip_set_cosine_variant(int32_t variant) { set_cosine_variant(variant); }
+#endif
 
 // ---- cosine scan ----------------------------------------------------------------
 

@@ -1,5 +1,6 @@
 #include "json.h"
 
+#include <charconv>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -170,10 +171,11 @@ struct Parser {
             while (p < end && (*p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E' ||
                                (*p >= '0' && *p <= '9')))
                 ++p;
-            std::string tmp(s, p);
-            char* ep = nullptr;
-            v.num = std::strtod(tmp.c_str(), &ep);
-            if (ep == tmp.c_str()) fail("bad number");
+            // std::from_chars is locale-independent: a host that called setlocale(LC_NUMERIC, "de_DE") must still
+            // read "1e-12" / "0.1" (strtod would stop at the '.', silently changing layer_norm_eps or rope_theta).
+            const char* q = (*s == '+') ? s + 1 : s;
+            const std::from_chars_result r = std::from_chars(q, p, v.num);
+            if (r.ec != std::errc() || r.ptr != p) fail("bad number");
             v.type = Json::Number;
         } else if (c == 'N' && end - p >= 3 && std::memcmp(p, "NaN", 3) == 0) {
             p += 3;  // Python's json writes NaN/Infinity into some config files

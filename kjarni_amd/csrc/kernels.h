@@ -41,11 +41,22 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
                        const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
                        GemmEpilogue epi, hipStream_t stream);
 
-// Tuning hook: which tiling variant launch_gemm uses (0 = default).
-void set_gemm_variant(int variant);
+// R5 + R3 of the post-norm layer in one launch: Y = LayerNorm(A W^T + bias + R) * gamma + beta, R == Y allowed
+// (cpu/encoder/encoder_layer.rs:129-147, 155-176).  Row widths the kernel covers: see ..._supported();
+// anything else returns hipErrorInvalidValue and the caller runs launch_gemm + launch_layernorm.
+bool gemm_residual_layernorm_supported(int N, int K);
+hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
+                                          const float* R, int64_t ldr, const float* gamma, const float* beta, float eps,
+                                          float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream);
+
+#ifdef KJARNI_TUNING
+// Kernel A/B switches of the tuning build (kjarni_amd/lib/libkjarni_ffi_tuning.so, tools/ only).  Process-wide
+// atomics; the shipped library has none of them.
+void set_gemm_variant(int variant);       // gemm.hip
 int gemm_variant();
 void set_attention_variant(int variant);  // 0 = default, 1 = non-persistent kernel
 void set_cosine_variant(int variant);     // 0 = default, 1 = streaming passes only (no GEMM route for many queries)
+#endif
 
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.
 // qkv is [tokens, 3*hidden] (Q | K | V), mask is u32 [batch, seq], ctx is

@@ -355,10 +355,14 @@ void LlmModel::forward(const uint32_t* ids, int n)
     hip_check(hipSetDevice(device_), "hipSetDevice");
     if (n < 1) throw std::runtime_error("forward needs at least one token");
     if (cache_len_ + n > cache_cap_) throw std::runtime_error("context is full");
+#ifdef KJARNI_TUNING
     static const int kMinGemmRows = [] {
         const char* v = std::getenv("KJARNI_HIP_LLM_PREFILL_MIN");  // measurements: rows from which the matrix-core route is used
         return v ? std::atoi(v) : 24;
     }();
+#else
+    constexpr int kMinGemmRows = 24;  // rows from which the matrix-core route is used
+#endif
     const int kvd = cfg_.kv_heads * cfg_.head_dim;
     if (n >= kMinGemmRows && cfg_.hidden % 32 == 0 && cfg_.inter % 32 == 0 && kvd % 4 == 0 && cfg_.head_dim % 2 == 0) {
         prefill_rows(ids, n);

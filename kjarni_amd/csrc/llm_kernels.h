@@ -29,7 +29,9 @@ struct LlmGemvArgs {
     const int* row_off_ptr = nullptr;
 };
 hipError_t launch_llm_gemv(const LlmGemvArgs& args, hipStream_t stream);
+#ifdef KJARNI_TUNING
 void set_llm_gemv_variant(int variant);  // 0 = default (single-row kernel for rows == 1), 1 = always the multi-row kernel
+#endif
 
 // One new token: RMSNorm + Q|K|V projection + RoPE in one launch; Q -> Q[n_heads*head_dim], K / V -> row `pos`
 // (or *pos_ptr) of the caches [*, n_kv_heads*head_dim].  W is the fused [Q;K;V] matrix.

@@ -8,6 +8,8 @@
 //   layer     cpu/decoder/rope_decoder_layer.rs:18-41, cpu/decoder/decoder_attention.rs:44-170,
 //             cpu/feedforward/swiglu.rs:32-57
 //   greedy    common/sampling.rs:83-88
+#include <atomic>
+
 #include "device_utils.h"
 #include "llm_kernels.h"
 
@@ -16,7 +18,11 @@ namespace kjarni {
 namespace {
 
 constexpr int LLM_MAX_ROWS = 8;
-int g_llm_gemv_variant = 0;  // 1 = always the multi-row kernel (tests / measurements)
+#ifdef KJARNI_TUNING
+std::atomic<int> g_llm_gemv_variant{0};  // 1 = always the multi-row kernel; 3..6 columns per workgroup; 7 = narrow chunks -- tuning build only
+#else
+constexpr int g_llm_gemv_variant = 0;
+#endif
 
 
 struct F8 {
@@ -779,7 +785,9 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
         // Two columns per workgroup measured best on every projection of the 1B and 8B shapes (1, 4 and 8 were 2-18 % slower
         // end to end): the chip wants many small workgroups more than it wants deep per-lane load queues.
         int opw = 2;
+#ifdef KJARNI_TUNING
         if (g_llm_gemv_variant >= 3 && g_llm_gemv_variant <= 6) opw = 1 << (g_llm_gemv_variant - 3);  // measurements: 3 -> 1 ... 6 -> 8
+#endif
         if (opw > 8) opw = 8;
         if (chunks > 2 && opw > 4) opw = 4;
         if (chunks > 4 && opw > 2) opw = 2;
@@ -870,7 +878,9 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+#ifdef KJARNI_TUNING
 void set_llm_gemv_variant(int v) { g_llm_gemv_variant = v; }
+#endif
 
 hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int bf16, const float* bias, const float* R, int64_t ldr, float* Y,
                                int64_t ldy, int M, int N, int K, hipStream_t stream)

@@ -441,7 +441,9 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
     hip_check(hipMemset(m->dbest_, 0, sizeof(unsigned long long) * kMaxLanes), "memset(pick scratch)");
     hip_check(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking), "hipStreamCreate");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(load)");
-    if (const char* v = std::getenv("KJARNI_HIP_GEMV_ROWS")) set_gemv_rows_variant(std::atoi(v));  // kernel A/B measurements only
+#ifdef KJARNI_TUNING
+    if (const char* v = std::getenv("KJARNI_HIP_GEMV_ROWS")) set_gemv_rows_variant(std::atoi(v));  // kernel A/B measurements
+#endif
     return m;
 }
 

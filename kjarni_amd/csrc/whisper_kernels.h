@@ -49,7 +49,9 @@ struct GemvArgs {
     GemmEpilogue epi = EPI_BIAS;
 };
 hipError_t launch_gemv_rows(const GemvArgs& args, hipStream_t stream);
+#ifdef KJARNI_TUNING
 void set_gemv_rows_variant(int variant);  // 0 = rows staged in LDS when there are several, 1 = always the per-wave kernel
+#endif
 
 // Attention of `rows` query rows over cached keys/values, split over `splits` key ranges + a combine pass.
 // n_keys_ptr (device int) given: keys = *n_keys_ptr + rows and the causal base = *n_keys_ptr (max_keys bounds it);

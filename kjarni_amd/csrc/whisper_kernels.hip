@@ -7,6 +7,8 @@
 //   decoder step   cpu/encoder_decoder/cpu_decoder.rs:457-516, decoder_cross_attn.rs:71-120,
 //                  encoder_decoder/decoder_self_attn.rs:52-146
 //   token choice   crates/kjarni-models/src/models/whisper/transcriber.rs:243-270
+#include <atomic>
+
 #include "device_utils.h"
 #include "whisper_kernels.h"
 
@@ -618,8 +620,14 @@ hipError_t launch_decoder_embed(const uint32_t* ids, int n, int hidden, int voca
     return hipGetLastError();
 }
 
-int g_gemv_rows_variant = 0;  // 1 = never stage the rows in LDS (measurements)
+#ifdef KJARNI_TUNING
+std::atomic<int> g_gemv_rows_variant{0};  // 1 = never stage the rows in LDS -- tuning build only
+#else
+constexpr int g_gemv_rows_variant = 0;
+#endif
+#ifdef KJARNI_TUNING
 void set_gemv_rows_variant(int v) { g_gemv_rows_variant = v; }
+#endif
 
 hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
 {

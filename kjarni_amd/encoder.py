@@ -138,6 +138,83 @@ class HipEncoder:
                                                            seq, fill, out_ptr, stream or None))
 
 
+class HipEncoderGroup:
+    """One replica of a BERT-family encoder per listed HIP device, driven from this process (kjarni_hip_group_*):
+    batches are cut into balanced contiguous row blocks, one host thread + stream per device.  devices=None uses
+    KJARNI_HIP_DEVICES / every visible device; a device may be listed twice."""
+
+    def __init__(self, model_dir: str, devices=None):
+        self._h = C.c_void_p()
+        devs = list(devices or [])
+        arr = (C.c_int32 * max(len(devs), 1))(*devs)
+        check_error(lib().kjarni_hip_group_load(str(model_dir).encode(), arr if devs else None, len(devs),
+                                                C.byref(self._h)))
+        L = lib()
+        self.size = int(L.kjarni_hip_group_size(self._h))
+        self.devices = [int(L.kjarni_hip_group_device(self._h, i)) for i in range(self.size)]
+        self.hidden_size = int(L.kjarni_hip_group_hidden_size(self._h))
+        self.num_labels = int(L.kjarni_hip_group_num_labels(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().kjarni_hip_group_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def transport(self) -> str:
+        return lib().kjarni_hip_group_transport(self._h).decode()
+
+    def shard(self, rows: int, i: int):
+        s, c = C.c_int64(0), C.c_int64(0)
+        check_error(lib().kjarni_hip_group_shard(self._h, rows, i, C.byref(s), C.byref(c)))
+        return int(s.value), int(c.value)
+
+    def embed(self, ids, mask, type_ids=None, pooling="mean", normalize: bool = True, fill: int = MASK_AUTO) -> np.ndarray:
+        ids, mask = _u32(ids), _u32(mask)
+        type_ids = None if type_ids is None else _u32(type_ids)
+        B, S = ids.shape
+        pool = _POOL_NAMES[pooling.lower()] if isinstance(pooling, str) else int(pooling)
+        out = np.empty((B, self.hidden_size), np.float32)
+        check_error(lib().kjarni_hip_group_embed_host(
+            self._h, _p(ids, _ffi._u32p), _p(mask, _ffi._u32p), _p(type_ids, _ffi._u32p), B, S, pool,
+            int(bool(normalize)), fill, _p(out, _ffi._f32p)))
+        return out
+
+    def logits(self, ids, mask, type_ids=None, fill: int = MASK_AUTO) -> np.ndarray:
+        ids, mask = _u32(ids), _u32(mask)
+        type_ids = None if type_ids is None else _u32(type_ids)
+        B, S = ids.shape
+        out = np.empty((B, self.num_labels), np.float32)
+        check_error(lib().kjarni_hip_group_logits_host(
+            self._h, _p(ids, _ffi._u32p), _p(mask, _ffi._u32p), _p(type_ids, _ffi._u32p), B, S, fill,
+            _p(out, _ffi._f32p)))
+        return out
+
+    def _ptr_array(self, ptrs):
+        return (C.c_void_p * self.size)(*[C.c_void_p(int(p)) for p in ptrs])
+
+    def embed_allgather(self, ids_ptrs, mask_ptrs, batch_total: int, seq: int, out_ptrs, type_ptrs=None,
+                        pooling: int = POOL_MEAN, normalize: bool = True, fill: int = MASK_AUTO):
+        """Raw device addresses, one per replica: its row block of ids / mask (/ types) and a full
+        [batch_total, hidden] output buffer on its device.  Returns when every buffer holds every row."""
+        check_error(lib().kjarni_hip_group_embed_allgather(
+            self._h, self._ptr_array(ids_ptrs), self._ptr_array(mask_ptrs),
+            self._ptr_array(type_ptrs) if type_ptrs else None, batch_total, seq, pooling, int(bool(normalize)), fill,
+            self._ptr_array(out_ptrs)))
+
+    def logits_allgather(self, ids_ptrs, mask_ptrs, type_ptrs, batch_total: int, seq: int, out_ptrs,
+                         fill: int = MASK_AUTO):
+        check_error(lib().kjarni_hip_group_logits_allgather(
+            self._h, self._ptr_array(ids_ptrs), self._ptr_array(mask_ptrs),
+            self._ptr_array(type_ptrs) if type_ptrs else None, batch_total, seq, fill, self._ptr_array(out_ptrs)))
+
+
 def cosine_search(queries, corpus, k: int, mode: int = COSINE_VECTOR_STORE, device: int = 0):
     """Brute-force cosine top-k on the GPU (VectorStore::search / Segment::search_vectors).
 

@@ -59,16 +59,44 @@ def layer_norm(x, gamma, beta, eps: float, iters: int = 0, device: int = 0) -> T
     return y, (float(ms.value) if iters > 0 else None)
 
 
+def linear_layer_norm(x, w, bias, residual, gamma, beta, eps: float, iters: int = 0, device: int = 0
+                      ) -> Tuple[np.ndarray, Optional[float]]:
+    """LayerNorm(x . w^T + bias + residual) * gamma + beta (kjarni_hip_op_linear_layer_norm)."""
+    x, w, bias, residual, gamma, beta = _c(x), _c(w), _c(bias), _c(residual), _c(gamma), _c(beta)
+    m, k = x.shape
+    n = w.shape[0]
+    y = np.empty((m, n), np.float32)
+    ms = C.c_float(0)
+    check_error(lib().kjarni_hip_op_linear_layer_norm(device, _f(x), _f(w), _f(bias), _f(residual), _f(gamma), _f(beta),
+                                                      float(eps), m, k, n, _f(y), iters, C.byref(ms)))
+    return y, (float(ms.value) if iters > 0 else None)
+
+
+def _tuning(name: str):
+    """Kernel A/B switches exist only in the tuning build: `make -C kjarni_amd/csrc tuning`, then run the tool with
+    KJARNI_FFI_LIB=kjarni_amd/lib/libkjarni_ffi_tuning.so.  The shipped library does not export them."""
+    try:
+        fn = getattr(lib(), name)
+    except AttributeError:
+        raise RuntimeError(f"{name} needs the tuning build (KJARNI_FFI_LIB=.../libkjarni_ffi_tuning.so)") from None
+    fn.restype, fn.argtypes = None, [C.c_int32]
+    return fn
+
+
+def has_tuning() -> bool:
+    return hasattr(lib(), "kjarni_hip_set_gemm_variant")
+
+
 def set_gemm_variant(v: int):
-    lib().kjarni_hip_set_gemm_variant(int(v))
+    _tuning("kjarni_hip_set_gemm_variant")(int(v))
 
 
 def set_attention_variant(v: int):
-    lib().kjarni_hip_set_attention_variant(int(v))
+    _tuning("kjarni_hip_set_attention_variant")(int(v))
 
 
 def set_cosine_variant(v: int):
-    lib().kjarni_hip_set_cosine_variant(int(v))
+    _tuning("kjarni_hip_set_cosine_variant")(int(v))
 
 
 def topk(scores, k: int, device: int = 0):

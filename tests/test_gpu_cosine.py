@@ -96,18 +96,15 @@ def test_many_queries_gemm_route_matches_streaming_and_oracle(n, dim, nq, mode):
     it does not take (n % 4 != 0, dim % 32 != 0) fall back to the streaming passes.  Both must agree
     with the oracle, zero rows and zero queries included."""
     import kjarni_amd
-    from kjarni_amd import ops
     corpus = _unit_rows(n, dim, seed=n) * np.float32(0.5)
     corpus[11] = 0.0
     queries = _unit_rows(nq, dim, seed=nq + 1) * np.float32(3.0)
     queries[2] = 0.0
     k = 12
     idx, sc = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
-    ops.set_cosine_variant(1)
-    try:
-        idx1, sc1 = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
-    finally:
-        ops.set_cosine_variant(0)
+    # the same queries in groups of 16: below 20 queries a call takes the streaming passes
+    parts = [kjarni_amd.cosine_search(queries[j0:j0 + 16], corpus, k, mode=mode) for j0 in range(0, nq, 16)]
+    idx1, sc1 = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
     assert idx.shape == idx1.shape == (nq, k)
     fin = np.isfinite(sc1)
     assert (np.isfinite(sc) == fin).all() and np.abs(sc[fin] - sc1[fin]).max() < 2e-6

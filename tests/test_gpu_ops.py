@@ -13,13 +13,11 @@ def _silu(x):
     return np.where(x <= -20, np.float32(0), np.where(x >= 20, x, y)).astype(np.float32)
 
 
-@pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (127, 384, 1152), (128, 384, 1536), (300, 1536, 384),
                                    (1000, 768, 768), (77, 100, 7), (5, 17, 4), (257, 64, 128), (130, 32, 128)])
-def test_linear_all_epilogues(m, k, n, variant):
+def test_linear_all_epilogues(m, k, n):
     # LinearLayer::matmul shapes incl. decode (m=1), odd dims (cpu/ops/tests.rs:78-116) and M tails
     from kjarni_amd import ops
-    ops.set_gemm_variant(variant)
     rng = np.random.default_rng(m * 7 + n)
     x = rng.standard_normal((m, k)).astype(np.float32)
     w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
@@ -40,7 +38,44 @@ def test_linear_all_epilogues(m, k, n, variant):
         assert np.abs(got - ref).max() < tol, (epi, float(np.abs(got - ref).max()))
     got, _ = ops.linear(x, w, None, None, ops.EPI_BIAS)      # no bias
     assert np.abs(got - O.linear(x, w)).max() < tol
-    ops.set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 384, 384), (63, 384, 384), (64, 1536, 384), (65, 384, 384), (300, 1536, 384),
+                                   (1000, 16, 384), (129, 256, 256), (200, 1024, 256), (77, 768, 768), (40, 100, 60)])
+@pytest.mark.parametrize("eps", [1e-12, 1e-5])
+def test_residual_projection_with_fused_layernorm(m, k, n, eps):
+    """out-proj / FC2 + residual + LayerNorm of the post-norm layer (encoder_layer.rs:129-147, 155-176) as ONE kernel
+    for 384- and 256-wide rows (whole rows per workgroup, M tails, a single K-step); other widths take GEMM + LayerNorm
+    behind the same entry point.  Reference: Linear, add, LayerNorm of the oracle."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(m * 13 + k + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = (rng.standard_normal((m, n)) * 2 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    ref = O.layer_norm(O.linear(x, w, b) + r, g, beta, eps)
+    got, _ = ops.linear_layer_norm(x, w, b, r, g, beta, eps)
+    assert got.shape == ref.shape and float(np.abs(got - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+    if eps == 1e-5:  # Nomic's projections have no biases
+        ref = O.layer_norm(O.linear(x, w) + r, g, beta, eps)
+        got, _ = ops.linear_layer_norm(x, w, None, r, g, beta, eps)
+        assert float(np.abs(got - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_fused_layernorm_constant_rows():
+    """A row whose 384 values are all equal has variance 0: the result is beta (eps inside the sqrt keeps it finite)."""
+    from kjarni_amd import ops
+    m, k, n = 70, 32, 384
+    x = np.zeros((m, k), np.float32)
+    w = np.ones((n, k), np.float32)
+    b = np.full(n, 3.0, np.float32)
+    r = np.full((m, n), -1.5, np.float32)
+    g = np.linspace(0.5, 1.5, n).astype(np.float32)
+    beta = np.linspace(-1, 1, n).astype(np.float32)
+    got, _ = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12)
+    assert np.isfinite(got).all() and float(np.abs(got - beta[None, :]).max()) < 1e-6
 
 
 @pytest.mark.parametrize("B,S,heads,d", [(2, 128, 12, 32), (3, 37, 12, 32), (2, 200, 12, 32), (1, 512, 4, 32),

@@ -1,0 +1,66 @@
+"""GEMM probes on the GPU box (HIP-event timed through kjarni_hip_op_*; >= 0.3 s per measurement so the clock settles).
+  1. K sweep of the plain projection GEMM: where does the main loop settle once prologue / epilogue are amortised?
+  2. residual projection + LayerNorm: the fused kernel against GEMM + LayerNorm (needs the tuning build for the A/B:
+     KJARNI_FFI_LIB=kjarni_amd/lib/libkjarni_ffi_tuning.so)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import torch  # noqa: F401  (HIP runtime first, as in bench.py)
+from kjarni_amd import ops
+
+M = int(os.environ.get("KB_M", 131072))
+rng = np.random.default_rng(0)
+PEAK = 157.3
+
+
+def iters_for(flops):
+    return max(10, int(0.35 / (flops / 120e12)))
+
+
+def sweep():
+    for n, ks in ((384, (384, 1536, 6144)), (1536, (384, 1536))):
+        for k in ks:
+            m = M if k * M * 4 < 3.3e9 else M // 2
+            x = rng.standard_normal((m, k), dtype=np.float32)
+            w = (rng.standard_normal((n, k), dtype=np.float32) * 0.05).astype(np.float32)
+            b = rng.standard_normal(n, dtype=np.float32)
+            fl = 2.0 * m * n * k
+            for _ in range(2):
+                _, ms = ops.linear(x, w, b, None, ops.EPI_BIAS, iters=iters_for(fl))
+                tf = fl / (ms * 1e-3) / 1e12
+                print(f"gemm bias      M={m} N={n:5d} K={k:5d} {ms:8.4f} ms {tf:7.2f} TFLOP/s ({tf / PEAK * 100:5.1f}% peak)", flush=True)
+
+
+def fused():
+    for name, k in (("out_proj", 384), ("fc2", 1536)):
+        n = 384
+        x = rng.standard_normal((M, k), dtype=np.float32)
+        w = (rng.standard_normal((n, k), dtype=np.float32) * 0.05).astype(np.float32)
+        b = rng.standard_normal(n, dtype=np.float32)
+        r = rng.standard_normal((M, n), dtype=np.float32)
+        g = np.ones(n, np.float32)
+        beta = np.zeros(n, np.float32)
+        fl = 2.0 * M * n * k
+        it = iters_for(fl)
+        for rnd in range(2):
+            for variant in ((0, 4) if ops.has_tuning() else (0,)):
+                if ops.has_tuning():
+                    ops.set_gemm_variant(variant)
+                y, ms = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12, iters=it)
+                tf = fl / (ms * 1e-3) / 1e12
+                tag = "fused          " if variant == 0 else "gemm+layernorm "
+                print(f"{name:8s} {tag} M={M} K={k:5d} {ms:8.4f} ms {tf:7.2f} TFLOP/s ({tf / PEAK * 100:5.1f}% peak) "
+                      f"row0 mean {float(y[0].mean()):+.2e} var {float(y[0].var()):.4f}", flush=True)
+        if ops.has_tuning():
+            ops.set_gemm_variant(0)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["fused", "sweep"]
+    if "fused" in what:
+        fused()
+    if "sweep" in what:
+        sweep()

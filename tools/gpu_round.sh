@@ -1,9 +1,10 @@
 #!/bin/bash
-# One GPU-box round: parity tests, kernel micro-benchmarks, bench with live roofline.
+# One GPU-box round: parity tests, the bench line (embed + rerank) with live roofline and the CPU leg.
 set -u
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/pytest_gpu.log
-KB_VARIANTS=0 python tools/kernel_bench.py 2>&1 | tee gpurun_out/kernel_bench.log
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>gpurun_out/bench.err | tee gpurun_out/bench.json
+( time python -m pytest tests -m gpu -q -x 2>&1 | tail -15 ) 2>&1 | tee gpurun_out/pytest_gpu.log
+python bench.py --steps 3 --warmup 1 ${BENCH_ARGS:-} 2>gpurun_out/bench.err | tee gpurun_out/bench.json
 tail -3 gpurun_out/bench.err
+python bench.py --workload rerank --steps 2 --warmup 1 2>gpurun_out/bench_rerank.err | tee gpurun_out/bench_rerank.json
+tail -3 gpurun_out/bench_rerank.err
