@@ -188,7 +188,7 @@ KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const f
                                          float* ms_out);
 /* y = LayerNorm(x . w^T + bias + residual) * gamma + beta -- the post-norm layer's residual projection with the
  * LayerNorm folded into the GEMM epilogue where the kernel covers the row width n (384, 256), otherwise GEMM + LayerNorm
- * (encoder_layer.rs:129-147, 155-176; layer_norm.rs:37-131). */
+ * (encoder_layer.rs:129-147, 155-176; layer_norm.rs:37-131).  bias may be NULL. */
 KjarniErrorCode kjarni_hip_op_linear_layer_norm(int32_t device, const float* x, const float* w, const float* bias,
                                                 const float* residual, const float* gamma, const float* beta, float eps,
                                                 int64_t m, int32_t k, int32_t n, float* y, int32_t iters, float* ms_out);

@@ -19,15 +19,19 @@
 // ds_read_b128 feeds four MFMAs: the k order inside an MFMA is free as long as A
 // and B agree) bank-conflict free.
 //
-// Software pipeline.  A K-step is BK/8 phases of 16 MFMAs and every memory
-// operation is issued under the MFMAs of an earlier phase (co-resident
-// workgroups run the same program almost in lockstep, so a wave cannot count on
-// its SIMD partner to cover its own bubbles):
+// Software pipeline.  A K-step is BK/8 = 4 phases of 16 MFMAs and every memory
+// operation is issued under the MFMAs of an earlier phase:
 //   phase p < last : read fragments kk = p+1                           | MFMA kk = p
-//   one early phase: + write tile t+1 (registers) to the other LDS buffer
-//                    + issue the global loads of tile t+2, one per MFMA
+//                    + 3, 3, 2 of the 8 staging pieces: write the piece of tile t+1 from its registers to the
+//                      other LDS buffer, then reload the same registers with the piece of tile t+2 --
+//                      one piece per 5 MFMAs
 //   last phase     : barrier, read fragments kk = 0 of tile t+1        | MFMA (from registers)
-// so the only exposed wait is the barrier skew itself.
+// Spreading the pieces matters: with all eight ds_write_b128 of a wave in one phase (and the eight waves of
+// a CU in near lockstep) the LDS store path, ~77 B/clk per CU, backs up past the 64-cycle MFMA shadow and the
+// in-order waves stall on issue; one store per five MFMAs measured +4 % (K = 1536) to +6 % (K = 384) on the
+// projection shapes (tools/lab/mfma_lab.hip).  An LDS-DMA variant (global_load_lds, XOR-swizzled unpadded
+// tiles) was bit-identical and slower (87 % vs 92 %): with two buffers its data has three phases to arrive,
+// the register-staged tile has a whole K-step.
 //
 // Epilogue: the wave's tile is transposed through its own LDS region (the operand
 // buffers are free after the last barrier) so that bias / activation / residual /
@@ -47,7 +51,7 @@ namespace kjarni {
 namespace {
 
 // Tuning hook, -DKJARNI_TUNING builds only (tools/kernel_bench.py; the shipped library has neither the
-// switch nor the extra kernels): 0 default, 2 BK=16 (3 workgroups/CU), 3 default tiling with the libm-grade
+// switch nor the extra kernels): 0 default, 3 default tiling with the libm-grade
 // erff in the GELU epilogue, 4 residual GEMMs without the fused LayerNorm, 9 diagnostic build without an
 // epilogue (micro-benchmark upper bound).
 #ifdef KJARNI_TUNING
@@ -70,10 +74,11 @@ struct Tile {
     static constexpr int V4_PER_ROW = BKT / 4;
     static constexpr int LOADS = BM * V4_PER_ROW / 256;  // float4 per thread per operand
     static constexpr int ROWS_PER_PASS = 256 / V4_PER_ROW;
-    static constexpr int MEM_PHASE = NKK > 2 ? 1 : 0;
+    static constexpr int PIECES = 2 * LOADS;                  // 16-byte loads per thread per K-step (A then W)
+    static constexpr int PIECES_PER_PHASE = (PIECES + NKK - 2) / (NKK - 1);  // spread over the phases before the barrier
     // Epilogue staging rows per wave per round: as many as fit in this tile's LDS.
     static constexpr int EPI_ROWS = (LDS_BYTES >= 4 * 64 * EPI_STRIDE * 4) ? 64 : 32;
-    static constexpr int WAVES_PER_SIMD = BKT == 16 ? 3 : 2;
+    static constexpr int WAVES_PER_SIMD = 2;
 };
 
 // silu_scalar, activations.rs:74-82
@@ -149,21 +154,32 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
 
     // Global staging pointers; rows past M are clamped (their results are never stored).
     const int ld_row = tid / T::V4_PER_ROW, ld_c4 = tid % T::V4_PER_ROW;
-    const float* ga_ptr[T::LOADS];
-    const float* gb_ptr[T::LOADS];
+    // Staging loads go through buffer descriptors: a wave-uniform 128-bit resource over this tile's rows, a 32-bit
+    // per-lane byte offset that never changes, and the K offset as a scalar operand.  The K-loop then carries no
+    // vector address arithmetic at all -- on this part the f32 MFMAs execute on the same FP32 lanes as the VALU,
+    // so every vector ALU instruction in the loop is time the matrix work does not get -- and rows past M read as
+    // zeros by the hardware bounds check (their results are never stored).
+    const int64_t rows_a = (M - m0 < BM) ? (M - m0) : BM;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A + m0 * lda), 0, (int)(((rows_a - 1) * lda + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(W + (int64_t)n0 * K), 0, (int)((int64_t)BN * K * 4), 0x00020000);
+    uint32_t offA[T::LOADS], offW[T::LOADS];
 #pragma unroll
     for (int i = 0; i < T::LOADS; ++i) {
-        int64_t m = m0 + ld_row + T::ROWS_PER_PASS * i;
-        m = m < M ? m : M - 1;
-        ga_ptr[i] = A + m * lda + ld_c4 * 4;
-        gb_ptr[i] = W + (int64_t)(n0 + ld_row + T::ROWS_PER_PASS * i) * K + ld_c4 * 4;
+        const int64_t r = ld_row + T::ROWS_PER_PASS * i;
+        offA[i] = (uint32_t)((r * lda + ld_c4 * 4) * 4);
+        offW[i] = (uint32_t)((r * K + ld_c4 * 4) * 4);
     }
     f32x4 ga[T::LOADS], gb[T::LOADS];
+    auto ld16 = [](__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, int k0) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, k0 * 4, 0));
+    };
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < T::LOADS; ++i) {
-            ga[i] = *reinterpret_cast<const f32x4*>(ga_ptr[i] + k0);
-            gb[i] = *reinterpret_cast<const f32x4*>(gb_ptr[i] + k0);
+            ga[i] = ld16(rsrcA, offA[i], k0);
+            gb[i] = ld16(rsrcW, offW[i], k0);
         }
     };
     const int st_off = ld_row * STRIDE + ld_c4 * 4;
@@ -173,6 +189,20 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
             *reinterpret_cast<f32x4*>(sA + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * i * STRIDE) = ga[i];
             *reinterpret_cast<f32x4*>(sB + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * i * STRIDE) = gb[i];
         }
+    };
+    // piece i < LOADS: A rows, else W rows
+    auto store_piece = [&](int stage, int i) {
+        if (i < T::LOADS)
+            *reinterpret_cast<f32x4*>(sA + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * i * STRIDE) = ga[i];
+        else
+            *reinterpret_cast<f32x4*>(sB + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * (i - T::LOADS) * STRIDE) =
+                gb[i - T::LOADS];
+    };
+    auto load_piece = [&](int i, int k0) {
+        if (i < T::LOADS)
+            ga[i] = ld16(rsrcA, offA[i], k0);
+        else
+            gb[i - T::LOADS] = ld16(rsrcW, offW[i - T::LOADS], k0);
     };
 
     f32x16 acc[2][2];
@@ -186,6 +216,9 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     const int nk = K / BK;
     const int a_off = (wr * 64 + l31) * STRIDE + half * 4;
     const int b_off = (wc * 64 + l31) * STRIDE + half * 4;
+    // The epilogue's bias slice, requested now: after the K-loop its latency would be exposed once per tile.
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n0 + wc * 64 + (lane & 15) * 4);
 
     // Prologue: tile 0 -> LDS[0], tile 1 in flight in registers, fragments kk=0 of tile 0.
     load_tiles(0);
@@ -217,32 +250,31 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
                 if (STORE)
                     read_frag<STRIDE>(nxt, sA + (cur ^ 1) * TILE_FLOATS + a_off, sB + (cur ^ 1) * TILE_FLOATS + b_off, 0);
             }
-            if (p == T::MEM_PHASE) {
-                // Memory traffic of the next tiles, interleaved one-for-one with this phase's MFMAs.
-                if (STORE) store_tiles(cur ^ 1);
-                if (LOAD) load_tiles((kt + 2) * BK);
-                mfma16(acc, use);
-                if (p + 1 < NKK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 x DS read first
-                if (STORE) {
+            // This phase's share of the staging pieces: LDS write of tile kt+1, then the same registers take tile kt+2.
+            constexpr int PP = T::PIECES_PER_PHASE;
 #pragma unroll
-                    for (int i = 0; i < 2 * T::LOADS; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-                    }
+            for (int i = 0; i < PP; ++i) {
+                const int piece = p * PP + i;
+                if (p + 1 < NKK && piece < T::PIECES) {
+                    if (STORE) store_piece(cur ^ 1, piece);
+                    if (LOAD) load_piece(piece, (kt + 2) * BK);
                 }
-                if (LOAD) {
+            }
+            mfma16(acc, use);
+            if (p + 1 < NKK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 x DS read first
 #pragma unroll
-                    for (int i = 0; i < 2 * T::LOADS; ++i) {
+            for (int i = 0; i < PP; ++i) {
+                const int piece = p * PP + i;
+                if (p + 1 < NKK && piece < T::PIECES && STORE) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA x 4
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+                    if (LOAD) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc, use);
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     static_assert((NKK & 1) == 0, "fragment double-buffer parity must repeat every K-step");
@@ -271,8 +303,6 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     float* sw = smem + wid * (EROWS * EPI_STRIDE);
     const int e_row = lane >> 4, e_c4 = lane & 15;
     const int n = n0 + wc * 64 + e_c4 * 4;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
     for (int round = 0; round < 64 / EROWS; ++round) {
 #pragma unroll
@@ -372,18 +402,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
     const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int64_t m0 = bid * BM;
 
-    // staging: thread -> (row, 16-byte column) of the [rows][BK] operand tiles
+    // staging: thread -> (row, 16-byte column) of the [rows][BK] operand tiles, through buffer descriptors (scalar
+    // K offset, constant 32-bit lane offsets: no vector address arithmetic in the K-loop; rows past M read as zeros)
     const int ld_row = tid >> 2, ld_c4 = tid & 3;
-    int64_t am = m0 + ld_row;
-    am = am < M ? am : M - 1;
-    const float* ga_ptr = A + am * lda + ld_c4 * 4;
-    const float* gb_ptr = W + (int64_t)ld_row * K + ld_c4 * 4;
-    const int64_t gb_step = (int64_t)64 * K;  // 64 rows of W between a thread's loads
-    f32x4 ga, gb[T::B_LOADS];
-    auto load_tiles = [&](int k0) {
-        ga = *reinterpret_cast<const f32x4*>(ga_ptr + k0);
+    const int64_t rows_a = (M - m0 < BM) ? (M - m0) : BM;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A + m0 * lda), 0, (int)(((rows_a - 1) * lda + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, (int)((int64_t)BN * K * 4), 0x00020000);
+    const uint32_t offA = (uint32_t)(((int64_t)ld_row * lda + ld_c4 * 4) * 4);
+    uint32_t offW[T::B_LOADS];
 #pragma unroll
-        for (int i = 0; i < T::B_LOADS; ++i) gb[i] = *reinterpret_cast<const f32x4*>(gb_ptr + i * gb_step + k0);
+    for (int i = 0; i < T::B_LOADS; ++i) offW[i] = (uint32_t)(((int64_t)(ld_row + 64 * i) * K + ld_c4 * 4) * 4);
+    f32x4 ga, gb[T::B_LOADS];
+    auto ld16 = [](__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, int k0) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, k0 * 4, 0));
+    };
+    auto load_tiles = [&](int k0) {
+        ga = ld16(rsrcA, offA, k0);
+#pragma unroll
+        for (int i = 0; i < T::B_LOADS; ++i) gb[i] = ld16(rsrcW, offW[i], k0);
     };
     const int st_off = ld_row * STRIDE + ld_c4 * 4;
     auto store_tiles = [&](int stage) {
@@ -436,24 +474,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
         constexpr bool STORE = decltype(store_tag)::value;
         constexpr bool LOAD = decltype(load_tag)::value;
         const int cur = kt & 1;
-        // phase 0: fragments kk = 1 | MFMAs kk = 0, with the next tiles' memory traffic one per MFMA
+        // phase 0: fragments kk = 1 | MFMAs kk = 0, with the 1 + B_LOADS staging pieces spread under them: piece =
+        // LDS write of tile kt+1 from its registers, then the same registers reloaded with tile kt+2
         read_frag(fr[1], cur, 1);
-        if (STORE) store_tiles(cur ^ 1);
-        if (LOAD) load_tiles((kt + 2) * BK);
+        float* wbase = smem + (cur ^ 1) * T::STAGE_FLOATS;
+        if (STORE) *reinterpret_cast<f32x4*>(wbase + st_off) = ga;
+        if (LOAD) ga = ld16(rsrcA, offA, (kt + 2) * BK);
+#pragma unroll
+        for (int i = 0; i < T::B_LOADS; ++i) {
+            if (STORE) *reinterpret_cast<f32x4*>(wbase + BM * STRIDE + st_off + 64 * i * STRIDE) = gb[i];
+            if (LOAD) gb[i] = ld16(rsrcW, offW[i], (kt + 2) * BK);
+        }
         mfma_phase(fr[0]);
         __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // DS reads first
         if (STORE) {
 #pragma unroll
             for (int i = 0; i < 1 + T::B_LOADS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-            }
-        }
-        if (LOAD) {
-#pragma unroll
-            for (int i = 0; i < 1 + T::B_LOADS; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, NT == 3 ? 2 : 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // DS write
+                if (LOAD) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -636,7 +678,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
                       int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
                       hipStream_t stream)
 {
+    // (a tile's rows are addressed through 32-bit buffer offsets: 128 rows of A must span less than 2 GiB)
     const bool aligned = (N % BN == 0) && (K % 32 == 0) && (lda % 4 == 0) && (ldy % 4 == 0) &&
+                         ((int64_t)BM * lda * 4 < (int64_t)1 << 31) && ((int64_t)BN * K * 4 < (int64_t)1 << 31) &&
                          ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
@@ -645,7 +689,6 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
     if (aligned) {
 #ifdef KJARNI_TUNING
         switch (g_gemm_variant) {
-        case 2: return launch_tiled<EPI, 16, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
         case 9: return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
         default: break;
         }
@@ -670,7 +713,7 @@ bool gemm_residual_layernorm_supported(int N, int K)
 #ifdef KJARNI_TUNING
     if (g_gemm_variant == 4) return false;
 #endif
-    return (N == 384 || N == 256) && K >= 16 && K % 16 == 0;
+    return (N == 384 || N == 256) && K >= 16 && K % 16 == 0;  // (rows are addressed through 32-bit buffer offsets)
 }
 
 hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
@@ -680,6 +723,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
     if (M <= 0) return hipSuccess;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!gemm_residual_layernorm_supported(N, K) || !R || !gamma || !beta || lda % 4 || ldr % 4 || ldy % 4 ||
+        (int64_t)64 * lda * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31 ||
         !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y))
         return hipErrorInvalidValue;
     if (N == 384) return launch_ln_tiled<3>(A, lda, W, bias, R, ldr, gamma, beta, eps, Y, ldy, M, K, stream);

@@ -20,6 +20,24 @@ def iters_for(flops):
     return max(10, int(0.35 / (flops / 120e12)))
 
 
+def prio():
+    """s_setprio 2 around the K-loop (default) against none (tuning variant 5), plain and GELU epilogues."""
+    if not ops.has_tuning():
+        return
+    for name, k, n, epi in (("qkv ", 384, 1152, ops.EPI_BIAS), ("fc1 ", 384, 1536, ops.EPI_BIAS_GELU), ("k1536", 1536, 384, ops.EPI_BIAS)):
+        x = rng.standard_normal((M, k), dtype=np.float32)
+        w = (rng.standard_normal((n, k), dtype=np.float32) * 0.05).astype(np.float32)
+        b = rng.standard_normal(n, dtype=np.float32)
+        fl = 2.0 * M * n * k
+        for _ in range(2):
+            for variant in (0, 5):
+                ops.set_gemm_variant(variant)
+                _, ms = ops.linear(x, w, b, None, epi, iters=iters_for(fl))
+                tf = fl / (ms * 1e-3) / 1e12
+                print(f"gemm {name} epi={epi} {'setprio' if variant == 0 else 'no prio'} {ms:8.4f} ms {tf:7.2f} TFLOP/s ({tf / PEAK * 100:5.1f}% peak)", flush=True)
+    ops.set_gemm_variant(0)
+
+
 def sweep():
     for n, ks in ((384, (384, 1536, 6144)), (1536, (384, 1536))):
         for k in ks:
@@ -51,7 +69,7 @@ def fused():
                     ops.set_gemm_variant(variant)
                 y, ms = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12, iters=it)
                 tf = fl / (ms * 1e-3) / 1e12
-                tag = "fused          " if variant == 0 else "gemm+layernorm "
+                tag = "fused           " if variant == 0 else "gemm+layernorm  "
                 print(f"{name:8s} {tag} M={M} K={k:5d} {ms:8.4f} ms {tf:7.2f} TFLOP/s ({tf / PEAK * 100:5.1f}% peak) "
                       f"row0 mean {float(y[0].mean()):+.2e} var {float(y[0].var()):.4f}", flush=True)
         if ops.has_tuning():
@@ -60,6 +78,8 @@ def fused():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fused", "sweep"]
+    if "prio" in what:
+        prio()
     if "fused" in what:
         fused()
     if "sweep" in what:
