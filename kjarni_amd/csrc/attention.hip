@@ -270,8 +270,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // an item is two 64-bit ballots per wave (bit k = key k kept), tested with
 // constant bit positions; an item without padding skips masking altogether.
 // ---------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __restrict__ qkv,
+// DIAG (tuning build only, tools/gemm_probe.py attn): 0 the kernel; knock-outs that show where an item's time goes --
+// 1 no softmax arithmetic, 2 no LDS staging of K / V after the first item, 3 no output stores, 4 no K / V / Q prefetch,
+// 5 no matrix work (memory only), 6 non-temporal K / V / Q loads.
+template <int D, int DIAG>
+__global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __restrict__ qkv,
                                                                 const uint32_t* __restrict__ mask,
                                                                 int64_t n_items, int seq, int heads,
                                                                 float scale, float mask_value,
@@ -295,36 +298,56 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
     unsigned long long keep_lo = ~0ull, keep_hi = ~0ull;
     const int q_row = wid * 32 + l31;
 
-    auto prefetch_kv = [&](int64_t it_) {
-        const int64_t b = it_ / heads;
-        const int h = (int)(it_ % heads);
-        const float* base = qkv + b * seq * row_stride + h * D;
+    // All global traffic of an item goes through buffer descriptors built from scalars (sentence, head): constant
+    // per-lane offsets, no 64-bit vector address arithmetic and no per-lane predication in the item loop -- rows at
+    // or past `seq` fall outside the descriptor and read as zeros / are not written (hardware bounds check).  The
+    // vector ALU is the resource the f32 MFMAs run on here, so address math there is matrix time lost.
+    uint32_t off_kv[STAGE_ITERS];
+#pragma unroll
+    for (int it = 0; it < STAGE_ITERS; ++it) {
+        const int f = tid + it * 256;
+        off_kv[it] = (uint32_t)(((int64_t)(f / V4_PER_ROW) * row_stride + (f % V4_PER_ROW) * 4) * 4);
+    }
+    const uint32_t off_q = (uint32_t)(((int64_t)q_row * row_stride + half * 4) * 4);
+    const uint32_t off_o = (uint32_t)(((int64_t)(wid * 32 + 4 * half) * hidden + l31) * 4);
+    const int span_in = (int)((((int64_t)seq - 1) * row_stride + D) * 4);   // bytes of one head's rows of Q, K or V
+    const int span_out = (int)((((int64_t)seq - 1) * hidden + D) * 4);
+    auto rsrc = [](const float* p, int bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+    };
+    auto ld16 = [](__amdgpu_buffer_rsrc_t r, uint32_t off, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, DIAG == 6 ? 2 : 0));
+    };
+    // (sentence, head) of an item advance with the grid stride without divisions
+    const int step_b = (int)(gridDim.x / (unsigned)heads), step_h = (int)(gridDim.x % (unsigned)heads);
+    int cur_b = (int)(blockIdx.x / (unsigned)heads), cur_h = (int)(blockIdx.x % (unsigned)heads);
+    auto advance = [&](int& bb, int& hh) {
+        bb += step_b;
+        hh += step_h;
+        if (hh >= heads) {
+            hh -= heads;
+            ++bb;
+        }
+    };
+
+    auto prefetch_kv = [&](int b, int h) {
+        const float* base = qkv + (int64_t)b * seq * row_stride + h * D;
+        const __amdgpu_buffer_rsrc_t rk = rsrc(base + hidden, span_in), rv = rsrc(base + 2 * hidden, span_in);
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
-            const int f = tid + it * 256;
-            const int r = f / V4_PER_ROW, c4 = f % V4_PER_ROW;
-            kreg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vreg[it] = kreg[it];
-            if (r < seq) {
-                kreg[it] = *reinterpret_cast<const f32x4*>(base + hidden + r * row_stride + c4 * 4);
-                vreg[it] = *reinterpret_cast<const f32x4*>(base + 2 * hidden + r * row_stride + c4 * 4);
-            }
+            kreg[it] = ld16(rk, off_kv[it], 0);
+            vreg[it] = ld16(rv, off_kv[it], 0);
         }
     };
     // Q fragments (B operand of S^T = K Q^T) and the keep-bits of keys 0..63 / 64..127.
-    auto prefetch_q = [&](int64_t it_) {
-        const int64_t b = it_ / heads;
-        const int h = (int)(it_ % heads);
-        const float* base = qkv + b * seq * row_stride + h * D;
+    auto prefetch_q = [&](int b, int h) {
+        const __amdgpu_buffer_rsrc_t rq = rsrc(qkv + (int64_t)b * seq * row_stride + h * D, span_in);
 #pragma unroll
-        for (int kk = 0; kk < D / 8; ++kk) {
-            qf[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q_row < seq) qf[kk] = *reinterpret_cast<const f32x4*>(base + q_row * row_stride + kk * 8 + half * 4);
-        }
+        for (int kk = 0; kk < D / 8; ++kk) qf[kk] = ld16(rq, off_q, kk * 32);
         bool k0 = lane < seq, k1 = lane + 64 < seq;
         if (mask != nullptr) {
-            if (k0) k0 = mask[b * seq + lane] != 0u;
-            if (k1) k1 = mask[b * seq + lane + 64] != 0u;
+            if (k0) k0 = mask[(int64_t)b * seq + lane] != 0u;
+            if (k1) k1 = mask[(int64_t)b * seq + lane + 64] != 0u;
         }
         keep_lo = __ballot(k0);
         keep_hi = __ballot(k1);
@@ -332,12 +355,38 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
 
     int64_t item = blockIdx.x;
     if (item < n_items) {
-        prefetch_kv(item);
-        prefetch_q(item);
+        prefetch_kv(cur_b, cur_h);
+        prefetch_q(cur_b, cur_h);
     }
+
+    // The finished item's output tile waits in registers and is stored right after the NEXT item's staging
+    // barrier: its stores are then older than that item's prefetch loads, so the (conservative) wait for those
+    // loads at the top of the following iteration no longer sits on a store issued a moment ago.
+    f32x16 o_pend[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_pend[dt][r] = 0.0f;
+    const float* pend_base = nullptr;
+    auto flush = [&]() {
+        if (pend_base == nullptr) return;
+        const __amdgpu_buffer_rsrc_t ro = rsrc(pend_base, span_out);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (DIAG != 3 || o_pend[0][r] == 123456.789f) {
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt) {
+                    const float val = o_pend[dt][r];  // (bit_cast straight on the vector-element lvalue reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, off_o,
+                                                          (((r & 3) + 8 * (r >> 2)) * hidden + dt * 32) * 4, 0);
+                }
+            }
+        }
+    };
 
     for (; item < n_items; item += gridDim.x) {
         // registers -> LDS (K row-major, V transposed)
+        if (DIAG != 2 || item == (int64_t)blockIdx.x)
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
             const int f = tid + it * 256;
@@ -346,11 +395,13 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
 #pragma unroll
             for (int c = 0; c < 4; ++c) sVt[(c4 * 4 + c) * SM::VT_STRIDE + r] = vreg[it][c];
         }
-        const int64_t b = item / heads;
-        const int h = (int)(item % heads);
+        const int b = cur_b, h = cur_h;
         const int64_t next = item + gridDim.x;
+        int nb = cur_b, nh = cur_h;
+        advance(nb, nh);
         __syncthreads();
-        if (next < n_items) prefetch_kv(next);  // in flight during this item's MFMAs + softmax
+        flush();                                               // the previous item's outputs
+        if (next < n_items && DIAG != 4) prefetch_kv(nb, nh);  // in flight during this item's MFMAs + softmax
 
         f32x16 s[4];
 #pragma unroll
@@ -362,70 +413,88 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
             for (int kk = 0; kk < D / 8; ++kk) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(pk + kk * 8);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[kk][c], s[kt], 0, 0, 0);
+                for (int c = 0; c < 4; ++c) {
+                    if (DIAG == 5) {
+                        s[kt][c] += kf[c] * qf[kk][c];  // memory-only diagnostic: no matrix work
+                    } else {
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[kk][c], s[kt], 0, 0, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);  // keep fragment live ranges short (register budget)
         }
 
         // Q fragments and mask bits of this item are consumed: fetch the next item's.
         const unsigned long long cur_lo = keep_lo, cur_hi = keep_hi;
-        if (next < n_items) prefetch_q(next);
+        if (next < n_items && DIAG != 4) prefetch_q(nb, nh);
 
         // scale (after the dot product, as the reference) then mask overwrite.
         const unsigned long long valid_lo = seq >= 64 ? ~0ull : ((1ull << seq) - 1ull);
         const unsigned long long valid_hi = seq >= 128 ? ~0ull : (seq > 64 ? ((1ull << (seq - 64)) - 1ull) : 0ull);
         const bool no_mask = (cur_lo == ~0ull) && (cur_hi == ~0ull);  // wave-uniform
-        // Softmax in the exp2 domain: t = score * log2(e), p = exp2(t - max t); one v_exp_f32 per
-        // element.  c1 folds the reference's 1/sqrt(d) scaling (applied after the dot product) with
-        // log2(e); a masked key's score is overwritten by mask_value (times log2 e).
+        // Softmax in the exp2 domain with as few vector-ALU instructions as it takes -- on this part the f32 MFMAs and
+        // the VALU share the FP32 lanes, so every VALU instruction here is time the matrix pipe idles:
+        //   max over the RAW dot products (c1 > 0, so max(c1 s) = c1 max(s); v_max3: two elements per instruction),
+        //   e = exp2(s c1 - max c1) as ONE fma + one v_exp_f32 per element (fma on packed pairs),
+        //   p = e (1/sum) on packed pairs (the query of a score is its LANE, of an output element its REGISTER, so
+        //   the scaling stays on P).
+        // c1 folds the reference's 1/sqrt(d) (applied after the dot product) with log2(e); a masked key's score is
+        // overwritten by mask_value, here as mask_value / scale in the raw domain (-1e9 stays ~-1e9 log2 e after the
+        // fma, -inf stays -inf).
         const float c1 = scale * 1.4426950408889634f;
-        const float masked_t = mask_value * 1.4426950408889634f;  // -1e9 -> -1.44e9, -inf -> -inf
-        float cmax = -INFINITY;
-        if (no_mask) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[kt][r] *= c1;
-                    cmax = fmaxf(cmax, s[kt][r]);
-                }
-        } else {
+        const float masked_raw = mask_value / scale;
+        if (DIAG != 1 && DIAG != 5) {
+        if (!no_mask) {
             // this lane's keys are bit (kt*32 + (r&3) + 8*(r>>2)) + 4*half of the 128-bit sets
             const unsigned sh = 4u * (unsigned)half;
             const unsigned keep_w[4] = {(unsigned)(cur_lo >> sh), (unsigned)(cur_lo >> (32 + sh)),
                                         (unsigned)(cur_hi >> sh), (unsigned)(cur_hi >> (32 + sh))};
             const unsigned val_w[4] = {(unsigned)(valid_lo >> sh), (unsigned)(valid_lo >> (32 + sh)),
                                        (unsigned)(valid_hi >> sh), (unsigned)(valid_hi >> (32 + sh))};
+            const bool all_valid = seq >= KCHUNK;  // wave-uniform
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
-                    float v = s[kt][r] * c1;
-                    v = (keep_w[kt] & bit) ? v : masked_t;     // masked key: score overwritten
-                    v = (val_w[kt] & bit) ? v : -INFINITY;     // key beyond seq: contributes exactly 0
+                    float v = (keep_w[kt] & bit) ? s[kt][r] : masked_raw;  // masked key: score overwritten
+                    if (!all_valid) v = (val_w[kt] & bit) ? v : -INFINITY;  // key beyond seq: contributes exactly 0
                     s[kt][r] = v;
-                    cmax = fmaxf(cmax, v);
                 }
         }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, kWave));
-        float csum = 0.0f;
+        float cmax = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] - cmax);  // NaN for an all -inf row, as the reference
-                s[kt][r] = e;
-                csum += e;
+            for (int r = 0; r < 16; r += 2) cmax = fmaxf(fmaxf(cmax, s[kt][r]), s[kt][r + 1]);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, kWave));
+        const float neg = -cmax * c1;  // (+inf for an all -inf row: exp2(-inf + inf) = NaN, as the reference)
+        const f32x2 c1v = {c1, c1}, negv = {neg, neg};
+        f32x2 sum2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = __builtin_elementwise_fma(f32x2{s[kt][r], s[kt][r + 1]}, c1v, negv);
+                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                s[kt][r] = e[0];
+                s[kt][r + 1] = e[1];
+                sum2 += e;
             }
+        float csum = sum2[0] + sum2[1];
         csum += __shfl_xor(csum, 32, kWave);
         if (csum > 0.0f) {  // activations.rs:236-241
             const float inv = 1.0f / csum;
+            const f32x2 invv = {inv, inv};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] *= inv;
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 pr = f32x2{s[kt][r], s[kt][r + 1]} * invv;
+                    s[kt][r] = pr[0];
+                    s[kt][r + 1] = pr[1];
+                }
+        }
         }
 
         f32x16 o[D / 32];
@@ -440,23 +509,25 @@ __global__ __launch_bounds__(256, 2) void attention_pipe_kernel(const float* __r
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 vf = *reinterpret_cast<const f32x4*>(pv + kt * 32 + g * 8);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kt][g * 4 + c], vf[c], o[dt], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) {
+                        if (DIAG == 5) {
+                            o[dt][c] += s[kt][g * 4 + c] * vf[c];
+                        } else {
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kt][g * 4 + c], vf[c], o[dt], 0, 0, 0);
+                        }
+                    }
                     if (g == 1 || g == 3) __builtin_amdgcn_sched_barrier(0);
                 }
         }
 
-        float* out_base = ctx + b * seq * (int64_t)hidden + h * D;
+        pend_base = ctx + (int64_t)b * seq * hidden + h * D;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = wid * 32 + acc_row(r, half);
-            if (q < seq) {
-#pragma unroll
-                for (int dt = 0; dt < D / 32; ++dt) out_base[(int64_t)q * hidden + dt * 32 + l31] = o[dt][r];
-            }
-        }
+        for (int dt = 0; dt < D / 32; ++dt) o_pend[dt] = o[dt];
+        cur_b = nb;
+        cur_h = nh;
         __syncthreads();  // everyone is done with sK / sVt before the next item overwrites them
     }
+    flush();
 }
 
 // Any-head-dim fallback (head_dim not 32/64, e.g. toy models in tests): one
@@ -519,18 +590,29 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         attr_set[dev & 63] = true;
     }
     const float scale = 1.0f / sqrtf((float)D);  // encoder_self_attention.rs:43
-    if (D == 32 && seq <= KCHUNK && g_attention_variant == 0) {
-        static bool pipe_attr[64] = {};
-        if (SM::BYTES > 64 * 1024 && !pipe_attr[dev & 63]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
-            if (e != hipSuccess) return e;
-            pipe_attr[dev & 63] = true;
-        }
+    if (D == 32 && seq <= KCHUNK && g_attention_variant != 1) {
         const int64_t n_items = batch * heads;
-        const int64_t max_blocks = 256 * 2;  // two resident workgroups per CU
+        // Three resident workgroups per CU (35.8 KiB of LDS and <= 168 VGPRs each): the third hides what two leave
+        // exposed of the K / V / Q streams' latency (measured 274 -> 264 us per launch of 12 288 items).
+        int64_t max_blocks = 256 * 3;
+#ifdef KJARNI_TUNING
+        if (g_attention_variant == 20) max_blocks = 256 * 2;
+#endif
         const unsigned grid = (unsigned)(n_items < max_blocks ? n_items : max_blocks);
-        hipLaunchKernelGGL(attention_pipe_kernel<D>, dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
+        // (AttnSmem<32>::BYTES = 35.8 KiB: below the 64 KiB opt-in threshold)
+        static_assert(D != 32 || SM::BYTES <= 64 * 1024, "the pipelined kernel would need the dynamic-LDS opt-in");
+#ifdef KJARNI_TUNING
+        switch (g_attention_variant) {
+        case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        case 16: hipLaunchKernelGGL((attention_pipe_kernel<D, 6>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        case 15: hipLaunchKernelGGL((attention_pipe_kernel<D, 5>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        case 14: hipLaunchKernelGGL((attention_pipe_kernel<D, 4>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        default: break;
+        }
+#endif
+        hipLaunchKernelGGL((attention_pipe_kernel<D, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
                            seq, heads, scale, mask_value, ctx);
         return hipGetLastError();
     }

@@ -38,6 +38,28 @@ def prio():
     ops.set_gemm_variant(0)
 
 
+def attn():
+    B, S, heads, d = 1024, 128, 12, 32
+    qkv = rng.standard_normal((B, S, 3 * heads * d), dtype=np.float32)
+    for ragged in (False, True):
+        mask = np.ones((B, S), np.uint32)
+        if ragged:
+            for b in range(B):
+                mask[b, rng.integers(16, S + 1):] = 0
+        names = {0: "kernel", 11: "no softmax", 12: "no LDS staging", 13: "no output stores", 14: "no prefetch", 15: "memory only", 20: "2 WG per CU", 16: "nt loads"}
+        for _ in range(2):
+            for variant in ((0, 20, 16, 11, 13, 14, 15) if ops.has_tuning() and not ragged else (0,)):
+                if ops.has_tuning():
+                    ops.set_attention_variant(variant)
+                ctx, ms = ops.attention(qkv, mask, heads, iters=1500)
+                fl = 4.0 * B * S * S * heads * d
+                print(f"attention B={B} S={S} h={heads} d={d} ragged={ragged} {names[variant]:18s}: {ms:.4f} ms "
+                      f"{fl / (ms * 1e-3) / 1e12:.2f} TFLOP/s {(4.0 * B * S * heads * d * 4) / (ms * 1e-3) / 1e9:.0f} GB/s algorithmic",
+                      flush=True)
+        if ops.has_tuning():
+            ops.set_attention_variant(0)
+
+
 def sweep():
     for n, ks in ((384, (384, 1536, 6144)), (1536, (384, 1536))):
         for k in ks:
@@ -78,6 +100,8 @@ def fused():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["fused", "sweep"]
+    if "attn" in what:
+        attn()
     if "prio" in what:
         prio()
     if "fused" in what:
