@@ -96,7 +96,7 @@ def host_description():
     return info
 
 
-def cpu_baseline(cfg, tensors, budget_s=36.0, cap_sentences=4096):
+def cpu_baseline(cfg, tensors, budget_s=60.0, cap_sentences=4096):
     """The reference's CPU path as oracle/kjarni_cpu_baseline.c ports it (fused QKV, 64-row / 4x3 AVX2 GEMM
     blocks, per-(b,h) attention GEMMs, persistent buffers), one thread per physical core (the reference pins its
     rayon pool that way, kjarni-ffi/src/lib.rs:37-40) -- of the cores this process is allowed to use: the GPU

@@ -185,7 +185,7 @@ private:
     EncoderConfig cfg_;
     int device_ = 0;
     size_t weight_bytes_ = 0;
-    std::atomic<int64_t> chunk_tokens_{131072};
+    std::atomic<int64_t> chunk_tokens_{262144};
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,

@@ -404,7 +404,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
 
     // staging: thread -> (row, 16-byte column) of the [rows][BK] operand tiles, through buffer descriptors (scalar
     // K offset, constant 32-bit lane offsets: no vector address arithmetic in the K-loop; rows past M read as zeros)
-    const int ld_row = tid >> 2, ld_c4 = tid & 3;
+    // A row of a tile is 64 bytes here, so the 8 lanes of one ds_write_b128 group cover two rows; with the
+    // 80-byte row stride rows r and r + 4 start 16 banks apart (320 B mod 128 B = 64 B): lanes 0-3 take row r,
+    // lanes 4-7 row r + 4 and the group touches every bank once (r and r + 1 would overlap in four banks: the
+    // PMC pass showed a third of this kernel's LDS cycles as bank conflicts with that map).
+    const int ld_grp = tid >> 3;
+    const int ld_row = (ld_grp >> 2) * 8 + (ld_grp & 3) + 4 * ((tid >> 2) & 1), ld_c4 = tid & 3;
     const int64_t rows_a = (M - m0 < BM) ? (M - m0) : BM;
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(A + m0 * lda), 0, (int)(((rows_a - 1) * lda + K) * 4), 0x00020000);

@@ -50,7 +50,7 @@ def timed(fn, sync, steps, warmup):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "families", "indexer", "search", "whisper", "llm", "chat"}  # "llm8b" only on request (writes 16 GB)
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "latency", "families", "indexer", "search", "whisper", "llm", "chat"}  # "llm8b" only on request (writes 16 GB)
     import numpy as np
     import torch
 
@@ -220,6 +220,55 @@ def main():
               "config": {"workload": f"{n} generated 100-word ASCII sentences, padded length {ids.shape[1]}"},
               "tokenise_only_sentences_per_s": round(n / dt_tok, 1), "host_threads": os.cpu_count(), "rows": int(out.shape[0])})
         del emb
+
+    if "latency" in which:
+        # BASELINE.json configs[0] is a single-sentence classify; the reference serves it on the calling thread
+        # (kjarni-ffi/src/lib.rs:25-32).  Per-call latency of the string-level entry points for ONE ~16-token sentence
+        # (tokenise + H2D + forward + D2H + result shaping), single caller and four concurrent callers on one handle.
+        import threading
+        cls_dir = os.path.join(tmp, "cache", "distilbert_distilbert-base-uncased-finetuned-sst-2-english")
+        synth.distilbert_sentiment(cls_dir, seed=2, n_layers=6, dim=768, n_heads=12, hidden_dim=3072)
+        synth.add_tokenizer(cls_dir)
+        sentence = "the quick brown fox jumps over the lazy dog near the old river bank today"
+        emb = kjarni_amd.Embedder("minilm-l6-v2", cache_dir=os.path.join(tmp, "cache"))
+        clf = kjarni_amd.Classifier(model_path=cls_dir)
+        tok = kjarni_amd.Tokenizer(os.path.join(emb_dir, "tokenizer.json"), 512)
+        n_tok = int(tok.encode_batch([sentence])[0].shape[1])
+
+        def lat(fn, n=400, warm=30):
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ts.sort()
+            return {"p50_ms": round(ts[len(ts) // 2], 4), "p99_ms": round(ts[int(len(ts) * 0.99)], 4), "min_ms": round(ts[0], 4)}
+
+        def concurrent(fn, threads=4, n=200):
+            res = [None] * threads
+
+            def run(i):
+                res[i] = lat(fn, n=n, warm=10)
+            th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            wall = time.perf_counter() - t0
+            return {"threads": threads, "calls_per_s": round(threads * (n + 10) / wall, 1),
+                    "p50_ms": round(float(np.median([r["p50_ms"] for r in res])), 4),
+                    "p99_ms": round(max(r["p99_ms"] for r in res), 4)}
+
+        emit({"metric": "latency of one sentence through the string-level C ABI", "unit": "ms", "tokens": n_tok, "n_gpus": 1,
+              "dtype": "f32", "data": "synthetic",
+              "kjarni_embedder_encode (minilm-l6-v2 shape)": lat(lambda: emb.encode(sentence)),
+              "kjarni_classifier_classify (distilbert-sst2 shape, 6 x 768)": lat(lambda: clf.classify(sentence)),
+              "kjarni_embedder_encode, 4 threads on one handle": concurrent(lambda: emb.encode(sentence)),
+              "kjarni_classifier_classify, 4 threads on one handle": concurrent(lambda: clf.classify(sentence))})
+        del emb, clf
 
     if "indexer" in which:
         rng = np.random.default_rng(0)

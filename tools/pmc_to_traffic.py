@@ -17,7 +17,9 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
             continue
         name = r["Kernel_Name"].replace("void kjarni::(anonymous namespace)::", "").replace(
             "kjarni::(anonymous namespace)::", "").split("(")[0]
-        if name.startswith("gemm_nt_f32_mfma<"):
+        if name.startswith("gemm_nt_f32_mfma_ln"):
+            name = "gemm_nt_f32_mfma_ln"
+        elif name.startswith("gemm_nt_f32_mfma<"):
             epi = int(name.split("<")[1].split(",")[0].rstrip(">"))
             name = f"gemm_nt_f32_mfma<{EPI.get(epi, epi)}>"
         name = name.split("<")[0] if name.startswith(("attention", "pool")) else name
@@ -30,6 +32,6 @@ for k, c in acc.items():
         res[k] = {"fetch_size_kib_raw": f, "write_size_kib": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
                   "launches_sampled": len(c["FETCH_SIZE"])}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
-                     "`python bench.py --steps 1 --warmup 1 --sentences 16384` (512-sentence chunks = the "
-                     "launch shape of the full run)", "kernels": res}, open(out, "w"), indent=1)
+                     "`python bench.py --steps 1 --warmup 1 --sentences 16384 --no-extras` (chunks of 2 048 sentences = "
+                     "262 144 tokens, the launch shape of the full run)", "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
