@@ -631,7 +631,9 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     const double f_fc1 = 2.0 * Td * Hd * Id, b_fc1 = 4.0 * (Td * Hd + Hd * Id + Td * Id);
     const double f_fc2 = 2.0 * Td * Hd * Id, b_fc2 = 4.0 * (Td * Id + Hd * Id + 2 * Td * Hd);
     const double b_ln = 8.0 * Td * Hd;
-    const bool fused_ln = fuse_layernorm();
+    // Up to 128 tokens the projections take the few-rows kernel (K split over the waves of a workgroup, gemm.hip) and
+    // LayerNorm stays its own small launch; beyond that the residual projections carry it in their epilogue.
+    const bool fused_ln = fuse_layernorm() && T > 128;
 
     hipEvent_t pe = prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
     hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,

@@ -52,7 +52,7 @@ namespace {
 
 // Tuning hook, -DKJARNI_TUNING builds only (tools/kernel_bench.py; the shipped library has neither the
 // switch nor the extra kernels): 0 default, 3 default tiling with the libm-grade
-// erff in the GELU epilogue, 4 residual GEMMs without the fused LayerNorm, 9 diagnostic build without an
+// erff in the GELU epilogue, 4 residual GEMMs without the fused LayerNorm, 6 no few-rows kernel, 9 diagnostic build without an
 // epilogue (micro-benchmark upper bound).
 #ifdef KJARNI_TUNING
 std::atomic<int> g_gemm_variant{0};
@@ -604,6 +604,102 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Few rows (M <= 128: one sentence to classify, a handful to embed -- BASELINE.json configs[0]).  The tiled kernels
+// above are sized for 10^5 rows; at M = 28 they run N / 128 workgroups that each walk the whole K dimension alone
+// (25-124 us per launch, 3-12 of the 256 CUs busy).  Here a workgroup of 16 waves owns 32 output columns for ALL rows
+// and splits K sixteen ways.  No operand staging: a wave's MFMA fragments come straight from global memory through
+// buffer descriptors (rows >= M read as zeros) -- every weight element is needed by exactly one wave.  Per 32-row
+// tile the sixteen partial tiles meet in LDS (64 KiB) and are summed in wave order, then bias / activation /
+// residual and 128-byte row-segment stores.  An output's arithmetic -- a k-ordered MFMA chain per K slice, then the
+// sixteen partials in order -- does not depend on M, so a row's result is the same in any batch of up to 128 rows.
+template <int EPI, int MT>
+__global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restrict__ A, int64_t lda,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            const float* R, int64_t ldr, float* Y, int64_t ldy, int M, int N,
+                                                            int K)
+{
+    constexpr int WAVES = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [WAVES][32][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int ks = K / WAVES;  // this wave's K slice (a multiple of 8)
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((((int64_t)M - 1) * lda + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * K), 0,
+                                                                        (int)((int64_t)32 * K * 4), 0x00020000);
+    uint32_t offA[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) offA[mt] = (uint32_t)(((int64_t)(mt * 32 + l31) * lda + half * 4) * 4);
+    const uint32_t offW = (uint32_t)(((int64_t)l31 * K + half * 4) * 4);
+    auto ld16 = [](__amdgpu_buffer_rsrc_t r, uint32_t off, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+    const int k_begin = wid * ks;
+    // fragments of step k + 8 are requested before the MFMAs of step k (past the slice they are never used; past the
+    // matrix the descriptor returns zeros)
+    f32x4 b = ld16(rW, offW, k_begin * 4);
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = ld16(rA, offA[mt], k_begin * 4);
+    for (int k = 0; k < ks; k += 8) {
+        const f32x4 nb = ld16(rW, offW, (k_begin + k + 8) * 4);
+        f32x4 na[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) na[mt] = ld16(rA, offA[mt], (k_begin + k + 8) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][c], b[c], acc[mt], 0, 0, 0);
+        b = nb;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = na[mt];
+    }
+    float* mine = smem + wid * (32 * 32);
+    const int n = n0 + (tid & 31);
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt > 0) __syncthreads();  // the previous tile's partials have been summed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[acc_row(r, half) * 32 + l31] = acc[mt][r];
+        __syncthreads();
+        // 1024 outputs, one per thread, column fastest
+        const int m = mt * 32 + (tid >> 5);
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += smem[w * (32 * 32) + tid];
+        if (m < M) {
+            v += bv;
+            if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)m * ldr + n];
+            if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)m * ldr + n]);
+            Y[(int64_t)m * ldy + n] = epilogue<EPI>(v);
+        }
+    }
+}
+
+template <int EPI>
+hipError_t launch_skinny(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr,
+                         float* Y, int64_t ldy, int M, int N, int K, hipStream_t stream)
+{
+    const dim3 grid((unsigned)(N / 32));
+    constexpr int LDS = 16 * 32 * 32 * 4;  // 64 KiB
+    if (M <= 32)
+        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 1>), grid, dim3(1024), LDS, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K);
+    else if (M <= 64)
+        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 2>), grid, dim3(1024), LDS, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K);
+    else
+        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 4>), grid, dim3(1024), LDS, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K);
+    return hipGetLastError();
+}
+
 // Any-shape fallback (odd hidden sizes in tests, tiny heads): 32x32 LDS tiles,
 // plain FMA.  Not on the MiniLM/BERT hot path.
 template <int EPI>
@@ -678,6 +774,20 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     return hipGetLastError();
 }
 
+// Shapes the few-rows kernel takes: M <= 128, whole 32-column tiles, K divisible by 8 x 16 waves, 16-byte rows.
+inline bool aligned6(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W,
+                     const float* Y, const float* bias, const float* R)
+{
+    (void)ldy;
+    (void)ldr;
+    (void)Y;
+    (void)bias;
+    (void)R;
+    return M <= 128 && N % 32 == 0 && K % 128 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (int64_t)128 * lda * 4 < ((int64_t)1 << 31) &&
+           (int64_t)32 * K * 4 < ((int64_t)1 << 31);
+}
+
 template <int EPI>
 hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
                       int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
@@ -691,6 +801,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
                          ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) &&
                          (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (R == nullptr || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(R) & 15) == 0));
+    // few rows: K split over the waves of a workgroup instead of a serial K-loop in N / 128 workgroups
+    if (aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && g_gemm_variant != 6)
+        return launch_skinny<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream);
     if (aligned) {
 #ifdef KJARNI_TUNING
         switch (g_gemm_variant) {

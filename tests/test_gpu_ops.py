@@ -35,7 +35,9 @@ def test_linear_all_epilogues(m, k, n):
              (ops.EPI_BIAS_MUL_SILU, r * 12, _silu(r * 12) * base)]
     for epi, res, ref in cases:
         got, _ = ops.linear(x, w, b, res, epi)
-        assert np.abs(got - ref).max() < tol, (epi, float(np.abs(got - ref).max()))
+        # (the SwiGLU product scales the projection, and its rounding, by silu(gate): tolerance relative to the result)
+        t = tol if epi != ops.EPI_BIAS_MUL_SILU else 1e-5 * max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() < t, (epi, float(np.abs(got - ref).max()))
     got, _ = ops.linear(x, w, None, None, ops.EPI_BIAS)      # no bias
     assert np.abs(got - O.linear(x, w)).max() < tol
 
@@ -62,6 +64,27 @@ def test_residual_projection_with_fused_layernorm(m, k, n, eps):
         ref = O.layer_norm(O.linear(x, w) + r, g, beta, eps)
         got, _ = ops.linear_layer_norm(x, w, None, r, g, beta, eps)
         assert float(np.abs(got - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (768, 3072), (1024, 32)])
+def test_few_rows_results_do_not_depend_on_the_batch(k, n):
+    """Up to 128 rows the projections run the split-K kernel; a row's result must be bit-identical whatever other rows
+    share the call (1, 32, 33, 64, 100, 128 rows: one to four 32-row tiles), and oracle-equal."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(k + n)
+    x = rng.standard_normal((128, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((128, n)).astype(np.float32)
+    full, _ = ops.linear(x, w, b, r, ops.EPI_BIAS_RESIDUAL)
+    ref = O.linear(x, w, b) + r
+    assert float(np.abs(full - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+    for m in (1, 32, 33, 64, 100):
+        part, _ = ops.linear(x[:m], w, b, r[:m], ops.EPI_BIAS_RESIDUAL)
+        assert np.array_equal(part, full[:m]), m
+    gelu, _ = ops.linear(x[:7], w, b, None, ops.EPI_BIAS_GELU)
+    assert float(np.abs(gelu - np.vectorize(O.gelu, otypes=[np.float32])(O.linear(x[:7], w, b))).max()) < 1e-5 * max(
+        1.0, float(np.abs(ref).max()))
 
 
 def test_fused_layernorm_constant_rows():
