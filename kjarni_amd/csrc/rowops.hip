@@ -196,26 +196,69 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
                                                    float* __restrict__ out)
 {
     __shared__ float red[4];
-    __shared__ float s_cnt;
-    __shared__ int s_last;
+    __shared__ int red_last[4];
+    __shared__ f32x4 part[256];
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     const float* base = hs + b * seq * (int64_t)hidden;
     const uint32_t* mrow = mask ? mask + b * seq : nullptr;
 
-    if (tid == 0) {
-        float cnt = 0.0f;
-        int last = 0;
-        for (int s = 0; s < seq; ++s) {
-            const float mv = mrow ? (float)mrow[s] : 1.0f;
-            cnt += mv;
-            if (mv > 0.0f) last = s;  // pooling/mod.rs:61-62 rposition(x > 0), else 0
-        }
-        s_cnt = cnt;
-        s_last = last;
+    // count of kept tokens and the last kept position (pooling/mod.rs:61-62 rposition(x > 0), else 0), all threads
+    // at once (mask values are 0 / 1: the float sum is exact in any order)
+    float cnt = 0.0f;
+    int last = 0;
+    for (int s = tid; s < seq; s += 256) {
+        const float mv = mrow ? (float)mrow[s] : 1.0f;
+        cnt += mv;
+        if (mv > 0.0f) last = s;
+    }
+    cnt = wave_sum(cnt);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, kWave));
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = cnt;
+        red_last[tid >> 6] = last;
     }
     __syncthreads();
-    const float cnt = s_cnt;
+    cnt = (red[0] + red[1]) + (red[2] + red[3]);
+    last = max(max(red_last[0], red_last[1]), max(red_last[2], red_last[3]));
+    __syncthreads();
+
+    const int nv4 = hidden >> 2;
+    if (MODE == POOL_MEAN && (hidden & 3) == 0 && nv4 <= 256) {
+        // 16-byte columns; with hidden = 384 two row groups share the block (192 lanes busy), each summing every
+        // second row; the groups' partial sums meet in LDS and are added in group order.
+        const int groups = 256 / nv4;
+        const int c4 = tid % nv4, g = tid / nv4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (g < groups) {
+            if (cnt == 0.0f) {
+                if (g == 0) a = *reinterpret_cast<const f32x4*>(base + c4 * 4);  // pooling/mod.rs:25-27: token 0
+            } else {
+                for (int s = g; s < seq; s += groups) {
+                    const float mv = mrow ? (float)mrow[s] : 1.0f;
+                    a += *reinterpret_cast<const f32x4*>(base + (int64_t)s * hidden + c4 * 4) * mv;
+                }
+            }
+            part[tid] = a;
+        }
+        __syncthreads();
+        float sq = 0.0f;
+        if (g == 0) {
+            for (int k = 1; k < groups; ++k) a += part[k * nv4 + c4];
+            if (cnt != 0.0f) a = a / cnt;
+            sq = (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+        }
+        if (normalize) {
+            sq = wave_sum(sq);
+            if ((tid & 63) == 0) red[tid >> 6] = sq;
+            __syncthreads();
+            const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+            if (norm > 0.0f) a = a / norm;  // traits.rs:529-536: divide only when the norm is > 0
+        }
+        if (g == 0) *reinterpret_cast<f32x4*>(out + b * hidden + c4 * 4) = a;
+        return;
+    }
 
     constexpr int MAXC = 4;  // hidden <= 1024
     float acc[MAXC];
@@ -247,11 +290,10 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
             }
             acc[j] = a;
         } else {
-            acc[j] = base[(int64_t)s_last * hidden + c];
+            acc[j] = base[(int64_t)last * hidden + c];
         }
         sq = fmaf(acc[j], acc[j], sq);
     }
-    float inv = 1.0f;
     if (normalize) {
         sq = wave_sum(sq);
         if ((tid & 63) == 0) red[tid >> 6] = sq;
@@ -263,7 +305,6 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
             for (int j = 0; j < MAXC; ++j) acc[j] = acc[j] / norm;
         }
     }
-    (void)inv;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
         const int c = tid + j * 256;
