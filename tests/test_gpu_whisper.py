@@ -248,11 +248,21 @@ def test_full_size_whisper_base_shape(tmp_path):
     g = kjarni_amd.HipWhisper(d)
     m = W.WhisperOracle(t, cfg)
     audio = synth.synthetic_audio(30.0, seed=12)
-    enc = m.encode_mel(W.log_mel(audio))
+    mel = W.log_mel(audio)
+    enc = m.encode_mel(mel)
+    # The encoder itself (conv stem + 6 pre-norm layers), the SAME mel on both sides: the 1e-4 bar.
+    same = g.encode_mel(mel)
+    assert same.shape == (1500, 512)
+    assert np.abs(same - enc[0]).max() < TOL, np.abs(same - enc[0]).max()
+    # From audio the two sides also compute the log-mel independently: the f32 DFT (twiddle angles, 400-term sums)
+    # differs by ~2e-3 in the mel INPUT between any two f32 evaluations -- the reference's values there are
+    # unpinned (mel.rs:2121-2140 tests shapes only) -- and six layers carry that to <= 5e-4 at the output.  This
+    # is an input tolerance of the DFT stage, not a tolerance of the encoder.
     got = g.encode_audio(audio)
     assert got.shape == (1500, 512)
-    assert np.abs(got - enc[0]).max() < 5e-4, np.abs(got - enc[0]).max()      # 6 layers on top of the f32 DFT noise
-    g.encode_mel(W.log_mel(audio), fetch=False)                                 # same mel on both sides: 1e-4
+    dft_input_tolerance = 5e-4
+    assert np.abs(got - enc[0]).max() < dft_input_tolerance, np.abs(got - enc[0]).max()
+    g.encode_mel(mel, fetch=False)                                              # decode below runs on the shared mel
     g.decode_begin()
     cross = m.precompute_cross_kv(enc)
     cache = [None] * len(m.dec_layers)
