@@ -209,7 +209,12 @@ std::unique_ptr<LlmModel> LlmModel::load(const std::string& dir, int device, int
         m->cos_ = m->upload_f32(cs);
         m->sin_ = m->upload_f32(sn);
     }
-    m->splits_ = std::max(1, std::min(64, (m->cache_cap_ + 255) / 256));
+    // key ranges per head: up to 512 keys each (128 of them are one register-held pass of the attention kernel); few enough
+    // that the output projection can merge the slabs itself
+    m->splits_ = std::max(1, std::min(64, (m->cache_cap_ + 511) / 512));
+#ifdef KJARNI_TUNING
+    if (const char* v = std::getenv("KJARNI_HIP_LLM_SPLITS")) m->splits_ = std::max(1, std::atoi(v));  // measurements
+#endif
     while ((m->cache_cap_ + m->splits_ - 1) / m->splits_ > 512) ++m->splits_;
     m->h_ = m->dalloc(8 * (size_t)H);
     m->q_ = m->dalloc(8 * (size_t)H);
@@ -259,11 +264,25 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
         hip_check(launch_rope(q_, H, n, c.heads, d, cos_, sin_, cache_len_, pp, 0, s), "rope q");
         hip_check(launch_rope(L.k_cache, kv, n, c.kv_heads, d, cos_, sin_, cache_len_, pp, 1, s), "rope k");
         }
+        // one token: the output projection merges the attention's per-split slabs itself (no combine launch)
+        const bool merge_in_proj = n == 1 && c.heads * d == H && llm_gemv_merges_attention(H, splits_, d);
         hip_check(launch_decode_attention(q_, H, n, L.k_cache, kv, L.v_cache, kv, cache_len_ + n, pp, cache_cap_, c.heads, d, cache_len_,
-                                          splits_, att_scratch_, ctx_, H, s, c.heads / c.kv_heads), "attention");
+                                          splits_, att_scratch_, merge_in_proj ? nullptr : ctx_, H, s, c.heads / c.kv_heads), "attention");
         LlmGemvArgs o;
         o.X = ctx_; o.ldx = H; o.rows = n; o.W = L.wo; o.bf16 = bf16_; o.R = h_; o.ldr = H; o.n_out = H; o.k = H; o.Y0 = h_; o.ldy0 = H;
+        if (merge_in_proj) {
+            o.X = att_scratch_; o.att_splits = splits_; o.att_head_dim = d;
+        }
         hip_check(launch_llm_gemv(o, s), "o proj");
+#ifdef KJARNI_TUNING
+        static const bool touch = std::getenv("KJARNI_HIP_LLM_TOUCH") != nullptr;  // measurements: weights already in the memory-side cache
+        if (touch && n == 1) {
+            const size_t wb = bf16_ ? 2 : 4;
+            hip_check(launch_touch(L.gate, (size_t)I * H * wb, reinterpret_cast<unsigned*>(att_scratch_), s), "touch");
+            hip_check(launch_touch(L.up, (size_t)I * H * wb, reinterpret_cast<unsigned*>(att_scratch_), s), "touch");
+            hip_check(launch_touch(L.down, (size_t)I * H * wb, reinterpret_cast<unsigned*>(att_scratch_), s), "touch");
+        }
+#endif
         LlmGemvArgs g;  // RMSNorm + SwiGLU (swiglu.rs:32-57)
         g.X = h_; g.ldx = H; g.rows = n; g.gamma = L.ln2; g.eps = c.eps; g.W = L.gate; g.W2 = L.up; g.bf16 = bf16_; g.swiglu = 1;
         g.n_out = I; g.k = H; g.Y0 = mid_; g.ldy0 = I;
@@ -272,10 +291,15 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
         dn.X = mid_; dn.ldx = I; dn.rows = n; dn.W = L.down; dn.bf16 = bf16_; dn.R = h_; dn.ldr = H; dn.n_out = H; dn.k = I; dn.Y0 = h_; dn.ldy0 = H;
         hip_check(launch_llm_gemv(dn, s), "down proj");
     }
-    hip_check(launch_rmsnorm(h_, final_norm_, c.eps, n, H, last_, s), "final norm");
     LlmGemvArgs lm;
-    lm.X = last_ + (size_t)(n - 1) * H; lm.ldx = H; lm.rows = 1; lm.W = lm_head_; lm.bf16 = bf16_; lm.n_out = c.vocab; lm.k = H;
+    lm.ldx = H; lm.rows = 1; lm.W = lm_head_; lm.bf16 = bf16_; lm.n_out = c.vocab; lm.k = H;
     lm.Y0 = logits_; lm.ldy0 = c.vocab;
+    if (n == 1 && llm_gemv_streams(H, lm_head_, nullptr)) {  // one token: the head normalises the row itself (and stores it)
+        lm.X = h_; lm.gamma = final_norm_; lm.eps = c.eps; lm.norm_out = last_;
+    } else {
+        hip_check(launch_rmsnorm(h_, final_norm_, c.eps, n, H, last_, s), "final norm");
+        lm.X = last_ + (size_t)(n - 1) * H;
+    }
     hip_check(launch_llm_gemv(lm, s), "lm head");
 }
 
@@ -527,6 +551,15 @@ std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, co
         size_t steps = std::min(burst, max_new_tokens - out.size());
         steps = std::min(steps, (size_t)cache_cap_ - (size_t)cache_len_);
         if (steps == 0) break;
+#ifdef KJARNI_TUNING
+        static const bool eager = std::getenv("KJARNI_HIP_LLM_EAGER") != nullptr;  // measurements: the same launches, not replayed
+        if (eager) {
+            for (size_t i = 0; i < steps; ++i) {
+                pass(reinterpret_cast<const uint32_t*>(token_), 1, true);
+                enqueue_argmax(true);
+            }
+        } else
+#endif
         for (size_t i = 0; i < steps; ++i) hip_check(hipGraphLaunch(exec, stream_), "graph launch");
         hip_check(hipMemcpyAsync(hist.data() + produced, hist_ + produced, steps * sizeof(int32_t), hipMemcpyDeviceToHost, stream_), "D2H tokens");
         hip_check(hipStreamSynchronize(stream_), "sync");

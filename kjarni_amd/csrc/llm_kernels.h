@@ -27,8 +27,16 @@ struct LlmGemvArgs {
     int64_t ldy12 = 0;
     int row_off = 0;
     const int* row_off_ptr = nullptr;
+    // att_splits > 0 (only where llm_gemv_merges_attention() says so): X is not the context row but the decode attention's
+    // slabs [k / att_head_dim heads][att_splits][att_head_dim + 4] (whisper_kernels.hip), merged while the weights stream in
+    int att_splits = 0, att_head_dim = 0;
+    float* norm_out = nullptr;     // rows == 1 with gamma (only where llm_gemv_streams()): the normalised row is also stored here
 };
 hipError_t launch_llm_gemv(const LlmGemvArgs& args, hipStream_t stream);
+// One row, + residual, no norm: can the projection merge `splits` attention slabs of `head_dim`-wide heads itself?
+bool llm_gemv_merges_attention(int k, int splits, int head_dim);
+// Does a one-row projection with these sizes take the weight-streaming kernel (which honours norm_out)?
+bool llm_gemv_streams(int k, const void* W, const void* W2);
 #ifdef KJARNI_TUNING
 void set_llm_gemv_variant(int variant);  // 0 = default (single-row kernel for rows == 1), 1 = always the multi-row kernel
 #endif
@@ -57,6 +65,9 @@ hipError_t launch_swiglu_mul(float* gate, const float* up, size_t n, hipStream_t
 hipError_t launch_rope(float* x, int64_t ldx, int rows, int n_heads, int head_dim, const float* cos_t, const float* sin_t, int pos,
                        const int* pos_ptr, int at_cache_row, hipStream_t stream);
 hipError_t launch_rmsnorm(const float* x, const float* gamma, float eps, int rows, int hidden, float* out, hipStream_t stream);
+#ifdef KJARNI_TUNING
+hipError_t launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);  // measurements: warm the memory-side cache
+#endif
 hipError_t launch_llm_embed(const uint32_t* ids, int n, int hidden, int vocab, const void* table, int bf16, float* out,
                             hipStream_t stream);
 // argmax (last maximum wins); best_scratch: one zero-initialised u64 (re-zeroed by the call); history/count/pos may be null.

@@ -345,6 +345,225 @@ __global__ __launch_bounds__(64 * NW) void llm_gemv_splitk_kernel(const float* _
     }
 }
 
+// Single-row GEMV as a weight STREAM (rows == 1, bf16 or f32 weights, K = 64 lanes x 8 elements x CH pieces): what a
+// decode step is made of is reading every weight once, so the kernel is built around keeping 16-byte loads in flight.
+// A few long-lived workgroups instead of thousands of two-column ones: the input row is normalised ONCE per workgroup
+// into LDS, then every wave walks whole weight rows -- a batch is RB rows x CH pieces = 16 (32 with the SwiGLU pair)
+// non-temporal 16-byte loads per lane, all issued before the first FMA (the weights are read once: nt keeps them
+// from evicting what the other kernels of the step re-read) -- multiplies them with its LDS-resident slice of x and
+// finishes each row with a wave reduction.  Rows are dealt batch by batch over all waves of the grid.
+template <int N>
+struct RawPieces {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v[N];
+};
+
+__device__ __forceinline__ RawPieces<1>::u32x4 load_nt16(const void* p)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
+// dot of 8 consecutive weights (one 16-byte bf16 piece, or the pair of f32 pieces p0 / p1) with x[0..7]
+__device__ __forceinline__ float dot8_bf16(RawPieces<1>::u32x4 p, const f32x4 xa, const f32x4 xb, float acc)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float lo = __uint_as_float(p[c] << 16), hi = __uint_as_float(p[c] & 0xFFFF0000u);
+        const float x0 = c < 2 ? xa[2 * c] : xb[2 * c - 4], x1 = c < 2 ? xa[2 * c + 1] : xb[2 * c - 3];
+        acc = fmaf(x0, lo, acc);
+        acc = fmaf(x1, hi, acc);
+    }
+    return acc;
+}
+
+constexpr int stream_rows_per_batch(int ch, int loads_per_piece, int nm, bool wide)
+{
+    return wide && 16 / (ch * loads_per_piece * nm) > 1 ? 16 / (ch * loads_per_piece * nm) : 1;
+}
+
+template <typename WT, int EPI, bool NORM, int CH, bool WIDE, bool LOOP, int THREADS, int ATT = 0>
+__global__ __launch_bounds__(THREADS) void llm_gemv_stream_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
+                                                              const WT* __restrict__ W, const WT* __restrict__ W2,
+                                                              const float* __restrict__ bias, const float* __restrict__ R,
+                                                              int n_out, float* __restrict__ Y, int att_splits, int att_head_dim,
+                                                              float* __restrict__ Xn)
+{
+    constexpr bool BF16 = sizeof(WT) == 2;
+    constexpr int K = CH * 512;
+    constexpr int NM = EPI == LE_SWIGLU ? 2 : 1;
+    constexpr int LOADS_PER_PIECE = BF16 ? 1 : 2;                                // 8 weights = 16 or 32 bytes
+    // rows per wave and batch: WIDE = 16 loads per lane in flight (large projections), else one row (a 2048-row projection
+    // then still gives every CU 8 waves); LOOP = the grid does not cover the rows (the vocabulary head), else one batch per wave
+    constexpr int RB = stream_rows_per_batch(CH, LOADS_PER_PIECE, NM, WIDE);
+    __shared__ __attribute__((aligned(16))) float xs[K];
+    constexpr int WAVES = THREADS / 64;  // 4 or 8: the larger workgroup halves the re-reads of the input row
+    __shared__ float red[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row bases stay in SGPRs
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int XV = K / (4 * THREADS);  // f32x4 pieces of the input row per thread
+    // Everything the workgroup reads is requested before anything is waited for: the input row (and gamma), then the first
+    // batch of weight rows.  The row is then normalised once per workgroup into LDS (x / sqrt(mean(x^2) + eps)) * gamma
+    // (rms_norm.rs:19-27) while the weights are still in flight; the counter waits are in issue order, so x must go first.
+    // ATT > 0: the row is the context row of the decode attention, still in ATT-or-fewer slabs per head (max, sum of exp,
+    // sum of exp * V: whisper_kernels.hip); their merge (the arithmetic of decode_attention_combine_kernel) happens here,
+    // under the weight requests, instead of in a launch of its own.
+    constexpr int AS = ATT > 0 ? ATT : 1;
+    f32x4 xv[XV], gv[XV], hv[XV][AS], av[XV][AS];
+    if (ATT > 0) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int col = (tid + i * THREADS) * 4, head = col / att_head_dim, j = col - head * att_head_dim;
+            const float* slab = X + (int64_t)head * att_splits * (att_head_dim + 4);
+#pragma unroll
+            for (int sp = 0; sp < AS; ++sp) {
+                const float* p = slab + (sp < att_splits ? sp : 0) * (att_head_dim + 4);
+                hv[i][sp] = *reinterpret_cast<const f32x4*>(p);
+                av[i][sp] = *reinterpret_cast<const f32x4*>(p + 4 + j);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) xv[i] = *reinterpret_cast<const f32x4*>(X + (tid + i * THREADS) * 4);
+    }
+    if (NORM) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) gv[i] = *reinterpret_cast<const f32x4*>(gamma + (tid + i * THREADS) * 4);
+    }
+    const int waves_total = gridDim.x * WAVES;
+    u32x4 raw[NM][RB][CH][LOADS_PER_PIECE];
+    auto issue = [&](int n0) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int n = n0 + r < n_out ? n0 + r : n_out - 1;
+                const char* row = reinterpret_cast<const char*>((m == 0 ? W : W2) + (int64_t)n * K);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int l = 0; l < LOADS_PER_PIECE; ++l)
+                        raw[m][r][c][l] = load_nt16(row + ((size_t)(c * 64 + lane) * 8) * sizeof(WT) + l * 16);
+            }
+    };
+    const int first = (blockIdx.x * WAVES + wave) * RB;
+    float bv[RB], rv[RB];  // the epilogue's bias / residual values, requested ahead of the batch's weights
+    auto issue_tail = [&](int n0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int n = n0 + r < n_out ? n0 + r : n_out - 1;
+            bv[r] = bias ? bias[n] : 0.0f;
+            rv[r] = EPI == LE_RESIDUAL ? R[n] : 0.0f;
+        }
+    };
+    issue_tail(first);
+    issue(first);  // unconditional (rows past the end clamp to the last one): a branch here would make the x wait drain the weights too
+    if (ATT > 0) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int sp = 0; sp < AS; ++sp)
+                if (sp < att_splits) M = fmaxf(M, hv[i][sp][0]);
+            float L = 0.0f;
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp = 0; sp < AS; ++sp) {
+                if (sp < att_splits) {
+                    const float w = (hv[i][sp][0] == -INFINITY) ? 0.0f : expf(hv[i][sp][0] - M);
+                    L = fmaf(hv[i][sp][1], w, L);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] = fmaf(av[i][sp][c], w, a[c]);
+                }
+            }
+            const float inv = L > 0.0f ? 1.0f / L : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xv[i][c] = L > 0.0f ? a[c] * inv : a[c];
+        }
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) ss += (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
+    if (NORM) {
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (WAVES == 8) tot += (red[4] + red[5]) + (red[6] + red[7]);
+        const float rms = sqrtf(tot / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < XV; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xv[i][c] = (xv[i][c] / rms) * gv[i][c];
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(xs + (tid + i * THREADS) * 4) = xv[i];
+    if (NORM && Xn && blockIdx.x == 0) {  // the normalised row is an output too (the model's last hidden state)
+#pragma unroll
+        for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(Xn + (tid + i * THREADS) * 4) = xv[i];
+    }
+    __syncthreads();
+
+    // Per batch of RB rows: the NEXT batch's bias / residual values and weights are requested before this batch's cross-lane
+    // sums and stores, which need no loads, so nothing ever waits with fresh requests behind it (the counter retires in
+    // issue order, and the tail values, older than their batch's weights, have landed once the products are done).
+    for (int n0 = first;;) {
+        float acc[NM][RB];
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[m][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + (c * 64 + lane) * 8);
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + (c * 64 + lane) * 8 + 4);
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    if (BF16) {
+                        acc[m][r] = dot8_bf16(raw[m][r][c][0], xa, xb, acc[m][r]);
+                    } else {
+                        const f32x4 wa = __builtin_bit_cast(f32x4, raw[m][r][c][0]);
+                        const f32x4 wb = __builtin_bit_cast(f32x4, raw[m][r][c][LOADS_PER_PIECE - 1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[m][r] = fmaf(xa[e], wa[e], acc[m][r]);
+                            acc[m][r] = fmaf(xb[e], wb[e], acc[m][r]);
+                        }
+                    }
+                }
+        }
+        float cb[RB], cr[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            cb[r] = bv[r];
+            cr[r] = rv[r];
+        }
+        const int next = n0 + waves_total * RB;
+        const bool more = LOOP && next < n_out;
+        if (LOOP && more) {
+            issue_tail(next);
+            issue(next);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            float v = wave_sum(acc[0][r]);
+            float up = 0.0f;
+            if (EPI == LE_SWIGLU) up = wave_sum(acc[NM - 1][r]);
+            const int n = n0 + r;
+            if (lane == 0 && n < n_out) {
+                v += cb[r];
+                if (EPI == LE_SWIGLU) v = (v / (1.0f + expf(-v))) * up;
+                if (EPI == LE_RESIDUAL) v += cr[r];
+                Y[n] = v;
+            }
+        }
+        if (!more) break;
+        n0 = next;
+    }
+}
+
 // Decode-step fusion of RMSNorm + Q|K|V projection + RoPE (decoder_attention.rs:61-97 for one new token).  Same split-K
 // layout as llm_gemv_splitk_kernel (the four waves of a workgroup share the K dimension, the row is normalised in
 // registers); a workgroup owns the PAIR of output columns (i, i + d/2) of one head, so it rotates its own two outputs
@@ -436,6 +655,109 @@ __global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restri
     float* out = kind == 0 ? Q : Kc + (int64_t)p * kv_dim;
     out[col] = va * c - vb * sn;
     out[col + half] = va * sn + vb * c;
+}
+
+// The same step in the weight-streaming form (K = 2048 / 4096 / 8192): one WAVE owns the pair of output columns, the row is
+// normalised once per workgroup into LDS, and every request (x, gamma, position, the pair's two weight rows, bias, the
+// rotation's cos / sin) is issued before anything is waited for.
+template <typename WT, int CH>
+__global__ __launch_bounds__(256) void llm_qkv_rope_stream_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
+                                                                  const WT* __restrict__ W, const float* __restrict__ bias,
+                                                                  int n_heads, int n_kv_heads, int head_dim,
+                                                                  const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                                  float* __restrict__ Q, float* __restrict__ Kc, float* __restrict__ Vc,
+                                                                  int pos, const int* __restrict__ pos_ptr)
+{
+    constexpr bool BF16 = sizeof(WT) == 2;
+    constexpr int K = CH * 512;
+    constexpr int LOADS_PER_PIECE = BF16 ? 1 : 2;
+    constexpr int XV = K / 1024;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float xs[K];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = head_dim >> 1;
+    const int q_dim = n_heads * head_dim, kv_dim = n_kv_heads * head_dim;
+    const int q_tasks = q_dim / 2, k_tasks = kv_dim / 2, tasks = q_tasks + 2 * k_tasks;
+    const int my = blockIdx.x * 4 + wave;
+    const int task = my < tasks ? my : tasks - 1;  // surplus waves redo the last pair and store nothing
+    int n_a, n_b, kind;  // the two output columns (rows of W) of this wave; 0 = Q, 1 = K, 2 = V
+    if (task < q_tasks + k_tasks) {
+        kind = task < q_tasks ? 0 : 1;
+        const int t = kind == 0 ? task : task - q_tasks;
+        const int head = t / half, i = t - head * half;
+        n_a = (kind == 0 ? 0 : q_dim) + head * head_dim + i;
+        n_b = n_a + half;
+    } else {
+        kind = 2;
+        n_a = q_dim + kv_dim + 2 * (task - q_tasks - k_tasks);
+        n_b = n_a + 1;
+    }
+    f32x4 xv[XV], gv[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        xv[i] = *reinterpret_cast<const f32x4*>(X + (tid + i * 256) * 4);
+        gv[i] = *reinterpret_cast<const f32x4*>(gamma + (tid + i * 256) * 4);
+    }
+    const int p = pos_ptr ? *pos_ptr : pos;
+    const int col = kind == 0 ? n_a : (kind == 1 ? n_a - q_dim : n_a - q_dim - kv_dim);
+    const int ri = kind == 2 ? 0 : col % head_dim;  // < half
+    const float ba = bias ? bias[n_a] : 0.0f, bb = bias ? bias[n_b] : 0.0f;
+    const float cs = cos_t[(int64_t)p * half + ri], sn = sin_t[(int64_t)p * half + ri];
+    u32x4 raw[2][CH][LOADS_PER_PIECE];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const char* row = reinterpret_cast<const char*>(W + (int64_t)(r == 0 ? n_a : n_b) * K);
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int l = 0; l < LOADS_PER_PIECE; ++l)
+                raw[r][c][l] = load_nt16(row + ((size_t)(c * 64 + lane) * 8) * sizeof(WT) + l * 16);
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) ss += (xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1]) + (xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3]);
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rms = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[i][c] = (xv[i][c] / rms) * gv[i][c];
+        *reinterpret_cast<f32x4*>(xs + (tid + i * 256) * 4) = xv[i];
+    }
+    __syncthreads();
+    float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + (c * 64 + lane) * 8);
+        const f32x4 xb = *reinterpret_cast<const f32x4*>(xs + (c * 64 + lane) * 8 + 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (BF16) {
+                acc[r] = dot8_bf16(raw[r][c][0], xa, xb, acc[r]);
+            } else {
+                const f32x4 wa = __builtin_bit_cast(f32x4, raw[r][c][0]);
+                const f32x4 wb = __builtin_bit_cast(f32x4, raw[r][c][LOADS_PER_PIECE - 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[r] = fmaf(xa[e], wa[e], acc[r]);
+                    acc[r] = fmaf(xb[e], wb[e], acc[r]);
+                }
+            }
+        }
+    }
+    const float va = wave_sum(acc[0]) + ba, vb = wave_sum(acc[1]) + bb;
+    if (lane != 0 || my >= tasks) return;
+    if (kind == 2) {
+        Vc[(int64_t)p * kv_dim + col] = va;
+        Vc[(int64_t)p * kv_dim + col + 1] = vb;
+        return;
+    }
+    float* out = kind == 0 ? Q : Kc + (int64_t)p * kv_dim;
+    out[col] = va * cs - vb * sn;  // rope/mod.rs:156-176
+    out[col + half] = va * sn + vb * cs;
 }
 
 // In-place rotation of `rows` rows of [n_heads * d] (rope/mod.rs:156-176): pairs (i, i + d/2), position =
@@ -776,6 +1098,78 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
     const bool norm = a.gamma != nullptr;
     // Staging the row in LDS pays when it also has to be normalised (otherwise every wave redoes the statistics); plain
     // projections keep the one-wave-per-column kernel, whose 4x larger grid hides latency better.
+    // One row, K = 2048 / 4096 / 8192: the weight-streaming kernel.
+    if (a.rows == 1 && a.seg_q == 0 && llm_gemv_streams(a.k, a.W, a.W2)) {
+        constexpr bool BF = sizeof(WT) == 2;
+        const int ch = a.k / 512;
+        const int nm = a.swiglu ? 2 : 1, lpp = BF ? 1 : 2;
+        // 16 loads per lane in flight where that still leaves >= 8 waves per CU, else one row per wave
+        const bool wide = a.n_out / stream_rows_per_batch(ch, lpp, nm, true) >= 2048;
+        const int rb = stream_rows_per_batch(ch, lpp, nm, wide);
+        const int batches = (a.n_out + rb - 1) / rb;
+        // 8-wave workgroups where they still cover every CU and staging the input row is the larger cost (a long row, or the
+        // attention slabs to merge: each workgroup stages the whole row, so fewer, larger ones re-read it less; measured on
+        // the 1B shape: down-proj 8.0 -> 7.6 us, output projection with the merge 6.4 -> 4.9 us, gate/up 12.8 -> 13.2 us);
+        // the layer's projections get one batch per wave, the vocabulary head loops
+        const bool big = batches >= 2048 && (ch >= 16 || a.att_splits > 0);
+        const int wpw = big ? 8 : 4;
+        const bool loop = (batches + wpw - 1) / wpw > 4096 / wpw;
+        const int wgs = loop ? 2048 / wpw : std::max(1, (batches + wpw - 1) / wpw);
+#define KJ_ST4(EPI, NORM, CH, WIDE, LOOP, THREADS)                                                                                   \
+    hipLaunchKernelGGL((llm_gemv_stream_kernel<WT, EPI, NORM, CH, WIDE, LOOP, THREADS>), dim3((unsigned)wgs), dim3(THREADS), 0, stream, \
+                       a.X, a.gamma, a.eps, W, W2, a.bias, a.R, a.n_out, a.Y0, 0, 0, a.norm_out)
+#define KJ_ST3(EPI, NORM, CH, WIDE, LOOP)                                                                                            \
+    do {                                                                                                                             \
+        if (big) KJ_ST4(EPI, NORM, CH, WIDE, LOOP, 512);                                                                             \
+        else KJ_ST4(EPI, NORM, CH, WIDE, LOOP, 256);                                                                                 \
+    } while (0)
+#define KJ_ST_ATT2(CH, WIDE, THREADS, ATT)                                                                                           \
+    hipLaunchKernelGGL((llm_gemv_stream_kernel<WT, LE_RESIDUAL, false, CH, WIDE, false, THREADS, ATT>), dim3((unsigned)wgs),         \
+                       dim3(THREADS), 0, stream, a.X, a.gamma, a.eps, W, W2, a.bias, a.R, a.n_out, a.Y0, a.att_splits, a.att_head_dim, \
+                       nullptr)
+#define KJ_ST_ATT(CH, ATT)                                                                                                           \
+    do {                                                                                                                             \
+        if (big && wide) KJ_ST_ATT2(CH, true, 512, ATT);                                                                             \
+        else if (big) KJ_ST_ATT2(CH, false, 512, ATT);                                                                               \
+        else if (wide) KJ_ST_ATT2(CH, true, 256, ATT);                                                                               \
+        else KJ_ST_ATT2(CH, false, 256, ATT);                                                                                        \
+    } while (0)
+        if (a.att_splits > 0) {  // the context row arrives as attention slabs
+            if (!llm_gemv_merges_attention(a.k, a.att_splits, a.att_head_dim) || !a.R || norm || a.swiglu || loop) return hipErrorInvalidValue;
+            if (ch == 4) KJ_ST_ATT(4, 8);
+            else KJ_ST_ATT(8, 4);
+            return hipGetLastError();
+        }
+#define KJ_ST2(EPI, NORM, CH)                                                                                                        \
+    do {                                                                                                                             \
+        if (loop) KJ_ST3(EPI, NORM, CH, true, true);                                                                                 \
+        else if (wide) KJ_ST3(EPI, NORM, CH, true, false);                                                                           \
+        else KJ_ST3(EPI, NORM, CH, false, false);                                                                                    \
+    } while (0)
+#define KJ_ST1(EPI, NORM)                                                                                                            \
+    do {                                                                                                                             \
+        if (ch == 4) KJ_ST2(EPI, NORM, 4);                                                                                           \
+        else if (ch == 8) KJ_ST2(EPI, NORM, 8);                                                                                      \
+        else KJ_ST2(EPI, NORM, 16);                                                                                                  \
+    } while (0)
+        if (a.swiglu) {
+            if (norm) KJ_ST1(LE_SWIGLU, true);
+            else KJ_ST1(LE_SWIGLU, false);
+        } else if (a.R) {
+            if (norm) KJ_ST1(LE_RESIDUAL, true);
+            else KJ_ST1(LE_RESIDUAL, false);
+        } else {
+            if (norm) KJ_ST1(LE_NONE, true);
+            else KJ_ST1(LE_NONE, false);
+        }
+#undef KJ_ST1
+#undef KJ_ST2
+#undef KJ_ST3
+#undef KJ_ST4
+#undef KJ_ST_ATT
+#undef KJ_ST_ATT2
+        return hipGetLastError();
+    }
     if (a.rows == 1 && a.seg_q == 0 && a.k <= SK_MAX_CHUNKS * 2048 && (g_llm_gemv_variant == 0 || g_llm_gemv_variant >= 3)) {
         // Long rows (down-proj: k = 8192 .. 14336) are spread over 16 waves per workgroup: a quarter of the loads per lane,
         // four times the waves in flight, at the same two columns per workgroup.
@@ -950,6 +1344,24 @@ hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, co
 {
     if ((k & 7) || k > 8192 || (head_dim & 1)) return hipErrorInvalidValue;
     const int tasks = (n_heads * head_dim + 2 * n_kv_heads * head_dim) / 2;
+    if ((k == 2048 || k == 4096 || k == 8192) && gamma && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && g_llm_gemv_variant != 8 &&
+        g_llm_gemv_variant != 1) {
+        const dim3 sgrid((unsigned)((tasks + 3) / 4));
+#define KJ_QKVS(WT, CH)                                                                                                              \
+    hipLaunchKernelGGL((llm_qkv_rope_stream_kernel<WT, CH>), sgrid, dim3(256), 0, stream, X, gamma, eps, static_cast<const WT*>(W),  \
+                       bias, n_heads, n_kv_heads, head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr)
+        if (bf16) {
+            if (k == 2048) KJ_QKVS(uint16_t, 4);
+            else if (k == 4096) KJ_QKVS(uint16_t, 8);
+            else KJ_QKVS(uint16_t, 16);
+        } else {
+            if (k == 2048) KJ_QKVS(float, 4);
+            else if (k == 4096) KJ_QKVS(float, 8);
+            else KJ_QKVS(float, 16);
+        }
+#undef KJ_QKVS
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)tasks);
     const int chunks = (k / 8 + 255) / 256;
 #define KJ_QKV(WT, CH)                                                                                                              \
@@ -968,8 +1380,23 @@ hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, co
     return hipGetLastError();
 }
 
+bool llm_gemv_streams(int k, const void* W, const void* W2)
+{
+    return (k == 2048 || k == 4096 || k == 8192) && g_llm_gemv_variant != 8 && g_llm_gemv_variant != 1 &&
+           (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (!W2 || (reinterpret_cast<uintptr_t>(W2) & 15) == 0);
+}
+
+bool llm_gemv_merges_attention(int k, int splits, int head_dim)
+{
+    if (g_llm_gemv_variant == 8 || g_llm_gemv_variant == 1) return false;  // measurements: the kernels before the streaming one
+    if (head_dim < 4 || (head_dim & 3) || k % head_dim) return false;
+    return (k == 2048 && splits >= 1 && splits <= 8) || (k == 4096 && splits >= 1 && splits <= 4);
+}
+
 hipError_t launch_llm_gemv(const LlmGemvArgs& a, hipStream_t stream)
 {
+    if (a.att_splits > 0 && (a.rows != 1 || a.seg_q != 0)) return hipErrorInvalidValue;
+    if (a.norm_out && !(a.rows == 1 && a.seg_q == 0 && a.gamma && llm_gemv_streams(a.k, a.W, a.W2))) return hipErrorInvalidValue;
     if (a.rows <= 0 || a.n_out <= 0) return hipSuccess;
     if (a.rows > LLM_MAX_ROWS || (a.k & 7) || (a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.X) & 15) ||
         (reinterpret_cast<uintptr_t>(a.W) & 15))
@@ -997,6 +1424,27 @@ hipError_t launch_rmsnorm(const float* x, const float* gamma, float eps, int row
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, eps, rows, hidden, out);
     return hipGetLastError();
 }
+
+#ifdef KJARNI_TUNING
+namespace {
+// Measurements only: pull `bytes` through the memory-side cache (plain loads, values discarded).
+__global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink)
+{
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;
+}
+}  // namespace
+
+hipError_t launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t stream)
+{
+    hipLaunchKernelGGL(touch_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const uint4*>(p), bytes / 16, sink);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t launch_llm_embed(const uint32_t* ids, int n, int hidden, int vocab, const void* table, int bf16, float* out,
                             hipStream_t stream)

@@ -335,13 +335,16 @@ __global__ __launch_bounds__(256) void gemv_rows_lds_kernel(const float* __restr
     }
 }
 
-// Cached attention for a few query rows, split over the keys ("flash decoding"): workgroup (head, split, row)
-// reduces its key range to (max, sum of exp, sum of exp * V); decode_attention_combine_kernel merges the
-// splits.  K rows are ldk floats apart with head h at columns [h*d, h*d+d); same for V.  The number of keys
-// is n_keys, or *n_keys_ptr + rows when the pointer is given (graph replay: keys = cache length + new rows).
-// causal >= 0 (or the pointer): query row s sees keys <= base + s (apply_causal_mask, utils/masks.rs:103-113:
-// masked scores are OVERWRITTEN with -1e9, which exp() then turns into exactly 0 next to any real score).
+// Cached attention for a few query rows, split over the keys ("flash decoding"): workgroup (head, split, row) reduces its
+// key range to a slab (max, sum of exp, sum of exp * V); the slabs are merged by decode_attention_combine_kernel, or by the
+// consumer of the context row itself (the LLM's output projection reads the slabs while its weights are in flight:
+// llm_kernels.hip).  K rows are ldk floats apart with head h at columns [h*d, h*d+d); same for V.  The number of keys is
+// n_keys, or *n_keys_ptr + rows when the pointer is given (graph replay: keys = cache length + new rows).
+// causal >= 0 (or the pointer): query row s sees keys <= base + s (apply_causal_mask, utils/masks.rs:103-113: masked scores
+// are OVERWRITTEN with -1e9, which exp() then turns into exactly 0 next to any real score).
+// Slab layout per (row, head, split): [max, sum, 0, 0, acc[head_dim]] (16-byte aligned pieces).
 constexpr int ATT_MAX_CHUNK = 512;
+constexpr int ATT_FAST = 8;  // keys per lane group that the short-range path holds in registers (128 keys per split at d = 64)
 
 __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const float* __restrict__ q, int64_t ldq,
                                                                        const float* __restrict__ K0, int64_t ldk,
@@ -353,8 +356,8 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
 {
     __shared__ float sc[ATT_MAX_CHUNK];
     __shared__ float red[4];
-    __shared__ f32x4 accs[256];
-    const int h = blockIdx.x, sp = blockIdx.y, s = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    __shared__ f32x4 accs[4 * 32];
+    const int h = blockIdx.x, sp = blockIdx.y, s = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = n_keys_ptr ? *n_keys_ptr : 0;
     // lanes: the rows are independent sequences in lock step -- each attends to its own cache (row s at K + s * stride),
     // all of them hold the same number of keys (the ones before this step plus this step's own), no mask between rows.
@@ -370,55 +373,92 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
     const int col = (h / kv_group) * head_dim + l * 4;  // grouped-query attention: kv_group query heads share a KV head
     const f32x4 qv = *reinterpret_cast<const f32x4*>(q + (int64_t)s * ldq + h * head_dim + l * 4);
 
-    float mx = -INFINITY;
-    for (int t = t0 + g; t < t1; t += groups) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(K + (int64_t)t * ldk + col);
-        float dot = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dot = fmaf(qv[c], kv[c], dot);
-        for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
-        float v = dot * scale;
-        if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
-        if (l == 0) sc[t - t0] = v;
-        mx = fmaxf(mx, v);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float sum = 0.0f;
-    for (int t = t0 + tid; t < t1; t += 256) {
-        const float e = expf(sc[t - t0] - mx);
-        sc[t - t0] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red[tid >> 6] = sum;
-    __syncthreads();
-    sum = red[0] + red[1] + red[2] + red[3];
+    auto block_max = [&](float v) {
+        v = wave_max(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        return m;
+    };
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const float t = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+        return t;
+    };
 
+    float mx = -INFINITY, sum = 0.0f;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = t0 + g; t < t1; t += groups) {
-        const float p = sc[t - t0];
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(V + (int64_t)t * ldv + col);
+    if (t1 - t0 <= ATT_FAST * groups) {
+        // Short ranges (a decode step over a few hundred cached keys is a chain of latencies, not of bytes): every K and V
+        // row of the range is requested at once and held in registers -- one memory round trip instead of one per pass.
+        f32x4 kr[ATT_FAST], vr[ATT_FAST];
+        const int last = t1 > t0 ? t1 - 1 : 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = fmaf(p, vv[c], acc[c]);
+        for (int j = 0; j < ATT_FAST; ++j) kr[j] = *reinterpret_cast<const f32x4*>(K + (int64_t)min(t0 + g + j * groups, last) * ldk + col);
+#pragma unroll
+        for (int j = 0; j < ATT_FAST; ++j) vr[j] = *reinterpret_cast<const f32x4*>(V + (int64_t)min(t0 + g + j * groups, last) * ldv + col);
+        float sv[ATT_FAST];
+#pragma unroll
+        for (int j = 0; j < ATT_FAST; ++j) {
+            const int t = t0 + g + j * groups;
+            float dot = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot = fmaf(qv[c], kr[j][c], dot);
+            for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+            float v = dot * scale;
+            if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
+            sv[j] = t < t1 ? v : -INFINITY;
+            mx = fmaxf(mx, sv[j]);
+        }
+        mx = block_max(mx);
+#pragma unroll
+        for (int j = 0; j < ATT_FAST; ++j) {
+            const float e = t0 + g + j * groups < t1 ? expf(sv[j] - mx) : 0.0f;
+            if (l == 0) sum += e;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(e, vr[j][c], acc[c]);
+        }
+        sum = block_sum(sum);
+    } else {
+        for (int t = t0 + g; t < t1; t += groups) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(K + (int64_t)t * ldk + col);
+            float dot = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dot = fmaf(qv[c], kv[c], dot);
+            for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+            float v = dot * scale;
+            if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
+            if (l == 0) sc[t - t0] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = block_max(mx);
+        for (int t = t0 + tid; t < t1; t += 256) {
+            const float e = expf(sc[t - t0] - mx);
+            sc[t - t0] = e;
+            sum += e;
+        }
+        sum = block_sum(sum);
+        for (int t = t0 + g; t < t1; t += groups) {
+            const float p = sc[t - t0];
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(V + (int64_t)t * ldv + col);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(p, vv[c], acc[c]);
+        }
     }
-    accs[tid] = acc;
+    // sum of exp * V over the workgroup: the lane groups of a wave by shuffles, the four waves through LDS
+    for (int off = lpk; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, kWave);
+    }
+    if (lane < lpk) accs[wave * lpk + lane] = acc;
     __syncthreads();
-    // part layout per (row, head, split): [max, sum, acc[head_dim]]
-    float* out = part + (((int64_t)s * gridDim.x + h) * splits + sp) * (head_dim + 2);
-    if (tid < lpk) {
-        f32x4 tot = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int gg = 0; gg < groups; ++gg) tot += accs[gg * lpk + tid];
-        *reinterpret_cast<f32x2*>(out + 2 + tid * 4) = f32x2{tot[0], tot[1]};
-        *reinterpret_cast<f32x2*>(out + 4 + tid * 4) = f32x2{tot[2], tot[3]};
-    }
-    if (tid == 0) {
-        out[0] = (t1 > t0) ? mx : -INFINITY;
-        out[1] = (t1 > t0) ? sum : 0.0f;
-    }
+    float* out = part + (((int64_t)s * gridDim.x + h) * splits + sp) * (head_dim + 4);
+    if (tid < lpk) *reinterpret_cast<f32x4*>(out + 4 + tid * 4) = (accs[tid] + accs[lpk + tid]) + (accs[2 * lpk + tid] + accs[3 * lpk + tid]);
+    if (tid == 0) *reinterpret_cast<f32x4*>(out) = f32x4{(t1 > t0) ? mx : -INFINITY, (t1 > t0) ? sum : 0.0f, 0.0f, 0.0f};
 }
 
 __global__ __launch_bounds__(128) void decode_attention_combine_kernel(const float* __restrict__ part, int heads, int splits,
@@ -426,15 +466,15 @@ __global__ __launch_bounds__(128) void decode_attention_combine_kernel(const flo
 {
     const int h = blockIdx.x, s = blockIdx.y, j = threadIdx.x;
     if (j >= head_dim) return;
-    const float* p = part + ((int64_t)s * heads + h) * splits * (head_dim + 2);
+    const float* p = part + ((int64_t)s * heads + h) * splits * (head_dim + 4);
     float M = -INFINITY;
-    for (int i = 0; i < splits; ++i) M = fmaxf(M, p[i * (head_dim + 2)]);
+    for (int i = 0; i < splits; ++i) M = fmaxf(M, p[i * (head_dim + 4)]);
     float L = 0.0f, a = 0.0f;
     for (int i = 0; i < splits; ++i) {
-        const float* pi = p + i * (head_dim + 2);
+        const float* pi = p + i * (head_dim + 4);
         const float w = (pi[0] == -INFINITY) ? 0.0f : expf(pi[0] - M);
         L = fmaf(pi[1], w, L);
-        a = fmaf(pi[2 + j], w, a);
+        a = fmaf(pi[4 + j], w, a);
     }
     ctx[(int64_t)s * ldc + h * head_dim + j] = L > 0.0f ? a * (1.0f / L) : a;
 }
@@ -680,7 +720,7 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
 
 size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int splits)
 {
-    return (size_t)rows * heads * splits * (head_dim + 2);
+    return (size_t)rows * heads * splits * (head_dim + 4);
 }
 
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
@@ -695,8 +735,9 @@ hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const 
     hipLaunchKernelGGL(decode_attention_partial_kernel, dim3((unsigned)heads, (unsigned)splits, (unsigned)rows), dim3(256), 0, stream,
                        q, ldq, K, ldk, V, ldv, n_keys, n_keys_ptr, rows, head_dim, 1.0f / sqrtf((float)head_dim), causal_base, splits,
                        kv_group < 1 ? 1 : kv_group, k_lane_stride, v_lane_stride, lanes, scratch);
-    hipLaunchKernelGGL(decode_attention_combine_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(128), 0, stream, scratch, heads,
-                       splits, head_dim, ctx, ldc);
+    if (ctx)  // ctx == nullptr: the caller merges the slabs itself (layout above)
+        hipLaunchKernelGGL(decode_attention_combine_kernel, dim3((unsigned)heads, (unsigned)rows), dim3(128), 0, stream, scratch, heads,
+                           splits, head_dim, ctx, ldc);
     return hipGetLastError();
 }
 

@@ -174,3 +174,27 @@ def test_production_head_sizes_prefill_and_decode(tmp_path, name):
     gpu.reset()
     exp = orc.generate(ids[:30], 6)
     assert gpu.generate(ids[:30], 6) == exp
+
+
+@pytest.mark.parametrize("store_bf16", [True, False], ids=["bf16-weights", "f32-weights"])
+def test_full_width_decode_step(tmp_path, store_bf16):
+    """The production widths of the decode step (hidden 2048, inner 8192: the Llama-3.2-1B row lengths, one layer, small
+    vocabulary): single-token steps go through the weight-streaming GEMV (K = 2048 and 8192, SwiGLU pair, residual,
+    RMSNorm folded in, the attention slabs merged by the output projection, the final norm by the vocabulary head), prompt
+    blocks through the matrix-core route; both against the oracle."""
+    base = dict(synth.LLAMA_TEST, hidden_size=2048, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=8,
+                intermediate_size=8192, vocab_size=20011, max_position_embeddings=512, head_dim=64)  # > 16384 rows: the head loops
+    base["rope_scaling"] = dict(base["rope_scaling"], original_max_position_embeddings=128)
+    orc, gpu, cfg = _pair(tmp_path, base, seed=9, bf16_values=True, store_bf16=store_bf16)
+    rng = np.random.default_rng(1)
+    cache = orc.new_cache()
+    gpu.reset()
+    for n in (7, 1, 1, 1, 30, 1):
+        ids = rng.integers(4, cfg["vocab_size"], n).tolist()
+        ref_h = orc.forward(ids, cache)[0]
+        h, logits = gpu.forward(ids)
+        k = (n - 1) % 8 + 1                                     # the rows of the last 8-row block come back
+        ref_l = orc.logits(ref_h[-1])
+        scale = max(1.0, float(np.abs(ref_h).max()))
+        assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, np.abs(h[-k:] - ref_h[-k:]).max()
+        assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max()))

@@ -442,26 +442,27 @@ def main():
                             "achieved": round(per_tok * len(out) / t_dec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(per_tok * len(out) / t_dec / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                             "algorithmic_bytes_per_token": int(per_tok)}}
-        from oracle import llm_oracle as LO
-        from oracle import oracle as O
-        try:
-            import psutil
-            cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-        except Exception:
-            cores = os.cpu_count() or 1
-        O.lib().ko_set_num_threads(int(cores))
-        orc = LO.LlmOracle(t_l, cfg_l)
-        cache = orc.new_cache()
-        t0 = time.perf_counter()
-        h = orc.forward(prompt[:16], cache)
-        c_pre = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        for i in range(4):
-            h = orc.forward([int(out[i])], cache)
-            orc.logits(h[0, -1])
-        c_dec = (time.perf_counter() - t0) / 4
-        res["cpu_baseline"] = {"value": round(1.0 / c_dec, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
-                               "sample": f"oracle: 16-token prefill {c_pre:.2f} s, 4 decode steps at {c_dec * 1e3:.0f} ms each (f32 weights)"}
+        if not os.environ.get("KJARNI_BENCH_NO_CPU"):                         # kernel A/B runs skip the CPU leg
+            from oracle import llm_oracle as LO
+            from oracle import oracle as O
+            try:
+                import psutil
+                cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+            except Exception:
+                cores = os.cpu_count() or 1
+            O.lib().ko_set_num_threads(int(cores))
+            orc = LO.LlmOracle(t_l, cfg_l)
+            cache = orc.new_cache()
+            t0 = time.perf_counter()
+            h = orc.forward(prompt[:16], cache)
+            c_pre = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for i in range(4):
+                h = orc.forward([int(out[i])], cache)
+                orc.logits(h[0, -1])
+            c_dec = (time.perf_counter() - t0) / 4
+            res["cpu_baseline"] = {"value": round(1.0 / c_dec, 2), "unit": "tokens/s", "cores": int(cores), "kind": "port",
+                                   "sample": f"oracle: 16-token prefill {c_pre:.2f} s, 4 decode steps at {c_dec * 1e3:.0f} ms each (f32 weights)"}
         emit(res)
 
     if "llm8b" in which:
