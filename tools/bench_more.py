@@ -38,6 +38,25 @@ def flops_per_row(H=384, L=6, I=1536, seq=S, head=0):
     return L * per_layer + head
 
 
+def usable_cores():
+    """Threads for a CPU leg: physical cores, capped by the affinity mask and the cgroup CPU quota (as bench.py's)."""
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        n = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        n = min(n, len(os.sched_getaffinity(0)))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def timed(fn, sync, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -373,11 +392,7 @@ def main():
                "decode_frac_hbm_peak": round(dec_bytes * len(ids) / t_dec / 1e9 / PEAK_HBM_GBS, 4)}
         # CPU restatement (oracle): one encoder pass + a few decoder steps, extrapolated to the same token count
         from oracle import whisper_oracle as WO
-        try:
-            import psutil
-            cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-        except Exception:
-            cores = os.cpu_count() or 1
+        cores = usable_cores()
         from oracle import oracle as O
         O.lib().ko_set_num_threads(int(cores))
         orc = WO.WhisperOracle(t_w, cfg_w)
@@ -438,18 +453,14 @@ def main():
                                       f"random init, 128-token prompt, {len(out)} generated tokens"},
                "ms_prefill_128": round(t_prefill * 1e3, 2), "prefill_tokens_per_s": round(128 / t_prefill, 1),
                "ms_per_token": round(t_dec * 1e3 / len(out), 4), "weight_bytes": dec.weight_bytes,
-               "roofline": {"kernel": "llm_gemv_kernel (weight stream) + decode_attention", "bound": "hbm",
+               "roofline": {"kernel": "llm_gemv_stream_kernel (weight stream) + decode_attention_partial", "bound": "hbm",
                             "achieved": round(per_tok * len(out) / t_dec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(per_tok * len(out) / t_dec / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                             "algorithmic_bytes_per_token": int(per_tok)}}
         if not os.environ.get("KJARNI_BENCH_NO_CPU"):                         # kernel A/B runs skip the CPU leg
             from oracle import llm_oracle as LO
             from oracle import oracle as O
-            try:
-                import psutil
-                cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
-            except Exception:
-                cores = os.cpu_count() or 1
+            cores = usable_cores()
             O.lib().ko_set_num_threads(int(cores))
             orc = LO.LlmOracle(t_l, cfg_l)
             cache = orc.new_cache()
