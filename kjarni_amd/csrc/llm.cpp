@@ -324,6 +324,7 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
         pg_ = dalloc(P * I);
         pu_ = dalloc(P * I);
         pids_ = reinterpret_cast<uint32_t*>(dalloc(P));
+        psplit_ = dalloc(prefill_gemm_scratch_floats(prefill_cap_, std::max(I, H)));
     }
     const size_t wsz = bf16_ ? 2 : 4;
     auto at = [&](const void* w, size_t elems) { return static_cast<const void*>(static_cast<const char*>(w) + elems * wsz); };
@@ -335,11 +336,11 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
             float* k_rows = L.k_cache + (size_t)cache_len_ * kv;
             float* v_rows = L.v_cache + (size_t)cache_len_ * kv;
             hip_check(launch_rmsnorm(ph_, L.ln1, c.eps, m, H, pn_, s), "rmsnorm 1");
-            hip_check(launch_prefill_gemm(pn_, H, L.wqkv, wb, L.bqkv, nullptr, 0, pq_, H, m, H, H, s), "q proj");
-            hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)H * H), wb, L.bqkv ? L.bqkv + H : nullptr, nullptr, 0, k_rows, kv, m, kv, H, s),
+            hip_check(launch_prefill_gemm(pn_, H, L.wqkv, wb, L.bqkv, nullptr, 0, pq_, H, m, H, H, s, psplit_), "q proj");
+            hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)H * H), wb, L.bqkv ? L.bqkv + H : nullptr, nullptr, 0, k_rows, kv, m, kv, H, s, psplit_),
                       "k proj");
             hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)(H + kv) * H), wb, L.bqkv ? L.bqkv + H + kv : nullptr, nullptr, 0, v_rows, kv, m,
-                                          kv, H, s), "v proj");
+                                          kv, H, s, psplit_), "v proj");
             hip_check(launch_rope(pq_, H, m, c.heads, d, cos_, sin_, cache_len_, nullptr, 0, s), "rope q");
             hip_check(launch_rope(L.k_cache, kv, m, c.kv_heads, d, cos_, sin_, cache_len_, nullptr, 1, s), "rope k");
             if (prefill_attention_supported(d)) {
@@ -353,12 +354,11 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
                                                       c.heads / c.kv_heads), "attention");
                 }
             }
-            hip_check(launch_prefill_gemm(pctx_, H, L.wo, wb, nullptr, ph_, H, ph_, H, m, H, H, s), "o proj");
+            hip_check(launch_prefill_gemm(pctx_, H, L.wo, wb, nullptr, ph_, H, ph_, H, m, H, H, s, psplit_), "o proj");
             hip_check(launch_rmsnorm(ph_, L.ln2, c.eps, m, H, pn_, s), "rmsnorm 2");
-            hip_check(launch_prefill_gemm(pn_, H, L.gate, wb, nullptr, nullptr, 0, pg_, I, m, I, H, s), "gate");
-            hip_check(launch_prefill_gemm(pn_, H, L.up, wb, nullptr, nullptr, 0, pu_, I, m, I, H, s), "up");
-            hip_check(launch_swiglu_mul(pg_, pu_, (size_t)m * I, s), "swiglu");
-            hip_check(launch_prefill_gemm(pg_, I, L.down, wb, nullptr, ph_, H, ph_, H, m, H, I, s), "down proj");
+            hip_check(launch_prefill_gemm(pn_, H, L.gate, wb, nullptr, nullptr, 0, pg_, I, m, I, H, s, psplit_), "gate");
+            hip_check(launch_prefill_gemm(pn_, H, L.up, wb, nullptr, nullptr, 0, pu_, I, m, I, H, s, psplit_, pg_), "up + swiglu");
+            hip_check(launch_prefill_gemm(pg_, I, L.down, wb, nullptr, ph_, H, ph_, H, m, H, I, s, psplit_), "down proj");
         }
         cache_len_ += m;
         if (done + m == n) {

@@ -48,8 +48,11 @@ hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, co
                                float* Vc, int pos, const int* pos_ptr, hipStream_t stream);
 
 // Prefill: Y[M, N] = A[M, K] . W[N, K]^T + bias (+ R) on the fp32 matrix cores, W bf16 or f32; K % 32 == 0.  R may alias Y.
+// split_scratch (prefill_gemm_scratch_floats() floats, or null): short prompts split K over up to 8 workgroups per tile.
 hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int bf16, const float* bias, const float* R, int64_t ldr, float* Y,
-                               int64_t ldy, int M, int N, int K, hipStream_t stream);
+                               int64_t ldy, int M, int N, int K, hipStream_t stream, float* split_scratch = nullptr,
+                               float* silu_gate = nullptr);  // silu_gate: [M, N] gate activations, overwritten with silu(gate) * (this product)
+size_t prefill_gemm_scratch_floats(int max_rows, int max_n);
 
 // Prefill: causal grouped-query attention of `rows` new rows (positions base .. base + rows - 1) over the cache rows
 // 0 .. base + rows - 1; head_dim in {16, 32, 64, 128}.

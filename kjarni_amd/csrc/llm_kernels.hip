@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     for (int i = lane; i < hidden; i += 64) out[(int64_t)r * hidden + i] = (row[i] / rms) * gamma[i];
 }
 
-// The same for a handful of rows (the decode step's final norm): one 256-thread workgroup per row, 16-byte loads.
+// The same with one 256-thread workgroup per row and 16-byte loads (hidden % 4 == 0).
 __global__ __launch_bounds__(256) void rmsnorm_block_kernel(const float* __restrict__ x, const float* __restrict__ gamma, float eps,
                                                             int hidden, float* __restrict__ out)
 {
@@ -895,7 +895,8 @@ constexpr int PG_BM = 64, PG_BN = 64, PG_BK = 32, PG_STRIDE = PG_BK + 4;
 template <typename WT, bool RESIDUAL>
 __global__ __launch_bounds__(256) void prefill_gemm_kernel(const float* __restrict__ A, int64_t lda, const WT* __restrict__ W,
                                                            const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
-                                                           int64_t ldy, int M, int N, int K, int m_tiles)
+                                                           int64_t ldy, int M, int N, int K, int m_tiles, int ksplit,
+                                                           float* __restrict__ P)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][PG_BM * PG_STRIDE];
     __shared__ __attribute__((aligned(16))) float sB[2][PG_BN * PG_STRIDE];
@@ -906,9 +907,14 @@ __global__ __launch_bounds__(256) void prefill_gemm_kernel(const float* __restri
     const int64_t nwg = gridDim.x;
     const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const int64_t q8 = nwg / 8, r8 = nwg % 8;
-    const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int64_t bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    // ksplit > 1 (short prompts: too few tiles for 256 CUs): slice ks of the K range, fastest index, so the slices of a
+    // tile run side by side; the partial tiles go to P[ks][M][N] and prefill_splitk_reduce_kernel adds them in order.
+    const int ks = (int)(bid0 % ksplit);
+    const int64_t bid = bid0 / ksplit;
     const int m0 = (int)(bid % m_tiles) * PG_BM;
     const int n0 = (int)(bid / m_tiles) * PG_BN;
+    const int k_len = K / ksplit, k_begin = ks * k_len;
 
     // A: 64 x 32 floats = 512 float4, two per thread.  W: f32 the same; bf16: 64 x 32 halves = 256 x 16 bytes, one per thread.
     const int a_row = tid >> 3, a_c4 = tid & 7;
@@ -948,14 +954,14 @@ __global__ __launch_bounds__(256) void prefill_gemm_kernel(const float* __restri
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int nk = K / PG_BK;
+    const int nk = k_len / PG_BK;
     const int fa = (wr * 32 + l31) * PG_STRIDE + half * 4, fb = (wc * 32 + l31) * PG_STRIDE + half * 4;
-    load(0);
+    load(k_begin);
     store(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load((kt + 1) * PG_BK);
+        if (kt + 1 < nk) load(k_begin + (kt + 1) * PG_BK);
 #pragma unroll
         for (int kk = 0; kk < PG_BK / 8; ++kk) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[cur][fa + kk * 8]);
@@ -968,6 +974,15 @@ __global__ __launch_bounds__(256) void prefill_gemm_kernel(const float* __restri
     }
     const int col = n0 + wc * 32 + l31;
     if (col < N) {
+        if (ksplit > 1) {
+            float* out = P + (int64_t)ks * M * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 32 + acc_row(r, half);
+                if (row < M) out[(int64_t)row * N + col] = acc[r];
+            }
+            return;
+        }
         const float bv = bias ? bias[col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -977,6 +992,31 @@ __global__ __launch_bounds__(256) void prefill_gemm_kernel(const float* __restri
                 if (RESIDUAL) v += R[(int64_t)row * ldr + col];
                 Y[(int64_t)row * ldy + col] = v;
             }
+        }
+    }
+}
+
+// Y = sum over the K slices (in slice order) + bias + residual: the epilogue of prefill_gemm_kernel for split launches.
+__global__ __launch_bounds__(256) void prefill_splitk_reduce_kernel(const float* __restrict__ P, int ksplit, const float* __restrict__ bias,
+                                                                    const float* R, int64_t ldr, float* Y, int64_t ldy, int M, int N,
+                                                                    float* G)
+{
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4, slab = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n4;
+        const int col = (int)(i - row * n4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(P + row * N + col);
+        for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4*>(P + s * slab + row * N + col);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+        if (R) v += *reinterpret_cast<const f32x4*>(R + row * ldr + col);
+        if (G) {  // this GEMM is the SwiGLU `up`: the gate buffer becomes silu(gate) * up (swiglu.rs:32-57)
+            const f32x4 g = *reinterpret_cast<const f32x4*>(G + row * ldy + col);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (g[c] / (1.0f + expf(-g[c]))) * v[c];
+            *reinterpret_cast<f32x4*>(G + row * ldy + col) = v;
+        } else {
+            *reinterpret_cast<f32x4*>(Y + row * ldy + col) = v;
         }
     }
 }
@@ -1276,16 +1316,38 @@ static hipError_t launch_gemv_t(const LlmGemvArgs& a, hipStream_t stream)
 void set_llm_gemv_variant(int v) { g_llm_gemv_variant = v; }
 #endif
 
+int prefill_gemm_ksplit(int M, int N, int K)
+{
+    const int tiles = ((M + PG_BM - 1) / PG_BM) * ((N + PG_BN - 1) / PG_BN);
+    int s = 1;
+    // up to 8 slices of >= 128 columns of K while the launch stays within ~4 workgroups per CU
+    while (s < 8 && tiles * s * 2 <= 1024 && K % (s * 2 * PG_BK) == 0 && K / (s * 2) >= 128) s *= 2;
+    return s;
+}
+
+size_t prefill_gemm_scratch_floats(int max_rows, int max_n)
+{
+    // ksplit * tiles <= 1024 tiles of 64 x 64, or one unsplit slab when there are more tiles than that
+    (void)max_rows;
+    (void)max_n;
+    return (size_t)1024 * PG_BM * PG_BN;
+}
+
 hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int bf16, const float* bias, const float* R, int64_t ldr, float* Y,
-                               int64_t ldy, int M, int N, int K, hipStream_t stream)
+                               int64_t ldy, int M, int N, int K, hipStream_t stream, float* split_scratch, float* silu_gate)
 {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (K % PG_BK || lda % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return hipErrorInvalidValue;
+    if (silu_gate && (ldy != N || (N & 3) || (reinterpret_cast<uintptr_t>(silu_gate) & 15))) return hipErrorInvalidValue;
     const int m_tiles = (M + PG_BM - 1) / PG_BM, n_tiles = (N + PG_BN - 1) / PG_BN;
-    const dim3 grid((unsigned)(m_tiles * n_tiles));
+    int ksplit = 1;
+    if (split_scratch && (N & 3) == 0 && (ldy & 3) == 0 && (!R || (ldr & 3) == 0) && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+        (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0) && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0))
+        ksplit = prefill_gemm_ksplit(M, N, K);
+    const dim3 grid((unsigned)(m_tiles * n_tiles * ksplit));
 #define KJ_PG(WT, RES)                                                                                                              \
     hipLaunchKernelGGL((prefill_gemm_kernel<WT, RES>), grid, dim3(256), 0, stream, A, lda, static_cast<const WT*>(W), bias, R, ldr, Y, ldy, \
-                       M, N, K, m_tiles)
+                       M, N, K, m_tiles, ksplit, split_scratch)
     if (bf16) {
         if (R) KJ_PG(uint16_t, true);
         else KJ_PG(uint16_t, false);
@@ -1294,6 +1356,14 @@ hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int b
         else KJ_PG(float, false);
     }
 #undef KJ_PG
+    if (ksplit > 1) {
+        const int64_t total = (int64_t)M * (N / 4);
+        const unsigned blocks = (unsigned)std::min<int64_t>(2048, (total + 255) / 256);
+        hipLaunchKernelGGL(prefill_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, split_scratch, ksplit, bias, R, ldr, Y, ldy, M, N,
+                           silu_gate);
+    } else if (silu_gate) {
+        return launch_swiglu_mul(silu_gate, Y, (size_t)M * N, stream);
+    }
     return hipGetLastError();
 }
 
@@ -1417,7 +1487,7 @@ hipError_t launch_rope(float* x, int64_t ldx, int rows, int n_heads, int head_di
 hipError_t launch_rmsnorm(const float* x, const float* gamma, float eps, int rows, int hidden, float* out, hipStream_t stream)
 {
     if (rows <= 0) return hipSuccess;
-    if (rows <= 16 && (hidden & 3) == 0) {
+    if ((hidden & 3) == 0) {  // one workgroup per row, 16-byte loads (the wave-per-row kernel with scalar loads: 16 vs 5 us at 128 rows)
         hipLaunchKernelGGL(rmsnorm_block_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, gamma, eps, hidden, out);
         return hipGetLastError();
     }

@@ -128,8 +128,12 @@ def test_bf16_weights(tmp_path):
 
 
 def _close(got, want):
-    """1e-4 absolute on O(1) values; a 4096-term f32 dot product with |logit| ~ 15 carries ~1e-5 relative rounding of its own."""
-    return np.allclose(got, want, atol=TOL, rtol=1e-5)
+    """1e-4 absolute on O(1) values, plus 1e-5 of the LARGEST logit: a 4096-term f32 dot product whose terms reach |logit| ~ 15
+    carries that much rounding whatever its own value is (the error follows the sum of |terms|, not the result), and the
+    oracle's single K chain and the prompt GEMMs' up-to-8 K slices do not round together.  Hidden states are held to 1e-4
+    absolute separately."""
+    got, want = np.asarray(got), np.asarray(want)
+    return bool(np.all(np.abs(got - want) <= TOL + 1e-5 * np.abs(want).max()))
 
 
 GEOMETRIES = {
