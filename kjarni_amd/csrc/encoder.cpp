@@ -51,7 +51,7 @@ EncoderModel::~EncoderModel()
         (void)hipEventDestroy(pe.stop);
     }
     for (auto& w : ws_all_) {
-        for (void* p : {(void*)w->hidden, (void*)w->qkv, (void*)w->ctx, (void*)w->mid, (void*)w->feat, w->stage})
+        for (void* p : {(void*)w->hidden, (void*)w->qkv, (void*)w->ctx, (void*)w->mid, (void*)w->feat, (void*)w->split, w->stage})
             if (p) (void)hipFree(p);
         if (w->done) (void)hipEventDestroy(w->done);
         if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -504,7 +504,8 @@ void EncoderModel::reserve(Workspace& ws, int64_t tokens, int64_t sentences)
         ws.done_pending = false;
     }
     ws.tokens = ws.sentences = 0;
-    for (float** p : {&ws.hidden, &ws.qkv, &ws.ctx, &ws.mid, &ws.feat})
+    ws.split_floats = 0;
+    for (float** p : {&ws.hidden, &ws.qkv, &ws.ctx, &ws.mid, &ws.feat, &ws.split})
         if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
@@ -515,6 +516,9 @@ void EncoderModel::reserve(Workspace& ws, int64_t tokens, int64_t sentences)
     hip_check(hipMalloc((void**)&ws.ctx, T * H * 4), "hipMalloc(ws_ctx)");
     hip_check(hipMalloc((void**)&ws.mid, T * I * 4), "hipMalloc(ws_mid)");
     hip_check(hipMalloc((void**)&ws.feat, (size_t)sentences * H * 4), "hipMalloc(ws_feat)");
+    const size_t split_floats = gemm_scratch_floats(tokens, cfg_.hidden);
+    hip_check(hipMalloc((void**)&ws.split, split_floats * 4), "hipMalloc(ws_split)");
+    ws.split_floats = split_floats;
     ws.tokens = tokens;
     ws.sentences = sentences;
 }
@@ -633,7 +637,9 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     const double b_ln = 8.0 * Td * Hd;
     // Up to 128 tokens the projections take the few-rows kernel (K split over the waves of a workgroup, gemm.hip) and
     // LayerNorm stays its own small launch; beyond that the residual projections carry it in their epilogue.
-    const bool fused_ln = fuse_layernorm() && T > 128;
+    const GemmScratch sc{ws.split, ws.split_floats};
+    // (up to 64 rows: the few-rows projection kernel + a LayerNorm launch)
+    const bool fused_ln = T > 64 && (fuse_layernorm() || (gemm_mid_layernorm_supported(T, H, H) && gemm_mid_layernorm_supported(T, H, I)));
 
     hipEvent_t pe = prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
     hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,
@@ -648,12 +654,12 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
         if (fused_ln) {
             hipEvent_t e = prof_start(kind, stream, flops, bytes);
             hip_check(launch_gemm_residual_layernorm(A, K, W, b, hidden, H, g, beta, cfg_.eps, hidden, H, T, H, K,
-                                                     stream), what);
+                                                     stream, sc), what);
             prof_stop(e, stream);
             return;
         }
         hipEvent_t e = prof_start(kind, stream, flops, bytes);
-        hip_check(launch_gemm(A, K, W, b, hidden, H, hidden, H, T, H, K, EPI_BIAS_RESIDUAL, stream), what);
+        hip_check(launch_gemm(A, K, W, b, hidden, H, hidden, H, T, H, K, EPI_BIAS_RESIDUAL, stream, sc), what);
         prof_stop(e, stream);
         e = prof_start(KK_LAYERNORM, stream, 0.0, b_ln);
         hip_check(launch_layernorm(hidden, g, beta, cfg_.eps, T, H, hidden, stream), "layernorm");
@@ -661,8 +667,7 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     };
     for (const DeviceLayer& L : layers_) {
         pe = prof_start(KK_GEMM_QKV, stream, f_qkv, b_qkv);
-        hip_check(launch_gemm(hidden, H, L.wqkv, L.bqkv, nullptr, 0, ws.qkv, 3 * H, T, 3 * H, H, EPI_BIAS,
-                              stream),
+        hip_check(launch_gemm(hidden, H, L.wqkv, L.bqkv, nullptr, 0, ws.qkv, 3 * H, T, 3 * H, H, EPI_BIAS, stream, sc),
                   "gemm(qkv)");
         prof_stop(pe, stream);
         if (rope_cos_) {
@@ -680,15 +685,15 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
             // SwiGLU (cpu/feedforward/swiglu.rs:40-50): the gate projection lands in ws.mid, the up projection's
             // epilogue multiplies it by silu(gate) in place (read then written by the same thread).
             pe = prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
-            hip_check(launch_gemm(hidden, H, L.wg, nullptr, nullptr, 0, ws.mid, I, T, I, H, EPI_BIAS, stream), "gemm(gate)");
+            hip_check(launch_gemm(hidden, H, L.wg, nullptr, nullptr, 0, ws.mid, I, T, I, H, EPI_BIAS, stream, sc), "gemm(gate)");
             prof_stop(pe, stream);
             pe = prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1 + 4.0 * Td * Id);
-            hip_check(launch_gemm(hidden, H, L.w1, L.b1, ws.mid, I, ws.mid, I, T, I, H, EPI_BIAS_MUL_SILU, stream),
+            hip_check(launch_gemm(hidden, H, L.w1, L.b1, ws.mid, I, ws.mid, I, T, I, H, EPI_BIAS_MUL_SILU, stream, sc),
                       "gemm(up * silu(gate))");
             prof_stop(pe, stream);
         } else {
             pe = prof_start(KK_GEMM_FC1, stream, f_fc1, b_fc1);
-            hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws.mid, I, T, I, H, cfg_.ffn_act, stream),
+            hip_check(launch_gemm(hidden, H, L.w1, L.b1, nullptr, 0, ws.mid, I, T, I, H, cfg_.ffn_act, stream, sc),
                       "gemm(fc1)");
             prof_stop(pe, stream);
         }

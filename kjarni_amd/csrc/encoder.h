@@ -78,6 +78,8 @@ struct KernelStat {
 struct Workspace {
     int64_t tokens = 0, sentences = 0;  // capacity of the activation buffers (0 whenever they are not all allocated)
     float *hidden = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *feat = nullptr;
+    float* split = nullptr;  // partial tiles of the mid-size GEMM route (gemm.hip), gemm_scratch_floats() floats
+    size_t split_floats = 0;
     void* stage = nullptr;  // ids / mask / types in, outputs back, for the host-pointer entry points
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;  // this workspace's own stream (host-pointer entry points run on it)

@@ -605,14 +605,15 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Few rows (M <= 128: one sentence to classify, a handful to embed -- BASELINE.json configs[0]).  The tiled kernels
+// Few rows (M <= kFewRowsMax = 64: one sentence to classify, a handful to embed -- BASELINE.json configs[0]).  The tiled kernels
 // above are sized for 10^5 rows; at M = 28 they run N / 128 workgroups that each walk the whole K dimension alone
 // (25-124 us per launch, 3-12 of the 256 CUs busy).  Here a workgroup of 16 waves owns 32 output columns for ALL rows
 // and splits K sixteen ways.  No operand staging: a wave's MFMA fragments come straight from global memory through
 // buffer descriptors (rows >= M read as zeros) -- every weight element is needed by exactly one wave.  Per 32-row
 // tile the sixteen partial tiles meet in LDS (64 KiB) and are summed in wave order, then bias / activation /
 // residual and 128-byte row-segment stores.  An output's arithmetic -- a k-ordered MFMA chain per K slice, then the
-// sixteen partials in order -- does not depend on M, so a row's result is the same in any batch of up to 128 rows.
+// sixteen partials in order -- does not depend on M, so a row's result is the same in any batch of up to 64 rows (the kernel itself takes up to 128;
+// from 65 rows the 64 x 64-tile route below is faster: 0.47 ms against 0.65 ms for a 128-token forward).
 template <int EPI, int MT>
 __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restrict__ A, int64_t lda,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
@@ -774,7 +775,221 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     return hipGetLastError();
 }
 
-// Shapes the few-rows kernel takes: M <= 128, whole 32-column tiles, K divisible by 8 x 16 waves, 16-byte rows.
+// ---- Calls of a few hundred to a few thousand rows (the reference's default batch is 32 sentences) ----------------------
+// The large-batch tiles (128 x 128, and 64 x 384 for the fused LayerNorm) are sized for 10^5 rows: at 4 096 rows the
+// 384-wide GEMMs are 64 workgroups on 256 CUs, each with the whole K-loop serial (FC2 + LN: 150 us of a 320 us layer).
+// Here: 64 x 64 tiles, four waves of one 32 x 32 MFMA tile, BK = 32, LDS double buffer; narrow outputs with a long K
+// (N <= 1024, K >= 1024) cut K into 4 slices.  Sliced launches, and every LayerNorm one, leave partial tiles in a scratch
+// slab per slice; mid_reduce_* adds the slabs in slice order and applies the epilogue (bias, activation, residual,
+// LayerNorm with a wave per row).  The slice count depends on (N, K) only, so a row's arithmetic does not depend on how
+// many rows the call has.
+constexpr int MID_BM = 64, MID_BN = 64, MID_BK = 32, MID_STRIDE = MID_BK + 4;
+
+inline int mid_ksplit(int N, int K) { return (N <= 1024 && K >= 1024 && K % (4 * MID_BK) == 0) ? 4 : 1; }
+
+template <int EPI, bool PARTIAL>
+__global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
+                                                       int64_t ldy, int M, int N, int K, int m_tiles, int ksplit,
+                                                       float* __restrict__ P)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2][MID_BM * MID_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sB[2][MID_BN * MID_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    // XCD-aware order (workgroups are dealt round-robin over the 8 XCDs): every XCD gets one contiguous run of
+    // (tile, slice) pairs, row tiles fastest, so the tiles sharing a weight panel sit behind the same L2.
+    const int64_t nwg = gridDim.x;
+    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int64_t q8 = nwg / 8, r8 = nwg % 8;
+    const int64_t bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int ks = (int)(bid0 % ksplit);
+    const int64_t bid = bid0 / ksplit;
+    const int m0 = (int)(bid % m_tiles) * MID_BM;
+    const int n0 = (int)(bid / m_tiles) * MID_BN;
+    const int k_len = K / ksplit, k_begin = ks * k_len;
+
+    // A and W tiles: 64 x 32 floats = 512 float4 each, two per thread (rows past the end repeat the last one)
+    const int t_row = tid >> 3, t_c4 = tid & 7;
+    const float *a_ptr[2], *b_ptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_ptr[i] = A + (int64_t)min(m0 + t_row + 32 * i, M - 1) * lda + t_c4 * 4 + k_begin;
+        b_ptr[i] = W + (int64_t)min(n0 + t_row + 32 * i, N - 1) * K + t_c4 * 4 + k_begin;
+    }
+    f32x4 ga[2], gb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ga[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
+            gb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
+        }
+    };
+    auto store = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&sA[stage][(t_row + 32 * i) * MID_STRIDE + t_c4 * 4]) = ga[i];
+            *reinterpret_cast<f32x4*>(&sB[stage][(t_row + 32 * i) * MID_STRIDE + t_c4 * 4]) = gb[i];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nk = k_len / MID_BK;
+    const int fa = (wr * 32 + l31) * MID_STRIDE + half * 4, fb = (wc * 32 + l31) * MID_STRIDE + half * 4;
+    // (a second K-step of global loads in flight measured no faster at 4 096 rows and 7 % slower at 1 024)
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load((kt + 1) * MID_BK);
+#pragma unroll
+        for (int kk = 0; kk < MID_BK / 8; ++kk) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[cur][fa + kk * 8]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&sB[cur][fb + kk * 8]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) store(cur ^ 1);
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col >= N) return;
+    if (PARTIAL) {
+        float* out = P + (int64_t)ks * M * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + acc_row(r, half);
+            if (row < M) out[(int64_t)row * N + col] = acc[r];
+        }
+        return;
+    }
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 32 + acc_row(r, half);
+        if (row < M) {
+            float v = acc[r] + bv;
+            if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * ldr + col];
+            else if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)row * ldr + col]);
+            else v = epilogue<EPI>(v);
+            Y[(int64_t)row * ldy + col] = v;
+        }
+    }
+}
+
+// Y = epilogue(sum of the K-slice slabs, in slice order): four columns per thread.
+template <int EPI>
+__global__ __launch_bounds__(256) void mid_reduce_kernel(const float* __restrict__ P, int ksplit, const float* __restrict__ bias,
+                                                         const float* R, int64_t ldr, float* Y, int64_t ldy, int M, int N)
+{
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4, slab = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n4;
+        const int col = (int)(i - row * n4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(P + row * N + col);
+        for (int s = 1; s < ksplit; ++s) v += *reinterpret_cast<const f32x4*>(P + s * slab + row * N + col);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            v += *reinterpret_cast<const f32x4*>(R + row * ldr + col);
+        } else if (EPI == EPI_BIAS_MUL_SILU) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(R + row * ldr + col);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= silu_ref(g[c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
+        }
+        *reinterpret_cast<f32x4*>(Y + row * ldy + col) = v;
+    }
+}
+
+// Y = LayerNorm(sum of the slabs + bias + R) * gamma + beta, one wave per row (N <= 256 * NCH): two-pass statistics as
+// normalization/layer_norm.rs (mean, then the mean of squared deviations), R == Y allowed.
+template <int NCH>
+__global__ __launch_bounds__(256) void mid_reduce_ln_kernel(const float* __restrict__ P, int ksplit, const float* __restrict__ bias,
+                                                            const float* R, int64_t ldr, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float* Y, int64_t ldy,
+                                                            int M, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t slab = (int64_t)M * N;
+    f32x4 v[NCH];
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < N) {
+            v[c] = *reinterpret_cast<const f32x4*>(P + row * N + col);
+            for (int k = 1; k < ksplit; ++k) v[c] += *reinterpret_cast<const f32x4*>(P + k * slab + row * N + col);
+            if (bias) v[c] += *reinterpret_cast<const f32x4*>(bias + col);
+            v[c] += *reinterpret_cast<const f32x4*>(R + row * ldr + col);
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c * 256 + lane * 4 < N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[c][e] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < N) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col), b = *reinterpret_cast<const f32x4*>(beta + col);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+            *reinterpret_cast<f32x4*>(Y + row * ldy + col) = o;
+        }
+    }
+}
+
+constexpr int64_t kFewRowsMax = 64, kMidMaxRows = 4096;
+
+inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
+                         const float* bias, const float* R)
+{
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return M > kFewRowsMax && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
+           al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && g_gemm_variant != 7;
+}
+
+template <int EPI>
+hipError_t launch_mid(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                      int64_t ldy, int M, int N, int K, hipStream_t stream, const GemmScratch& scratch)
+{
+    const int m_tiles = (M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
+    int ksplit = mid_ksplit(N, K);
+    if (ksplit > 1 && (size_t)ksplit * M * N > scratch.floats) ksplit = 1;
+    const dim3 grid((unsigned)(m_tiles * n_tiles * ksplit));
+    if (ksplit == 1) {
+        hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, false>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, 1,
+                           nullptr);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, true>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, ksplit,
+                       scratch.p);
+    const int64_t total = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL(mid_reduce_kernel<EPI>, dim3((unsigned)std::min<int64_t>(2048, (total + 255) / 256)), dim3(256), 0, stream, scratch.p,
+                       ksplit, bias, R, ldr, Y, ldy, M, N);
+    return hipGetLastError();
+}
+
+// Shapes the few-rows kernel takes: M <= 128 (64 when the caller lends the mid-size route its scratch), whole 32-column tiles, K divisible by 8 x 16 waves, 16-byte rows.
 inline bool aligned6(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W,
                      const float* Y, const float* bias, const float* R)
 {
@@ -791,7 +1006,7 @@ inline bool aligned6(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t 
 template <int EPI>
 hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
                       int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K,
-                      hipStream_t stream)
+                      hipStream_t stream, const GemmScratch& scratch)
 {
     // (a tile's rows are addressed through 32-bit buffer offsets: 128 rows of A must span less than 2 GiB)
     const bool aligned = (N % BN == 0) && (K % 32 == 0) && (lda % 4 == 0) && (ldy % 4 == 0) &&
@@ -802,8 +1017,12 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
                          (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (R == nullptr || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(R) & 15) == 0));
     // few rows: K split over the waves of a workgroup instead of a serial K-loop in N / 128 workgroups
-    if (aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && g_gemm_variant != 6)
+    const bool mid = scratch.p && mid_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R);
+    if (aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && g_gemm_variant != 6 && !mid)
         return launch_skinny<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream);
+    // a few hundred to a few thousand rows (and a caller that lends a scratch slab): quarter-size tiles, K slices
+    if (mid)
+        return launch_mid<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream, scratch);
     if (aligned) {
 #ifdef KJARNI_TUNING
         switch (g_gemm_variant) {
@@ -826,6 +1045,17 @@ void set_gemm_variant(int variant) { g_gemm_variant = variant; }
 int gemm_variant() { return g_gemm_variant; }
 #endif
 
+bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
+{
+    return M > kFewRowsMax && M <= kMidMaxRows && N <= 1024 && N % 4 == 0 && K % MID_BK == 0 && g_gemm_variant != 7;
+}
+
+size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n)
+{
+    // 4 K-slice slabs of the narrow (N <= 1024) outputs, for calls of up to kMidMaxRows rows
+    return (size_t)4 * (size_t)std::min<int64_t>(max_rows, kMidMaxRows) * (size_t)std::min(max_narrow_n, 1024);
+}
+
 bool gemm_residual_layernorm_supported(int N, int K)
 {
 #ifdef KJARNI_TUNING
@@ -836,10 +1066,28 @@ bool gemm_residual_layernorm_supported(int N, int K)
 
 hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
                                           const float* R, int64_t ldr, const float* gamma, const float* beta, float eps,
-                                          float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
+                                          float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream, GemmScratch scratch)
 {
     if (M <= 0) return hipSuccess;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (scratch.p && R && gamma && beta && N <= 1024 && al16(gamma) && al16(beta) && mid_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R)) {
+        const int ksplit = mid_ksplit(N, K);
+        if ((size_t)ksplit * M * N <= scratch.floats) {
+            const int m_tiles = ((int)M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
+            hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)(m_tiles * n_tiles * ksplit)), dim3(256), 0, stream, A, lda,
+                               W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p);
+            const dim3 rgrid((unsigned)((M + 3) / 4));
+#define KJ_MID_LN(NCH)                                                                                                              \
+    hipLaunchKernelGGL(mid_reduce_ln_kernel<NCH>, rgrid, dim3(256), 0, stream, scratch.p, ksplit, bias, R, ldr, gamma, beta, eps, Y, \
+                       ldy, (int)M, N)
+            if (N <= 256) KJ_MID_LN(1);
+            else if (N <= 512) KJ_MID_LN(2);
+            else if (N <= 768) KJ_MID_LN(3);
+            else KJ_MID_LN(4);
+#undef KJ_MID_LN
+            return hipGetLastError();
+        }
+    }
     if (!gemm_residual_layernorm_supported(N, K) || !R || !gamma || !beta || lda % 4 || ldr % 4 || ldy % 4 ||
         (int64_t)64 * lda * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31 ||
         !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y))
@@ -850,21 +1098,21 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
 
 hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
                        int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi,
-                       hipStream_t stream)
+                       hipStream_t stream, GemmScratch scratch)
 {
     if (M <= 0 || N <= 0 || K <= 0) return hipSuccess;
     switch (epi) {
-    case EPI_BIAS: return launch_epi<EPI_BIAS>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS: return launch_epi<EPI_BIAS>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
     case EPI_BIAS_GELU:
 #ifdef KJARNI_TUNING
-        if (g_gemm_variant == 3) return launch_epi<EPI_GELU_LIBM>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        if (g_gemm_variant == 3) return launch_epi<EPI_GELU_LIBM>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
 #endif
-        return launch_epi<EPI_BIAS_GELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-    case EPI_BIAS_GELU_NEW: return launch_epi<EPI_BIAS_GELU_NEW>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-    case EPI_BIAS_RELU: return launch_epi<EPI_BIAS_RELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-    case EPI_BIAS_TANH: return launch_epi<EPI_BIAS_TANH>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-    case EPI_BIAS_RESIDUAL: return launch_epi<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-    case EPI_BIAS_MUL_SILU: return launch_epi<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        return launch_epi<EPI_BIAS_GELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
+    case EPI_BIAS_GELU_NEW: return launch_epi<EPI_BIAS_GELU_NEW>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
+    case EPI_BIAS_RELU: return launch_epi<EPI_BIAS_RELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
+    case EPI_BIAS_TANH: return launch_epi<EPI_BIAS_TANH>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
+    case EPI_BIAS_RESIDUAL: return launch_epi<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
+    case EPI_BIAS_MUL_SILU: return launch_epi<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
     }
     return hipErrorInvalidValue;
 }

@@ -235,7 +235,21 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
             if (cnt == 0.0f) {
                 if (g == 0) a = *reinterpret_cast<const f32x4*>(base + c4 * 4);  // pooling/mod.rs:25-27: token 0
             } else {
-                for (int s = g; s < seq; s += groups) {
+                // eight rows requested before the first is added (the adds keep their order): a lone sentence is a chain
+                // of memory round trips otherwise (31 us for 128 tokens)
+                int s = g;
+                for (; s + 7 * groups < seq; s += 8 * groups) {
+                    f32x4 v[8];
+                    float mv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = *reinterpret_cast<const f32x4*>(base + (int64_t)(s + j * groups) * hidden + c4 * 4);
+                        mv[j] = mrow ? (float)mrow[s + j * groups] : 1.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a += v[j] * mv[j];
+                }
+                for (; s < seq; s += groups) {
                     const float mv = mrow ? (float)mrow[s] : 1.0f;
                     a += *reinterpret_cast<const f32x4*>(base + (int64_t)s * hidden + c4 * 4) * mv;
                 }

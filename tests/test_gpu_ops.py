@@ -14,9 +14,11 @@ def _silu(x):
 
 
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (127, 384, 1152), (128, 384, 1536), (300, 1536, 384),
-                                   (1000, 768, 768), (77, 100, 7), (5, 17, 4), (257, 64, 128), (130, 32, 128)])
+                                   (1000, 768, 768), (77, 100, 7), (5, 17, 4), (257, 64, 128), (130, 32, 128),
+                                   (4096, 384, 1536), (4097, 384, 384), (4200, 1536, 384), (2000, 3072, 768)])
 def test_linear_all_epilogues(m, k, n):
-    # LinearLayer::matmul shapes incl. decode (m=1), odd dims (cpu/ops/tests.rs:78-116) and M tails
+    # LinearLayer::matmul shapes incl. decode (m=1), odd dims (cpu/ops/tests.rs:78-116) and M tails; the three routes:
+    # up to 64 rows (K over the waves), 65 .. 4096 rows (64 x 64 tiles, K slices for narrow outputs), more (128 x 128)
     from kjarni_amd import ops
     rng = np.random.default_rng(m * 7 + n)
     x = rng.standard_normal((m, k)).astype(np.float32)
@@ -43,7 +45,8 @@ def test_linear_all_epilogues(m, k, n):
 
 
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (63, 384, 384), (64, 1536, 384), (65, 384, 384), (300, 1536, 384),
-                                   (1000, 16, 384), (129, 256, 256), (200, 1024, 256), (77, 768, 768), (40, 100, 60)])
+                                   (1000, 16, 384), (129, 256, 256), (200, 1024, 256), (77, 768, 768), (40, 100, 60),
+                                   (1000, 3072, 768), (4096, 1536, 384), (4097, 1536, 384), (4300, 384, 384), (700, 4096, 1024)])
 @pytest.mark.parametrize("eps", [1e-12, 1e-5])
 def test_residual_projection_with_fused_layernorm(m, k, n, eps):
     """out-proj / FC2 + residual + LayerNorm of the post-norm layer (encoder_layer.rs:129-147, 155-176) as ONE kernel
@@ -68,23 +71,48 @@ def test_residual_projection_with_fused_layernorm(m, k, n, eps):
 
 @pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (768, 3072), (1024, 32)])
 def test_few_rows_results_do_not_depend_on_the_batch(k, n):
-    """Up to 128 rows the projections run the split-K kernel; a row's result must be bit-identical whatever other rows
-    share the call (1, 32, 33, 64, 100, 128 rows: one to four 32-row tiles), and oracle-equal."""
+    """Up to 64 rows the projections run the split-K kernel; a row's result must be bit-identical whatever other rows
+    share the call (1, 32, 33, 50, 64 rows: one or two 32-row tiles), and oracle-equal."""
     from kjarni_amd import ops
     rng = np.random.default_rng(k + n)
-    x = rng.standard_normal((128, k)).astype(np.float32)
+    x = rng.standard_normal((64, k)).astype(np.float32)
     w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
     b = rng.standard_normal(n).astype(np.float32)
-    r = rng.standard_normal((128, n)).astype(np.float32)
+    r = rng.standard_normal((64, n)).astype(np.float32)
     full, _ = ops.linear(x, w, b, r, ops.EPI_BIAS_RESIDUAL)
     ref = O.linear(x, w, b) + r
     assert float(np.abs(full - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
-    for m in (1, 32, 33, 64, 100):
+    for m in (1, 32, 33, 50):
         part, _ = ops.linear(x[:m], w, b, r[:m], ops.EPI_BIAS_RESIDUAL)
         assert np.array_equal(part, full[:m]), m
     gelu, _ = ops.linear(x[:7], w, b, None, ops.EPI_BIAS_GELU)
     assert float(np.abs(gelu - np.vectorize(O.gelu, otypes=[np.float32])(O.linear(x[:7], w, b))).max()) < 1e-5 * max(
         1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (384, 1152), (3072, 768)])
+def test_mid_size_results_do_not_depend_on_the_batch(k, n):
+    """65 .. 4096 rows take 64 x 64 tiles with a K-slice count that depends on (N, K) only: a row's result is
+    bit-identical whatever other rows share the call (also with the fused LayerNorm), and oracle-equal."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(k * 3 + n)
+    M = 1300
+    x = rng.standard_normal((M, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((M, n)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    full, _ = ops.linear(x, w, b, r, ops.EPI_BIAS_RESIDUAL)
+    ref = O.linear(x, w, b) + r
+    assert float(np.abs(full - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+    full_ln, _ = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12)
+    for m in (65, 129, 640, 1299):
+        part, _ = ops.linear(x[:m], w, b, r[:m], ops.EPI_BIAS_RESIDUAL)
+        assert np.array_equal(part, full[:m]), m
+        if n <= 1024:
+            part_ln, _ = ops.linear_layer_norm(x[:m], w, b, r[:m], g, beta, 1e-12)
+            assert np.array_equal(part_ln, full_ln[:m]), m
 
 
 def test_fused_layernorm_constant_rows():

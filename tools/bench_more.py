@@ -171,6 +171,27 @@ def main():
                   "config": {"workload": "65 536 sentences x 128 through kjarni_hip_encoder_embed_host (pageable host memory)"}})
         del enc
 
+    if "sweep" in which:
+        # Calls of the sizes real callers make (the reference's default batch is 32, kjarni-ffi/src/embedder.rs): host
+        # pointers in and out, one call at a time, sentences/s against the call size and the padded length.
+        enc = kjarni_amd.HipEncoder(emb_dir, 0)
+        rows = []
+        for seq in (32, 128):
+            for b in (1, 2, 4, 8, 16, 32, 64, 128, 256, 1024, 4096):
+                ids, mask = synth.synthetic_ids(b, seq, seed=1)
+                reps = max(3, min(200, 4096 // b))
+                enc.embed(ids, mask)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    enc.embed(ids, mask)
+                dt = (time.perf_counter() - t0) / reps
+                rows.append({"batch": b, "seq": seq, "ms_per_call": round(dt * 1e3, 4), "sentences_per_s": round(b / dt, 1),
+                             "frac_fp32_mfma_peak": round(b * flops_per_row(seq=seq) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
+        emit({"metric": "sentences/sec minilm-l6-v2 embed against the call size (host pointers, one call at a time)",
+              "unit": "sentences/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic", "value": rows[-1]["sentences_per_s"],
+              "config": {"workload": "kjarni_hip_encoder_embed_host, batch 1 .. 4096 x seq 32 / 128"}, "calls": rows})
+        del enc
+
     if "scan" in which:
         dim, k = 384, 10
         for n in (100_000, 1_000_000, 10_000_000):

@@ -1,0 +1,26 @@
+"""Encoder calls of a given size in a loop (for rocprofv3): python tools/mid_probe.py [batch] [seq] [reps]."""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402  (before the HIP library: it brings its own runtime)
+from tests import synth  # noqa: E402
+import kjarni_amd  # noqa: E402
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+seq = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+with tempfile.TemporaryDirectory() as tmp:
+    d = os.path.join(tmp, "m")
+    synth.minilm_embedder(d, seed=0)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    ids, mask = synth.synthetic_ids(b, seq, seed=1)
+    enc.embed(ids, mask)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        enc.embed(ids, mask)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"batch {b} x {seq}: {dt * 1e3:.3f} ms per call = {b / dt:.0f} sentences/s", flush=True)
