@@ -13,6 +13,9 @@ import kjarni_amd  # noqa: E402
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 seq = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+if os.environ.get("GEMM_VARIANT"):  # tuning build only (KJARNI_FFI_LIB=.../libkjarni_ffi_tuning.so)
+    from kjarni_amd import ops
+    ops.set_gemm_variant(int(os.environ["GEMM_VARIANT"]))
 with tempfile.TemporaryDirectory() as tmp:
     d = os.path.join(tmp, "m")
     synth.minilm_embedder(d, seed=0)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# PMC passes over encoder calls of 32 x 128 tokens (the mid-size GEMM route)
+set -u
+mkdir -p gpurun_out/pmcm
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+run() { name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmcm/$name -- python tools/mid_probe.py 32 128 10 > gpurun_out/pmcm/$name.log 2>&1
+  echo "$name rc=$?"; }
+run a GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA
+run b GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
+run c GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM
+python tools/pmc_summary.py gpurun_out/pmcm | grep -A14 "gemm_nt_f32_mid" | tee gpurun_out/pmcm/summary.txt
+find gpurun_out/pmcm -name "*.csv" -delete
