@@ -202,3 +202,25 @@ def test_full_width_decode_step(tmp_path, store_bf16):
         scale = max(1.0, float(np.abs(ref_h).max()))
         assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, np.abs(h[-k:] - ref_h[-k:]).max()
         assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max()))
+
+
+def test_decode_over_several_key_ranges(tmp_path):
+    """A 2 048-token context gives the decode attention four key ranges per head, merged inside the output projection:
+    steps over 8 keys (three ranges empty), ~130 keys (register-held ranges) and ~700 keys (176 keys per range: the looping
+    path), each against the oracle; the 690-token prompt in between goes through the prompt kernels."""
+    base = dict(synth.LLAMA_TEST, hidden_size=2048, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=8,
+                intermediate_size=8192, vocab_size=1003, max_position_embeddings=2048, head_dim=64)
+    base["rope_scaling"] = dict(base["rope_scaling"], original_max_position_embeddings=512)
+    orc, gpu, cfg = _pair(tmp_path, base, seed=11, bf16_values=True, store_bf16=True)
+    rng = np.random.default_rng(5)
+    cache = orc.new_cache()
+    gpu.reset()
+    for n in (7, 1, 1, 120, 1, 1, 560, 1, 1, 1):
+        ids = rng.integers(4, cfg["vocab_size"], n).tolist()
+        ref_h = orc.forward(ids, cache)[0]
+        h, logits = gpu.forward(ids)
+        k = (n - 1) % 8 + 1
+        ref_l = orc.logits(ref_h[-1])
+        scale = max(1.0, float(np.abs(ref_h).max()))
+        assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
+        assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
