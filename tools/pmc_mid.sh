@@ -8,6 +8,7 @@ run() { name=$1; shift
   echo "$name rc=$?"; }
 run a GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA
 run b GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
-run c GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM
-python tools/pmc_summary.py gpurun_out/pmcm | grep -A14 "gemm_nt_f32_mid" | tee gpurun_out/pmcm/summary.txt
+run c GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_VMEM SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES
+run d GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
+python tools/pmc_summary.py gpurun_out/pmcm | grep -A32 "gemm_nt_f32_mid<0, false>" | tee gpurun_out/pmcm/summary.txt
 find gpurun_out/pmcm -name "*.csv" -delete
