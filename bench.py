@@ -27,6 +27,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   value_host_ptrs / value_ragged  (N = 1, embed) the same workload through host pointers
                 (H2D of ids/mask + D2H of the embeddings inside the timed region) and with
                 ragged lengths U{16..128}.
+  value_by_call_size  (N = 1, embed) one host-pointer call at a time of 1 / 32 / 256 sentences.
 """
 import argparse
 import json
@@ -353,8 +354,21 @@ def main():
             enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), n_local, S, out.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         extras["value_ragged"] = round(2 * n_local / (time.perf_counter() - t1), 1)
+        # the sizes callers make: one call at a time of 1 / 32 / 256 sentences through host pointers (the reference's default
+        # batch is 32, crates/kjarni-ffi/src/embedder.rs); 1 and 32 take the few-rows / mid-size GEMM routes
+        by_call = {}
+        for b in (1, 32, 256):
+            reps = max(8, 2048 // b)
+            enc.embed(ids_np[:b], mask_np[:b])
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                enc.embed(ids_np[:b], mask_np[:b])
+            dtc = (time.perf_counter() - t1) / reps
+            by_call[str(b)] = {"ms_per_call": round(dtc * 1e3, 4), "sentences_per_s": round(b / dtc, 1)}
+        extras["value_by_call_size"] = by_call
         extras["extras_note"] = ("value_host_ptrs: ids/mask handed over as host buffers, embeddings returned to the "
-                                 "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128; 2 steps each")
+                                 "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128; 2 steps each; "
+                                 "value_by_call_size: one host-pointer call at a time of 1 / 32 / 256 sentences x 128 tokens")
 
     if rank == 0:
         total = n_total * args.steps
