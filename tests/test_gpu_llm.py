@@ -182,8 +182,8 @@ def test_production_head_sizes_prefill_and_decode(tmp_path, name):
 
 @pytest.mark.parametrize("store_bf16", [True, False], ids=["bf16-weights", "f32-weights"])
 def test_full_width_decode_step(tmp_path, store_bf16):
-    """The production widths of the decode step (hidden 2048, inner 8192: the Llama-3.2-1B row lengths, one layer, small
-    vocabulary): single-token steps go through the weight-streaming GEMV (K = 2048 and 8192, SwiGLU pair, residual,
+    """The production widths of the decode step (hidden 2048, inner 8192: the Llama-3.2-1B row lengths, one layer, a
+    vocabulary of 20 011 rows so that the head takes its looping form): single-token steps go through the weight-streaming GEMV (K = 2048 and 8192, SwiGLU pair, residual,
     RMSNorm folded in, the attention slabs merged by the output projection, the final norm by the vocabulary head), prompt
     blocks through the matrix-core route; both against the oracle."""
     base = dict(synth.LLAMA_TEST, hidden_size=2048, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=8,
