@@ -775,7 +775,7 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     return hipGetLastError();
 }
 
-// ---- Calls of a few hundred to a few thousand rows (the reference's default batch is 32 sentences) ----------------------
+// ---- Calls of 65 .. 8192 rows (the reference's default batch is 32 sentences) --------------------------------------------
 // The large-batch tiles (128 x 128, and 64 x 384 for the fused LayerNorm) are sized for 10^5 rows: at 4 096 rows the
 // 384-wide GEMMs are 64 workgroups on 256 CUs, each with the whole K-loop serial (FC2 + LN: 150 us of a 320 us layer).
 // Here: 64 x 64 tiles, four waves of one 32 x 32 MFMA tile, BK = 32, LDS double buffer; narrow outputs with a long K
@@ -791,35 +791,42 @@ template <int EPI, bool PARTIAL>
 __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                        const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
                                                        int64_t ldy, int M, int N, int K, int m_tiles, int ksplit,
-                                                       float* __restrict__ P, int n_tiles, int row_major_tiles)
+                                                       float* __restrict__ P, int n_tiles, int total)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][MID_BM * MID_STRIDE];
     __shared__ __attribute__((aligned(16))) float sB[2][MID_BN * MID_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
-    // XCD-aware order (workgroups are dealt round-robin over the 8 XCDs): every XCD gets one contiguous run of
-    // (tile, slice) pairs, COLUMN tiles fastest: an XCD then works on a block of rows against the whole weight matrix, and
-    // both (a few hundred rows of A, all of W: 1-3 MB) stay in its 4 MB L2.  Row tiles fastest -- right for 10^5 rows, where a
-    // weight panel is shared by thousands of tiles -- makes every XCD stream all of A once per 2-3 column tiles here.
-    const int64_t nwg = gridDim.x;
-    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    const int64_t q8 = nwg / 8, r8 = nwg % 8;
-    const int64_t bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int ks = (int)(bid0 % ksplit);
-    const int64_t bid = bid0 / ksplit;
-    const int m0 = row_major_tiles ? (int)(bid / n_tiles) * MID_BM : (int)(bid % m_tiles) * MID_BM;
-    const int n0 = row_major_tiles ? (int)(bid % n_tiles) * MID_BN : (int)(bid / m_tiles) * MID_BN;
-    const int k_len = K / ksplit, k_begin = ks * k_len;
+    const int t_row = tid >> 3, t_c4 = tid & 7;  // staging: 64 x 32 floats = 512 float4 per operand tile, two per thread
+    const int k_len = K / ksplit, nk = k_len / MID_BK;
+    const int fa = (wr * 32 + l31) * MID_STRIDE + half * 4, fb = (wc * 32 + l31) * MID_STRIDE + half * 4;
 
-    // A and W tiles: 64 x 32 floats = 512 float4 each, two per thread (rows past the end repeat the last one)
-    const int t_row = tid >> 3, t_c4 = tid & 7;
+    // The `total` (tile, K-slice) pairs are walked by the gridDim.x workgroups the chip holds at once: workgroup w takes
+    // pairs w, w + gridDim.x, ... (a finished workgroup's successor would otherwise wait for a dispatch: 10 % at 4 096
+    // rows), and requests the first operand tiles of its next pair before it stores the results of the current one.
+    // Order of the pairs, XCD-aware (workgroups are dealt round-robin over the 8 XCDs; gridDim.x is a multiple of 8 whenever
+    // a workgroup takes more than one pair): every XCD gets one contiguous run, COLUMN tiles fastest -- an XCD then works on
+    // a block of rows against the whole weight matrix, and both (a few hundred rows of A, all of W: 1-3 MB) stay in its
+    // 4 MB L2.
+    const int64_t q8 = total / 8, r8 = total % 8;
+    struct Pair {
+        int m0, n0, ks;
+    };
+    auto pair_of = [&](int64_t w) {
+        const int64_t xcd = w % 8, slot = w / 8;
+        const int64_t bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        const int64_t bid = bid0 / ksplit;
+        return Pair{(int)(bid / n_tiles) * MID_BM, (int)(bid % n_tiles) * MID_BN, (int)(bid0 % ksplit)};
+    };
     const float *a_ptr[2], *b_ptr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_ptr[i] = A + (int64_t)min(m0 + t_row + 32 * i, M - 1) * lda + t_c4 * 4 + k_begin;
-        b_ptr[i] = W + (int64_t)min(n0 + t_row + 32 * i, N - 1) * K + t_c4 * 4 + k_begin;
-    }
     f32x4 ga[2], gb[2];
+    auto point_at = [&](const Pair& p) {  // (rows past the end repeat the last one)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_ptr[i] = A + (int64_t)min(p.m0 + t_row + 32 * i, M - 1) * lda + t_c4 * 4 + p.ks * k_len;
+            b_ptr[i] = W + (int64_t)min(p.n0 + t_row + 32 * i, N - 1) * K + t_c4 * 4 + p.ks * k_len;
+        }
+    };
     auto load = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -834,49 +841,59 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__
             *reinterpret_cast<f32x4*>(&sB[stage][(t_row + 32 * i) * MID_STRIDE + t_c4 * 4]) = gb[i];
         }
     };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int nk = k_len / MID_BK;
-    const int fa = (wr * 32 + l31) * MID_STRIDE + half * 4, fb = (wc * 32 + l31) * MID_STRIDE + half * 4;
-    // (a second K-step of global loads in flight measured no faster at 4 096 rows and 7 % slower at 1 024)
+
+    Pair cur_pair = pair_of(blockIdx.x);
+    point_at(cur_pair);
     load(0);
-    store(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load((kt + 1) * MID_BK);
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        f32x16 acc;
 #pragma unroll
-        for (int kk = 0; kk < MID_BK / 8; ++kk) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[cur][fa + kk * 8]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&sB[cur][fb + kk * 8]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
-        }
-        if (kt + 1 < nk) store(cur ^ 1);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        store(0);
         __syncthreads();
-    }
-    const int col = n0 + wc * 32 + l31;
-    if (col >= N) return;
-    if (PARTIAL) {
-        float* out = P + (int64_t)ks * M * N;
+        // (a second K-step of global loads in flight measured no faster at 4 096 rows and 7 % slower at 1 024)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load((kt + 1) * MID_BK);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 32 + acc_row(r, half);
-            if (row < M) out[(int64_t)row * N + col] = acc[r];
+            for (int kk = 0; kk < MID_BK / 8; ++kk) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[cur][fa + kk * 8]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&sB[cur][fb + kk * 8]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
+            }
+            if (kt + 1 < nk) store(cur ^ 1);
+            __syncthreads();
         }
-        return;
-    }
-    const float bv = bias ? bias[col] : 0.0f;
+        const Pair done = cur_pair;
+        if (w + gridDim.x < total) {
+            cur_pair = pair_of(w + gridDim.x);
+            point_at(cur_pair);
+            load(0);
+        }
+        const int col = done.n0 + wc * 32 + l31;
+        if (col < N) {
+            if (PARTIAL) {
+                float* out = P + (int64_t)done.ks * M * N;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 32 + acc_row(r, half);
-        if (row < M) {
-            float v = acc[r] + bv;
-            if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * ldr + col];
-            else if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)row * ldr + col]);
-            else v = epilogue<EPI>(v);
-            Y[(int64_t)row * ldy + col] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = done.m0 + wr * 32 + acc_row(r, half);
+                    if (row < M) out[(int64_t)row * N + col] = acc[r];
+                }
+            } else {
+                const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = done.m0 + wr * 32 + acc_row(r, half);
+                    if (row < M) {
+                        float v = acc[r] + bv;
+                        if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * ldr + col];
+                        else if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)row * ldr + col]);
+                        else v = epilogue<EPI>(v);
+                        Y[(int64_t)row * ldy + col] = v;
+                    }
+                }
+            }
         }
     }
 }
@@ -960,7 +977,8 @@ __global__ __launch_bounds__(256) void mid_reduce_ln_kernel(const float* __restr
     }
 }
 
-constexpr int64_t kFewRowsMax = 64, kMidMaxRows = 4096;
+constexpr int64_t kFewRowsMax = 64, kMidMaxRows = 8192;
+constexpr int kMidResident = 256 * 4;  // workgroups of gemm_nt_f32_mid the chip holds at once (36 KiB of LDS each)
 
 inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
                          const float* bias, const float* R)
@@ -977,16 +995,17 @@ hipError_t launch_mid(const float* A, int64_t lda, const float* W, const float* 
     const int m_tiles = (M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
     int ksplit = mid_ksplit(N, K);
     if (ksplit > 1 && (size_t)ksplit * M * N > scratch.floats) ksplit = 1;
-    const dim3 grid((unsigned)(m_tiles * n_tiles * ksplit));
+    const int total = m_tiles * n_tiles * ksplit;
+    const dim3 grid((unsigned)std::min(total, g_gemm_variant == 5 ? total : kMidResident));
     if (ksplit == 1) {
         hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, false>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, 1,
-                           nullptr, n_tiles, g_gemm_variant != 5);
+                           nullptr, n_tiles, total);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, true>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, ksplit,
-                       scratch.p, n_tiles, g_gemm_variant != 5);
-    const int64_t total = (int64_t)M * (N / 4);
-    hipLaunchKernelGGL(mid_reduce_kernel<EPI>, dim3((unsigned)std::min<int64_t>(2048, (total + 255) / 256)), dim3(256), 0, stream, scratch.p,
+                       scratch.p, n_tiles, total);
+    const int64_t quads = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL(mid_reduce_kernel<EPI>, dim3((unsigned)std::min<int64_t>(2048, (quads + 255) / 256)), dim3(256), 0, stream, scratch.p,
                        ksplit, bias, R, ldr, Y, ldy, M, N);
     return hipGetLastError();
 }
@@ -1076,8 +1095,9 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         const int ksplit = mid_ksplit(N, K);
         if ((size_t)ksplit * M * N <= scratch.floats) {
             const int m_tiles = ((int)M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
-            hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)(m_tiles * n_tiles * ksplit)), dim3(256), 0, stream, A, lda,
-                               W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p, n_tiles, g_gemm_variant != 5);
+            const int total = m_tiles * n_tiles * ksplit;
+            hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)std::min(total, g_gemm_variant == 5 ? total : kMidResident)),
+                               dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p, n_tiles, total);
             const dim3 rgrid((unsigned)((M + 3) / 4));
 #define KJ_MID_LN(NCH)                                                                                                              \
     hipLaunchKernelGGL(mid_reduce_ln_kernel<NCH>, rgrid, dim3(256), 0, stream, scratch.p, ksplit, bias, R, ldr, gamma, beta, eps, Y, \

@@ -15,10 +15,10 @@ def _silu(x):
 
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (127, 384, 1152), (128, 384, 1536), (300, 1536, 384),
                                    (1000, 768, 768), (77, 100, 7), (5, 17, 4), (257, 64, 128), (130, 32, 128),
-                                   (4096, 384, 1536), (4097, 384, 384), (4200, 1536, 384), (2000, 3072, 768)])
+                                   (4096, 384, 1536), (8192, 384, 384), (8193, 384, 384), (8300, 1536, 384), (2000, 3072, 768)])
 def test_linear_all_epilogues(m, k, n):
     # LinearLayer::matmul shapes incl. decode (m=1), odd dims (cpu/ops/tests.rs:78-116) and M tails; the three routes:
-    # up to 64 rows (K over the waves), 65 .. 4096 rows (64 x 64 tiles, K slices for narrow outputs), more (128 x 128)
+    # up to 64 rows (K over the waves), 65 .. 8192 rows (64 x 64 tiles, K slices for narrow outputs), more (128 x 128)
     from kjarni_amd import ops
     rng = np.random.default_rng(m * 7 + n)
     x = rng.standard_normal((m, k)).astype(np.float32)
@@ -46,7 +46,7 @@ def test_linear_all_epilogues(m, k, n):
 
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (63, 384, 384), (64, 1536, 384), (65, 384, 384), (300, 1536, 384),
                                    (1000, 16, 384), (129, 256, 256), (200, 1024, 256), (77, 768, 768), (40, 100, 60),
-                                   (1000, 3072, 768), (4096, 1536, 384), (4097, 1536, 384), (4300, 384, 384), (700, 4096, 1024)])
+                                   (1000, 3072, 768), (8192, 1536, 384), (8193, 1536, 384), (8400, 384, 384), (700, 4096, 1024)])
 @pytest.mark.parametrize("eps", [1e-12, 1e-5])
 def test_residual_projection_with_fused_layernorm(m, k, n, eps):
     """out-proj / FC2 + residual + LayerNorm of the post-norm layer (encoder_layer.rs:129-147, 155-176) as ONE kernel
@@ -92,7 +92,7 @@ def test_few_rows_results_do_not_depend_on_the_batch(k, n):
 
 @pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (384, 1152), (3072, 768)])
 def test_mid_size_results_do_not_depend_on_the_batch(k, n):
-    """65 .. 4096 rows take 64 x 64 tiles with a K-slice count that depends on (N, K) only: a row's result is
+    """65 .. 8192 rows take 64 x 64 tiles with a K-slice count that depends on (N, K) only: a row's result is
     bit-identical whatever other rows share the call (also with the fused LayerNorm), and oracle-equal."""
     from kjarni_amd import ops
     rng = np.random.default_rng(k * 3 + n)
