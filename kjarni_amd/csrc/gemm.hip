@@ -127,7 +127,7 @@ __device__ __forceinline__ void mfma16(f32x16 (&acc)[2][2], const Frag& f)
 template <int EPI, int BKT, int DIAG>
 __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mfma(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
-    const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int n_tiles)
+    const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int n_tiles, int64_t total_tiles)
 // R and Y are NOT __restrict__: the encoder's residual GEMMs run in place (R == Y, encoder.cpp); every
 // element is read by the one lane that later stores it, and all of a round's residual loads precede its stores.
 {
@@ -144,10 +144,13 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     const int l31 = lane & 31, half = lane >> 5;
 
     // Workgroups are dealt round-robin over the 8 XCDs (private L2 each).  Remap so that every
-    // XCD walks one contiguous run of tiles (N fastest).  Bijective for any grid size.
-    const int64_t nwg = gridDim.x;
-    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    // XCD walks one contiguous run of tiles (N fastest).  Bijective for any tile count.
+    // The grid is the workgroups the chip holds at once; workgroup w takes tiles w, w + gridDim.x, ... (gridDim.x is a
+    // multiple of 8 whenever it is smaller than the tile count): a finished workgroup's successor does not wait for a dispatch.
+    const int64_t nwg = total_tiles;
     const int64_t q8 = nwg / 8, r8 = nwg % 8;
+    for (int64_t wg = blockIdx.x; wg < total_tiles; wg += gridDim.x) {
+    const int64_t xcd = wg % 8, slot = wg / 8;
     const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int64_t m0 = (bid / n_tiles) * BM;
     const int n0 = (int)(bid % n_tiles) * BN;
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
         if (sacc == 123456.789f) Y[0] = sacc;
-        return;
+        __syncthreads();
+        continue;
     }
 
     // Epilogue through LDS (wave-private region, LDS operations of one wave execute in order).
@@ -346,6 +350,8 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
             if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
         }
     }
+    __syncthreads();  // the epilogue's LDS staging overlaps the operand tiles of the next tile
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -385,7 +391,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* R, int64_t ldr, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    float* Y, int64_t ldy, int64_t M, int K)
+    float* Y, int64_t ldy, int64_t M, int K, int64_t total_tiles)
 {
     using T = LnTile<NT>;
     constexpr int BM = T::BM, BK = T::BK, STRIDE = T::STRIDE, BN = T::BN;
@@ -396,9 +402,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
     const int wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int64_t nwg = gridDim.x;
-    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    // (persistent over the row tiles, as gemm_nt_f32_mfma)
+    const int64_t nwg = total_tiles;
     const int64_t q8 = nwg / 8, r8 = nwg % 8;
+    for (int64_t wg = blockIdx.x; wg < total_tiles; wg += gridDim.x) {
+    const int64_t xcd = wg % 8, slot = wg / 8;
     const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int64_t m0 = bid * BM;
 
@@ -580,6 +588,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
             }
         }
     }
+    __syncthreads();  // the epilogue tile overlaps the operand tiles of the next row tile
+    }
 }
 
 template <int NT>
@@ -598,9 +608,11 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
         if (e != hipSuccess) return e;
         attr_set[dev & 63] = true;
     }
-    dim3 grid((unsigned)((M + T::BM - 1) / T::BM));
+    const int64_t total = (M + T::BM - 1) / T::BM;
+    // (a grid of the 512 resident workgroups measured +0.6 % on the K = 384 shape and -0.6 % on K = 1536: one workgroup per tile)
+    dim3 grid((unsigned)(g_gemm_variant == 11 ? std::min<int64_t>(total, 256 * 2) : total));
     hipLaunchKernelGGL((gemm_nt_f32_mfma_ln<NT>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias, R, ldr,
-                       gamma, beta, eps, Y, ldy, M, K);
+                       gamma, beta, eps, Y, ldy, M, K, total);
     return hipGetLastError();
 }
 
@@ -769,9 +781,15 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     }
     const int n_tiles = N / BN;
     const int64_t m_tiles = (M + BM - 1) / BM;
-    dim3 grid((unsigned)(m_tiles * n_tiles));
+    const int64_t total = m_tiles * n_tiles;
+    // The kernel walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  With the plain epilogue a grid of the workgroups the
+    // chip holds at once measured +2.2 % (QKV shape: no dispatch between a workgroup's tiles); with the GELU epilogue -1.1 %
+    // (the barrier that ends a tile waits for the slowest wave's epilogue), so those launch one workgroup per tile.
+    const int64_t resident = (int64_t)256 * T::WAVES_PER_SIMD;
+    const bool persistent = EPI == EPI_BIAS && g_gemm_variant != 10;
+    dim3 grid((unsigned)(persistent ? std::min(total, resident) : total));
     hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
-                       R, ldr, Y, ldy, M, N, K, n_tiles);
+                       R, ldr, Y, ldy, M, N, K, n_tiles, total);
     return hipGetLastError();
 }
 

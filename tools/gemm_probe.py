@@ -38,6 +38,30 @@ def prio():
     ops.set_gemm_variant(0)
 
 
+def persist():
+    """Persistent tile loops (default) against one workgroup per tile (tuning variant 10): the four shapes of the headline."""
+    if not ops.has_tuning():
+        return
+    for name, k, n, epi, ln in (("qkv  ", 384, 1152, ops.EPI_BIAS, False), ("fc1  ", 384, 1536, ops.EPI_BIAS_GELU, False),
+                                ("out+ln", 384, 384, None, True), ("fc2+ln", 1536, 384, None, True)):
+        x = rng.standard_normal((M, k), dtype=np.float32)
+        w = (rng.standard_normal((n, k), dtype=np.float32) * 0.05).astype(np.float32)
+        b = rng.standard_normal(n, dtype=np.float32)
+        r = rng.standard_normal((M, n), dtype=np.float32) if ln else None
+        g = np.ones(n, np.float32)
+        fl = 2.0 * M * n * k
+        for _ in range(2):
+            for variant in (10, 0):
+                ops.set_gemm_variant(variant)
+                if ln:
+                    _, ms = ops.linear_layer_norm(x, w, b, r, g, b, 1e-12, iters=iters_for(fl))
+                else:
+                    _, ms = ops.linear(x, w, b, None, epi, iters=iters_for(fl))
+                tf = fl / (ms * 1e-3) / 1e12
+                print(f"gemm {name} {'persistent' if variant == 0 else 'tile per WG'} {ms:8.4f} ms {tf:7.2f} TFLOP/s ({tf / PEAK * 100:5.1f}% peak)", flush=True)
+    ops.set_gemm_variant(0)
+
+
 def attn():
     B, S, heads, d = 1024, 128, 12, 32
     qkv = rng.standard_normal((B, S, 3 * heads * d), dtype=np.float32)
@@ -104,6 +128,8 @@ if __name__ == "__main__":
         attn()
     if "prio" in what:
         prio()
+    if "persist" in what:
+        persist()
     if "fused" in what:
         fused()
     if "sweep" in what:
