@@ -313,7 +313,15 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
     const LlmConfig& c = cfg_;
     const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d, I = c.inter;
     const int wb = bf16_ ? 1 : 0;
-    constexpr int kChunk = 1024;
+    constexpr int kChunk = 2048;
+#ifdef KJARNI_TUNING
+    static const int kTileRows = [] {
+        const char* v = std::getenv("KJARNI_HIP_LLM_TILE_ROWS");  // measurements
+        return v ? std::atoi(v) : 1792;
+    }();
+#else
+    constexpr int kTileRows = 1792;  // rows from which the projections take the encoder's 128 x 128-tile f32 GEMM (measured crossover)
+#endif
     if (!ph_) {
         prefill_cap_ = kChunk;
         const size_t P = (size_t)prefill_cap_;
@@ -325,6 +333,7 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
         pu_ = dalloc(P * I);
         pids_ = reinterpret_cast<uint32_t*>(dalloc(P));
         psplit_ = dalloc(prefill_gemm_scratch_floats(prefill_cap_, std::max(I, H)));
+        if (bf16_) pw32_ = dalloc(std::max((size_t)(H + 2 * kv) * H, (size_t)I * H));
     }
     const size_t wsz = bf16_ ? 2 : 4;
     auto at = [&](const void* w, size_t elems) { return static_cast<const void*>(static_cast<const char*>(w) + elems * wsz); };
@@ -332,15 +341,34 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
         const int m = std::min(prefill_cap_, n - done);
         hip_check(hipMemcpyAsync(pids_, ids_host + done, (size_t)m * 4, hipMemcpyHostToDevice, s), "H2D ids");
         hip_check(launch_llm_embed(pids_, m, H, c.vocab, embed_, wb, ph_, s), "embed");
+        // Y[m, N] = A W^T (+ bias) (+ R), or with `gate`: gate = silu(gate) * (A W^T).  Blocks of >= kTileRows rows run the
+        // encoder's 128 x 128-tile f32 GEMM (gemm.hip), bf16 weights on an f32 copy made just before (100 MB moved per 69 GFLOP
+        // at 2 048 rows).  Measured on the 1B shape: 2 048 rows 46.2 -> 42.6 ms, 1 792 rows 40.4 -> 39.1 ms, 1 536 rows 33.1 -> 36.1 ms
+        // (the 2 048-wide projections are then 192 tiles on 256 CUs): hence kTileRows.
+        const bool tiles = m >= kTileRows && H % 128 == 0 && I % 128 == 0 && kv % 128 == 0 && (!bf16_ || pw32_);
+        auto proj = [&](const float* Ain, int lda, const void* W, const float* bias, const float* R, float* Y, int ldy, int N, int K,
+                        float* gate, const char* what) {
+            if (!tiles) {
+                hip_check(launch_prefill_gemm(Ain, lda, W, wb, bias, R, ldy, Y, ldy, m, N, K, s, psplit_, gate), what);
+                return;
+            }
+            const float* W32 = static_cast<const float*>(W);
+            if (bf16_) {
+                hip_check(launch_widen_bf16(W, pw32_, (size_t)N * K, s), "widen");
+                W32 = pw32_;
+            }
+            if (gate)
+                hip_check(launch_gemm(Ain, lda, W32, bias, gate, ldy, gate, ldy, m, N, K, EPI_BIAS_MUL_SILU, s), what);
+            else
+                hip_check(launch_gemm(Ain, lda, W32, bias, R, ldy, Y, ldy, m, N, K, R ? EPI_BIAS_RESIDUAL : EPI_BIAS, s), what);
+        };
         for (const Layer& L : layers_) {
             float* k_rows = L.k_cache + (size_t)cache_len_ * kv;
             float* v_rows = L.v_cache + (size_t)cache_len_ * kv;
             hip_check(launch_rmsnorm(ph_, L.ln1, c.eps, m, H, pn_, s), "rmsnorm 1");
-            hip_check(launch_prefill_gemm(pn_, H, L.wqkv, wb, L.bqkv, nullptr, 0, pq_, H, m, H, H, s, psplit_), "q proj");
-            hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)H * H), wb, L.bqkv ? L.bqkv + H : nullptr, nullptr, 0, k_rows, kv, m, kv, H, s, psplit_),
-                      "k proj");
-            hip_check(launch_prefill_gemm(pn_, H, at(L.wqkv, (size_t)(H + kv) * H), wb, L.bqkv ? L.bqkv + H + kv : nullptr, nullptr, 0, v_rows, kv, m,
-                                          kv, H, s, psplit_), "v proj");
+            proj(pn_, H, L.wqkv, L.bqkv, nullptr, pq_, H, H, H, nullptr, "q proj");
+            proj(pn_, H, at(L.wqkv, (size_t)H * H), L.bqkv ? L.bqkv + H : nullptr, nullptr, k_rows, kv, kv, H, nullptr, "k proj");
+            proj(pn_, H, at(L.wqkv, (size_t)(H + kv) * H), L.bqkv ? L.bqkv + H + kv : nullptr, nullptr, v_rows, kv, kv, H, nullptr, "v proj");
             hip_check(launch_rope(pq_, H, m, c.heads, d, cos_, sin_, cache_len_, nullptr, 0, s), "rope q");
             hip_check(launch_rope(L.k_cache, kv, m, c.kv_heads, d, cos_, sin_, cache_len_, nullptr, 1, s), "rope k");
             if (prefill_attention_supported(d)) {
@@ -354,11 +382,11 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
                                                       c.heads / c.kv_heads), "attention");
                 }
             }
-            hip_check(launch_prefill_gemm(pctx_, H, L.wo, wb, nullptr, ph_, H, ph_, H, m, H, H, s, psplit_), "o proj");
+            proj(pctx_, H, L.wo, nullptr, ph_, ph_, H, H, H, nullptr, "o proj");
             hip_check(launch_rmsnorm(ph_, L.ln2, c.eps, m, H, pn_, s), "rmsnorm 2");
-            hip_check(launch_prefill_gemm(pn_, H, L.gate, wb, nullptr, nullptr, 0, pg_, I, m, I, H, s, psplit_), "gate");
-            hip_check(launch_prefill_gemm(pn_, H, L.up, wb, nullptr, nullptr, 0, pu_, I, m, I, H, s, psplit_, pg_), "up + swiglu");
-            hip_check(launch_prefill_gemm(pg_, I, L.down, wb, nullptr, ph_, H, ph_, H, m, H, I, s, psplit_), "down proj");
+            proj(pn_, H, L.gate, nullptr, nullptr, pg_, I, I, H, nullptr, "gate");
+            proj(pn_, H, L.up, nullptr, nullptr, pu_, I, I, H, pg_, "up + swiglu");
+            proj(pg_, I, L.down, nullptr, ph_, ph_, H, H, I, nullptr, "down proj");
         }
         cache_len_ += m;
         if (done + m == n) {

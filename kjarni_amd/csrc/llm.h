@@ -107,6 +107,7 @@ private:
     // prefill workspace (allocated on first use)
     float *ph_ = nullptr, *pn_ = nullptr, *pq_ = nullptr, *pctx_ = nullptr, *pg_ = nullptr, *pu_ = nullptr;
     uint32_t* pids_ = nullptr;
+    float* pw32_ = nullptr;    // f32 copy of the weight matrix a long prompt's GEMM is working on (bf16 checkpoints)
     float* psplit_ = nullptr;  // K-slice partial tiles of the prompt GEMMs (short prompts)
     float* host_logits_ = nullptr;  // pinned
     int prefill_cap_ = 0;

@@ -53,6 +53,8 @@ hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int b
                                int64_t ldy, int M, int N, int K, hipStream_t stream, float* split_scratch = nullptr,
                                float* silu_gate = nullptr);  // silu_gate: [M, N] gate activations, overwritten with silu(gate) * (this product)
 size_t prefill_gemm_scratch_floats(int max_rows, int max_n);
+// bf16 -> f32 copy of n values (n % 8 == 0): long prompts run the f32 tile GEMM (gemm.hip) on a widened weight matrix.
+hipError_t launch_widen_bf16(const void* src, float* dst, size_t n, hipStream_t stream);
 
 // Prefill: causal grouped-query attention of `rows` new rows (positions base .. base + rows - 1) over the cache rows
 // 0 .. base + rows - 1; head_dim in {16, 32, 64, 128}.

@@ -1367,6 +1367,27 @@ hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int b
     return hipGetLastError();
 }
 
+namespace {
+// bf16 -> f32, eight values per thread (a long prompt's projections run the encoder's f32 tile GEMM on a widened copy)
+__global__ __launch_bounds__(256) void widen_bf16_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n8)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const F8 w = load8(src, (int64_t)i);
+        *reinterpret_cast<f32x4*>(dst + i * 8) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+        *reinterpret_cast<f32x4*>(dst + i * 8 + 4) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+    }
+}
+}  // namespace
+
+hipError_t launch_widen_bf16(const void* src, float* dst, size_t n, hipStream_t stream)
+{
+    if (n & 7) return hipErrorInvalidValue;
+    const size_t n8 = n >> 3;
+    hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)std::min<size_t>(4096, (n8 + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const uint16_t*>(src), dst, n8);
+    return hipGetLastError();
+}
+
 bool prefill_attention_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
 
 hipError_t launch_prefill_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V, int64_t ldv, int base,

@@ -224,3 +224,26 @@ def test_decode_over_several_key_ranges(tmp_path):
         scale = max(1.0, float(np.abs(ref_h).max()))
         assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
         assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
+
+
+@pytest.mark.parametrize("store_bf16", [True, False], ids=["bf16-weights", "f32-weights"])
+def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
+    """Prompt blocks of >= 1 792 rows run the encoder's 128 x 128-tile GEMM (bf16 weights on a widened copy), shorter ones the
+    64 x 64 kernel; a 1 900-token prompt, a 2 300-token one (a 2 048-row block + a 252-row block) and decode steps on top."""
+    base = dict(synth.LLAMA_TEST, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                intermediate_size=512, vocab_size=777, max_position_embeddings=4096, head_dim=64)
+    base["rope_scaling"] = dict(base["rope_scaling"], original_max_position_embeddings=1024)
+    orc, gpu, cfg = _pair(tmp_path, base, seed=13, bf16_values=True, store_bf16=store_bf16)
+    rng = np.random.default_rng(6)
+    for n_prompt in (1900, 2300):
+        cache = orc.new_cache()
+        gpu.reset()
+        for n in (n_prompt, 1, 1):
+            ids = rng.integers(4, cfg["vocab_size"], n).tolist()
+            ref_h = orc.forward(ids, cache)[0]
+            h, logits = gpu.forward(ids)
+            k = (n - 1) % 8 + 1
+            ref_l = orc.logits(ref_h[-1])
+            scale = max(1.0, float(np.abs(ref_h).max()))
+            assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
+            assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
