@@ -437,6 +437,8 @@ std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int dev
     m->dpos_ = reinterpret_cast<int*>(m->dalloc(4));
     m->dcount_ = reinterpret_cast<int*>(m->dalloc(4));
     m->att_scratch_ = m->dalloc(decode_attention_scratch_floats(8, c.heads, d, std::max(kSelfSplits, kCrossSplits)));
+    m->gemm_scratch_floats_ = gemm_scratch_floats(8192, c.d_model);
+    m->gemm_scratch_ = m->dalloc(m->gemm_scratch_floats_);
     m->dbest_ = reinterpret_cast<unsigned long long*>(m->dalloc(2 * (size_t)kMaxLanes));
     hip_check(hipMemset(m->dbest_, 0, sizeof(unsigned long long) * kMaxLanes), "memset(pick scratch)");
     hip_check(hipStreamCreateWithFlags(&m->stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -479,22 +481,23 @@ void WhisperModel::conv_and_encode(const float* mel_t, int ld_mel, int frames)
     const int H = cfg_.d_model, C = cfg_.num_mel_bins, heads = cfg_.heads, d = H / heads, I = cfg_.encoder_ffn;
     const int T1 = frames, T2 = (frames + 2 - 3) / 2 + 1;
     const int k2 = round_up(3 * H, 32);
+    const GemmScratch sc{gemm_scratch_, gemm_scratch_floats_};  // 1 500 / 3 000 rows: the 64 x 64-tile route of gemm.hip
     if (frames > max_frames_ || frames < 1) throw std::runtime_error("mel has too many frames for the workspace");
     // conv1 (stride 1) + tanh-GELU, conv2 (stride 2) + tanh-GELU: mel.rs:303-311
     hip_check(launch_im2col3(mel_t, ld_mel, frames, C, 1, 1, T1, k_conv1_, cols_, s), "im2col conv1");
-    hip_check(launch_gemm(cols_, k_conv1_, conv1_w_, conv1_b_, nullptr, 0, conv1_out_, H, T1, H, k_conv1_, EPI_BIAS_GELU_NEW, s), "conv1");
+    hip_check(launch_gemm(cols_, k_conv1_, conv1_w_, conv1_b_, nullptr, 0, conv1_out_, H, T1, H, k_conv1_, EPI_BIAS_GELU_NEW, s, sc), "conv1");
     hip_check(launch_im2col3(conv1_out_, H, T1, H, 2, 1, T2, k2, cols_, s), "im2col conv2");
-    hip_check(launch_gemm(cols_, k2, conv2_w_, conv2_b_, nullptr, 0, hidden_, H, T2, H, k2, EPI_BIAS_GELU_NEW, s), "conv2");
+    hip_check(launch_gemm(cols_, k2, conv2_w_, conv2_b_, nullptr, 0, hidden_, H, T2, H, k2, EPI_BIAS_GELU_NEW, s, sc), "conv2");
     hip_check(launch_add_rows(hidden_, T2, H, T2, enc_pos_, enc_pos_rows_, s), "positions");
     // pre-norm encoder layers, mask of ones (transcriber.rs:134-138; encoder_layer.rs:195-212)
     for (const EncLayer& L : enc_) {
         hip_check(launch_layernorm(hidden_, L.ln1_g, L.ln1_b, 1e-5f, T2, H, normed_, s), "ln1");
-        hip_check(launch_gemm(normed_, H, L.wqkv, L.bqkv, nullptr, 0, qkv_, 3 * H, T2, 3 * H, H, EPI_BIAS, s), "qkv");
+        hip_check(launch_gemm(normed_, H, L.wqkv, L.bqkv, nullptr, 0, qkv_, 3 * H, T2, 3 * H, H, EPI_BIAS, s, sc), "qkv");
         hip_check(launch_attention(qkv_, ones_, 1, T2, heads, d, -1e9f, ctx_, s), "attention");
-        hip_check(launch_gemm(ctx_, H, L.wo, L.bo, hidden_, H, hidden_, H, T2, H, H, EPI_BIAS_RESIDUAL, s), "out proj");
+        hip_check(launch_gemm(ctx_, H, L.wo, L.bo, hidden_, H, hidden_, H, T2, H, H, EPI_BIAS_RESIDUAL, s, sc), "out proj");
         hip_check(launch_layernorm(hidden_, L.ln2_g, L.ln2_b, 1e-5f, T2, H, normed_, s), "ln2");
-        hip_check(launch_gemm(normed_, H, L.w1, L.b1, nullptr, 0, mid_, I, T2, I, H, EPI_BIAS_GELU, s), "fc1");
-        hip_check(launch_gemm(mid_, I, L.w2, L.b2, hidden_, H, hidden_, H, T2, H, I, EPI_BIAS_RESIDUAL, s), "fc2");
+        hip_check(launch_gemm(normed_, H, L.w1, L.b1, nullptr, 0, mid_, I, T2, I, H, EPI_BIAS_GELU, s, sc), "fc1");
+        hip_check(launch_gemm(mid_, I, L.w2, L.b2, hidden_, H, hidden_, H, T2, H, I, EPI_BIAS_RESIDUAL, s, sc), "fc2");
     }
     hip_check(launch_layernorm(hidden_, enc_ln_g_, enc_ln_b_, 1e-5f, T2, H, hidden_, s), "final ln");
     enc_frames_ = T2;

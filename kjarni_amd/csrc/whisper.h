@@ -149,6 +149,8 @@ private:
     int32_t *dtoken_ = nullptr, *dhist_ = nullptr;
     int *dpos_ = nullptr, *dcount_ = nullptr;
     float* att_scratch_ = nullptr;
+    float* gemm_scratch_ = nullptr;  // partial tiles of the encoder's mid-size GEMM route (gemm.hip)
+    size_t gemm_scratch_floats_ = 0;
     int cache_len_ = 0, cache_cap_ = 0, last_rows_ = 0, hist_cap_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraphExec_t graphs_[2] = {nullptr, nullptr};
