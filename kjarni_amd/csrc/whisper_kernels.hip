@@ -256,6 +256,69 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
     }
 }
 
+// gemv_rows_kernel for ONE row whose length is 256 KCH floats, with every request of the wave issued before anything is
+// waited for: the weight row (non-temporal), bias / residual, the input row, gamma / beta -- then the statistics, the
+// normalisation and the dot product run on registers.  A decode step is a chain of ~5 us launches, each a chain of memory
+// round trips: the general kernel pays one for the row, a second for the weights and a third for the residual.  Same
+// lane-to-chunk map, LayerNorm arithmetic and summation order: results are bit-identical to gemv_rows_kernel's.
+template <int EPI, bool LN, int KCH>
+__global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, const float* __restrict__ R, int n_out,
+                                                            int seg, float* __restrict__ Y0, float* __restrict__ Y1,
+                                                            float* __restrict__ Y2, int64_t ldy12, int row_off,
+                                                            const int* __restrict__ row_off_ptr)
+{
+    constexpr int K = 256 * KCH;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (n >= n_out) return;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + n * (int64_t)K);
+    f32x4 x[KCH], w[KCH], g[KCH], bt[KCH];
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) x[j] = *reinterpret_cast<const f32x4*>(X + (lane + 64 * j) * 4);
+    if (LN) {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            g[j] = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * j) * 4);
+            bt[j] = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * j) * 4);
+        }
+    }
+    const float b = bias ? bias[n] : 0.0f;
+    const float res = EPI == EPI_BIAS_RESIDUAL ? R[n] : 0.0f;
+    const int which = seg > 0 ? (int)(n / seg) : 0;
+    const int64_t r0 = which == 0 ? 0 : (row_off_ptr ? *row_off_ptr : row_off);
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) w[j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    if (LN) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+        const float mu = wave_sum(s) / (float)K;
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KCH; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = fmaf(x[j][c] - mu, x[j][c] - mu, v);
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)K + eps);
+#pragma unroll
+        for (int j = 0; j < KCH; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[j][c] = (x[j][c] - mu) * rstd * g[j][c] + bt[j][c];
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = fmaf(x[j][c], w[j][c], acc);
+    float v = wave_sum(acc) + b;
+    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+    if (EPI == EPI_BIAS_RESIDUAL) v += res;
+    const int64_t col = seg > 0 ? n - (int64_t)which * seg : n;
+    float* Y = which == 0 ? Y0 : (which == 1 ? Y1 : Y2);
+    if (lane == 0) Y[(which == 0 ? 0 : r0 * ldy12) + col] = v;
+}
+
 // The same projection for 2..8 rows (several tokens of one sequence, or the lanes of a lock-step decode): the rows are
 // (normalised and) staged in LDS once per workgroup -- wave w prepares rows w, w + 4 -- instead of being re-read and
 // re-normalised from L2 by every wave for every row.  Lane-to-chunk assignment, LayerNorm arithmetic and reduction order
@@ -699,6 +762,37 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
         }                                                                                                                        \
     } while (0)
     const bool ln = a.gamma != nullptr;
+    // one row of 512 or 2048 floats (the Whisper-base decoder's widths): the variant with every request issued up front
+    const int kch = a.k / 256;
+    if (a.rows == 1 && a.k % 256 == 0 && (kch == 2 || kch == 8) && g_gemv_rows_variant == 0 && (!ln || a.beta) &&
+        (!ln || ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0)) {
+#define KJ_FAST2(EPI, LN, KCH)                                                                                                    \
+    hipLaunchKernelGGL((gemv_row_fast_kernel<EPI, LN, KCH>), grid, dim3(256), 0, stream, a.X, a.gamma, a.beta, a.eps, a.W, a.bias, \
+                       a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr)
+#define KJ_FAST(EPI, LN)                                                                                                          \
+    do {                                                                                                                          \
+        if (kch == 2) KJ_FAST2(EPI, LN, 2);                                                                                       \
+        else KJ_FAST2(EPI, LN, 8);                                                                                                \
+    } while (0)
+        switch (a.epi) {
+        case EPI_BIAS:
+            if (ln) KJ_FAST(EPI_BIAS, true);
+            else KJ_FAST(EPI_BIAS, false);
+            break;
+        case EPI_BIAS_GELU:
+            if (ln) KJ_FAST(EPI_BIAS_GELU, true);
+            else KJ_FAST(EPI_BIAS_GELU, false);
+            break;
+        case EPI_BIAS_RESIDUAL:
+            if (ln) KJ_FAST(EPI_BIAS_RESIDUAL, true);
+            else KJ_FAST(EPI_BIAS_RESIDUAL, false);
+            break;
+        default: return hipErrorInvalidValue;
+        }
+#undef KJ_FAST
+#undef KJ_FAST2
+        return hipGetLastError();
+    }
     switch (a.epi) {
     case EPI_BIAS:
         if (ln) KJ_GEMV(EPI_BIAS, true);
