@@ -398,6 +398,89 @@ __global__ __launch_bounds__(256) void gemv_rows_lds_kernel(const float* __restr
     }
 }
 
+// gemv_rows_lds_kernel for rows of 256 KCH floats with the wave's weight row, bias and residual values requested before the
+// rows are staged (they do not depend on them): the staging's three passes over X then run under the weight round trip.
+// Same arithmetic and order as gemv_rows_lds_kernel: bit-identical results.
+template <int EPI, bool LN, int KCH>
+__global__ __launch_bounds__(256) void gemv_rows_lds_fast_kernel(const float* __restrict__ X, int64_t ldx, int rows,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                 const float* __restrict__ R, int64_t ldr, int n_out, int seg,
+                                                                 float* __restrict__ Y0, int64_t ldy0, float* __restrict__ Y1,
+                                                                 float* __restrict__ Y2, int64_t ldy12, int row_off,
+                                                                 const int* __restrict__ row_off_ptr)
+{
+    extern __shared__ __attribute__((aligned(16))) float gx[];  // [rows][k]
+    constexpr int k = 256 * KCH;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nc = n < n_out ? n : n_out - 1;  // surplus waves of the last workgroup still help staging
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + nc * (int64_t)k);
+    f32x4 w[KCH];
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) w[j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    const float b = bias ? bias[nc] : 0.0f;
+    float res[GEMV_MAX_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) res[r] = (EPI == EPI_BIAS_RESIDUAL && r < rows) ? R[r * ldr + nc] : 0.0f;
+    const int which = seg > 0 ? (int)(nc / seg) : 0;
+    const int64_t r0 = which == 0 ? 0 : (row_off_ptr ? *row_off_ptr : row_off);
+    for (int r = wave; r < rows; r += 4) {
+        f32x4 x[KCH];
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) x[j] = *reinterpret_cast<const f32x4*>(X + r * ldx + (lane + 64 * j) * 4);
+        if (LN) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KCH; ++j) s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+            const float mu = wave_sum(s) / (float)k;
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KCH; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v = fmaf(x[j][c] - mu, x[j][c] - mu, v);
+            const float rs = 1.0f / sqrtf(wave_sum(v) / (float)k + eps);
+#pragma unroll
+            for (int j = 0; j < KCH; ++j) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * j) * 4);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * j) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[j][c] = (x[j][c] - mu) * rs * g[c] + bt[c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) *reinterpret_cast<f32x4*>(gx + (int64_t)r * k + (lane + 64 * j) * 4) = x[j];
+    }
+    __syncthreads();
+    if (n >= n_out) return;
+    float acc[GEMV_MAX_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+            if (r < rows) {
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(gx + (int64_t)r * k + (lane + 64 * j) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r] = fmaf(xr[c], w[j][c], acc[r]);
+            }
+        }
+    }
+    const int64_t col = seg > 0 ? n - (int64_t)which * seg : n;
+    float* Y = which == 0 ? Y0 : (which == 1 ? Y1 : Y2);
+    const int64_t ldy = which == 0 ? ldy0 : ldy12;
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+        if (r < rows) {
+            float v = wave_sum(acc[r]) + b;
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            if (EPI == EPI_BIAS_RESIDUAL) v += res[r];
+            if (lane == 0) Y[(r0 + r) * ldy + col] = v;
+        }
+    }
+}
+
 // Cached attention for a few query rows, split over the keys ("flash decoding"): workgroup (head, split, row) reduces its
 // key range to a slab (max, sum of exp, sum of exp * V); the slabs are merged by decode_attention_combine_kernel, or by the
 // consumer of the context row itself (the LLM's output projection reads the slabs while its weights are in flight:
@@ -744,9 +827,25 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
     const dim3 grid((unsigned)((a.n_out + 3) / 4));
     const size_t lds = (size_t)a.rows * a.k * sizeof(float);
     const bool staged = a.rows >= 2 && lds <= 64 * 1024 && g_gemv_rows_variant == 0;
+    const bool staged_fast = staged && a.k % 256 == 0 && (a.k / 256 == 2 || a.k / 256 == 8) && (!a.gamma || a.beta) &&
+                             ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0;
+#define KJ_STAGED_FAST(EPI, LN, KCH)                                                                                             \
+    do {                                                                                                                         \
+        auto kern = gemv_rows_lds_fast_kernel<EPI, LN, KCH>;                                                                     \
+        if (lds > 48 * 1024) {                                                                                                   \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                     (int)lds);                                                                  \
+            if (e != hipSuccess) return e;                                                                                       \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a.X, a.ldx, a.rows, a.gamma, a.beta, a.eps, a.W, a.bias, a.R, a.ldr, \
+                           a.n_out, a.seg, a.Y0, a.ldy0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr);                         \
+    } while (0)
 #define KJ_GEMV(EPI, LN)                                                                                                         \
     do {                                                                                                                         \
-        if (staged) {                                                                                                            \
+        if (staged_fast) {                                                                                                       \
+            if (a.k == 512) KJ_STAGED_FAST(EPI, LN, 2);                                                                          \
+            else KJ_STAGED_FAST(EPI, LN, 8);                                                                                     \
+        } else if (staged) {                                                                                                     \
             auto kern = gemv_rows_lds_kernel<EPI, LN>;                                                                           \
             if (lds > 48 * 1024) {                                                                                               \
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
@@ -809,6 +908,7 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
     default: return hipErrorInvalidValue;
     }
 #undef KJ_GEMV
+#undef KJ_STAGED_FAST
     return hipGetLastError();
 }
 
