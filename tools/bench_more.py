@@ -69,7 +69,7 @@ def timed(fn, sync, steps, warmup):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "strings", "latency", "families", "indexer", "search", "whisper", "llm", "chat"}  # "llm8b" only on request (writes 16 GB)
+    which = set(sys.argv[1:]) or {"rerank", "scan", "ragged", "host", "sweep", "strings", "latency", "families", "indexer", "search", "whisper", "llm", "chat"}  # "llm8b" only on request (writes 16 GB)
     import numpy as np
     import torch
 
