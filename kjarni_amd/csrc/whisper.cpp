@@ -564,13 +564,21 @@ void WhisperModel::decoder_pass(const uint32_t* ids_dev, int n, bool device_pos)
             a.row_off = cache_len_; a.row_off_ptr = pos_ptr; a.epi = EPI_BIAS;
             hip_check(launch_gemv_rows(a, s), "ln1 + qkv");
         }
+        // one token: the output projections merge the attention's per-split slabs themselves (no combine launches)
+        const bool merge_self = n == 1 && gemv_row_att_supported(H, kSelfSplits, d), merge_cross = n == 1 && gemv_row_att_supported(H, kCrossSplits, d);
         hip_check(launch_decode_attention(dq_, H, n, L.self_k, H, L.self_v, H, cache_len_ + n, pos_ptr, cache_cap_, heads, d, cache_len_,
-                                          kSelfSplits, att_scratch_, dctx_, H, s), "self attention");
-        gemv(dctx_, H, nullptr, nullptr, L.wo, L.bo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "self out");
+                                          kSelfSplits, att_scratch_, merge_self ? nullptr : dctx_, H, s), "self attention");
+        if (merge_self)
+            hip_check(launch_gemv_row_att(att_scratch_, kSelfSplits, d, L.wo, L.bo, dh_, H, H, dh_, s), "self out");
+        else
+            gemv(dctx_, H, nullptr, nullptr, L.wo, L.bo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "self out");
         gemv(dh_, H, L.ln2_g, L.ln2_b, L.cq, L.cbq, nullptr, H, H, dq_, EPI_BIAS, "ln2 + cross q");
         hip_check(launch_decode_attention(dq_, H, n, L.cross_kv, 2 * H, L.cross_kv + H, 2 * H, enc_frames_, nullptr, enc_frames_, heads, d, -1,
-                                          kCrossSplits, att_scratch_, dctx_, H, s), "cross attention");
-        gemv(dctx_, H, nullptr, nullptr, L.co, L.cbo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "cross out");
+                                          kCrossSplits, att_scratch_, merge_cross ? nullptr : dctx_, H, s), "cross attention");
+        if (merge_cross)
+            hip_check(launch_gemv_row_att(att_scratch_, kCrossSplits, d, L.co, L.cbo, dh_, H, H, dh_, s), "cross out");
+        else
+            gemv(dctx_, H, nullptr, nullptr, L.co, L.cbo, dh_, H, H, dh_, EPI_BIAS_RESIDUAL, "cross out");
         gemv(dh_, H, L.ln3_g, L.ln3_b, L.w1, L.b1, nullptr, I, H, dmid_, EPI_BIAS_GELU, "ln3 + fc1");
         gemv(dmid_, I, nullptr, nullptr, L.w2, L.b2, dh_, H, I, dh_, EPI_BIAS_RESIDUAL, "fc2");
     }

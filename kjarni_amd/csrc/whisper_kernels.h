@@ -57,6 +57,11 @@ void set_gemv_rows_variant(int variant);  // 0 = rows staged in LDS when there a
 // n_keys_ptr (device int) given: keys = *n_keys_ptr + rows and the causal base = *n_keys_ptr (max_keys bounds it);
 // causal_base < 0 = no causal mask.  scratch: decode_attention_scratch_floats(...) floats.
 size_t decode_attention_scratch_floats(int rows, int heads, int head_dim, int splits);
+// One-token output projection fed by the attention's slabs (launch_decode_attention with ctx == nullptr):
+// Y[n] = merged(slabs) . W[n, :] + bias[n] + R[n], k = heads * head_dim in {512, 2048}, splits <= 16.
+bool gemv_row_att_supported(int k, int splits, int head_dim);
+hipError_t launch_gemv_row_att(const float* slabs, int splits, int head_dim, const float* W, const float* bias, const float* R, int n_out,
+                               int k, float* Y, hipStream_t stream);
 hipError_t launch_decode_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V,
                                    int64_t ldv, int n_keys, const int* n_keys_ptr, int max_keys, int heads, int head_dim,
                                    int causal_base, int splits, float* scratch, float* ctx, int64_t ldc, hipStream_t stream,

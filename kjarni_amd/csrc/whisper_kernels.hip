@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 template <int EPI, bool LN, int KCH>
 __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, const float* __restrict__ R, int n_out,
-                                                            int seg, float* __restrict__ Y0, float* __restrict__ Y1,
+                                                            const float* __restrict__ bias, const float* R, int n_out,
+                                                            int seg, float* Y0, float* __restrict__ Y1,
                                                             float* __restrict__ Y2, int64_t ldy12, int row_off,
                                                             const int* __restrict__ row_off_ptr)
 {
@@ -398,6 +398,74 @@ __global__ __launch_bounds__(256) void gemv_rows_lds_kernel(const float* __restr
     }
 }
 
+// The attention output projection of a one-token step, fed by the decode attention's per-split slabs instead of a context
+// row: Y[n] = merged(slabs) . W[n, :] + bias[n] + R[n].  The workgroup merges the slabs once into LDS (the arithmetic of
+// decode_attention_combine_kernel, element for element) while its four weight rows are in flight, then each wave takes its
+// dot product in gemv_row_fast_kernel's order -- bit-identical to combine + projection, one launch fewer.
+constexpr int ATT_MERGE_MAX_SPLITS = 16;
+
+template <int KCH>
+__global__ __launch_bounds__(256) void gemv_row_att_kernel(const float* __restrict__ part, int splits, int head_dim,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* R, int n_out, float* Y)  // R == Y in place
+{
+    constexpr int K = 256 * KCH;
+    __shared__ __attribute__((aligned(16))) float gx[K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nc = n < n_out ? n : n_out - 1;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + nc * (int64_t)K);
+    f32x4 w[KCH];
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) w[j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    const float b = bias ? bias[nc] : 0.0f;
+    const float res = R[nc];
+    const int stride = head_dim + 4;
+    for (int q = tid; q < K / 4; q += 256) {
+        const int col = q * 4, head = col / head_dim, j = col - head * head_dim;
+        const float* slab = part + (int64_t)head * splits * stride;
+        f32x2 hd[ATT_MERGE_MAX_SPLITS];
+        f32x4 av[ATT_MERGE_MAX_SPLITS];
+#pragma unroll
+        for (int i = 0; i < ATT_MERGE_MAX_SPLITS; ++i) {  // every slab of the head requested at once
+            const float* p = slab + (i < splits ? i : 0) * stride;
+            hd[i] = *reinterpret_cast<const f32x2*>(p);
+            av[i] = *reinterpret_cast<const f32x4*>(p + 4 + j);
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < ATT_MERGE_MAX_SPLITS; ++i)
+            if (i < splits) M = fmaxf(M, hd[i][0]);
+        float L = 0.0f;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < ATT_MERGE_MAX_SPLITS; ++i) {
+            if (i < splits) {
+                const float wgt = (hd[i][0] == -INFINITY) ? 0.0f : expf(hd[i][0] - M);
+                L = fmaf(hd[i][1], wgt, L);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = fmaf(av[i][c], wgt, a[c]);
+            }
+        }
+        const float inv = 1.0f / L;
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = L > 0.0f ? a[c] * inv : a[c];
+        *reinterpret_cast<f32x4*>(gx + col) = o;
+    }
+    __syncthreads();
+    if (n >= n_out) return;
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (lane + 64 * j) * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = fmaf(x[c], w[j][c], acc);
+    }
+    const float v = wave_sum(acc) + b + res;
+    if (lane == 0) Y[n] = v;
+}
+
 // gemv_rows_lds_kernel for rows of 256 KCH floats with the wave's weight row, bias and residual values requested before the
 // rows are staged (they do not depend on them): the staging's three passes over X then run under the weight round trip.
 // Same arithmetic and order as gemv_rows_lds_kernel: bit-identical results.
@@ -405,8 +473,8 @@ template <int EPI, bool LN, int KCH>
 __global__ __launch_bounds__(256) void gemv_rows_lds_fast_kernel(const float* __restrict__ X, int64_t ldx, int rows,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float eps, const float* __restrict__ W, const float* __restrict__ bias,
-                                                                 const float* __restrict__ R, int64_t ldr, int n_out, int seg,
-                                                                 float* __restrict__ Y0, int64_t ldy0, float* __restrict__ Y1,
+                                                                 const float* R, int64_t ldr, int n_out, int seg,
+                                                                 float* Y0, int64_t ldy0, float* __restrict__ Y1,
                                                                  float* __restrict__ Y2, int64_t ldy12, int row_off,
                                                                  const int* __restrict__ row_off_ptr)
 {
@@ -909,6 +977,24 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
     }
 #undef KJ_GEMV
 #undef KJ_STAGED_FAST
+    return hipGetLastError();
+}
+
+bool gemv_row_att_supported(int k, int splits, int head_dim)
+{
+    return (k == 512 || k == 2048) && splits >= 1 && splits <= ATT_MERGE_MAX_SPLITS && head_dim >= 4 && (head_dim & 3) == 0 &&
+           k % head_dim == 0 && g_gemv_rows_variant == 0;
+}
+
+hipError_t launch_gemv_row_att(const float* slabs, int splits, int head_dim, const float* W, const float* bias, const float* R, int n_out,
+                               int k, float* Y, hipStream_t stream)
+{
+    if (!gemv_row_att_supported(k, splits, head_dim) || !R || (reinterpret_cast<uintptr_t>(W) & 15)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n_out + 3) / 4));
+    if (k == 512)
+        hipLaunchKernelGGL(gemv_row_att_kernel<2>, grid, dim3(256), 0, stream, slabs, splits, head_dim, W, bias, R, n_out, Y);
+    else
+        hipLaunchKernelGGL(gemv_row_att_kernel<8>, grid, dim3(256), 0, stream, slabs, splits, head_dim, W, bias, R, n_out, Y);
     return hipGetLastError();
 }
 
