@@ -680,12 +680,38 @@ __global__ __launch_bounds__(128) void decode_attention_combine_kernel(const flo
 {
     const int h = blockIdx.x, s = blockIdx.y, j = threadIdx.x;
     if (j >= head_dim) return;
-    const float* p = part + ((int64_t)s * heads + h) * splits * (head_dim + 4);
+    const int stride = head_dim + 4;
+    const float* p = part + ((int64_t)s * heads + h) * splits * stride;
+    if (splits <= 16) {  // every slab requested before the first is used (same arithmetic, same order: one round trip, not `splits`)
+        f32x2 hd[16];
+        float av[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float* pi = p + (i < splits ? i : 0) * stride;
+            hd[i] = *reinterpret_cast<const f32x2*>(pi);
+            av[i] = pi[4 + j];
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < splits) M = fmaxf(M, hd[i][0]);
+        float L = 0.0f, a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < splits) {
+                const float w = (hd[i][0] == -INFINITY) ? 0.0f : expf(hd[i][0] - M);
+                L = fmaf(hd[i][1], w, L);
+                a = fmaf(av[i], w, a);
+            }
+        }
+        ctx[(int64_t)s * ldc + h * head_dim + j] = L > 0.0f ? a * (1.0f / L) : a;
+        return;
+    }
     float M = -INFINITY;
-    for (int i = 0; i < splits; ++i) M = fmaxf(M, p[i * (head_dim + 4)]);
+    for (int i = 0; i < splits; ++i) M = fmaxf(M, p[i * stride]);
     float L = 0.0f, a = 0.0f;
     for (int i = 0; i < splits; ++i) {
-        const float* pi = p + i * (head_dim + 4);
+        const float* pi = p + i * stride;
         const float w = (pi[0] == -INFINITY) ? 0.0f : expf(pi[0] - M);
         L = fmaf(pi[1], w, L);
         a = fmaf(pi[4 + j], w, a);
