@@ -549,6 +549,67 @@ __global__ __launch_bounds__(256) void gemv_rows_lds_fast_kernel(const float* __
     }
 }
 
+// The vocabulary head for 2..8 rows: Y[r, n] = X[r, :] . W[n, :] + bias[n] over tens of thousands of columns.  A workgroup
+// stages the rows in LDS once and then takes 4 CPW columns (CPW per wave, all their weight rows requested up front): with one
+// column per wave the staging traffic (rows x k floats per workgroup) was twice the weight traffic.  Same per-element
+// arithmetic and order as gemv_rows_lds_kernel.
+template <int KCH, int CPW>
+__global__ __launch_bounds__(256) void gemv_rows_head_kernel(const float* __restrict__ X, int64_t ldx, int rows,
+                                                             const float* __restrict__ W, const float* __restrict__ bias, int n_out,
+                                                             float* __restrict__ Y, int64_t ldy)
+{
+    extern __shared__ __attribute__((aligned(16))) float gx[];  // [rows][k]
+    constexpr int k = 256 * KCH;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * CPW;
+    f32x4 w[CPW][KCH];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int64_t nc = n0 + c < n_out ? n0 + c : n_out - 1;
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(W + nc * (int64_t)k);
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) w[c][j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    }
+    float b[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) b[c] = bias ? bias[n0 + c < n_out ? n0 + c : n_out - 1] : 0.0f;
+    for (int r = wave; r < rows; r += 4) {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j)
+            *reinterpret_cast<f32x4*>(gx + (int64_t)r * k + (lane + 64 * j) * 4) =
+                *reinterpret_cast<const f32x4*>(X + r * ldx + (lane + 64 * j) * 4);
+    }
+    __syncthreads();
+    float acc[GEMV_MAX_ROWS][CPW];
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) acc[r][c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KCH; ++j) {
+#pragma unroll
+        for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+            if (r < rows) {
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(gx + (int64_t)r * k + (lane + 64 * j) * 4);
+#pragma unroll
+                for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[r][c] = fmaf(xr[e], w[c][j][e], acc[r][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GEMV_MAX_ROWS; ++r) {
+        if (r < rows) {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const float v = wave_sum(acc[r][c]) + b[c];
+                if (lane == 0 && n0 + c < n_out) Y[r * ldy + n0 + c] = v;
+            }
+        }
+    }
+}
+
 // Cached attention for a few query rows, split over the keys ("flash decoding"): workgroup (head, split, row) reduces its
 // key range to a slab (max, sum of exp, sum of exp * V); the slabs are merged by decode_attention_combine_kernel, or by the
 // consumer of the context row itself (the LLM's output projection reads the slabs while its weights are in flight:
@@ -923,6 +984,12 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
     const bool staged = a.rows >= 2 && lds <= 64 * 1024 && g_gemv_rows_variant == 0;
     const bool staged_fast = staged && a.k % 256 == 0 && (a.k / 256 == 2 || a.k / 256 == 8) && (!a.gamma || a.beta) &&
                              ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0;
+    if (staged_fast && !a.gamma && a.epi == EPI_BIAS && a.seg <= 0 && a.n_out >= 8192 && a.k == 512) {  // the vocabulary head
+        constexpr int CPW = 4;
+        hipLaunchKernelGGL((gemv_rows_head_kernel<2, CPW>), dim3((unsigned)((a.n_out + 4 * CPW - 1) / (4 * CPW))), dim3(256), lds, stream,
+                           a.X, a.ldx, a.rows, a.W, a.bias, a.n_out, a.Y0, a.ldy0);
+        return hipGetLastError();
+    }
 #define KJ_STAGED_FAST(EPI, LN, KCH)                                                                                             \
     do {                                                                                                                         \
         auto kern = gemv_rows_lds_fast_kernel<EPI, LN, KCH>;                                                                     \
