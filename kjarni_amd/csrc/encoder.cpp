@@ -651,7 +651,8 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     // writes them, and no other workgroup touches those rows.
     auto residual_ln = [&](int kind, const float* A, int K, const float* W, const float* b, const float* g,
                            const float* beta, double flops, double bytes, const char* what) {
-        if (fused_ln) {
+        // (a handful of rows: only the long-K projection takes the fused route -- K slices + a LayerNorm reduce)
+        if (fused_ln || (T <= 64 && gemm_mid_layernorm_supported(T, H, K))) {
             hipEvent_t e = prof_start(kind, stream, flops, bytes);
             hip_check(launch_gemm_residual_layernorm(A, K, W, b, hidden, H, g, beta, cfg_.eps, hidden, H, T, H, K,
                                                      stream, sc), what);

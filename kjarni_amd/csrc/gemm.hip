@@ -999,10 +999,10 @@ constexpr int64_t kFewRowsMax = 64, kMidMaxRows = 8192;
 constexpr int kMidResident = 256 * 4;  // workgroups of gemm_nt_f32_mid the chip holds at once (36 KiB of LDS each)
 
 inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
-                         const float* bias, const float* R)
+                         const float* bias, const float* R, int64_t min_rows = kFewRowsMax + 1)
 {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return M > kFewRowsMax && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
+    return M >= min_rows && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
            al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && g_gemm_variant != 7;
 }
 
@@ -1086,9 +1086,14 @@ void set_gemm_variant(int variant) { g_gemm_variant = variant; }
 int gemm_variant() { return g_gemm_variant; }
 #endif
 
+// Rows from which the residual + LayerNorm GEMMs take the K-sliced route: with a long K (>= 1024: the FC2 shape) from the
+// first row -- the few-rows kernel has N / 32 = 12 workgroups there, each with a 12-step serial K chain (17 us for one
+// sentence, + 4 us of LayerNorm launch; sliced + reduce: 13 us) -- otherwise from kFewRowsMax + 1.
+inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 : kFewRowsMax + 1; }
+
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
 {
-    return M > kFewRowsMax && M <= kMidMaxRows && N <= 1024 && N % 4 == 0 && K % MID_BK == 0 && g_gemm_variant != 7;
+    return M >= mid_ln_min_rows(N, K) && M <= kMidMaxRows && N <= 1024 && N % 4 == 0 && K % MID_BK == 0 && g_gemm_variant != 7;
 }
 
 size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n)
@@ -1111,7 +1116,8 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
 {
     if (M <= 0) return hipSuccess;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (scratch.p && R && gamma && beta && N <= 1024 && al16(gamma) && al16(beta) && mid_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R)) {
+    if (scratch.p && R && gamma && beta && N <= 1024 && al16(gamma) && al16(beta) &&
+        mid_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R, mid_ln_min_rows(N, K))) {
         const int ksplit = mid_ksplit(N, K);
         if ((size_t)ksplit * M * N <= scratch.floats) {
             const int m_tiles = ((int)M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
