@@ -1,0 +1,53 @@
+"""Concurrency soak of one encoder handle: N host threads issue calls of mixed sizes (all three projection routes, workspaces
+growing and being reused) for a while; every result must equal the single-threaded result bit for bit:
+python tools/stress_encoder.py [threads] [seconds]."""
+import os
+import sys
+import tempfile
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import torch  # noqa: F401
+from tests import synth
+import kjarni_amd
+
+
+def main():
+    n_threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "m")
+        synth.minilm_embedder(d, seed=5)
+        enc = kjarni_amd.HipEncoder(d, 0)
+        shapes = [(1, 12), (2, 30), (5, 64), (16, 40), (32, 128), (70, 128), (100, 90), (300, 128), (3, 500)]
+        inputs = [synth.synthetic_ids(b, s, seed=50 + i, ragged=True) for i, (b, s) in enumerate(shapes)]
+        refs = [enc.embed(i, m) for i, m in inputs]
+        errors, calls = [], [0] * n_threads
+        stop = time.time() + seconds
+
+        def work(t):
+            rng = np.random.default_rng(t)
+            try:
+                while time.time() < stop and not errors:
+                    j = int(rng.integers(0, len(inputs)))
+                    got = enc.embed(*inputs[j])
+                    if not np.array_equal(got, refs[j]):
+                        errors.append(f"thread {t}: shape {shapes[j]} differs by {float(np.abs(got - refs[j]).max()):.3e}")
+                    calls[t] += 1
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        print(f"{sum(calls)} calls from {n_threads} threads in {seconds:.0f} s: {'OK, all bit-identical' if not errors else errors[:3]}")
+        sys.exit(1 if errors else 0)
+
+
+if __name__ == "__main__":
+    main()
