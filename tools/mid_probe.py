@@ -16,6 +16,9 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 if os.environ.get("GEMM_VARIANT"):  # tuning build only (KJARNI_FFI_LIB=.../libkjarni_ffi_tuning.so)
     from kjarni_amd import ops
     ops.set_gemm_variant(int(os.environ["GEMM_VARIANT"]))
+if os.environ.get("ATTN_VARIANT"):
+    from kjarni_amd import ops
+    ops.set_attention_variant(int(os.environ["ATTN_VARIANT"]))
 with tempfile.TemporaryDirectory() as tmp:
     d = os.path.join(tmp, "m")
     synth.minilm_embedder(d, seed=0)
