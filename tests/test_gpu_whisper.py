@@ -277,3 +277,20 @@ def test_full_size_whisper_base_shape(tmp_path):
     assert a == b and len(a) <= 61 and all(t < W.FIRST_SPECIAL_TOKEN or t == W.EOT_TOKEN for t in a)
     ts = g.greedy(m.prompt_tokens(50259, False, True), True, 40)
     assert all(t < W.FIRST_SPECIAL_TOKEN or t == W.EOT_TOKEN or t >= W.TIMESTAMP_BEGIN for t in ts)
+
+
+def test_full_size_lock_step_equals_sequential(tmp_path, monkeypatch):
+    """The Whisper-base widths take kernels of their own (512 / 2 048-float rows with every request issued up front, the
+    attention slabs merged inside the one-token output projections, a 16-column vocabulary head for the lanes): three chunks
+    decoded in lock step must give, token for token, what chunk-by-chunk decoding gives."""
+    import kjarni_amd
+    d = str(tmp_path / "openai_whisper-base")
+    synth.whisper_model(d, seed=11, base=True)
+    audio = synth.synthetic_audio(30.0 * 2 + 9.0, seed=4)            # 3 chunks
+    tr = kjarni_amd.Transcriber(model_path=d, timestamps=False, max_tokens=24)
+    lanes = tr.transcribe_audio(audio, 16000)
+    monkeypatch.setenv("KJARNI_HIP_WHISPER_LANES", "1")
+    seq = tr.transcribe_audio(audio, 16000)
+    monkeypatch.delenv("KJARNI_HIP_WHISPER_LANES")
+    assert lanes.text == seq.text and len(seq.text) > 0
+    assert [(s.start, s.end, s.text) for s in seq.segments] == [(s.start, s.end, s.text) for s in lanes.segments]
