@@ -1388,6 +1388,167 @@ hipError_t launch_widen_bf16(const void* src, float* dst, size_t n, hipStream_t 
     return hipGetLastError();
 }
 
+namespace {
+// Causal grouped-query attention of a long prompt block on the fp32 matrix cores (the flash-style kernel above is a vector-ALU
+// kernel: 27 TFLOP/s, a quarter of a 2 048-token prompt's time).  Structure of the encoder's attention_kernel (attention.hip):
+// a workgroup owns 128 queries of one head (4 waves x 32), walks the keys in chunks of 128 staged in LDS (K row-major, V
+// transposed), S^T = K Q^T and O += P V as 32 x 32 x 2 MFMA tiles, online softmax in the exp2 domain with the running
+// (max, sum) on lane == query.  Causality: query row i of the block sees keys <= base + i (decoder_attention.rs:99-160,
+// utils/masks.rs:103-113 overwrite masked scores with -1e9, whose exp is exactly 0 next to the unmasked diagonal score --
+// here they are simply left out); chunks past a workgroup's last query are never visited, a wave skips the chunks past its
+// own last query, and only the chunks that straddle a wave's diagonal pay for the per-element test.
+constexpr int PM_Q = 128, PM_K = 128;
+template <int D>
+struct PmSmem {
+    static constexpr int K_STRIDE = D + 4, VT_STRIDE = PM_K + 4;
+    static constexpr int K_FLOATS = PM_K * K_STRIDE, VT_FLOATS = D * VT_STRIDE;
+    static constexpr int BYTES = (K_FLOATS + VT_FLOATS) * 4;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, D <= 64 ? 2 : 1) void prefill_attention_mfma_kernel(const float* __restrict__ q, int64_t ldq, int rows,
+                                                                                       const float* __restrict__ K, int64_t ldk,
+                                                                                       const float* __restrict__ V, int64_t ldv, int base,
+                                                                                       int kv_group, float scale, float* __restrict__ ctx,
+                                                                                       int64_t ldc)
+{
+    using SM = PmSmem<D>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;                  // [128][D + 4]
+    float* sVt = smem + SM::K_FLOATS;  // [D][128 + 4]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    // A query block's work grows with its index (block i walks i + 1 key chunks when nothing is cached).  All workgroups of a
+    // launch are resident at once, two per CU, and workgroups L and L + 256 tend to share one: the upper half of the heads
+    // walks the blocks in reverse, so the pairs add up to the same work.
+    const int h = blockIdx.y, kvh = h / kv_group;
+    const int qb = (2 * (int)blockIdx.y >= (int)gridDim.y) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const float* q_base = q + h * D;
+    const float* k_base = K + kvh * D;
+    const float* v_base = V + kvh * D;
+
+    const int q_wave0 = qb * PM_Q + wid * 32;  // first query row of this wave
+    const int q_row = q_wave0 + l31;
+    f32x4 qf[D / 8];  // B operand of S^T = K Q^T: lane supplies Q[q][8 kk + 4 half + c]
+#pragma unroll
+    for (int kk = 0; kk < D / 8; ++kk)
+        qf[kk] = q_row < rows ? *reinterpret_cast<const f32x4*>(q_base + (int64_t)q_row * ldq + kk * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+    float run_max = -INFINITY, run_sum = 0.0f;
+    const int n_keys = base + rows;
+    const int last_q_wg = min(rows, qb * PM_Q + PM_Q) - 1;     // last query row of the workgroup
+    const int last_q_wave = min(rows - 1, q_wave0 + 31);        // (below q_wave0 when the wave has no query: it only helps staging)
+    const int n_chunks = (base + last_q_wg) / PM_K + 1;
+    const float c1 = scale * 1.4426950408889634f;
+
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int key0 = ch * PM_K;
+        if (ch > 0) __syncthreads();  // everyone done reading the previous chunk
+        constexpr int V4_PER_ROW = D / 4;
+        for (int f = tid; f < PM_K * V4_PER_ROW; f += 256) {
+            const int r = f / V4_PER_ROW, c4 = f % V4_PER_ROW;
+            const int key = key0 + r;
+            f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (key < n_keys) {
+                kv = *reinterpret_cast<const f32x4*>(k_base + (int64_t)key * ldk + c4 * 4);
+                vv = *reinterpret_cast<const f32x4*>(v_base + (int64_t)key * ldv + c4 * 4);
+            }
+            *reinterpret_cast<f32x4*>(sK + r * SM::K_STRIDE + c4 * 4) = kv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sVt[(c4 * 4 + c) * SM::VT_STRIDE + r] = vv[c];
+        }
+        __syncthreads();
+        if (q_wave0 >= rows || key0 > base + last_q_wave) continue;  // no query here, or every key of the chunk is in this wave's future
+        const bool plain = key0 + PM_K - 1 <= base + q_wave0;      // every key visible to every query of the wave
+
+        f32x16 s[4];  // S^T tiles: 4 key tiles x 32 queries, K = D
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
+            const float* pk = sK + (kt * 32 + l31) * SM::K_STRIDE + half * 4;
+#pragma unroll
+            for (int kk = 0; kk < D / 8; ++kk) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(pk + kk * 8);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[kk][c], s[kt], 0, 0, 0);
+            }
+        }
+        float cmax = -INFINITY;
+        if (plain) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[kt][r] *= c1;
+                    cmax = fmaxf(cmax, s[kt][r]);
+                }
+        } else {
+            const int limit = base + q_row;  // this lane's query sees keys <= limit
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kt * 32 + acc_row(r, half);
+                    const float v = key <= limit ? s[kt][r] * c1 : -INFINITY;
+                    s[kt][r] = v;
+                    cmax = fmaxf(cmax, v);
+                }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, kWave));
+        const float new_max = fmaxf(run_max, cmax);
+        // (a lane without a query, or whose keys of this chunk are all in its future, keeps new_max == run_max)
+        const float alpha = (run_max == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(run_max - new_max);
+        float csum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = __builtin_amdgcn_exp2f(s[kt][r] - new_max);
+                if (new_max == -INFINITY) e = 0.0f;
+                s[kt][r] = e;
+                csum += e;
+            }
+        csum += __shfl_xor(csum, 32, kWave);
+        run_sum = run_sum * alpha + csum;
+        run_max = new_max;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // O's rows are queries indexed by (reg, half); alpha lives on lane == query
+            const float a = __shfl(alpha, acc_row(r, half), kWave);
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) o[dt][r] *= a;
+        }
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt) {  // O += P V: A = P (query l31, keys 8 g + 4 half + c), B = V^T[d][key]
+            const float* pv = sVt + (dt * 32 + l31) * SM::VT_STRIDE + half * 4;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(pv + kt * 32 + g * 8);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[kt][g * 4 + c], vf[c], o[dt], 0, 0, 0);
+                }
+        }
+    }
+    const float inv = run_sum > 0.0f ? 1.0f / run_sum : 1.0f;
+    float* out_base = ctx + h * D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = q_wave0 + acc_row(r, half);
+        const float is = __shfl(inv, acc_row(r, half), kWave);
+        if (qq < rows) {
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) out_base[(int64_t)qq * ldc + dt * 32 + l31] = o[dt][r] * is;
+        }
+    }
+}
+}  // namespace
+
 bool prefill_attention_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
 
 hipError_t launch_prefill_attention(const float* q, int64_t ldq, int rows, const float* K, int64_t ldk, const float* V, int64_t ldv, int base,
@@ -1395,6 +1556,27 @@ hipError_t launch_prefill_attention(const float* q, int64_t ldq, int rows, const
 {
     if (rows <= 0) return hipSuccess;
     if (!prefill_attention_supported(head_dim)) return hipErrorInvalidValue;
+    // long blocks of 64- / 128-wide heads: the matrix-core kernel
+    if (rows >= 256 && (head_dim == 64 || head_dim == 128) && g_llm_gemv_variant != 9 && (ldq & 3) == 0 && (ldk & 3) == 0 && (ldv & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15) == 0) {
+        const dim3 mgrid((unsigned)((rows + PM_Q - 1) / PM_Q), (unsigned)heads);
+        const float mscale = 1.0f / sqrtf((float)head_dim);
+        const int g = kv_group < 1 ? 1 : kv_group;
+        if (head_dim == 64) {
+            auto kern = prefill_attention_mfma_kernel<64>;
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     PmSmem<64>::BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, mgrid, dim3(256), PmSmem<64>::BYTES, stream, q, ldq, rows, K, ldk, V, ldv, base, g, mscale, ctx, ldc);
+        } else {
+            auto kern = prefill_attention_mfma_kernel<128>;
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     PmSmem<128>::BYTES);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, mgrid, dim3(256), PmSmem<128>::BYTES, stream, q, ldq, rows, K, ldk, V, ldv, base, g, mscale, ctx, ldc);
+        }
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((rows + PA_Q - 1) / PA_Q), (unsigned)heads);
     const int LD = head_dim + 4;
     const size_t lds = ((size_t)(PA_Q + 2 * PA_K) * LD + (size_t)PA_Q * (PA_K + 4)) * sizeof(float);

@@ -247,3 +247,25 @@ def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
             scale = max(1.0, float(np.abs(ref_h).max()))
             assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
             assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
+
+
+@pytest.mark.parametrize("head_dim,heads,kv_heads", [(64, 8, 2), (128, 4, 2), (128, 4, 4)], ids=["d64-gqa4", "d128-gqa2", "d128-mha"])
+def test_prompt_attention_on_the_matrix_cores(tmp_path, head_dim, heads, kv_heads):
+    """Prompt blocks of >= 256 rows with 64- / 128-wide heads take the MFMA causal attention kernel: a first block (no keys
+    before it), a second one on top of the cache (base > 0, a block that ends inside a 128-key chunk), then single tokens."""
+    base = dict(synth.LLAMA_TEST, hidden_size=heads * head_dim, num_hidden_layers=2, num_attention_heads=heads, num_key_value_heads=kv_heads,
+                intermediate_size=512, vocab_size=600, max_position_embeddings=2048, head_dim=head_dim)
+    base["rope_scaling"] = dict(base["rope_scaling"], original_max_position_embeddings=512)
+    orc, gpu, cfg = _pair(tmp_path, base, seed=17)
+    rng = np.random.default_rng(8)
+    cache = orc.new_cache()
+    gpu.reset()
+    for n in (300, 1, 457, 1, 1):
+        ids = rng.integers(4, cfg["vocab_size"], n).tolist()
+        ref_h = orc.forward(ids, cache)[0]
+        h, logits = gpu.forward(ids)
+        k = (n - 1) % 8 + 1
+        ref_l = orc.logits(ref_h[-1])
+        scale = max(1.0, float(np.abs(ref_h).max()))
+        assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
+        assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
