@@ -317,10 +317,10 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
 #ifdef KJARNI_TUNING
     static const int kTileRows = [] {
         const char* v = std::getenv("KJARNI_HIP_LLM_TILE_ROWS");  // measurements
-        return v ? std::atoi(v) : 1792;
+        return v ? std::atoi(v) : 512;
     }();
 #else
-    constexpr int kTileRows = 1792;  // rows from which the projections take the encoder's 128 x 128-tile f32 GEMM (measured crossover)
+    constexpr int kTileRows = 512;  // rows from which a projection may take the encoder's 128 x 128-tile f32 GEMM (if its tiles fill the chip)
 #endif
     if (!ph_) {
         prefill_cap_ = kChunk;
@@ -345,9 +345,16 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
         // encoder's 128 x 128-tile f32 GEMM (gemm.hip), bf16 weights on an f32 copy made just before (100 MB moved per 69 GFLOP
         // at 2 048 rows).  Measured on the 1B shape: 2 048 rows 46.2 -> 42.6 ms, 1 792 rows 40.4 -> 39.1 ms, 1 536 rows 33.1 -> 36.1 ms
         // (the 2 048-wide projections are then 192 tiles on 256 CUs): hence kTileRows.
-        const bool tiles = m >= kTileRows && H % 128 == 0 && I % 128 == 0 && kv % 128 == 0 && (!bf16_ || pw32_);
+        // per projection: the 128 x 128 tiles when they number at least one per CU (m / 128 x N / 128 >= 208), from kTileRows rows
+        const bool tile_shapes = H % 128 == 0 && I % 128 == 0 && kv % 128 == 0 && (!bf16_ || pw32_);
         auto proj = [&](const float* Ain, int lda, const void* W, const float* bias, const float* R, float* Y, int ldy, int N, int K,
                         float* gate, const char* what) {
+#ifdef KJARNI_TUNING
+            static const int min_tiles = [] { const char* v = std::getenv("KJARNI_HIP_LLM_MIN_TILES"); return v ? std::atoi(v) : 208; }();
+#else
+            constexpr int min_tiles = 208;  // measured on the 1B shape: 192 tiles (1 536 rows x 2 048 columns) are faster on the 64 x 64 kernel, 224 on the tiles
+#endif
+            const bool tiles = tile_shapes && m >= kTileRows && (int64_t)((m + 127) / 128) * (N / 128) >= min_tiles;
             if (!tiles) {
                 hip_check(launch_prefill_gemm(Ain, lda, W, wb, bias, R, ldy, Y, ldy, m, N, K, s, psplit_, gate), what);
                 return;
