@@ -21,6 +21,11 @@ inside the timed region.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel, timed live with HIP events on its launch stream over
                 the timed region (libkjarni_ffi's profiler)
+  rerank        (embed workload) the 100 000-pair STRONG-scaling rerank leg run after the embed region, same timing rules:
+                {"pairs_per_s", "ms_per_step", "n_gpus", "scaling": "strong", ...}
+  collective    (N > 1) the start-up smoke of the communicator: backend, ranks seen, RCCL version
+  max_abs_err_vs_oracle  64 sampled rows of the last timed step's output against the CPU oracle (checked after the
+                timed region; the run fails above 1e-4)
   cpu_baseline  (N = 1, embed) the port of the reference's CPU path (oracle/
                 kjarni_cpu_baseline.c) timed on this host: calls of 32 and of 256, with the
                 reference's serial row loops and with them parallelised
@@ -214,6 +219,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer and ragged legs")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of sampled output rows")
+    ap.add_argument("--no-rerank-leg", action="store_true",
+                    help="embed workload: skip the 100 000-pair strong-scaling rerank leg that follows the embed region")
+    ap.add_argument("--rerank-steps", type=int, default=0, help="timed steps of the rerank leg (default min(steps, 5))")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing self-test without a GPU: gloo + a host stub instead of the HIP encoder")
     args = ap.parse_args()
@@ -253,6 +262,25 @@ def main():
         dev = torch.device("cuda", local_rank)
         if world > 1:
             dist.init_process_group("nccl", device_id=dev)
+    comm_info = None
+    if world > 1:
+        # Start-up smoke of the collective layer: the communicator must span exactly the ranks --gpus asked for, and a
+        # sum of ones over it must come back as that count (on the GPU path this is an RCCL all-reduce over xGMI).
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == world, f"all-reduce over {world} ranks returned {ones.item()}"
+        version = None
+        if not dry:
+            try:
+                version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        comm_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_version": version,
+                     "allreduce_of_ones": int(ones.item())}
+        if rank == 0:
+            print(f"bench.py: {comm_info['backend']} communicator over {comm_info['ranks']} ranks"
+                  f" (RCCL {version}); all-reduce of ones = {comm_info['allreduce_of_ones']}", file=sys.stderr, flush=True)
 
     S = SEQ
     rerank = args.workload == "rerank"
@@ -333,6 +361,89 @@ def main():
         assert emb.shape == (n_total, H)
         norms = torch.linalg.vector_norm(emb[:: max(1, n_total // 4096)], dim=1)
         assert torch.allclose(norms, torch.ones_like(norms), atol=1e-4), "embeddings are not L2-normalised"
+
+    # Parity of what the timed region produced: 64 sampled rows of the LAST timed step's output (this rank's block; the
+    # first and last row of the block and of its first 2 048-sentence chunk included) against the CPU oracle on the same
+    # ids.  The oracle is the checker here, after the clock has stopped; it never produces anything that is reported
+    # as throughput.
+    parity = {}
+    if rank == 0 and not dry and not args.no_parity_check:
+        from oracle import oracle as O
+        orc = O.OracleModel(tensors, cfg, blocked_gemm=True)
+        prng = np.random.default_rng(123)
+        edge = [0, n_local - 1, min(2047, n_local - 1), min(2048, n_local - 1)]
+        sel = np.unique(np.concatenate([np.array(edge), prng.choice(n_local, min(64, n_local), replace=False)]))[:64]
+        sel_t = torch.from_numpy(sel).to(dev)
+        take = lambda a: np.ascontiguousarray(a[sel_t].cpu().numpy().view(np.uint32))
+        if rerank:
+            start, _ = D.shard_rows(n_total, world, rank)
+            got = result_holder["scores"][start + sel_t].cpu().numpy()
+            ref = orc.rerank_scores(take(ids), take(mask), take(types))
+        else:
+            got = result_holder["emb"][rank * n_local + sel_t].cpu().numpy()
+            ref = orc.embed_batch(take(ids), take(mask))
+        parity = {"max_abs_err_vs_oracle": float(np.abs(got - ref).max()), "rows_checked_vs_oracle": int(len(sel)),
+                  "parity_tolerance": 1e-4}
+        assert parity["max_abs_err_vs_oracle"] < 1e-4, f"timed output differs from the oracle: {parity}"
+
+    # The north star's scaling target (>= 6x from 1 to 8 GPUs) is on the sharded RERANK path, and the driver only ever
+    # runs the default workload: so the default run carries that leg too -- the same 100 000 pairs in total at every N
+    # (strong scaling), balanced row blocks, all-gather of the scores, the host's stable descending sort, timed the
+    # same way (barrier + synchronize either side, max over ranks).
+    rerank_leg = None
+    if not rerank and not args.no_rerank_leg:
+        with tempfile.TemporaryDirectory(prefix=f"kjarni_bench_ce_r{rank}_") as tmp:
+            ce_cfg, ce_tensors = synth.minilm_cross_encoder(tmp, seed=1)
+            ce = HostStubEncoder() if dry else kjarni_amd.HipEncoder(tmp, local_rank)
+        if args.chunk_tokens and not dry:
+            ce.set_chunk_tokens(args.chunk_tokens)
+        p_total = args.pairs
+        p_start, p_local = D.shard_rows(p_total, world, rank)
+        pi, pm, pt = synth.synthetic_pairs(p_total, S, seed=1)
+        pi_d, pm_d, pt_d = (to_dev(a[p_start:p_start + p_local]) for a in (pi, pm, pt))
+        r_steps = args.rerank_steps or max(1, min(args.steps, 5))
+        held = {}
+
+        def rerank_step():
+            held["scores"] = D.sharded_rerank_scores(ce, pi_d, pm_d, pt_d, n_total=p_total)
+            held["order"] = D.rerank_order_arrays(held["scores"])
+
+        for _ in range(1 if args.warmup else 0):
+            rerank_step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(r_steps):
+            rerank_step()
+        sync()
+        r_elapsed = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([r_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r_elapsed = float(t.item())
+        sc, order = held["scores"], held["order"]
+        assert sc.shape == (p_total,) and bool(torch.isfinite(sc).all()), "rerank scores are not finite"
+        assert bool((order[1][:-1] >= order[1][1:]).all()), "rerank order is not descending"
+        rerank_leg = {"pairs_per_s": round(p_total * r_steps / r_elapsed, 1), "ms_per_step": round(r_elapsed / r_steps * 1e3, 3),
+                      "n_gpus": world, "scaling": "strong", "steps": r_steps, "pairs_per_step": p_total,
+                      "pairs_per_gpu": p_local, "unit": "pairs/s",
+                      "workload": f"minilm-l6-v2-cross-encoder Reranker over {p_total} synthetic query-doc pairs x {S} tokens in "
+                                  f"total, row blocks over {world} GPU(s), all-gather of the scores + the host's stable "
+                                  "descending sort inside the timed region (BASELINE.json configs[2])"}
+        if rank == 0 and not dry and not args.no_parity_check:
+            from oracle import oracle as O
+            prng = np.random.default_rng(321)
+            sel = np.unique(np.concatenate([np.array([0, p_local - 1]), prng.choice(p_local, min(32, p_local), replace=False)]))[:32]
+            ref = O.OracleModel(ce_tensors, ce_cfg, blocked_gemm=True).rerank_scores(
+                *(np.ascontiguousarray(a[p_start + sel]) for a in (pi, pm, pt)))
+            got = sc[torch.from_numpy(p_start + sel).to(sc.device)].cpu().numpy()
+            rerank_leg["max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+            rerank_leg["rows_checked_vs_oracle"] = int(len(sel))
+            assert rerank_leg["max_abs_err_vs_oracle"] < 1e-4, f"rerank scores differ from the oracle: {rerank_leg}"
+        if not dry:
+            fr = flops_per_sentence(H, ce.num_layers, ce_cfg["intermediate_size"], S) + 2 * H * H + 2 * H
+            rerank_leg["e2e_frac_fp32_mfma_peak"] = round(rerank_leg["pairs_per_s"] * fr / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)
+            ce.close()
+        del pi, pm, pt, pi_d, pm_d, pt_d, held
 
     extras = {}
     if rank == 0 and world == 1 and not rerank and not dry and not args.no_extras:
@@ -439,6 +550,11 @@ def main():
                                 "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2) if s["flops"] else None,
                                 "gbs": round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)}
                     for s in all_stats if s["launches"]}
+        result.update(parity)
+        if rerank_leg:
+            result["rerank"] = rerank_leg
+        if comm_info:
+            result["collective"] = comm_info
         result.update(extras)
         if world == 1 and not rerank and not dry and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, tensors)

@@ -75,6 +75,14 @@ static inline float ko_act(float x, int act)
     }
 }
 
+/* The same scalars over an array (activations.rs:94-107 apply_activation_slice maps them over a slice); for tests that check
+ * millions of activations at once. */
+KO_API void ko_activation_array(float *x, int64_t n, int act)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) x[i] = ko_act(x[i], act);
+}
+
 /* activations.rs:223-242 softmax_inplace: max, exp(x-max), sum, scale by 1/sum if sum > 0 */
 KO_API void ko_softmax_row(float *row, int n)
 {

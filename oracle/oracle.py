@@ -67,6 +67,7 @@ def lib():
         L.ko_relu.restype = C.c_float
         L.ko_relu.argtypes = [C.c_float]
         L.ko_softmax_row.argtypes = [_f32p, C.c_int]
+        L.ko_activation_array.argtypes = [_f32p, C.c_int64, C.c_int]
         L.ko_layer_norm.argtypes = [_f32p, _f32p, _f32p, C.c_float, C.c_int64, C.c_int, _f32p]
         for fn in (L.ko_linear, L.ko_linear_blocked):
             fn.argtypes = [_f32p, _f32p, _f32p, C.c_int64, C.c_int, C.c_int, _f32p]
@@ -138,6 +139,16 @@ def gelu(x: float) -> float:
 
 def gelu_new(x: float) -> float:
     return float(lib().ko_gelu_new(float(x)))
+
+
+ACT_GELU, ACT_GELU_NEW, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+
+
+def activation(x, act: int) -> np.ndarray:
+    """gelu_scalar / gelu_new_scalar / relu / tanhf applied element by element (activations.rs:56-71)."""
+    y = f32(x).copy()
+    lib().ko_activation_array(_f(y), y.size, int(act))
+    return y
 
 
 def softmax_rows(x: np.ndarray) -> np.ndarray:

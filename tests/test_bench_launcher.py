@@ -29,8 +29,15 @@ def test_plain_invocation_spawns_its_ranks(workload, extra):
     if workload == "rerank":
         assert r["scaling"] == "strong" and r["config"]["rows_per_step"] == 257 and r["config"]["rows_per_gpu"] == 129
         assert r["unit"] == "pairs/s"
+        assert "rerank" not in r
     else:
         assert r["scaling"] == "weak" and r["config"]["rows_per_step"] == 130 and r["unit"] == "sentences/s"
+        # the default workload also carries the north star's strong-scaling rerank leg, on the same N
+        leg = r["rerank"]
+        assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["pairs_per_step"] == 100000
+        assert leg["pairs_per_gpu"] == 50000 and leg["pairs_per_s"] > 0 and leg["ms_per_step"] > 0 and leg["steps"] == 2
+    # the communicator the ranks built spans exactly --gpus ranks (gloo here, RCCL on the GPU path)
+    assert r["collective"]["ranks"] == 2 and r["collective"]["allreduce_of_ones"] == 2
     assert r["value"] > 0 and r["higher_is_better"] is True and r["vs_baseline"] is None
 
 
@@ -46,3 +53,10 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], capture_output=True,
                        text=True, timeout=120, env=env, cwd=ROOT)
     assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+def test_single_rank_has_no_collective_and_can_skip_the_rerank_leg():
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--sentences", "10", "--no-rerank-leg"])
+    assert r["n_gpus"] == 1 and "collective" not in r and "rerank" not in r
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--sentences", "10", "--pairs", "77"])
+    assert r["rerank"]["pairs_per_step"] == 77 and r["rerank"]["n_gpus"] == 1

@@ -130,3 +130,34 @@ def test_errors(minilm):
     with pytest.raises(kjarni_amd.KjarniException) as ei:
         enc.embed(big, big)
     assert ei.value.code == kjarni_amd.KjarniError.INVALID_CONFIG
+
+
+# ---- the HIP path against the committed second opinion (HF BertModel in float64, tests/golden/encoder_fixtures.npz;
+# ---- tests/test_oracle_fixtures.py holds the oracle to the same file on the CPU)
+FIXTURE_CASES = [(1, 8), (3, 8), (64, 8), (1, 128), (3, 128), (64, 128)]
+
+
+@pytest.fixture(scope="module")
+def fixtures():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder_fixtures.npz"))
+
+
+@pytest.mark.parametrize("B,S", FIXTURE_CASES)
+def test_embeddings_equal_the_hf_fixtures(minilm, fixtures, B, S):
+    enc, _ = minilm  # synth.minilm_embedder(seed=0): the weights the fixtures were made with (digest checked on the CPU side)
+    tag = f"embed_{B}x{S}"
+    got = enc.embed(fixtures[tag + "_ids"], fixtures[tag + "_mask"])
+    assert float(np.abs(got - fixtures[tag + "_embeddings"]).max()) < TOL
+    if tag + "_hidden" in fixtures:
+        h = enc.hidden_states(fixtures[tag + "_ids"], fixtures[tag + "_mask"])
+        real = fixtures[tag + "_mask"].astype(bool)
+        assert float(np.abs(h - fixtures[tag + "_hidden"])[real].max()) < TOL
+
+
+@pytest.mark.parametrize("B,S", FIXTURE_CASES)
+def test_rerank_logits_equal_the_hf_fixtures(cross, fixtures, B, S):
+    enc, _ = cross   # synth.minilm_cross_encoder(seed=1)
+    tag = f"pairs_{B}x{S}"
+    got = enc.logits(fixtures[tag + "_ids"], fixtures[tag + "_mask"], fixtures[tag + "_types"])
+    assert float(np.abs(got - fixtures[tag + "_logits"]).max()) < TOL

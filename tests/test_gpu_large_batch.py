@@ -1,0 +1,292 @@
+"""The large-batch route under the oracle.
+
+BASELINE.json configs[1] (65 536 x 128 embed) and configs[2] (100 000 rerank pairs) run chunks of 2 048 sentences:
+the 128 x 128-tile GEMM walks its tiles in a persistent loop (more than 768 tiles), the fused residual + LayerNorm
+GEMM runs above 8 192 rows, and the pipelined attention kernel walks (sentence, head) items with the next item's
+Q / K / V in flight (more than 768 items = more than 64 sentences).  Nothing below 8 193 tokens per call enters any of
+them, so these tests do, against the CPU oracle (cpu/encoder/traits.rs:66-139, encoder_self_attention.rs:143-307):
+
+ (a) a whole 262 144-token chunk plus a ragged tail through the 2-layer model, every row;
+ (b) the projections at 16 384 rows with every epilogue, attention at 200 sentences;
+ (c) the full configs once: sampled rows against the oracle, rows re-encoded in 64-sentence calls, chunk invariance;
+ (d) seeded random sweeps of call sizes / GEMM shapes (formerly tools/encoder_fuzz.py, tools/gemm_fuzz.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4      # north_star: logits / embeddings within 1e-4 of the reference CPU path
+OP_TOL = 1e-5   # single operators
+
+
+def _oracle(tensors, cfg):
+    # the reference's own 4 x 3 AVX2 block kernel order (cpu/kernels/x86/f32.rs:8-127) -- and 4x faster on the host
+    return O.OracleModel(tensors, cfg, blocked_gemm=True)
+
+
+@pytest.fixture(scope="module")
+def minilm2(tmp_path_factory):
+    import kjarni_amd
+    d = str(tmp_path_factory.mktemp("minilm2"))
+    cfg, t = synth.minilm_embedder(d, seed=5, num_hidden_layers=2)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    yield enc, _oracle(t, cfg)
+    enc.close()
+
+
+@pytest.fixture(scope="module")
+def cross2(tmp_path_factory):
+    import kjarni_amd
+    d = str(tmp_path_factory.mktemp("cross2"))
+    cfg, t = synth.minilm_cross_encoder(d, seed=6, num_hidden_layers=2)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    yield enc, _oracle(t, cfg)
+    enc.close()
+
+
+@pytest.fixture(scope="module")
+def minilm6(tmp_path_factory):
+    import kjarni_amd
+    d = str(tmp_path_factory.mktemp("minilm6"))
+    cfg, t = synth.minilm_embedder(d, seed=0)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    yield enc, _oracle(t, cfg)
+    enc.close()
+
+
+@pytest.fixture(scope="module")
+def cross6(tmp_path_factory):
+    import kjarni_amd
+    d = str(tmp_path_factory.mktemp("cross6"))
+    cfg, t = synth.minilm_cross_encoder(d, seed=1)
+    enc = kjarni_amd.HipEncoder(d, 0)
+    yield enc, _oracle(t, cfg)
+    enc.close()
+
+
+# ------------------------------------------------------------------------------------------------ (a)
+@pytest.mark.parametrize("B,S,ragged", [(2100, 128, True), (300, 100, True), (2048, 128, False)])
+def test_whole_chunk_and_tail_embed_every_row(minilm2, B, S, ragged):
+    """2 100 x 128 = one full 2 048-sentence chunk (18 432 QKV tiles, 24 576 attention items) + a 52-sentence tail on the
+    mid-size route; 300 x 100 = 30 000 tokens in one chunk with a sequence length that is not a tile multiple."""
+    enc, orc = minilm2
+    ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=ragged)
+    got = enc.embed(ids, mask)
+    ref = orc.embed_batch(ids, mask)
+    err = np.abs(got - ref).max(axis=1)
+    assert np.isfinite(got).all()
+    assert float(err.max()) < TOL, (int(err.argmax()), float(err.max()))
+
+
+def test_whole_chunk_and_tail_rerank_logits_every_row(cross2):
+    enc, orc = cross2
+    ids, mask, types = synth.synthetic_pairs(2060, 128, seed=9)
+    rng = np.random.default_rng(9)
+    for i in rng.choice(2060, 700, replace=False):  # a third of the pairs are shorter than the padded length
+        n = int(rng.integers(24, 128))
+        ids[i, n - 1] = 102
+        ids[i, n:] = 0
+        mask[i, n:] = 0
+    got = enc.logits(ids, mask, types)[:, 0]
+    ref = orc.rerank_scores(ids, mask, types)
+    err = np.abs(got - ref)
+    assert float(err.max()) < TOL, (int(err.argmax()), float(err.max()))
+
+
+def test_hidden_states_of_a_large_call(minilm2):
+    """hidden_states writes the layer outputs straight into the caller's buffer (no pooling): 80 x 128 = 10 240 tokens
+    is above the 8 192-row boundary, so the fused LayerNorm tile kernel produces what is compared."""
+    import kjarni_amd
+    enc, orc = minilm2
+    ids, mask = synth.synthetic_ids(80, 128, seed=80, ragged=True)
+    for fill, mv in ((kjarni_amd.MASK_NEG_1E9, O.MASK_ALLOC), (kjarni_amd.MASK_NEG_INF, O.MASK_NOALLOC)):
+        got = enc.hidden_states(ids, mask, fill=fill)
+        ref = orc.forward(ids, mask, None, mv)
+        assert float(np.abs(got - ref).max()) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ (b)
+@pytest.mark.parametrize("m,k,n", [(16384, 384, 1152), (16384, 384, 1536), (16400, 1536, 384), (16384, 384, 384),
+                                   (100000, 384, 1152), (98400, 384, 128)])
+def test_linear_on_the_persistent_tiles(m, k, n):
+    """128 x 128 tiles: 1 152 / 1 536 / 387 / 384 / 7 038 / 769 tiles -- the plain epilogue loops over tiles above 768,
+    the others run one workgroup per tile; M tails included."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(m + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32)
+    base = O.linear(x, w, b, blocked=True)
+    tol = OP_TOL * max(1.0, float(np.abs(base).max()))
+    cases = [(ops.EPI_BIAS, None, base),
+             (ops.EPI_BIAS_GELU, None, O.activation(base, O.ACT_GELU)),
+             (ops.EPI_BIAS_RESIDUAL, r, base + r)]
+    if m <= 20000:
+        cases += [(ops.EPI_BIAS_GELU_NEW, None, O.activation(base, O.ACT_GELU_NEW)),
+                  (ops.EPI_BIAS_RELU, None, np.maximum(base, 0)),
+                  (ops.EPI_BIAS_TANH, None, O.activation(base, O.ACT_TANH))]
+    for epi, res, ref in cases:
+        got, _ = ops.linear(x, w, b, res, epi)
+        err = float(np.abs(got - ref).max())
+        assert err < tol, (epi, err)
+    got, _ = ops.linear(x, w, None, None, ops.EPI_BIAS)
+    assert float(np.abs(got - O.linear(x, w, blocked=True)).max()) < tol
+
+
+@pytest.mark.parametrize("m,k", [(16384, 384), (16400, 1536), (70001, 384)])
+def test_fused_layernorm_projection_on_large_calls(m, k):
+    from kjarni_amd import ops
+    n = 384
+    rng = np.random.default_rng(m + k)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = (rng.standard_normal((m, n)) * 2 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    ref = O.layer_norm(O.linear(x, w, b, blocked=True) + r, g, beta, 1e-12)
+    got, _ = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12)
+    assert float(np.abs(got - ref).max()) < OP_TOL * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("B,S", [(200, 128), (200, 100), (200, 37), (1100, 128), (70, 128)])
+def test_attention_on_the_item_loop(B, S):
+    """d = 32, S <= 128 and more than 768 (sentence, head) items: the persistent kernel with prefetch and deferred stores;
+    70 x 12 = 840 items is the first size past one item per workgroup."""
+    from kjarni_amd import ops
+    heads, d = 12, 32
+    H = heads * d
+    rng = np.random.default_rng(B + S)
+    qkv = rng.standard_normal((B, S, 3 * H)).astype(np.float32)
+    mask = np.ones((B, S), np.uint32)
+    for b in range(B):
+        if b % 3:
+            mask[b, rng.integers(max(1, S // 8), S + 1):] = 0
+    q, k, v = (np.ascontiguousarray(qkv[..., i * H:(i + 1) * H]) for i in range(3))
+    for mv in (O.MASK_ALLOC, O.MASK_NOALLOC):
+        ref = O.attention(q, k, v, mask.astype(np.float32), heads, mask_value=mv)
+        got, _ = ops.attention(qkv, mask, heads, mask_value=float(mv))
+        assert float(np.abs(got - ref).max()) < OP_TOL
+    got, _ = ops.attention(qkv, None, heads)
+    assert float(np.abs(got - O.attention(q, k, v, None, heads)).max()) < OP_TOL
+
+
+# ------------------------------------------------------------------------------------------------ (c)
+def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6):
+    """BASELINE.json configs[1] once: 65 536 x 128 through one call (32 chunks).  64 sampled rows (chunk edges included)
+    against the oracle; those and 192 more re-encoded in 64-sentence calls (mid-size route) agree to 1e-5; another
+    chunk size gives the same vectors."""
+    enc, orc = minilm6
+    N, S = 65536, 128
+    ids, mask = synth.synthetic_ids(N, S, seed=0)
+    rid, rmask = synth.synthetic_ids(N, S, seed=7, ragged=True)
+    ids[1::2], mask[1::2] = rid[1::2], rmask[1::2]   # every other sentence ragged
+    full = enc.embed(ids, mask)
+    assert full.shape == (N, 384) and np.isfinite(full).all()
+    rng = np.random.default_rng(1)
+    edge = np.array([0, 1, 2047, 2048, 2049, 4095, 4096, 65535, 65534, 63488, 63487])
+    rows = np.unique(np.concatenate([edge, rng.choice(N, 256 - len(edge), replace=False)]))
+    for s in range(0, len(rows), 64):
+        sel = rows[s:s + 64]
+        small = enc.embed(np.ascontiguousarray(ids[sel]), np.ascontiguousarray(mask[sel]))
+        assert float(np.abs(small - full[sel]).max()) < 1e-5
+    sel = np.concatenate([edge, rows[::5]])[:64]
+    ref = orc.embed_batch(np.ascontiguousarray(ids[sel]), np.ascontiguousarray(mask[sel]))
+    err = np.abs(full[sel] - ref).max(axis=1)
+    assert float(err.max()) < TOL, (int(sel[err.argmax()]), float(err.max()))
+    enc.set_chunk_tokens(128 * 1000)   # 1 000-sentence chunks: 65 full ones and a 536-sentence tail
+    try:
+        other = enc.embed(ids, mask)
+    finally:
+        enc.set_chunk_tokens(262144)
+    assert float(np.abs(other - full).max()) < 1e-5
+
+
+def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6):
+    """BASELINE.json configs[2] on one GPU: 100 000 pairs x 128."""
+    enc, orc = cross6
+    N, S = 100000, 128
+    ids, mask, types = synth.synthetic_pairs(N, S, seed=1)
+    full = enc.logits(ids, mask, types)[:, 0]
+    assert full.shape == (N,) and np.isfinite(full).all()
+    rng = np.random.default_rng(2)
+    edge = np.array([0, 2047, 2048, 99999, 98304, 98303, 12499, 12500])
+    rows = np.unique(np.concatenate([edge, rng.choice(N, 128 - len(edge), replace=False)]))
+    for s in range(0, len(rows), 64):
+        sel = rows[s:s + 64]
+        small = enc.logits(*(np.ascontiguousarray(a[sel]) for a in (ids, mask, types)))[:, 0]
+        assert float(np.abs(small - full[sel]).max()) < 1e-5
+    sel = np.concatenate([edge, rows[::3]])[:48]
+    ref = orc.rerank_scores(*(np.ascontiguousarray(a[sel]) for a in (ids, mask, types)))
+    err = np.abs(full[sel] - ref)
+    assert float(err.max()) < TOL, (int(sel[err.argmax()]), float(err.max()))
+    order = np.argsort(-full, kind="stable")
+    assert (full[order][:-1] >= full[order][1:]).all()
+
+
+# ------------------------------------------------------------------------------------------------ (d)
+def test_call_size_sweep_against_the_oracle(minilm2):
+    """Seeded sweep over (sentences, padded length): the three projection routes (<= 64 tokens, 65 .. 8 192, more), both
+    attention kernels, ragged masks."""
+    enc, orc = minilm2
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for i in range(24):
+        seq = int(rng.integers(1, 160))
+        tokens = int(rng.choice([40, 64, 65, 300, 2000, 8192, 8300, 20000, 50000]))
+        b = max(1, tokens // seq)
+        ids, mask = synth.synthetic_ids(b, seq, seed=100 + i, ragged=True)
+        got = enc.embed(ids, mask)
+        ref = orc.embed_batch(ids, mask)
+        err = float(np.abs(got - ref).max())
+        worst = max(worst, err)
+        assert err < TOL, (i, b, seq, err)
+    assert worst > 0.0
+
+
+def test_projection_shape_sweep_against_float64():
+    """Seeded sweep of projection shapes and epilogues over all GEMM routes against a float64 evaluation (tolerance
+    2e-5 relative to the largest result: f32 accumulation over K <= 3 072)."""
+    from kjarni_amd import ops
+    from scipy.special import erf
+    rng = np.random.default_rng(0)
+    for i in range(60):
+        m = int(rng.choice([1, 7, 33, 64, 65, 100, 129, 500, 1000, 2049, 4096, 4100, 8192, 8193, 9000, 12000, 20000]))
+        if rng.random() < 0.4:
+            m = int(rng.integers(1, 12000))
+        n = int(rng.choice([4, 32, 60, 64, 128, 256, 384, 388, 512, 768, 1024, 1152, 1536, 2048]))
+        k = int(rng.choice([32, 64, 96, 128, 384, 512, 768, 1024, 1536, 2048, 3072]))
+        x = rng.standard_normal((m, k)).astype(np.float32)
+        w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32) if rng.random() < 0.8 else None
+        r = rng.standard_normal((m, n)).astype(np.float32)
+        base = x.astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if b is not None else 0.0)
+        kind = int(rng.integers(0, 5))
+        if kind == 4 and n < 64:  # LayerNorm over a handful of columns is ill-conditioned in f32 whatever computes it
+            kind = 2
+        if kind == 0:
+            got, _ = ops.linear(x, w, b, None, ops.EPI_BIAS)
+            ref = base
+        elif kind == 1:
+            got, _ = ops.linear(x, w, b, None, ops.EPI_BIAS_GELU)
+            ref = 0.5 * base * (1.0 + erf(base / np.sqrt(2.0)))
+        elif kind == 2:
+            got, _ = ops.linear(x, w, b, r, ops.EPI_BIAS_RESIDUAL)
+            ref = base + r
+        elif kind == 3:
+            got, _ = ops.linear(x, w, b, r, ops.EPI_BIAS_MUL_SILU)
+            ref = (r / (1.0 + np.exp(-r.astype(np.float64)))) * base
+        else:
+            g = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+            beta = (0.1 * rng.standard_normal(n)).astype(np.float32)
+            got, _ = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12)
+            v = base + r
+            mu = v.mean(axis=1, keepdims=True)
+            ref = (v - mu) / np.sqrt(((v - mu) ** 2).mean(axis=1, keepdims=True) + 1e-12) * g + beta
+        err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
+        assert err < 2e-5, (i, kind, m, n, k, err)
