@@ -465,6 +465,15 @@ def main():
             enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), n_local, S, out.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         extras["value_ragged"] = round(2 * n_local / (time.perf_counter() - t1), 1)
+        extras["ragged_kept_token_fraction"] = round(float(rmask.sum()) / rmask.size, 4)
+        enc.set_packing(False)   # the same ragged batch on the padded layout (every [PAD] row computed, as the reference does)
+        enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), 1024, S, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), n_local, S, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        extras["value_ragged_padded_layout"] = round(n_local / (time.perf_counter() - t1), 1)
+        enc.set_packing(True)
         # the sizes callers make: one call at a time of 1 / 32 / 256 sentences through host pointers (the reference's default
         # batch is 32, crates/kjarni-ffi/src/embedder.rs); 1 and 32 take the few-rows / mid-size GEMM routes
         by_call = {}
@@ -478,7 +487,8 @@ def main():
             by_call[str(b)] = {"ms_per_call": round(dtc * 1e3, 4), "sentences_per_s": round(b / dtc, 1)}
         extras["value_by_call_size"] = by_call
         extras["extras_note"] = ("value_host_ptrs: ids/mask handed over as host buffers, embeddings returned to the "
-                                 "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128; 2 steps each; "
+                                 "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128, run over the kept tokens only "
+                                 "(packed rows); value_ragged_padded_layout: the same batch with every [PAD] row computed; 2 steps each; "
                                  "value_by_call_size: one host-pointer call at a time of 1 / 32 / 256 sentences x 128 tokens")
 
     if rank == 0:

@@ -72,6 +72,11 @@ int32_t kjarni_hip_encoder_num_labels(const KjarniHipEncoder* enc); /* 0: no cla
 int32_t kjarni_hip_encoder_device(const KjarniHipEncoder* enc);
 /* Tokens processed per internal chunk (workspace size); 0 keeps the default. */
 KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64_t tokens);
+/* Ragged batches: embed / logits run the layers over the kept tokens only (mask != 0) when a call has padding, every
+ * sentence keeps its token 0 and the mask holds only 0 / 1 -- a padded token is observable through neither output
+ * (pooling skips it, pooling/mod.rs:11-33; as a key its score is overwritten, utils/masks.rs:4-36).  On by default;
+ * 0 makes every call take the padded layout (what hidden_states always does).  Results agree to rounding (<= 1e-6). */
+KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
 /* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
  * calls may be made concurrently from any number of host threads and on any streams, as on the reference's
@@ -120,7 +125,8 @@ KjarniErrorCode kjarni_hip_encoder_logits_host(KjarniHipEncoder* enc, const uint
  * independent on this path, so a batch is cut into balanced contiguous row blocks -- floor(rows / n) each, the first
  * rows % n one more (kjarni_hip_group_shard) -- one host thread + one stream per device, no exchange inside the
  * layer loop.  This is what the string-level handles (kjarni_embedder_*, kjarni_reranker_*, kjarni_classifier_*)
- * use internally with the devices of KJARNI_HIP_DEVICES="0,1,..." (default: every visible device; a device may be
+ * use internally with the devices of KJARNI_HIP_DEVICES="0,1,..." (default: every visible device -- or, in a process
+ * whose launcher exported LOCAL_RANK (one process per GPU), that one device; a device may be
  * listed twice); n_devices = 0 here means the same list.  A batch smaller than 8 rows per device uses fewer
  * devices, chosen in rotation. */
 typedef struct KjarniHipEncoderGroup KjarniHipEncoderGroup;
@@ -146,7 +152,8 @@ KjarniErrorCode kjarni_hip_group_logits_host(KjarniHipEncoderGroup* group, const
  * at a full [batch_total, hidden] (or [batch_total, num_labels]) buffer on device i.  Every replica computes its block
  * in place, then ONE collective leaves the whole output in every buffer: ncclAllGather over xGMI (grouped
  * ncclBroadcast when the blocks differ by a row) when the devices are distinct, peer copies otherwise.  Returns when
- * the collective has completed.  type_ids_dev may be NULL.  kjarni_hip_group_transport: "rccl" or "memcpy". */
+ * the collective has completed.  type_ids_dev may be NULL.  kjarni_hip_group_transport: "rccl" or "memcpy"
+ * ("memcpy (ncclCommInitAll failed: ...)" when RCCL is present but could not build the communicator). */
 KjarniErrorCode kjarni_hip_group_embed_allgather(KjarniHipEncoderGroup* group, const uint32_t* const* ids_dev,
                                                  const uint32_t* const* mask_dev, const uint32_t* const* type_ids_dev,
                                                  int64_t batch_total, int32_t seq, KjarniHipPooling pooling,
@@ -354,6 +361,8 @@ void kjarni_hip_decoder_free(KjarniHipDecoder* decoder);
 KjarniErrorCode kjarni_hip_decoder_dims(const KjarniHipDecoder* decoder, int32_t* hidden, int32_t* layers, int32_t* vocab,
                                         int32_t* context, int32_t* weights_bf16, uint64_t* weight_bytes);
 KjarniErrorCode kjarni_hip_decoder_reset(KjarniHipDecoder* decoder); /* empty KV cache */
+/* Prompt projections that took the 128 x 128-tile GEMM route since load (0 on NULL): a route counter for tests. */
+uint64_t kjarni_hip_decoder_tile_gemm_calls(const KjarniHipDecoder* decoder);
 /* CpuDecoder::forward + final norm + lm head (llama/cpu_decoder.rs:196-219): appends n tokens to the cache;
  * the prompt is processed 8 rows at a time and hidden_out receives the final-normed rows of the LAST block,
  * f32 [((n-1) mod 8) + 1, hidden]; logits_out f32 [vocab] of the last position.  Either may be NULL. */

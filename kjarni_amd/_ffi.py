@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 import numpy as np
 
@@ -388,6 +388,7 @@ SIGNATURES = {
     "kjarni_hip_decoder_dims": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                           POINTER(c_int32), POINTER(C.c_uint64)]),
     "kjarni_hip_decoder_reset": (c_int32, [c_void_p]),
+    "kjarni_hip_decoder_tile_gemm_calls": (c_uint64, [c_void_p]),
     "kjarni_hip_decoder_forward": (c_int32, [c_void_p, _u32p, c_int32, _f32p, _f32p]),
     "kjarni_hip_decoder_generate": (c_int32, [c_void_p, _u32p, c_size_t, c_size_t, c_float, c_int32, KjarniTokenCallbackFn, c_void_p,
                                               _u32p, c_size_t, POINTER(c_size_t)]),
@@ -412,6 +413,7 @@ SIGNATURES = {
     "kjarni_hip_encoder_num_labels": (c_int32, [c_void_p]),
     "kjarni_hip_encoder_device": (c_int32, [c_void_p]),
     "kjarni_hip_encoder_set_chunk_tokens": (c_int32, [c_void_p, c_int64]),
+    "kjarni_hip_encoder_set_packing": (c_int32, [c_void_p, c_int32]),
     "kjarni_hip_encoder_hidden_states": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                                    c_int32, c_void_p, c_void_p]),
     "kjarni_hip_encoder_embed": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

@@ -59,7 +59,7 @@ template <int D>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv,
                                                         const uint32_t* __restrict__ mask, int seq,
                                                         int heads, float scale, float mask_value,
-                                                        float* __restrict__ ctx)
+                                                        const int32_t* __restrict__ cu, float* __restrict__ ctx)
 {
     using SM = AttnSmem<D>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,7 +77,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     const int64_t b = blockIdx.z;
     const int hidden = heads * D;
     const int64_t row_stride = 3 * (int64_t)hidden;
-    const float* base = qkv + b * seq * row_stride;
+    // packed rows: the sentence is rows cu[b] .. cu[b+1], all of them kept tokens; the grid covers the longest sentence
+    int64_t row0 = b * seq;
+    if (cu) {
+        row0 = cu[b];
+        seq = cu[b + 1] - cu[b];
+        mask = nullptr;
+        if (qb * QBLK >= seq) return;
+    }
+    const float* base = qkv + row0 * row_stride;
     const float* q_base = base + h * D;
     const float* k_base = base + hidden + h * D;
     const float* v_base = base + 2 * hidden + h * D;
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         if (tid < KCHUNK) {
             const int key = key0 + tid;
             float mv = -1.0f;
-            if (key < seq) mv = (mask == nullptr || mask[b * seq + key] != 0u) ? 1.0f : 0.0f;
+            if (key < seq) mv = (mask == nullptr || mask[row0 + key] != 0u) ? 1.0f : 0.0f;
             sMask[tid] = mv;
             plain = mv == 1.0f;
         }
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) inv_sum[r] = __shfl(inv, acc_row(r, half), kWave);
     }
-    float* out_base = ctx + b * seq * (int64_t)hidden + h * D;
+    float* out_base = ctx + row0 * (int64_t)hidden + h * D;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q = qb * QBLK + wid * 32 + acc_row(r, half);
@@ -273,11 +281,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // DIAG (tuning build only, tools/gemm_probe.py attn): 0 the kernel; knock-outs that show where an item's time goes --
 // 1 no softmax arithmetic, 2 no LDS staging of K / V after the first item, 3 no output stores, 4 no K / V / Q prefetch,
 // 5 no matrix work (memory only), 6 non-temporal K / V / Q loads.
-template <int D, int DIAG>
+// VARLEN (packed rows of a ragged batch): item (b, h) is rows cu[b] .. cu[b+1], every key a kept token -- no mask; a wave
+// whose 32 queries lie past the sentence's end, and 32-key tiles past it, are skipped (wave-uniform branches), so an
+// item costs ceil(len / 32)^2 / 16 of a 128-token one.
+template <int D, int DIAG, bool VARLEN>
 __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __restrict__ qkv,
                                                                 const uint32_t* __restrict__ mask,
                                                                 int64_t n_items, int seq, int heads,
                                                                 float scale, float mask_value,
+                                                                const int32_t* __restrict__ cu,
                                                                 float* __restrict__ ctx)
 {
     using SM = AttnSmem<D>;
@@ -310,8 +322,19 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
     }
     const uint32_t off_q = (uint32_t)(((int64_t)q_row * row_stride + half * 4) * 4);
     const uint32_t off_o = (uint32_t)(((int64_t)(wid * 32 + 4 * half) * hidden + l31) * 4);
-    const int span_in = (int)((((int64_t)seq - 1) * row_stride + D) * 4);   // bytes of one head's rows of Q, K or V
-    const int span_out = (int)((((int64_t)seq - 1) * hidden + D) * 4);
+    auto span_in_of = [&](int len) { return (int)((((int64_t)len - 1) * row_stride + D) * 4); };  // bytes of one head's rows of Q, K or V
+    auto span_out_of = [&](int len) { return (int)((((int64_t)len - 1) * hidden + D) * 4); };
+    // first row and length of an item's sentence (scalars)
+    auto item_rows = [&](int b, int64_t& row0, int& len) {
+        if (VARLEN) {
+            const int c0 = __builtin_amdgcn_readfirstlane(cu[b]), c1 = __builtin_amdgcn_readfirstlane(cu[b + 1]);
+            row0 = c0;
+            len = c1 - c0;
+        } else {
+            row0 = (int64_t)b * seq;
+            len = seq;
+        }
+    };
     auto rsrc = [](const float* p, int bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
     };
@@ -330,8 +353,12 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         }
     };
 
+    int64_t pre_row0 = 0;  // rows of the item whose K / V / Q were requested last
+    int pre_len = seq;
     auto prefetch_kv = [&](int b, int h) {
-        const float* base = qkv + (int64_t)b * seq * row_stride + h * D;
+        item_rows(b, pre_row0, pre_len);
+        const float* base = qkv + pre_row0 * row_stride + h * D;
+        const int span_in = span_in_of(pre_len);
         const __amdgpu_buffer_rsrc_t rk = rsrc(base + hidden, span_in), rv = rsrc(base + 2 * hidden, span_in);
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
@@ -340,17 +367,19 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         }
     };
     // Q fragments (B operand of S^T = K Q^T) and the keep-bits of keys 0..63 / 64..127.
-    auto prefetch_q = [&](int b, int h) {
-        const __amdgpu_buffer_rsrc_t rq = rsrc(qkv + (int64_t)b * seq * row_stride + h * D, span_in);
+    auto prefetch_q = [&](int b, int h) {  // (after prefetch_kv of the same item: pre_row0 / pre_len are its rows)
+        const __amdgpu_buffer_rsrc_t rq = rsrc(qkv + pre_row0 * row_stride + h * D, span_in_of(pre_len));
 #pragma unroll
         for (int kk = 0; kk < D / 8; ++kk) qf[kk] = ld16(rq, off_q, kk * 32);
-        bool k0 = lane < seq, k1 = lane + 64 < seq;
-        if (mask != nullptr) {
-            if (k0) k0 = mask[(int64_t)b * seq + lane] != 0u;
-            if (k1) k1 = mask[(int64_t)b * seq + lane + 64] != 0u;
+        if (!VARLEN) {
+            bool k0 = lane < seq, k1 = lane + 64 < seq;
+            if (mask != nullptr) {
+                if (k0) k0 = mask[(int64_t)b * seq + lane] != 0u;
+                if (k1) k1 = mask[(int64_t)b * seq + lane + 64] != 0u;
+            }
+            keep_lo = __ballot(k0);
+            keep_hi = __ballot(k1);
         }
-        keep_lo = __ballot(k0);
-        keep_hi = __ballot(k1);
     };
 
     int64_t item = blockIdx.x;
@@ -358,6 +387,8 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         prefetch_kv(cur_b, cur_h);
         prefetch_q(cur_b, cur_h);
     }
+    int64_t cur_row0 = pre_row0;  // rows of the item the loop body computes
+    int cur_len = pre_len;
 
     // The finished item's output tile waits in registers and is stored right after the NEXT item's staging
     // barrier: its stores are then older than that item's prefetch loads, so the (conservative) wait for those
@@ -368,9 +399,10 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_pend[dt][r] = 0.0f;
     const float* pend_base = nullptr;
+    int pend_len = seq;
     auto flush = [&]() {
         if (pend_base == nullptr) return;
-        const __amdgpu_buffer_rsrc_t ro = rsrc(pend_base, span_out);
+        const __amdgpu_buffer_rsrc_t ro = rsrc(pend_base, span_out_of(pend_len));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (DIAG != 3 || o_pend[0][r] == 123456.789f) {
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
 #pragma unroll
             for (int c = 0; c < 4; ++c) sVt[(c4 * 4 + c) * SM::VT_STRIDE + r] = vreg[it][c];
         }
-        const int b = cur_b, h = cur_h;
+        const int h = cur_h;
         const int64_t next = item + gridDim.x;
         int nb = cur_b, nh = cur_h;
         advance(nb, nh);
@@ -403,9 +435,13 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         flush();                                               // the previous item's outputs
         if (next < n_items && DIAG != 4) prefetch_kv(nb, nh);  // in flight during this item's MFMAs + softmax
 
+        const int len = cur_len;                                       // (VARLEN: this sentence's; else seq)
+        const int nkt = VARLEN ? ((len + 31) >> 5) : 4;                // 32-key tiles that hold keys
+        const bool wave_on = !VARLEN || wid * 32 < len;                // wave-uniform: do this wave's queries exist
         f32x16 s[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+            if (VARLEN && !(wave_on && kt < nkt)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
             const float* pk = sK + (kt * 32 + l31) * SM::K_STRIDE + half * 4;
@@ -429,9 +465,9 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         if (next < n_items && DIAG != 4) prefetch_q(nb, nh);
 
         // scale (after the dot product, as the reference) then mask overwrite.
-        const unsigned long long valid_lo = seq >= 64 ? ~0ull : ((1ull << seq) - 1ull);
-        const unsigned long long valid_hi = seq >= 128 ? ~0ull : (seq > 64 ? ((1ull << (seq - 64)) - 1ull) : 0ull);
-        const bool no_mask = (cur_lo == ~0ull) && (cur_hi == ~0ull);  // wave-uniform
+        const unsigned long long valid_lo = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        const unsigned long long valid_hi = len >= 128 ? ~0ull : (len > 64 ? ((1ull << (len - 64)) - 1ull) : 0ull);
+        const bool no_mask = VARLEN ? (len & 31) == 0 : (cur_lo == ~0ull) && (cur_hi == ~0ull);  // wave-uniform
         // Softmax in the exp2 domain with as few vector-ALU instructions as it takes -- on this part the f32 MFMAs and
         // the VALU share the FP32 lanes, so every VALU instruction here is time the matrix pipe idles:
         //   max over the RAW dot products (c1 > 0, so max(c1 s) = c1 max(s); v_max3: two elements per instruction),
@@ -443,7 +479,7 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         // fma, -inf stays -inf).
         const float c1 = scale * 1.4426950408889634f;
         const float masked_raw = mask_value / scale;
-        if (DIAG != 1 && DIAG != 5) {
+        if (DIAG != 1 && DIAG != 5 && wave_on) {
         if (!no_mask) {
             // this lane's keys are bit (kt*32 + (r&3) + 8*(r>>2)) + 4*half of the 128-bit sets
             const unsigned sh = 4u * (unsigned)half;
@@ -451,28 +487,33 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
                                         (unsigned)(cur_hi >> sh), (unsigned)(cur_hi >> (32 + sh))};
             const unsigned val_w[4] = {(unsigned)(valid_lo >> sh), (unsigned)(valid_lo >> (32 + sh)),
                                        (unsigned)(valid_hi >> sh), (unsigned)(valid_hi >> (32 + sh))};
-            const bool all_valid = seq >= KCHUNK;  // wave-uniform
+            const bool all_valid = len >= KCHUNK;  // wave-uniform
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (VARLEN && kt != nkt - 1) continue;  // only the last tile that holds keys is partial
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
-                    float v = (keep_w[kt] & bit) ? s[kt][r] : masked_raw;  // masked key: score overwritten
+                    float v = (VARLEN || (keep_w[kt] & bit)) ? s[kt][r] : masked_raw;  // masked key: score overwritten
                     if (!all_valid) v = (val_w[kt] & bit) ? v : -INFINITY;  // key beyond seq: contributes exactly 0
                     s[kt][r] = v;
                 }
+            }
         }
         float cmax = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
+            if (VARLEN && kt >= nkt) continue;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) cmax = fmaxf(fmaxf(cmax, s[kt][r]), s[kt][r + 1]);
+        }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, kWave));
         const float neg = -cmax * c1;  // (+inf for an all -inf row: exp2(-inf + inf) = NaN, as the reference)
         const f32x2 c1v = {c1, c1}, negv = {neg, neg};
         f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
+            if (VARLEN && kt >= nkt) continue;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 t = __builtin_elementwise_fma(f32x2{s[kt][r], s[kt][r + 1]}, c1v, negv);
@@ -481,19 +522,22 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
                 s[kt][r + 1] = e[1];
                 sum2 += e;
             }
+        }
         float csum = sum2[0] + sum2[1];
         csum += __shfl_xor(csum, 32, kWave);
         if (csum > 0.0f) {  // activations.rs:236-241
             const float inv = 1.0f / csum;
             const f32x2 invv = {inv, inv};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (VARLEN && kt >= nkt) continue;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const f32x2 pr = f32x2{s[kt][r], s[kt][r + 1]} * invv;
                     s[kt][r] = pr[0];
                     s[kt][r + 1] = pr[1];
                 }
+            }
         }
         }
 
@@ -504,7 +548,8 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
             const float* pv = sVt + (dt * 32 + l31) * SM::VT_STRIDE + half * 4;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (VARLEN && !(wave_on && kt < nkt)) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 vf = *reinterpret_cast<const f32x4*>(pv + kt * 32 + g * 8);
@@ -518,13 +563,17 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
                     }
                     if (g == 1 || g == 3) __builtin_amdgcn_sched_barrier(0);
                 }
+            }
         }
 
-        pend_base = ctx + (int64_t)b * seq * hidden + h * D;
+        pend_base = ctx + cur_row0 * hidden + h * D;
+        pend_len = len;
 #pragma unroll
         for (int dt = 0; dt < D / 32; ++dt) o_pend[dt] = o[dt];
         cur_b = nb;
         cur_h = nh;
+        cur_row0 = pre_row0;
+        cur_len = pre_len;
         __syncthreads();  // everyone is done with sK / sVt before the next item overwrites them
     }
     flush();
@@ -536,7 +585,7 @@ __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __re
                                                                const uint32_t* __restrict__ mask,
                                                                int seq, int heads, int head_dim,
                                                                float scale, float mask_value,
-                                                               float* __restrict__ ctx)
+                                                               const int32_t* __restrict__ cu, float* __restrict__ ctx)
 {
     extern __shared__ float srow[];  // [seq]
     const int lane = threadIdx.x;
@@ -544,7 +593,14 @@ __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __re
     const int64_t b = blockIdx.z;
     const int hidden = heads * head_dim;
     const int64_t rs = 3 * (int64_t)hidden;
-    const float* base = qkv + b * seq * rs;
+    int64_t row0 = b * seq;
+    if (cu) {  // packed rows
+        row0 = cu[b];
+        seq = cu[b + 1] - cu[b];
+        mask = nullptr;
+        if (q >= seq) return;
+    }
+    const float* base = qkv + row0 * rs;
     const float* qv = base + q * rs + h * head_dim;
     float mx = -INFINITY;
     for (int j = lane; j < seq; j += 64) {
@@ -552,7 +608,7 @@ __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __re
         float s = 0.0f;
         for (int d = 0; d < head_dim; ++d) s = fmaf(qv[d], kv[d], s);
         s *= scale;
-        if (mask && mask[b * seq + j] == 0u) s = mask_value;
+        if (mask && mask[row0 + j] == 0u) s = mask_value;
         srow[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -570,13 +626,13 @@ __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __re
         float acc = 0.0f;
         for (int j = 0; j < seq; ++j)
             acc = fmaf(srow[j] * inv, base[j * rs + 2 * hidden + h * head_dim + d], acc);
-        ctx[(b * seq + q) * (int64_t)hidden + h * head_dim + d] = acc;
+        ctx[(row0 + q) * (int64_t)hidden + h * head_dim + d] = acc;
     }
 }
 
 template <int D>
 hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads,
-                    float mask_value, float* ctx, hipStream_t stream)
+                    float mask_value, float* ctx, hipStream_t stream, const int32_t* cu)
 {
     using SM = AttnSmem<D>;
     static bool attr_set[64] = {};
@@ -603,26 +659,34 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         static_assert(D != 32 || SM::BYTES <= 64 * 1024, "the pipelined kernel would need the dynamic-LDS opt-in");
 #ifdef KJARNI_TUNING
         switch (g_attention_variant) {
-        case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
-        case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
-        case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
-        case 16: hipLaunchKernelGGL((attention_pipe_kernel<D, 6>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
-        case 15: hipLaunchKernelGGL((attention_pipe_kernel<D, 5>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
-        case 14: hipLaunchKernelGGL((attention_pipe_kernel<D, 4>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, ctx); return hipGetLastError();
+        case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 16: hipLaunchKernelGGL((attention_pipe_kernel<D, 6, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 15: hipLaunchKernelGGL((attention_pipe_kernel<D, 5, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 14: hipLaunchKernelGGL((attention_pipe_kernel<D, 4, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
         default: break;
         }
 #endif
-        hipLaunchKernelGGL((attention_pipe_kernel<D, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
-                           seq, heads, scale, mask_value, ctx);
+        if (cu)
+            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, true>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, nullptr, n_items,
+                               seq, heads, scale, mask_value, cu, ctx);
+        else
+            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
+                               seq, heads, scale, mask_value, nullptr, ctx);
         return hipGetLastError();
     }
     // grid.z is limited to 65535 sentences per launch.
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
         dim3 grid((unsigned)((seq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)nb);
-        hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), SM::BYTES, stream,
-                           qkv + b0 * seq * 3 * (int64_t)heads * D, mask ? mask + b0 * seq : nullptr,
-                           seq, heads, scale, mask_value, ctx + b0 * seq * (int64_t)heads * D);
+        if (cu)  // packed rows: absolute row offsets come from cu
+            hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), SM::BYTES, stream, qkv, nullptr, seq, heads, scale, mask_value,
+                               cu + b0, ctx);
+        else
+            hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), SM::BYTES, stream,
+                               qkv + b0 * seq * 3 * (int64_t)heads * D, mask ? mask + b0 * seq : nullptr,
+                               seq, heads, scale, mask_value, nullptr, ctx + b0 * seq * (int64_t)heads * D);
     }
     return hipGetLastError();
 }
@@ -634,20 +698,24 @@ void set_attention_variant(int v) { g_attention_variant = v; }
 #endif
 
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads,
-                            int head_dim, float mask_value, float* ctx, hipStream_t stream)
+                            int head_dim, float mask_value, float* ctx, hipStream_t stream, const int32_t* cu)
 {
     if (batch <= 0 || seq <= 0) return hipSuccess;
     const bool aligned = ((heads * head_dim) % 4 == 0) && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
-    if (head_dim == 32 && aligned) return launch_d<32>(qkv, mask, batch, seq, heads, mask_value, ctx, stream);
-    if (head_dim == 64 && aligned) return launch_d<64>(qkv, mask, batch, seq, heads, mask_value, ctx, stream);
+    if (head_dim == 32 && aligned) return launch_d<32>(qkv, mask, batch, seq, heads, mask_value, ctx, stream, cu);
+    if (head_dim == 64 && aligned) return launch_d<64>(qkv, mask, batch, seq, heads, mask_value, ctx, stream, cu);
     const float scale = 1.0f / sqrtf((float)head_dim);
     for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
         const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
         dim3 grid((unsigned)seq, (unsigned)heads, (unsigned)nb);
-        hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream,
-                           qkv + b0 * seq * 3 * (int64_t)heads * head_dim,
-                           mask ? mask + b0 * seq : nullptr, seq, heads, head_dim, scale, mask_value,
-                           ctx + b0 * seq * (int64_t)heads * head_dim);
+        if (cu)
+            hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream, qkv, nullptr, seq, heads,
+                               head_dim, scale, mask_value, cu + b0, ctx);
+        else
+            hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream,
+                               qkv + b0 * seq * 3 * (int64_t)heads * head_dim,
+                               mask ? mask + b0 * seq : nullptr, seq, heads, head_dim, scale, mask_value, nullptr,
+                               ctx + b0 * seq * (int64_t)heads * head_dim);
     }
     return hipGetLastError();
 }

@@ -51,7 +51,8 @@ EncoderModel::~EncoderModel()
         (void)hipEventDestroy(pe.stop);
     }
     for (auto& w : ws_all_) {
-        for (void* p : {(void*)w->hidden, (void*)w->qkv, (void*)w->ctx, (void*)w->mid, (void*)w->feat, (void*)w->split, w->stage})
+        for (void* p : {(void*)w->hidden, (void*)w->qkv, (void*)w->ctx, (void*)w->mid, (void*)w->feat, (void*)w->split, w->stage,
+                        (void*)w->tok_src, (void*)w->cu, (void*)w->lens})
             if (p) (void)hipFree(p);
         if (w->done) (void)hipEventDestroy(w->done);
         if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -496,31 +497,46 @@ EncoderModel::Lease::~Lease()
 void EncoderModel::reserve(Workspace& ws, int64_t tokens, int64_t sentences)
 {
     if (tokens <= ws.tokens && sentences <= ws.sentences) return;
-    tokens = std::max(tokens, ws.tokens);
-    sentences = std::max(sentences, ws.sentences);
     // Earlier launches on this workspace may still be reading the buffers.
     if (ws.done_pending) {
         hip_check(hipEventSynchronize(ws.done), "hipEventSynchronize(workspace)");
         ws.done_pending = false;
     }
-    ws.tokens = ws.sentences = 0;
-    ws.split_floats = 0;
-    for (float** p : {&ws.hidden, &ws.qkv, &ws.ctx, &ws.mid, &ws.feat, &ws.split})
-        if (*p) {
-            (void)hipFree(*p);
-            *p = nullptr;
+    const size_t H = (size_t)cfg_.hidden, I = (size_t)cfg_.inter;
+    // the per-token buffers and the per-sentence buffer grow independently (a ragged call on packed rows holds more
+    // sentences per chunk than a padded one of the same token count)
+    if (tokens > ws.tokens) {
+        ws.tokens = 0;
+        ws.split_floats = 0;
+        for (float** p : {&ws.hidden, &ws.qkv, &ws.ctx, &ws.mid, &ws.split})
+            if (*p) {
+                (void)hipFree(*p);
+                *p = nullptr;
+            }
+        if (ws.tok_src) {
+            (void)hipFree(ws.tok_src);
+            ws.tok_src = nullptr;
         }
-    const size_t H = (size_t)cfg_.hidden, I = (size_t)cfg_.inter, T = (size_t)tokens;
-    hip_check(hipMalloc((void**)&ws.hidden, T * H * 4), "hipMalloc(ws_hidden)");
-    hip_check(hipMalloc((void**)&ws.qkv, T * 3 * H * 4), "hipMalloc(ws_qkv)");
-    hip_check(hipMalloc((void**)&ws.ctx, T * H * 4), "hipMalloc(ws_ctx)");
-    hip_check(hipMalloc((void**)&ws.mid, T * I * 4), "hipMalloc(ws_mid)");
-    hip_check(hipMalloc((void**)&ws.feat, (size_t)sentences * H * 4), "hipMalloc(ws_feat)");
-    const size_t split_floats = gemm_scratch_floats(tokens, cfg_.hidden);
-    hip_check(hipMalloc((void**)&ws.split, split_floats * 4), "hipMalloc(ws_split)");
-    ws.split_floats = split_floats;
-    ws.tokens = tokens;
-    ws.sentences = sentences;
+        const size_t T = (size_t)tokens;
+        hip_check(hipMalloc((void**)&ws.hidden, T * H * 4), "hipMalloc(ws_hidden)");
+        hip_check(hipMalloc((void**)&ws.qkv, T * 3 * H * 4), "hipMalloc(ws_qkv)");
+        hip_check(hipMalloc((void**)&ws.ctx, T * H * 4), "hipMalloc(ws_ctx)");
+        hip_check(hipMalloc((void**)&ws.mid, T * I * 4), "hipMalloc(ws_mid)");
+        hip_check(hipMalloc((void**)&ws.tok_src, T * sizeof(int32_t)), "hipMalloc(ws_tok_src)");
+        const size_t split_floats = gemm_scratch_floats(tokens, cfg_.hidden);
+        hip_check(hipMalloc((void**)&ws.split, split_floats * 4), "hipMalloc(ws_split)");
+        ws.split_floats = split_floats;
+        ws.tokens = tokens;
+    }
+    if (sentences > ws.sentences) {
+        ws.sentences = 0;
+        if (ws.feat) {
+            (void)hipFree(ws.feat);
+            ws.feat = nullptr;
+        }
+        hip_check(hipMalloc((void**)&ws.feat, (size_t)sentences * H * 4), "hipMalloc(ws_feat)");
+        ws.sentences = sentences;
+    }
 }
 
 void* EncoderModel::reserve_stage(Workspace& ws, size_t bytes)
@@ -546,6 +562,7 @@ const char* const kKindNames[KK_COUNT] = {"embed_layernorm", "gemm_qkv", "attent
 
 void EncoderModel::profile_begin(uint32_t kinds_mask)
 {
+    DeviceGuard guard;
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     std::lock_guard<std::mutex> lock(prof_mu_);
@@ -601,6 +618,7 @@ void EncoderModel::prof_stop(hipEvent_t stop, hipStream_t stream)
 
 std::vector<KernelStat> EncoderModel::profile_end()
 {
+    DeviceGuard guard;
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     std::lock_guard<std::mutex> lock(prof_mu_);
@@ -622,15 +640,18 @@ std::vector<KernelStat> EncoderModel::profile_end()
 // no final norm, :300-302).  `hidden` is both the residual stream and the output.
 void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                                  int64_t batch, int seq, float mask_value, float* hidden,
-                                 hipStream_t stream)
+                                 hipStream_t stream, const PackView* pack)
 {
     const int H = cfg_.hidden, I = cfg_.inter;
-    const int64_t T = batch * seq;
+    // rows of every activation buffer: all tokens of the padded layout, or the kept tokens only (packed rows)
+    const int64_t T = pack ? pack->tokens : batch * seq;
+    const int32_t* cu = pack ? pack->cu : nullptr;
+    const int32_t* tok_src = pack ? pack->tok_src : nullptr;
     const double Td = (double)T, Hd = H, Id = I;
     // Algorithmic work per launch (2*M*N*K per GEMM; attention = QK^T + PV), and
     // algorithmic bytes (each operand read once, each output written once).
     const double f_qkv = 2.0 * Td * 3 * Hd * Hd, b_qkv = 4.0 * (Td * Hd + 3 * Hd * Hd + Td * 3 * Hd);
-    const double f_att = 4.0 * (double)batch * seq * seq * Hd, b_att = 4.0 * (Td * 3 * Hd + Td * Hd);
+    const double f_att = 4.0 * (pack ? pack->sum_len_sq : (double)batch * seq * seq) * Hd, b_att = 4.0 * (Td * 3 * Hd + Td * Hd);
     const double f_out = 2.0 * Td * Hd * Hd, b_out = 4.0 * (Td * Hd * 3 + Hd * Hd);
     const double f_fc1 = 2.0 * Td * Hd * Id, b_fc1 = 4.0 * (Td * Hd + Hd * Id + Td * Id);
     const double f_fc2 = 2.0 * Td * Hd * Id, b_fc2 = 4.0 * (Td * Id + Hd * Id + 2 * Td * Hd);
@@ -644,7 +665,7 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     hipEvent_t pe = prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
     hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,
                                      seq, H, cfg_.vocab, cfg_.max_pos, cfg_.type_vocab, cfg_.pos_offset,
-                                     0, hidden, stream),
+                                     0, hidden, stream, tok_src),
               "embed_layernorm");
     prof_stop(pe, stream);
     // hidden = LN(A W^T + b + hidden), in place: a workgroup owns whole rows, reads its residual rows before it
@@ -673,12 +694,12 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
         prof_stop(pe, stream);
         if (rope_cos_) {
             pe = prof_start(KK_ROPE, stream, 0.0, 4.0 * (4 * Td * Hd));
-            hip_check(launch_rope_qk(ws.qkv, rope_cos_, rope_sin_, T, seq, cfg_.heads, H / cfg_.heads, stream), "rope");
+            hip_check(launch_rope_qk(ws.qkv, rope_cos_, rope_sin_, T, seq, cfg_.heads, H / cfg_.heads, stream, tok_src), "rope");
             prof_stop(pe, stream);
         }
         pe = prof_start(KK_ATTENTION, stream, f_att, b_att);
-        hip_check(launch_attention(ws.qkv, mask, batch, seq, cfg_.heads, H / cfg_.heads, mask_value,
-                                   ws.ctx, stream),
+        hip_check(launch_attention(ws.qkv, pack ? nullptr : mask, batch, pack ? pack->max_len : seq, cfg_.heads, H / cfg_.heads,
+                                   mask_value, ws.ctx, stream, cu),
                   "attention");
         prof_stop(pe, stream);
         residual_ln(KK_GEMM_OUT, ws.ctx, H, L.wo, L.bo, L.ln1_g, L.ln1_b, f_out, b_out, "gemm(out_proj)");
@@ -723,10 +744,111 @@ void EncoderModel::hidden_states(const uint32_t* ids, const uint32_t* mask, cons
     }
 }
 
+// Ragged batches.  The reference pads every sentence of a call to the longest (BatchLongest, pipeline/encoder/
+// loader.rs:98-115) and computes all rows; a padded token's hidden state is observable through neither embed (pooling
+// skips it, pooling/mod.rs:11-33) nor logits (token 0 only), and as a KEY it contributes exactly 0 to every kept
+// query's softmax (utils/masks.rs:4-36: score overwritten by -1e9 / -inf).  So embed / logits run the layers over the
+// kept tokens only; hidden_states (which returns padded rows too) keeps the padded layout.  Not packed: calls without
+// padding, a sentence whose token 0 is masked (CLS / the all-masked row rules need the padded rows), mask values other
+// than 0 / 1.
+void EncoderModel::plan_packing(Workspace& ws, const uint32_t* mask_dev, const uint32_t* mask_host, int64_t batch, int seq,
+                                hipStream_t stream, PackPlan& plan)
+{
+    plan.packed = false;
+    if (!packing_ || !mask_dev || batch <= 0 || seq <= 1) return;
+    std::vector<uint32_t> lens((size_t)batch);
+    if (mask_host) {
+        for (int64_t b = 0; b < batch; ++b) {
+            const uint32_t* row = mask_host + b * seq;
+            uint32_t n = 0, over = 0;
+            for (int s = 0; s < seq; ++s) {
+                n += row[s] != 0u;
+                over |= row[s];
+            }
+            lens[(size_t)b] = n | ((over > 1u || row[0] == 0u) ? 0x80000000u : 0u);
+        }
+    } else {
+        // the mask lives on the device: one small kernel + a read-back of 4 bytes per sentence.  A single sentence is
+        // not worth the round trip (a lone sentence is normally as long as its padded length).
+        if (batch == 1) return;
+        if ((size_t)batch > ws.lens_cap) {
+            if (ws.done_pending) {
+                hip_check(hipEventSynchronize(ws.done), "hipEventSynchronize(lens)");
+                ws.done_pending = false;
+            }
+            ws.lens_cap = 0;
+            if (ws.lens) (void)hipFree(ws.lens);
+            ws.lens = nullptr;
+            hip_check(hipMalloc((void**)&ws.lens, (size_t)batch * sizeof(uint32_t)), "hipMalloc(lens)");
+            ws.lens_cap = (size_t)batch;
+        }
+        hip_check(launch_mask_lengths(mask_dev, batch, seq, ws.lens, stream), "mask_lengths");
+        hip_check(hipMemcpyAsync(lens.data(), ws.lens, (size_t)batch * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "D2H lens");
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(lens)");
+    }
+    int64_t total = 0;
+    for (uint32_t l : lens) {
+        if (l & 0x80000000u) return;
+        total += l;
+    }
+    if (total == batch * seq) return;  // nothing is padded
+
+    // chunks: maximal runs of whole sentences within chunk_tokens_ packed rows (a row index must also fit 31 bits)
+    const int64_t cap = std::max<int64_t>(chunk_tokens_, seq);
+    const int64_t max_nb = std::max<int64_t>(1, ((int64_t)1 << 31) / seq - 1);
+    plan.cu.reserve((size_t)batch + 64);
+    for (int64_t b = 0; b < batch;) {
+        PackPlan::Chunk c{b, 0, 0, 0, 0.0, plan.cu.size()};
+        plan.cu.push_back(0);
+        while (b < batch && c.nb < max_nb && c.tokens + (int64_t)lens[(size_t)b] <= cap) {
+            const int l = (int)lens[(size_t)b];
+            c.tokens += l;
+            c.max_len = std::max(c.max_len, l);
+            c.sum_len_sq += (double)l * l;
+            plan.cu.push_back((int32_t)c.tokens);
+            ++c.nb;
+            ++b;
+        }
+        plan.max_tokens = std::max(plan.max_tokens, c.tokens);
+        plan.max_sentences = std::max(plan.max_sentences, c.nb);
+        plan.chunks.push_back(c);
+    }
+    if (plan.cu.size() > ws.cu_ints) {
+        if (ws.done_pending) {
+            hip_check(hipEventSynchronize(ws.done), "hipEventSynchronize(cu)");
+            ws.done_pending = false;
+        }
+        ws.cu_ints = 0;
+        if (ws.cu) (void)hipFree(ws.cu);
+        ws.cu = nullptr;
+        hip_check(hipMalloc((void**)&ws.cu, plan.cu.size() * sizeof(int32_t)), "hipMalloc(cu)");
+        ws.cu_ints = plan.cu.size();
+    }
+    hip_check(hipMemcpyAsync(ws.cu, plan.cu.data(), plan.cu.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream), "H2D cu");
+    // (device-pointer entry points return without synchronising: the copy must have read plan.cu before it goes away)
+    if (!mask_host) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(cu)");
+    plan.packed = true;
+}
+
 void EncoderModel::embed_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                             int64_t batch, int seq, PoolMode pool, bool normalize, float mask_value, float* out,
-                            hipStream_t stream)
+                            hipStream_t stream, const PackPlan& plan)
 {
+    if (plan.packed) {
+        reserve(ws, plan.max_tokens, plan.max_sentences);
+        for (const PackPlan::Chunk& c : plan.chunks) {
+            const PackView pv{ws.cu + c.cu_off, ws.tok_src, c.tokens, c.max_len, c.sum_len_sq};
+            hip_check(launch_pack_index(mask + c.b0 * seq, pv.cu, c.nb, seq, ws.tok_src, stream), "pack_index");
+            forward_chunk(ws, ids + c.b0 * seq, nullptr, type_ids ? type_ids + c.b0 * seq : nullptr, c.nb, seq, mask_value,
+                          ws.hidden, stream, &pv);
+            hipEvent_t pe = prof_start(KK_POOL, stream, 0.0, 4.0 * ((double)c.tokens * cfg_.hidden + (double)c.nb * cfg_.hidden));
+            hip_check(launch_pool(ws.hidden, nullptr, c.nb, seq, cfg_.hidden, pool, normalize ? 1 : 0,
+                                  out + c.b0 * (int64_t)cfg_.hidden, stream, pv.cu),
+                      "pool");
+            prof_stop(pe, stream);
+        }
+        return;
+    }
     const int64_t per = sentences_per_chunk(seq);
     reserve(ws, std::min(per, batch) * seq, std::min(per, batch));
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
@@ -743,10 +865,33 @@ void EncoderModel::embed_on(Workspace& ws, const uint32_t* ids, const uint32_t* 
 }
 
 void EncoderModel::logits_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
-                             int64_t batch, int seq, float mask_value, float* out, hipStream_t stream)
+                             int64_t batch, int seq, float mask_value, float* out, hipStream_t stream, const PackPlan& plan)
 {
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
     const int H = cfg_.hidden;
+    if (plan.packed) {
+        reserve(ws, plan.max_tokens, plan.max_sentences);
+        for (const PackPlan::Chunk& c : plan.chunks) {
+            const PackView pv{ws.cu + c.cu_off, ws.tok_src, c.tokens, c.max_len, c.sum_len_sq};
+            hip_check(launch_pack_index(mask + c.b0 * seq, pv.cu, c.nb, seq, ws.tok_src, stream), "pack_index");
+            forward_chunk(ws, ids + c.b0 * seq, nullptr, type_ids ? type_ids + c.b0 * seq : nullptr, c.nb, seq, mask_value,
+                          ws.hidden, stream, &pv);
+            // CLS rows (the first row of every sentence: token 0 is kept, or the call would not be packed) gathered into
+            // ws.ctx, which the layers are done with; then the head as in the padded layout.
+            hip_check(launch_pool(ws.hidden, nullptr, c.nb, seq, H, POOL_CLS, 0, ws.ctx, stream, pv.cu), "gather CLS rows");
+            const float* feat = ws.ctx;
+            if (cfg_.head_kind == 1 || cfg_.head_kind == 2) {
+                hip_check(launch_gemm(ws.ctx, H, head_dense_w_, head_dense_b_, nullptr, 0, ws.feat, H, c.nb, H, H,
+                                      cfg_.head_kind == 1 ? EPI_BIAS_TANH : EPI_BIAS_RELU, stream),
+                          "gemm(head dense)");
+                feat = ws.feat;
+            }
+            hip_check(launch_small_linear(feat, H, head_cls_w_, head_cls_b_, c.nb, H, cfg_.num_labels,
+                                          out + c.b0 * cfg_.num_labels, stream),
+                      "classifier");
+        }
+        return;
+    }
     const int64_t per = sentences_per_chunk(seq);
     reserve(ws, std::min(per, batch) * seq, std::min(per, batch));
     for (int64_t b0 = 0; b0 < batch; b0 += per) {
@@ -775,15 +920,23 @@ void EncoderModel::embed(const uint32_t* ids, const uint32_t* mask, const uint32
 {
     if (batch <= 0 || seq <= 0) return;
     Lease lease(*this, stream, false);
-    embed_on(lease.ws(), ids, mask, type_ids, batch, seq, pool, normalize, mask_value, out, stream);
+    // (the activation buffers of a padded chunk first: an oversized call fails here, before any kernel has read its pointers)
+    reserve(lease.ws(), std::min(sentences_per_chunk(seq), batch) * seq, std::min(sentences_per_chunk(seq), batch));
+    PackPlan plan;
+    plan_packing(lease.ws(), mask, nullptr, batch, seq, stream, plan);
+    embed_on(lease.ws(), ids, mask, type_ids, batch, seq, pool, normalize, mask_value, out, stream, plan);
 }
 
 void EncoderModel::logits(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
                           int seq, float mask_value, float* out, hipStream_t stream)
 {
     if (batch <= 0 || seq <= 0) return;
+    if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
     Lease lease(*this, stream, false);
-    logits_on(lease.ws(), ids, mask, type_ids, batch, seq, mask_value, out, stream);
+    reserve(lease.ws(), std::min(sentences_per_chunk(seq), batch) * seq, std::min(sentences_per_chunk(seq), batch));
+    PackPlan plan;
+    plan_packing(lease.ws(), mask, nullptr, batch, seq, stream, plan);
+    logits_on(lease.ws(), ids, mask, type_ids, batch, seq, mask_value, out, stream, plan);
 }
 
 // ---- host-pointer entry points ------------------------------------------------------------------------
@@ -833,7 +986,9 @@ void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const u
 {
     run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.hidden, out,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
-                 embed_on(ws, i, k, t, batch, seq, pool, normalize, mask_value, o, st);
+                 PackPlan plan;  // (lives until run_host has synchronised the stream)
+                 plan_packing(ws, k, mask, batch, seq, st, plan);
+                 embed_on(ws, i, k, t, batch, seq, pool, normalize, mask_value, o, st, plan);
              });
 }
 
@@ -843,7 +998,9 @@ void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const 
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
     run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.num_labels, out,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
-                 logits_on(ws, i, k, t, batch, seq, mask_value, o, st);
+                 PackPlan plan;
+                 plan_packing(ws, k, mask, batch, seq, st, plan);
+                 logits_on(ws, i, k, t, batch, seq, mask_value, o, st, plan);
              });
 }
 

@@ -30,6 +30,20 @@ struct InvalidDeviceList : std::runtime_error {  // KJARNI_HIP_DEVICES / an expl
 };
 
 void hip_check(hipError_t e, const char* what);
+
+// Entry points select their model's device with hipSetDevice, which is state of the CALLING host thread: a caller that
+// shares the thread with other HIP code (torch, its own kernels) must find its current device unchanged afterwards.
+class DeviceGuard {
+public:
+    DeviceGuard() { ok_ = hipGetDevice(&prev_) == hipSuccess; }
+    ~DeviceGuard() { if (ok_) (void)hipSetDevice(prev_); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+private:
+    int prev_ = 0;
+    bool ok_ = false;
+};
 int visible_device_count();  // 0 when no HIP device / runtime is usable
 
 struct EncoderConfig {
@@ -80,12 +94,42 @@ struct Workspace {
     float *hidden = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr, *feat = nullptr;
     float* split = nullptr;  // partial tiles of the mid-size GEMM route (gemm.hip), gemm_scratch_floats() floats
     size_t split_floats = 0;
+    // ragged batches (packed rows, rowops.hip): row -> padded token index for `tokens` rows; per-chunk prefix sums of the
+    // sentence lengths; the device-side length scan of the device-pointer entry points
+    int32_t* tok_src = nullptr;
+    int32_t* cu = nullptr;
+    size_t cu_ints = 0;
+    uint32_t* lens = nullptr;
+    size_t lens_cap = 0;
     void* stage = nullptr;  // ids / mask / types in, outputs back, for the host-pointer entry points
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;  // this workspace's own stream (host-pointer entry points run on it)
     hipEvent_t done = nullptr;     // recorded behind the last launch that used the buffers
     hipStream_t done_stream = nullptr;
     bool done_pending = false;
+};
+
+// How a ragged call is cut into chunks of packed rows (host side; built once per call).
+struct PackPlan {
+    struct Chunk {
+        int64_t b0, nb;      // sentences [b0, b0 + nb) of the call
+        int64_t tokens;      // kept tokens = packed rows of the chunk
+        int max_len;         // the longest sentence
+        double sum_len_sq;   // sum of len^2 (attention work)
+        size_t cu_off;       // this chunk's nb + 1 prefix sums inside `cu`
+    };
+    bool packed = false;
+    std::vector<Chunk> chunks;
+    std::vector<int32_t> cu;
+    int64_t max_tokens = 0, max_sentences = 0;
+};
+// The packed rows of one chunk as the kernels see them (device pointers).
+struct PackView {
+    const int32_t* cu;
+    const int32_t* tok_src;
+    int64_t tokens;
+    int max_len;
+    double sum_len_sq;
 };
 
 class EncoderModel {
@@ -101,6 +145,9 @@ public:
     size_t weight_bytes() const { return weight_bytes_; }
     void set_chunk_tokens(int64_t t) { if (t > 0) chunk_tokens_ = t; }
     int64_t chunk_tokens() const { return chunk_tokens_; }
+    // Ragged batches run over the kept tokens only (embed / logits; default on).  Off: every call takes the padded layout.
+    void set_packing(bool on) { packing_ = on; }
+    bool packing() const { return packing_; }
 
     // All pointers are DEVICE pointers on this model's device; work is enqueued
     // on `stream` and not synchronised.  ids/mask/type_ids: u32 [batch, seq].
@@ -151,6 +198,7 @@ private:
         hipStream_t stream() const { return stream_; }
 
     private:
+        DeviceGuard guard_;  // first member: the caller's device comes back after everything else is released
         EncoderModel& m_;
         Workspace* ws_;
         hipStream_t stream_;
@@ -161,12 +209,19 @@ private:
     void run_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq,
                   size_t out_floats, float* out, F&& body);
     // Runs embeddings + all layers for `batch` sentences into hidden (device, [batch*seq, H]).
+    // pack != null: the chunk's rows are its kept tokens only (mask is not read; hidden is [pack->tokens, H]).
     void forward_chunk(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
-                       int64_t batch, int seq, float mask_value, float* hidden, hipStream_t stream);
+                       int64_t batch, int seq, float mask_value, float* hidden, hipStream_t stream,
+                       const PackView* pack = nullptr);
     void embed_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
-                  int seq, PoolMode pool, bool normalize, float mask_value, float* out, hipStream_t stream);
+                  int seq, PoolMode pool, bool normalize, float mask_value, float* out, hipStream_t stream,
+                  const PackPlan& plan);
     void logits_on(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
-                   int seq, float mask_value, float* out, hipStream_t stream);
+                   int seq, float mask_value, float* out, hipStream_t stream, const PackPlan& plan);
+    // Decides whether the call runs on packed rows and, if so, cuts it into chunks and uploads the prefix sums.
+    // mask_host: the same mask on the host when the caller has it (no device round trip), else null.
+    void plan_packing(Workspace& ws, const uint32_t* mask_dev, const uint32_t* mask_host, int64_t batch, int seq,
+                      hipStream_t stream, PackPlan& plan);
     int64_t sentences_per_chunk(int seq) const;
     // LayerNorm folded into the residual GEMMs' epilogue when the kernel covers this model's row width.
     bool fuse_layernorm() const;
@@ -188,6 +243,7 @@ private:
     int device_ = 0;
     size_t weight_bytes_ = 0;
     std::atomic<int64_t> chunk_tokens_{262144};
+    std::atomic<bool> packing_{true};
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,

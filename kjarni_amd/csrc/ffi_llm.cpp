@@ -47,6 +47,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_decoder_dims(const KjarniHipDecoder* d,
     return KJARNI_OK;
 }
 
+KJARNI_EXPORT uint64_t kjarni_hip_decoder_tile_gemm_calls(const KjarniHipDecoder* d) { return d ? d->model->tile_gemm_calls() : 0; }
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_decoder_reset(KjarniHipDecoder* d)
 {
     if (!d) return KJARNI_ERROR_NULL_POINTER;

@@ -1136,10 +1136,17 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
             return hipGetLastError();
         }
     }
-    if (!gemm_residual_layernorm_supported(N, K) || !R || !gamma || !beta || lda % 4 || ldr % 4 || ldy % 4 ||
+    if (!R || !gamma || !beta) return hipErrorInvalidValue;
+    if (!gemm_residual_layernorm_supported(N, K) || lda % 4 || ldr % 4 || ldy % 4 ||
         (int64_t)64 * lda * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31 ||
-        !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y))
-        return hipErrorInvalidValue;
+        !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y)) {
+        // Neither fused form takes this call (an output pointer that is 4- but not 16-byte aligned, a row width the
+        // tile kernel does not cover with a call outside the K-sliced range, ...): the same result in two launches.
+        if (ldy != N) return hipErrorInvalidValue;  // (launch_layernorm works on contiguous rows)
+        const hipError_t e = launch_gemm(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, EPI_BIAS_RESIDUAL, stream, scratch);
+        if (e != hipSuccess) return e;
+        return launch_layernorm(Y, gamma, beta, eps, M, N, Y, stream);
+    }
     if (N == 384) return launch_ln_tiled<3>(A, lda, W, bias, R, ldr, gamma, beta, eps, Y, ldy, M, K, stream);
     return launch_ln_tiled<2>(A, lda, W, bias, R, ldr, gamma, beta, eps, Y, ldy, M, K, stream);
 }

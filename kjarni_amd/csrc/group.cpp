@@ -28,6 +28,17 @@ std::vector<int> devices_from_env()
     } else if (const char* one = std::getenv("KJARNI_HIP_DEVICE")) {
         out.push_back(std::atoi(one));
     } else {
+        // Under a one-process-per-GPU launcher (torchrun and friends export LOCAL_RANK) every rank sees every GPU:
+        // replicas on all of them from every rank would be N^2 models.  A rank keeps to its own device.
+        const char* lr = std::getenv("LOCAL_RANK");
+        if (lr && *lr) {
+            char* end = nullptr;
+            const long v = std::strtol(lr, &end, 10);
+            if (end != lr && v >= 0 && (n == 0 || v < n)) {
+                out.push_back((int)v);
+                return out;
+            }
+        }
         for (int i = 0; i < n; ++i) out.push_back(i);
         if (out.empty()) out.push_back(0);  // EncoderModel::load reports the missing GPU
     }
@@ -244,7 +255,10 @@ bool EncoderGroup::ensure_rccl()
     for (auto& m : replicas_) devs.push_back(m->device());
     std::vector<ncclComm_t> comms(devs.size());
     const ncclResult_t e = r->CommInitAll(comms.data(), (int)devs.size(), devs.data());
-    if (e != ncclSuccess) return false;
+    if (e != ncclSuccess) {  // the copy transport takes over -- and transport() says why
+        transport_note_ = std::string("memcpy (ncclCommInitAll failed: ") + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error") + ")";
+        return false;
+    }
     comms_.assign(comms.begin(), comms.end());
     rccl_ = r;
     return true;
@@ -253,7 +267,9 @@ bool EncoderGroup::ensure_rccl()
 const char* EncoderGroup::transport()
 {
     std::lock_guard<std::mutex> lock(coll_mu_);
-    return ensure_rccl() ? "rccl" : "memcpy";
+    DeviceGuard guard;
+    if (ensure_rccl()) return "rccl";
+    return transport_note_.empty() ? "memcpy" : transport_note_.c_str();
 }
 
 // Every out_dev[i] holds block i (rows shard(rows_total, n, i)) at its place; afterwards every buffer holds all
@@ -267,26 +283,40 @@ void EncoderGroup::gather(float* const* out_dev, int64_t rows_total, int64_t wid
         const RcclApi& r = *static_cast<RcclApi*>(rccl_);
         const bool even = rows_total % (int64_t)n == 0;
         nccl_check(r, r.GroupStart(), "ncclGroupStart");
-        for (size_t i = 0; i < n; ++i) {
+        // Nothing throws between GroupStart and GroupEnd: the first failure is remembered, the bracket is always closed
+        // and the streams drained, so a failed collective leaves neither an open RCCL group on this thread nor
+        // unsynchronised streams behind.
+        ncclResult_t first = ncclSuccess;
+        const char* first_what = nullptr;
+        auto note = [&](ncclResult_t e, const char* what) {
+            if (e != ncclSuccess && first == ncclSuccess) {
+                first = e;
+                first_what = what;
+            }
+        };
+        for (size_t i = 0; i < n && first == ncclSuccess; ++i) {
             ncclComm_t comm = static_cast<ncclComm_t>(comms_[i]);
             if (even) {
                 // in place: the send buffer is this rank's slot of the receive buffer
-                nccl_check(r, r.AllGather(out_dev[i] + start[i] * width, out_dev[i], (size_t)(count[i] * width), ncclFloat,
-                                          comm, streams_[i]),
-                           "ncclAllGather");
+                note(r.AllGather(out_dev[i] + start[i] * width, out_dev[i], (size_t)(count[i] * width), ncclFloat, comm, streams_[i]),
+                     "ncclAllGather");
             } else {
-                for (size_t root = 0; root < n; ++root)
+                for (size_t root = 0; root < n && first == ncclSuccess; ++root)
                     if (count[root] > 0)
-                        nccl_check(r, r.Broadcast(out_dev[i] + start[root] * width, out_dev[i] + start[root] * width,
-                                                  (size_t)(count[root] * width), ncclFloat, (int)root, comm, streams_[i]),
-                                   "ncclBroadcast");
+                        note(r.Broadcast(out_dev[i] + start[root] * width, out_dev[i] + start[root] * width,
+                                         (size_t)(count[root] * width), ncclFloat, (int)root, comm, streams_[i]),
+                             "ncclBroadcast");
             }
         }
-        nccl_check(r, r.GroupEnd(), "ncclGroupEnd");
+        note(r.GroupEnd(), "ncclGroupEnd");
+        hipError_t sync_err = hipSuccess;
         for (size_t i = 0; i < n; ++i) {
-            hip_check(hipSetDevice(replicas_[i]->device()), "hipSetDevice");
-            hip_check(hipStreamSynchronize(streams_[i]), "hipStreamSynchronize(all-gather)");
+            hipError_t e = hipSetDevice(replicas_[i]->device());
+            if (e == hipSuccess) e = hipStreamSynchronize(streams_[i]);
+            if (e != hipSuccess && sync_err == hipSuccess) sync_err = e;
         }
+        nccl_check(r, first, first_what ? first_what : "rccl");
+        hip_check(sync_err, "hipStreamSynchronize(all-gather)");
         return;
     }
     // Copy transport (a device listed twice, or no RCCL in the process): wait for every block, then each
@@ -317,6 +347,7 @@ void EncoderGroup::allgather_embed(const uint32_t* const* ids_dev, const uint32_
 {
     if (batch_total <= 0) return;
     std::lock_guard<std::mutex> lock(coll_mu_);
+    DeviceGuard guard;
     const size_t n = replicas_.size();
     const int64_t H = config().hidden;
     if (streams_.empty()) {
@@ -342,6 +373,7 @@ void EncoderGroup::allgather_logits(const uint32_t* const* ids_dev, const uint32
 {
     if (batch_total <= 0) return;
     std::lock_guard<std::mutex> lock(coll_mu_);
+    DeviceGuard guard;
     const size_t n = replicas_.size();
     const int64_t L = config().num_labels;
     if (streams_.empty()) {

@@ -88,6 +88,7 @@ private:
     std::mutex coll_mu_;                // one collective at a time per group
     bool distinct_ = true;
     bool rccl_tried_ = false;
+    std::string transport_note_;        // why RCCL is not the transport, when its initialisation failed
     void* rccl_ = nullptr;              // RcclApi*, group.cpp
     std::vector<void*> comms_;
 };

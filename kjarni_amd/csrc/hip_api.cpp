@@ -112,6 +112,13 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncod
     return KJARNI_OK;
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on)
+{
+    if (!enc) return KJARNI_ERROR_NULL_POINTER;
+    enc->model->set_packing(on != 0);
+    return KJARNI_OK;
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
                                                                const uint32_t* mask_dev,
                                                                const uint32_t* type_ids_dev, int64_t batch,

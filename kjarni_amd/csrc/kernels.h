@@ -29,7 +29,16 @@ hipError_t launch_embed_layernorm(const uint32_t* ids, const uint32_t* type_ids,
                                   const float* pos, const float* type, const float* gamma,
                                   const float* beta, float eps, int64_t tokens, int seq, int hidden,
                                   int vocab, int max_pos, int type_vocab, int pos_offset,
-                                  int scale_embeddings, float* out, hipStream_t stream);
+                                  int scale_embeddings, float* out, hipStream_t stream, const int32_t* tok_src = nullptr);
+
+// Ragged batches run over the kept tokens only ("packed rows", rowops.hip): sentence b of a chunk is rows
+// cu[b] .. cu[b+1] of every activation buffer, tok_src[row] is that token's index in the padded [batch, seq] arrays.
+//   launch_mask_lengths: lens[b] = kept tokens of sentence b, bit 31 = the sentence needs the padded layout
+//   launch_pack_index:   tok_src from mask + cu
+// The kernels below that take `cu` / `tok_src` read the packed layout when it is non-null.
+hipError_t launch_mask_lengths(const uint32_t* mask, int64_t batch, int seq, uint32_t* lens, hipStream_t stream);
+hipError_t launch_pack_index(const uint32_t* mask, const int32_t* cu, int64_t batch, int seq, int32_t* tok_src,
+                             hipStream_t stream);
 
 // R3: row LayerNorm, in == out allowed.
 hipError_t launch_layernorm(const float* in, const float* gamma, const float* beta, float eps,
@@ -71,19 +80,20 @@ void set_cosine_variant(int variant);     // 0 = default, 1 = streaming passes o
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.
 // qkv is [tokens, 3*hidden] (Q | K | V), mask is u32 [batch, seq], ctx is
 // [tokens, hidden] with heads merged.
+// Packed rows: cu != null, mask is ignored (every row is a kept token), seq = the longest sentence of the call.
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq,
                             int heads, int head_dim, float mask_value, float* ctx,
-                            hipStream_t stream);
+                            hipStream_t stream, const int32_t* cu = nullptr);
 
 // RoPE on the Q and K thirds of qkv [tokens, 3*hidden] in place, position = token index within its sentence
 // (RoPE::apply_3d with offset 0, cpu/rope/mod.rs:118-170, 210-245; encoder_self_attention.rs:81-85).
 // cos / sin are the reference's caches [>= seq, head_dim].
 hipError_t launch_rope_qk(float* qkv, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
-                          int head_dim, hipStream_t stream);
+                          int head_dim, hipStream_t stream, const int32_t* tok_src = nullptr);
 
 // R11: pooling (+ optional L2 normalisation) of [batch, seq, hidden].
 hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t batch, int seq,
-                       int hidden, PoolMode mode, int normalize, float* out, hipStream_t stream);
+                       int hidden, PoolMode mode, int normalize, float* out, hipStream_t stream, const int32_t* cu = nullptr);
 
 // R12 tail: logits[b, n] = feat[b,:] . Wc[n,:] + bc[n]  for small num_labels.
 hipError_t launch_small_linear(const float* feat, int64_t ld, const float* w, const float* bias,

@@ -359,6 +359,7 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
                 hip_check(launch_prefill_gemm(Ain, lda, W, wb, bias, R, ldy, Y, ldy, m, N, K, s, psplit_, gate), what);
                 return;
             }
+            ++tile_gemm_calls_;
             const float* W32 = static_cast<const float*>(W);
             if (bf16_) {
                 hip_check(launch_widen_bf16(W, pw32_, (size_t)N * K, s), "widen");

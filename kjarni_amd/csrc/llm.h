@@ -59,6 +59,9 @@ public:
     size_t weight_bytes() const { return weight_bytes_; }
     int context() const { return cache_cap_; }
     int cache_len() const { return cache_len_; }
+    // Prompt projections that ran the encoder's 128 x 128-tile GEMM since load (the other route is the 64 x 64 prompt kernel):
+    // lets a test assert which route a geometry took.
+    uint64_t tile_gemm_calls() const { return tile_gemm_calls_; }
 
     void reset();  // empty KV cache
     // Appends n tokens (any n: processed 8 rows at a time); the logits of the last position stay on the device.
@@ -111,6 +114,7 @@ private:
     float* psplit_ = nullptr;  // K-slice partial tiles of the prompt GEMMs (short prompts)
     float* host_logits_ = nullptr;  // pinned
     int prefill_cap_ = 0;
+    uint64_t tile_gemm_calls_ = 0;
     hipStream_t stream_ = nullptr;
     hipGraphExec_t graph_ = nullptr;
 };

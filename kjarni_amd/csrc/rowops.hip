@@ -69,18 +69,20 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int64_t tokens,
     int seq, int hidden, int vocab, int max_pos, int type_vocab, int pos_offset, int scale_embeddings,
-    float* __restrict__ out)
+    const int32_t* __restrict__ tok_src, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= tokens) return;
     const int nv4 = hidden >> 2;
-    const int s = (int)(t % seq);
-    const uint32_t id = ids[t];
+    // packed rows (ragged batches): output row t is the token at index tok_src[t] of the padded [batch, seq] arrays
+    const int64_t src = tok_src ? (int64_t)tok_src[t] : t;
+    const int s = (int)(src % seq);
+    const uint32_t id = ids[src];
     const bool has_word = id < (uint32_t)vocab;
     const bool has_pos = pos != nullptr && (pos_offset + s) < max_pos;
     const bool has_type = type != nullptr && type_vocab > 0;
-    uint32_t ty = (has_type && type_ids) ? type_ids[t] : 0u;
+    uint32_t ty = (has_type && type_ids) ? type_ids[src] : 0u;
     if (has_type && ty >= (uint32_t)type_vocab) ty = (uint32_t)type_vocab - 1;
     const float* wrow = word + (int64_t)id * hidden;
     const float* prow = pos + (int64_t)(pos_offset + s) * hidden;
@@ -161,17 +163,18 @@ __global__ __launch_bounds__(256) void embed_generic_kernel(
     const uint32_t* __restrict__ ids, const uint32_t* __restrict__ type_ids,
     const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
     int64_t tokens, int seq, int hidden, int vocab, int max_pos, int type_vocab, int pos_offset,
-    int scale_embeddings, float* __restrict__ out)
+    int scale_embeddings, const int32_t* __restrict__ tok_src, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= tokens) return;
-    const int s = (int)(t % seq);
-    const uint32_t id = ids[t];
+    const int64_t src = tok_src ? (int64_t)tok_src[t] : t;
+    const int s = (int)(src % seq);
+    const uint32_t id = ids[src];
     const bool has_word = id < (uint32_t)vocab;
     const bool has_pos = pos != nullptr && (pos_offset + s) < max_pos;
     const bool has_type = type != nullptr && type_vocab > 0;
-    uint32_t ty = (has_type && type_ids) ? type_ids[t] : 0u;
+    uint32_t ty = (has_type && type_ids) ? type_ids[src] : 0u;
     if (has_type && ty >= (uint32_t)type_vocab) ty = (uint32_t)type_vocab - 1;
     const float sc = sqrtf((float)hidden);
     for (int i = lane; i < hidden; i += 64) {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void embed_generic_kernel(
 template <int MODE>
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
                                                    const uint32_t* __restrict__ mask, int seq,
-                                                   int hidden, int normalize,
+                                                   int hidden, int normalize, const int32_t* __restrict__ cu,
                                                    float* __restrict__ out)
 {
     __shared__ float red[4];
@@ -200,8 +203,10 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
     __shared__ f32x4 part[256];
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
-    const float* base = hs + b * seq * (int64_t)hidden;
-    const uint32_t* mrow = mask ? mask + b * seq : nullptr;
+    // packed rows: sentence b is rows cu[b] .. cu[b+1] of hs, every one of them a kept token
+    if (cu) seq = cu[b + 1] - cu[b];
+    const float* base = hs + (cu ? (int64_t)cu[b] : b * seq) * (int64_t)hidden;
+    const uint32_t* mrow = (mask && !cu) ? mask + b * seq : nullptr;
 
     // count of kept tokens and the last kept position (pooling/mod.rs:61-62 rposition(x > 0), else 0), all threads
     // at once (mask values are 0 / 1: the float sum is exact in any order)
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restric
 template <int V>
 __global__ __launch_bounds__(256) void rope_qk_kernel(float* __restrict__ qkv, const float* __restrict__ cos_t,
                                                       const float* __restrict__ sin_t, int64_t tokens, int seq, int heads,
-                                                      int head_dim)
+                                                      int head_dim, const int32_t* __restrict__ tok_src)
 {
     const int half = head_dim >> 1, hv = half / V, hidden = heads * head_dim;
     const int64_t per_tok = (int64_t)2 * heads * hv, total = tokens * per_tok;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(float* __restrict__ qkv, c
         const int part = item / (heads * hv);
         item -= part * heads * hv;
         const int h = item / hv, i = (item - h * hv) * V;
-        const int s = (int)(t % seq);
+        const int s = (int)((tok_src ? (int64_t)tok_src[t] : t) % seq);
         float* r = qkv + t * 3 * hidden + part * hidden + h * head_dim + i;
         const float* c = cos_t + (int64_t)s * head_dim + i;
         const float* sn = sin_t + (int64_t)s * head_dim + i;
@@ -414,12 +419,76 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(float* __restrict__ qkv, c
     }
 }
 
+// ---------------------------------------------------------------------------
+// Ragged batches (BatchLongest padding, pipeline/encoder/loader.rs:98-115): the forward pass can run over the KEPT
+// tokens only -- a padded key contributes exactly 0 to every softmax row (utils/masks.rs:4-36 overwrites its score with
+// -1e9 / -inf) and pooling skips padded rows (pooling/mod.rs:11-33) -- so the projections never see [PAD] rows.
+//
+// mask_lengths_kernel: lens[b] = number of kept tokens of sentence b; bit 31 set when the packed layout cannot stand
+// in for the padded one: mask[b, 0] == 0 (CLS pooling and the classification head read token 0; an all-masked sentence
+// pools token 0 and, with the -1e9 fill, attends uniformly to its padding) or a mask value other than 0 / 1 (the mean
+// pool multiplies by the mask value, traits.rs:71 `as f32`).
+// pack_index_kernel: tok_src[cu[b] + r] = b * seq + s for the r-th kept token (ascending s) of sentence b.
+// One wave per sentence, ballots over 64 tokens at a time.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_lengths_kernel(const uint32_t* __restrict__ mask, int64_t batch, int seq,
+                                                           uint32_t* __restrict__ lens)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const uint32_t* row = mask + b * seq;
+    int count = 0;
+    bool bad = false;
+    for (int s0 = 0; s0 < seq; s0 += 64) {
+        const int s = s0 + lane;
+        const uint32_t mv = s < seq ? row[s] : 0u;
+        bad = bad || mv > 1u || (s == 0 && mv == 0u);
+        count += __popcll(__ballot(mv != 0u));
+    }
+    bad = __ballot(bad) != 0ull;
+    if (lane == 0) lens[b] = (uint32_t)count | (bad ? 0x80000000u : 0u);
+}
+
+__global__ __launch_bounds__(256) void pack_index_kernel(const uint32_t* __restrict__ mask, const int32_t* __restrict__ cu,
+                                                         int64_t batch, int seq, int32_t* __restrict__ tok_src)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const uint32_t* row = mask + b * seq;
+    int32_t* dst = tok_src + cu[b];
+    int done = 0;
+    for (int s0 = 0; s0 < seq; s0 += 64) {
+        const int s = s0 + lane;
+        const bool keep = s < seq && row[s] != 0u;
+        const unsigned long long bits = __ballot(keep);
+        if (keep) dst[done + __popcll(bits & ((1ull << lane) - 1ull))] = (int32_t)(b * seq + s);
+        done += __popcll(bits);
+    }
+}
+
 inline unsigned rows_to_blocks(int64_t rows) { return (unsigned)((rows + 3) / 4); }
 
 }  // namespace
 
+hipError_t launch_mask_lengths(const uint32_t* mask, int64_t batch, int seq, uint32_t* lens, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mask_lengths_kernel, dim3(rows_to_blocks(batch)), dim3(256), 0, stream, mask, batch, seq, lens);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_index(const uint32_t* mask, const int32_t* cu, int64_t batch, int seq, int32_t* tok_src,
+                             hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_index_kernel, dim3(rows_to_blocks(batch)), dim3(256), 0, stream, mask, cu, batch, seq, tok_src);
+    return hipGetLastError();
+}
+
 hipError_t launch_rope_qk(float* qkv, const float* cos_t, const float* sin_t, int64_t tokens, int seq, int heads,
-                          int head_dim, hipStream_t stream)
+                          int head_dim, hipStream_t stream, const int32_t* tok_src)
 {
     if (tokens <= 0) return hipSuccess;
     if (head_dim < 2 || (head_dim & 1) || seq <= 0) return hipErrorInvalidValue;
@@ -429,9 +498,9 @@ hipError_t launch_rope_qk(float* qkv, const float* cos_t, const float* sin_t, in
     const int64_t total = tokens * 2 * heads * (vec ? half / 4 : half);
     const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
     if (vec)
-        hipLaunchKernelGGL(rope_qk_kernel<4>, dim3(grid), dim3(256), 0, stream, qkv, cos_t, sin_t, tokens, seq, heads, head_dim);
+        hipLaunchKernelGGL(rope_qk_kernel<4>, dim3(grid), dim3(256), 0, stream, qkv, cos_t, sin_t, tokens, seq, heads, head_dim, tok_src);
     else
-        hipLaunchKernelGGL(rope_qk_kernel<1>, dim3(grid), dim3(256), 0, stream, qkv, cos_t, sin_t, tokens, seq, heads, head_dim);
+        hipLaunchKernelGGL(rope_qk_kernel<1>, dim3(grid), dim3(256), 0, stream, qkv, cos_t, sin_t, tokens, seq, heads, head_dim, tok_src);
     return hipGetLastError();
 }
 
@@ -439,17 +508,17 @@ hipError_t launch_embed_layernorm(const uint32_t* ids, const uint32_t* type_ids,
                                   const float* pos, const float* type, const float* gamma,
                                   const float* beta, float eps, int64_t tokens, int seq, int hidden,
                                   int vocab, int max_pos, int type_vocab, int pos_offset,
-                                  int scale_embeddings, float* out, hipStream_t stream)
+                                  int scale_embeddings, float* out, hipStream_t stream, const int32_t* tok_src)
 {
     if (tokens <= 0) return hipSuccess;
     if (hidden % 4 == 0 && hidden <= 256 * MAX_V4_PER_LANE) {
         hipLaunchKernelGGL(embed_layernorm_kernel, dim3(rows_to_blocks(tokens)), dim3(256), 0, stream,
                            ids, type_ids, word, pos, type, gamma, beta, eps, tokens, seq, hidden,
-                           vocab, max_pos, type_vocab, pos_offset, scale_embeddings, out);
+                           vocab, max_pos, type_vocab, pos_offset, scale_embeddings, tok_src, out);
     } else {
         hipLaunchKernelGGL(embed_generic_kernel, dim3(rows_to_blocks(tokens)), dim3(256), 0, stream,
                            ids, type_ids, word, pos, type, tokens, seq, hidden, vocab, max_pos,
-                           type_vocab, pos_offset, scale_embeddings, out);
+                           type_vocab, pos_offset, scale_embeddings, tok_src, out);
         if (gamma != nullptr)
             hipLaunchKernelGGL(layernorm_generic_kernel, dim3(rows_to_blocks(tokens)), dim3(256), 0,
                                stream, out, gamma, beta, eps, tokens, hidden, out);
@@ -471,7 +540,7 @@ hipError_t launch_layernorm(const float* in, const float* gamma, const float* be
 }
 
 hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t batch, int seq,
-                       int hidden, PoolMode mode, int normalize, float* out, hipStream_t stream)
+                       int hidden, PoolMode mode, int normalize, float* out, hipStream_t stream, const int32_t* cu)
 {
     if (batch <= 0) return hipSuccess;
     if (hidden > 1024 || seq <= 0) return hipErrorInvalidValue;
@@ -479,19 +548,19 @@ hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t
     switch (mode) {
     case POOL_MEAN:
         hipLaunchKernelGGL(pool_kernel<POOL_MEAN>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, out);
+                           hidden, normalize, cu, out);
         break;
     case POOL_CLS:
         hipLaunchKernelGGL(pool_kernel<POOL_CLS>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, out);
+                           hidden, normalize, cu, out);
         break;
     case POOL_MAX:
         hipLaunchKernelGGL(pool_kernel<POOL_MAX>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, out);
+                           hidden, normalize, cu, out);
         break;
     case POOL_LAST:
         hipLaunchKernelGGL(pool_kernel<POOL_LAST>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, out);
+                           hidden, normalize, cu, out);
         break;
     default: return hipErrorInvalidValue;
     }

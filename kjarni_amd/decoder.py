@@ -29,6 +29,10 @@ class HipDecoder:
     def reset(self):
         check_error(lib().kjarni_hip_decoder_reset(self._h))
 
+    def tile_gemm_calls(self) -> int:
+        """Prompt projections that took the 128 x 128-tile GEMM route since load."""
+        return int(lib().kjarni_hip_decoder_tile_gemm_calls(self._h))
+
     def forward(self, ids: Sequence[int], fetch: bool = True):
         a = np.ascontiguousarray(ids, np.uint32)
         hidden = np.empty(((a.size - 1) % 8 + 1, self.hidden), np.float32) if fetch else None   # rows of the last 8-row block

@@ -63,6 +63,10 @@ class HipEncoder:
     def set_chunk_tokens(self, tokens: int):
         check_error(lib().kjarni_hip_encoder_set_chunk_tokens(self._h, int(tokens)))
 
+    def set_packing(self, on: bool):
+        """Ragged batches over the kept tokens only (default on); off = the padded layout for every call."""
+        check_error(lib().kjarni_hip_encoder_set_packing(self._h, 1 if on else 0))
+
     KINDS = ("embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm", "gemm_fc1", "gemm_fc2",
              "pool", "head", "rope")
 

@@ -476,11 +476,12 @@ def llm_tensors(cfg: dict, seed: int = 0, std: float = 0.05, bf16: bool = False)
     return t
 
 
-def llm_model(path: str, base: dict, seed: int = 0, bf16_values: bool = False, store_bf16: bool = False, **over):
+def llm_model(path: str, base: dict, seed: int = 0, bf16_values: bool = False, store_bf16: bool = False, std: float = 0.05,
+              **over):
     """Writes config.json + model.safetensors.  store_bf16: the 2-D weights are stored as BF16 tensors."""
     cfg = dict(base)
     cfg.update(over)
-    t = llm_tensors(cfg, seed, bf16=bf16_values or store_bf16)
+    t = llm_tensors(cfg, seed, std=std, bf16=bf16_values or store_bf16)
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump(cfg, f, indent=1)

@@ -1,7 +1,9 @@
 """Several devices behind one handle (kjarni_hip_group_*, KJARNI_HIP_DEVICES for the string-level handles) and
 concurrent calls on one handle.  The GPU box has one device, so the fan-out is exercised with that device listed
 twice (two replicas, two host threads, two streams) and the RCCL path with a one-rank communicator; results must be
-bit-equal to the single-replica result and oracle-equal."""
+oracle-equal and equal to the single-replica result to rounding (1e-6): the projections pick their tile route by the
+number of token rows in a call (<= 64, 65 .. 8 192, more), so a row block of a call and the whole call
+are bit-equal only when both land in the same range."""
 import ctypes as C
 import os
 import subprocess
@@ -26,18 +28,22 @@ def test_host_fanout_matches_single_device_and_oracle(tmp_path):
     grp = kjarni_amd.HipEncoderGroup(str(tmp_path / "e"), [0, 0])
     assert grp.size == 2 and grp.devices == [0, 0] and grp.hidden_size == cfg["hidden_size"]
     assert [grp.shard(9, i) for i in range(2)] == [(0, 5), (5, 4)]
-    for n in (1, 15, 16, 37, 260):   # below 16 rows only one replica works; 37 = uneven blocks
-        ids, mask = synth.synthetic_ids(n, 64, seed=n, ragged=True)
+    orc = O.OracleModel(t, cfg, blocked_gemm=True)
+    # below 16 rows only one replica works; 37 = uneven blocks; 200 x 64 padded = 12 800 token rows whole, 6 400 per block:
+    # the whole call and its blocks straddle the 8 192-row boundary between the tile routes
+    for n, ragged in ((1, True), (15, True), (16, True), (37, True), (260, True), (200, False)):
+        ids, mask = synth.synthetic_ids(n, 64, seed=n, ragged=ragged)
         got = grp.embed(ids, mask)
-        assert np.array_equal(got, one.embed(ids, mask))
-        if n <= 37:
-            assert float(np.abs(got - O.OracleModel(t, cfg).embed_batch(ids, mask)).max()) < 1e-4
+        assert float(np.abs(got - one.embed(ids, mask)).max()) <= 1e-6, n
+        assert float(np.abs(got - orc.embed_batch(ids, mask)).max()) < 1e-4, n
+    ids, mask = synth.synthetic_ids(1, 64, seed=1, ragged=True)   # one replica, same rows, same route: bit-equal
+    assert np.array_equal(grp.embed(ids, mask), one.embed(ids, mask))
     cfg, t = synth.minilm_cross_encoder(str(tmp_path / "c"), seed=1, num_hidden_layers=2)
     one = kjarni_amd.HipEncoder(str(tmp_path / "c"))
     grp = kjarni_amd.HipEncoderGroup(str(tmp_path / "c"), [0, 0])
     ids, mask, types = synth.synthetic_pairs(41, 64, seed=2)
     got = grp.logits(ids, mask, types)
-    assert np.array_equal(got, one.logits(ids, mask, types))
+    assert float(np.abs(got - one.logits(ids, mask, types)).max()) <= 1e-6
     assert float(np.abs(got[:, 0] - O.OracleModel(t, cfg).rerank_scores(ids, mask, types)).max()) < 1e-4
 
 
@@ -64,7 +70,12 @@ def test_device_resident_allgather(tmp_path, devices, transport, n):
     grp.embed_allgather([t.data_ptr() for t in ids_d], [t.data_ptr() for t in mask_d], n, 32,
                         [t.data_ptr() for t in outs], fill=kjarni_amd.MASK_NEG_INF)
     for o in outs:
-        assert np.array_equal(o.cpu().numpy(), want)
+        got = o.cpu().numpy()
+        assert np.array_equal(got, outs[0].cpu().numpy())   # every buffer holds the same rows after the collective
+        if len(devices) == 1:
+            assert np.array_equal(got, want)                 # one replica = the same call
+        else:
+            assert float(np.abs(got - want).max()) <= 1e-6
 
 
 def test_string_level_handles_fan_out_with_kjarni_hip_devices(tmp_path):
@@ -91,8 +102,14 @@ def test_string_level_handles_fan_out_with_kjarni_hip_devices(tmp_path):
                            text=True, timeout=300, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-1500:]
         outs[devs] = (np.load(a), np.load(b))
-    assert np.array_equal(outs["0"][0], outs["0,0"][0]) and np.array_equal(outs["0"][1], outs["0,0"][1])
     assert outs["0"][0].shape == (45, 384)
+    assert float(np.abs(outs["0"][0] - outs["0,0"][0]).max()) <= 1e-6
+    # rerank: the same (index -> score) pairs to rounding; equal texts tie, and their order may follow the rounding
+    by_index = lambda a: a[np.argsort(a[:, 0], kind="stable")]  # noqa: E731
+    a, b = by_index(outs["0"][1]), by_index(outs["0,0"][1])
+    assert np.array_equal(a[:, 0], b[:, 0]) and float(np.abs(a[:, 1] - b[:, 1]).max()) <= 1e-6
+    for r in (outs["0"][1], outs["0,0"][1]):
+        assert (r[:-1, 1] >= r[1:, 1]).all()
 
 
 def test_bad_device_list_is_invalid_config(tmp_path):

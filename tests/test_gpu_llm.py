@@ -228,16 +228,21 @@ def test_decode_over_several_key_ranges(tmp_path):
 
 @pytest.mark.parametrize("store_bf16", [True, False], ids=["bf16-weights", "f32-weights"])
 def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
-    """Prompt blocks of >= 1 792 rows run the encoder's 128 x 128-tile GEMM (bf16 weights on a widened copy), shorter ones the
-    64 x 64 kernel; a 1 900-token prompt, a 2 300-token one (a 2 048-row block + a 252-row block) and decode steps on top."""
-    base = dict(synth.LLAMA_TEST, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
-                intermediate_size=512, vocab_size=777, max_position_embeddings=4096, head_dim=64)
+    """A projection of a prompt block runs the encoder's 128 x 128-tile GEMM when its tiles number at least 208 (llm.cpp), bf16
+    weights on a widened f32 copy, else the 64 x 64 prompt kernel.  Hidden 1 792 = 14 x 128 with a 1 792-wide FFN: a 2 048-row
+    block has 16 x 14 = 224 tiles for q, o (in-place residual), gate, up * silu(gate) and down (in-place residual) -- five tiled
+    projections per layer -- while k / v (256 wide: 32 tiles) and the 1 900-row prompt (15 x 14 = 210 ... also tiled) and the
+    252-row tail (not tiled) take their own routes.  The route is asserted through the library's counter."""
+    base = dict(synth.LLAMA_TEST, hidden_size=1792, num_hidden_layers=2, num_attention_heads=14, num_key_value_heads=2,
+                intermediate_size=1792, vocab_size=777, max_position_embeddings=4096, head_dim=128)
     base["rope_scaling"] = dict(base["rope_scaling"], original_max_position_embeddings=1024)
-    orc, gpu, cfg = _pair(tmp_path, base, seed=13, bf16_values=True, store_bf16=store_bf16)
+    orc, gpu, cfg = _pair(tmp_path, base, seed=13, bf16_values=True, store_bf16=store_bf16, std=0.02)
     rng = np.random.default_rng(6)
-    for n_prompt in (1900, 2300):
+    assert gpu.tile_gemm_calls() == 0
+    for n_prompt, tiled_blocks in ((1500, 0), (2300, 1)):
         cache = orc.new_cache()
         gpu.reset()
+        before = gpu.tile_gemm_calls()
         for n in (n_prompt, 1, 1):
             ids = rng.integers(4, cfg["vocab_size"], n).tolist()
             ref_h = orc.forward(ids, cache)[0]
@@ -247,6 +252,9 @@ def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
             scale = max(1.0, float(np.abs(ref_h).max()))
             assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
             assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
+        # 1 500 rows: 12 x 14 = 168 tiles per projection, below the threshold; 2 300 rows = a 2 048-row block (224 tiles: q, o,
+        # gate, up, down tiled in each of the 2 layers) + a 252-row block (below the 512-row floor)
+        assert gpu.tile_gemm_calls() - before == tiled_blocks * 5 * cfg["num_hidden_layers"], (n_prompt, gpu.tile_gemm_calls() - before)
 
 
 @pytest.mark.parametrize("head_dim,heads,kv_heads", [(64, 8, 2), (128, 4, 2), (128, 4, 4)], ids=["d64-gqa4", "d128-gqa2", "d128-mha"])
