@@ -30,16 +30,11 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "tuning.h"
 
 namespace kjarni {
 
 namespace {
-
-#ifdef KJARNI_TUNING
-std::atomic<int> g_attention_variant{0};  // 0: persistent pipelined kernel for seq <= 128 (default), 1: plain kernel -- tuning build only
-#else
-constexpr int g_attention_variant = 0;
-#endif
 
 constexpr int QBLK = 128;   // queries per workgroup
 constexpr int KCHUNK = 128; // keys per LDS chunk
@@ -646,19 +641,17 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         attr_set[dev & 63] = true;
     }
     const float scale = 1.0f / sqrtf((float)D);  // encoder_self_attention.rs:43
-    if (D == 32 && seq <= KCHUNK && g_attention_variant != 1) {
+    if (D == 32 && seq <= KCHUNK && !tune::no_pipelined_attention()) {
         const int64_t n_items = batch * heads;
         // Three resident workgroups per CU (35.8 KiB of LDS and <= 168 VGPRs each): the third hides what two leave
         // exposed of the K / V / Q streams' latency (measured 274 -> 264 us per launch of 12 288 items).
         int64_t max_blocks = 256 * 3;
-#ifdef KJARNI_TUNING
-        if (g_attention_variant == 20) max_blocks = 256 * 2;
-#endif
+        if (tune::attention_two_workgroups_per_cu()) max_blocks = 256 * 2;
         const unsigned grid = (unsigned)(n_items < max_blocks ? n_items : max_blocks);
         // (AttnSmem<32>::BYTES = 35.8 KiB: below the 64 KiB opt-in threshold)
         static_assert(D != 32 || SM::BYTES <= 64 * 1024, "the pipelined kernel would need the dynamic-LDS opt-in");
 #ifdef KJARNI_TUNING
-        switch (g_attention_variant) {
+        switch (tune::attention_knockout() + 10) {
         case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
         case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
         case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
@@ -692,10 +685,6 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
 }
 
 }  // namespace
-
-#ifdef KJARNI_TUNING
-void set_attention_variant(int v) { g_attention_variant = v; }
-#endif
 
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads,
                             int head_dim, float mask_value, float* ctx, hipStream_t stream, const int32_t* cu)

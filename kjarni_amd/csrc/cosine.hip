@@ -20,16 +20,12 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "tuning.h"
 
 namespace kjarni {
 
 namespace {
 
-#ifdef KJARNI_TUNING
-std::atomic<int> g_scan_variant{0};  // 1 = never take the GEMM route -- tuning build only
-#else
-constexpr int g_scan_variant = 0;
-#endif
 constexpr int SCAN_NQ = 4;       // queries held in registers per pass
 constexpr int SCAN_MAX_V4 = 4;   // dim <= 1024 on the float4 path
 
@@ -550,7 +546,7 @@ hipError_t launch_cosine_scores(const float* queries, int nq, const float* corpu
                            ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
     // Crossover: a streaming pass per 4 queries costs about as much as the GEMM route from ~20 queries on.
     if (nq >= 20 && aligned16 && dim % 32 == 0 && n_docs % 4 == 0 && n_docs >= 128 && n_docs < (int64_t)INT32_MAX &&
-        g_scan_variant != 1)
+        !tune::scan_streaming_only())
         return scan_gemm(queries, nq, corpus, n_docs, dim, mode, scores, stream);
     return scan_passes(queries, nq, corpus, n_docs, dim, mode, scores, n_docs, stream);
 }
@@ -595,10 +591,6 @@ hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_
 }
 
 }  // namespace
-
-#ifdef KJARNI_TUNING
-void set_cosine_variant(int variant) { g_scan_variant = variant; }
-#endif
 
 // Workspace: two ping-pong key buffers sized for the first level's output, plus
 // one `upper` key per query.

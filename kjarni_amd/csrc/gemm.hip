@@ -45,20 +45,13 @@
 
 #include "device_utils.h"
 #include "kernels.h"
+#include "tuning.h"
 
 namespace kjarni {
 
 namespace {
 
-// Tuning hook, -DKJARNI_TUNING builds only (tools/kernel_bench.py; the shipped library has neither the
-// switch nor the extra kernels): 0 default, 3 default tiling with the libm-grade
-// erff in the GELU epilogue, 4 residual GEMMs without the fused LayerNorm, 6 no few-rows kernel, 9 diagnostic build without an
-// epilogue (micro-benchmark upper bound).
-#ifdef KJARNI_TUNING
-std::atomic<int> g_gemm_variant{0};
-#else
-[[maybe_unused]] constexpr int g_gemm_variant = 0;
-#endif
+// (the tune:: predicates are the A/B switches of the tuning build, tuning.h: constant false in the shipped library)
 
 constexpr int EPI_GELU_LIBM = 100;
 constexpr int BM = 128, BN = 128;
@@ -610,7 +603,7 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
     }
     const int64_t total = (M + T::BM - 1) / T::BM;
     // (a grid of the 512 resident workgroups measured +0.6 % on the K = 384 shape and -0.6 % on K = 1536: one workgroup per tile)
-    dim3 grid((unsigned)(g_gemm_variant == 11 ? std::min<int64_t>(total, 256 * 2) : total));
+    dim3 grid((unsigned)(tune::persistent_layernorm_tiles() ? std::min<int64_t>(total, 256 * 2) : total));
     hipLaunchKernelGGL((gemm_nt_f32_mfma_ln<NT>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias, R, ldr,
                        gamma, beta, eps, Y, ldy, M, K, total);
     return hipGetLastError();
@@ -786,7 +779,7 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     // chip holds at once measured +2.2 % (QKV shape: no dispatch between a workgroup's tiles); with the GELU epilogue -1.1 %
     // (the barrier that ends a tile waits for the slowest wave's epilogue), so those launch one workgroup per tile.
     const int64_t resident = (int64_t)256 * T::WAVES_PER_SIMD;
-    const bool persistent = EPI == EPI_BIAS && g_gemm_variant != 10;
+    const bool persistent = EPI == EPI_BIAS && !tune::no_persistent_tile_loop();
     dim3 grid((unsigned)(persistent ? std::min(total, resident) : total));
     hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
                        R, ldr, Y, ldy, M, N, K, n_tiles, total);
@@ -1003,7 +996,7 @@ inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int6
 {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return M >= min_rows && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
-           al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && g_gemm_variant != 7;
+           al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && !tune::no_mid_route();
 }
 
 template <int EPI>
@@ -1014,7 +1007,7 @@ hipError_t launch_mid(const float* A, int64_t lda, const float* W, const float* 
     int ksplit = mid_ksplit(N, K);
     if (ksplit > 1 && (size_t)ksplit * M * N > scratch.floats) ksplit = 1;
     const int total = m_tiles * n_tiles * ksplit;
-    const dim3 grid((unsigned)std::min(total, g_gemm_variant == 5 ? total : kMidResident));
+    const dim3 grid((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : kMidResident));
     if (ksplit == 1) {
         hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, false>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, 1,
                            nullptr, n_tiles, total);
@@ -1059,17 +1052,14 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
     const bool mid = scratch.p && mid_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R);
     // (not when the 128 x 128 tiles fill the chip anyway -- 64 queries against a 10^7-row corpus: 11.5 ms tiled, 13.7 ms here)
     const bool tiles_fill_chip = aligned && ((M + BM - 1) / BM) * (int64_t)(N / BN) >= 768;
-    if (aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && g_gemm_variant != 6 && !mid && !tiles_fill_chip)
+    if (aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route() && !mid && !tiles_fill_chip)
         return launch_skinny<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream);
     // a few hundred to a few thousand rows (and a caller that lends a scratch slab): quarter-size tiles, K slices
     if (mid)
         return launch_mid<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream, scratch);
     if (aligned) {
 #ifdef KJARNI_TUNING
-        switch (g_gemm_variant) {
-        case 9: return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-        default: break;
-        }
+        if (tune::tiles_without_epilogue()) return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
 #endif
         return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
@@ -1081,11 +1071,6 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
 
 }  // namespace
 
-#ifdef KJARNI_TUNING
-void set_gemm_variant(int variant) { g_gemm_variant = variant; }
-int gemm_variant() { return g_gemm_variant; }
-#endif
-
 // Rows from which the residual + LayerNorm GEMMs take the K-sliced route: with a long K (>= 1024: the FC2 shape) from the
 // first row -- the few-rows kernel has N / 32 = 12 workgroups there, each with a 12-step serial K chain (17 us for one
 // sentence, + 4 us of LayerNorm launch; sliced + reduce: 13 us) -- otherwise from kFewRowsMax + 1.
@@ -1093,7 +1078,7 @@ inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 :
 
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
 {
-    return M >= mid_ln_min_rows(N, K) && M <= kMidMaxRows && N <= 1024 && N % 4 == 0 && K % MID_BK == 0 && g_gemm_variant != 7;
+    return M >= mid_ln_min_rows(N, K) && M <= kMidMaxRows && N <= 1024 && N % 4 == 0 && K % MID_BK == 0 && !tune::no_mid_route();
 }
 
 size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n)
@@ -1104,9 +1089,7 @@ size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n)
 
 bool gemm_residual_layernorm_supported(int N, int K)
 {
-#ifdef KJARNI_TUNING
-    if (g_gemm_variant == 4) return false;
-#endif
+    if (tune::no_fused_layernorm()) return false;
     return (N == 384 || N == 256) && K >= 16 && K % 16 == 0;  // (rows are addressed through 32-bit buffer offsets)
 }
 
@@ -1122,7 +1105,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         if ((size_t)ksplit * M * N <= scratch.floats) {
             const int m_tiles = ((int)M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
             const int total = m_tiles * n_tiles * ksplit;
-            hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)std::min(total, g_gemm_variant == 5 ? total : kMidResident)),
+            hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : kMidResident)),
                                dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p, n_tiles, total);
             const dim3 rgrid((unsigned)((M + 3) / 4));
 #define KJ_MID_LN(NCH)                                                                                                              \
@@ -1160,7 +1143,7 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
     case EPI_BIAS: return launch_epi<EPI_BIAS>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
     case EPI_BIAS_GELU:
 #ifdef KJARNI_TUNING
-        if (g_gemm_variant == 3) return launch_epi<EPI_GELU_LIBM>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
+        if (tune::gelu_through_libm()) return launch_epi<EPI_GELU_LIBM>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
 #endif
         return launch_epi<EPI_BIAS_GELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);
     case EPI_BIAS_GELU_NEW: return launch_epi<EPI_BIAS_GELU_NEW>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream, scratch);

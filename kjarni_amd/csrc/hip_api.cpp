@@ -8,6 +8,7 @@
 #include "../../include/kjarni_hip.h"
 #include "ffi_common.h"
 #include "group.h"
+#include "tuning.h"
 
 using namespace kjarni;
 
@@ -485,10 +486,11 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear_layer_norm(int32_t device, co
 }
 
 #ifdef KJARNI_TUNING
-// Kernel A/B switches: exported by the tuning build only (kjarni_amd/lib/libkjarni_ffi_tuning.so, tools/).
-KJARNI_EXPORT void kjarni_hip_set_gemm_variant(int32_t variant) { set_gemm_variant(variant); }
-KJARNI_EXPORT void kjarni_hip_set_attention_variant(int32_t variant) { set_attention_variant(variant); }
-KJARNI_EXPORT void kjarni_hip_set_cosine_variant(int32_t variant) { set_cosine_variant(variant); }
+// Kernel A/B switches (tuning.h): exported by the tuning build only (kjarni_amd/lib/libkjarni_ffi_tuning.so, tools/).
+namespace kjarni { namespace tune { std::atomic<int> g_gemm{0}, g_attention{0}, g_cosine{0}; } }
+KJARNI_EXPORT void kjarni_hip_set_gemm_variant(int32_t variant) { kjarni::tune::g_gemm = variant; }
+KJARNI_EXPORT void kjarni_hip_set_attention_variant(int32_t variant) { kjarni::tune::g_attention = variant; }
+KJARNI_EXPORT void kjarni_hip_set_cosine_variant(int32_t variant) { kjarni::tune::g_cosine = variant; }
 #endif
 
 // ---- cosine scan ----------------------------------------------------------------

@@ -68,14 +68,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
                                           float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream,
                                           GemmScratch scratch = GemmScratch());
 
-#ifdef KJARNI_TUNING
-// Kernel A/B switches of the tuning build (kjarni_amd/lib/libkjarni_ffi_tuning.so, tools/ only).  Process-wide
-// atomics; the shipped library has none of them.
-void set_gemm_variant(int variant);       // gemm.hip
-int gemm_variant();
-void set_attention_variant(int variant);  // 0 = default, 1 = non-persistent kernel
-void set_cosine_variant(int variant);     // 0 = default, 1 = streaming passes only (no GEMM route for many queries)
-#endif
+// (the kernel A/B switches of the tuning build live in tuning.h)
 
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.
 // qkv is [tokens, 3*hidden] (Q | K | V), mask is u32 [batch, seq], ctx is

@@ -1,0 +1,56 @@
+// Every A/B switch of the TUNING build (make tuning -> libkjarni_ffi_tuning.so, -DKJARNI_TUNING; tools/ only) in one
+// place.  The shipped library is compiled without KJARNI_TUNING: each predicate below is then a constant `false`, so
+// the product dispatch in gemm.hip / attention.hip / cosine.hip reads -- and compiles -- as if the switch were absent.
+//
+// gemm variant (kjarni_hip_set_gemm_variant):
+//    3  erf-GELU epilogue through libm-grade erff instead of the A&S 7.1.26 polynomial
+//    4  residual projections without the fused LayerNorm kernel
+//    5  mid-size route: one workgroup per tile instead of the persistent tile loop
+//    6  no few-rows (K over the waves) kernel
+//    7  no mid-size (64 x 64 tiles, K slices) route
+//    9  128 x 128 tiles without an epilogue (micro-benchmark upper bound)
+//   10  plain-epilogue 128 x 128 tiles without the persistent tile loop
+//   11  fused LayerNorm tiles as a persistent launch (two workgroups per CU)
+// attention variant (kjarni_hip_set_attention_variant):
+//    1  never the persistent pipelined kernel (d = 32, seq <= 128)
+//   11..16  knock-out diagnostics of the pipelined kernel (its DIAG template parameter 1..6)
+//   20  two resident workgroups per CU instead of three
+// cosine variant (kjarni_hip_set_cosine_variant):
+//    1  streaming passes only (no GEMM route for many queries)
+#pragma once
+
+#ifdef KJARNI_TUNING
+#include <atomic>
+#endif
+
+namespace kjarni {
+namespace tune {
+
+#ifdef KJARNI_TUNING
+extern std::atomic<int> g_gemm, g_attention, g_cosine;  // defined in hip_api.cpp
+inline int gemm() { return g_gemm.load(std::memory_order_relaxed); }
+inline int attention() { return g_attention.load(std::memory_order_relaxed); }
+inline int cosine() { return g_cosine.load(std::memory_order_relaxed); }
+#else
+constexpr int gemm() { return 0; }
+constexpr int attention() { return 0; }
+constexpr int cosine() { return 0; }
+#endif
+
+inline bool gelu_through_libm() { return gemm() == 3; }
+inline bool no_fused_layernorm() { return gemm() == 4; }
+inline bool mid_one_workgroup_per_tile() { return gemm() == 5; }
+inline bool no_few_rows_route() { return gemm() == 6; }
+inline bool no_mid_route() { return gemm() == 7; }
+inline bool tiles_without_epilogue() { return gemm() == 9; }
+inline bool no_persistent_tile_loop() { return gemm() == 10; }
+inline bool persistent_layernorm_tiles() { return gemm() == 11; }
+
+inline bool no_pipelined_attention() { return attention() == 1; }
+inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }
+inline bool attention_two_workgroups_per_cu() { return attention() == 20; }
+
+inline bool scan_streaming_only() { return cosine() == 1; }
+
+}  // namespace tune
+}  // namespace kjarni
