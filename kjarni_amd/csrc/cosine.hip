@@ -16,6 +16,7 @@
 // (orderable score bits << 32 | ~index) with LDS bitonic networks: each block
 // reduces a segment of 2048..16384 candidates to its best KPAD, levels repeat until
 // one block is left.
+#include <algorithm>
 #include <atomic>
 
 #include "device_utils.h"
@@ -435,24 +436,6 @@ void dispatch_reduce(int kpad, const float* scores, const uint64_t* in_keys, int
 
 namespace {
 
-// scores[j][d] holds dot(q_j, doc_d) on entry, the cosine on exit.
-__global__ __launch_bounds__(256) void cosine_finish_kernel(float* __restrict__ scores, int64_t stride,
-                                                            const float* __restrict__ qn2,
-                                                            const float* __restrict__ dn2, int64_t n4, int mode)
-{
-    const int j = blockIdx.y;
-    const float q2 = qn2[j];
-    f32x4* row = reinterpret_cast<f32x4*>(scores + (int64_t)j * stride);
-    const f32x4* dn = reinterpret_cast<const f32x4*>(dn2);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 v = row[i];
-        const f32x4 d = dn[i];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = cosine_finish(v[c], q2, d[c], mode);
-        row[i] = v;
-    }
-}
-
 template <int NV4, int R, int NQ>
 void launch_stream(const float* queries, const float* corpus, int64_t n_groups, int mode, float* scores,
                    int64_t score_stride, hipStream_t stream)
@@ -498,40 +481,233 @@ bool dispatch_stream(int dim, const float* queries, const float* corpus, int64_t
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Many queries (20 or more): the fused matrix-core scan.
+//
+// dot(q_j, doc_d) for a block of up to 64 queries is a [64, dim] x [n_docs, dim]^T product, so the corpus is read ONCE
+// for the block (a streaming pass serves 4 queries).  One launch does everything VectorStore::search /
+// Segment::search_vectors do per document (kjarni-search/src/vector.rs:131-166, kjarni-rag/src/segment.rs:307-371):
+// the dot products on the f32 matrix cores, ||doc||^2 from the very registers that stage the document rows (every
+// document byte crosses HBM once and is touched twice in registers), and the cosine with the mode's zero-norm guard in
+// the epilogue.  Both roofs are close for 64 queries: 32 flop per corpus byte = 4.9 TB/s at the f32 MFMA peak.
+//
+// Tile: 64 queries (rows past nq read as zeros) x 256 documents, BK = 16; four waves, wave w = documents 64 w ..
+// 64 w + 63 against all 64 queries (2 x 2 MFMA tiles of 32 x 32).  LDS: two stages of [64 + 256][16 + 4] floats
+// (51 KiB: three workgroups per CU); the staging map and the 80-byte row stride are those of gemm_nt_f32_mfma_ln
+// (conflict-free 16-byte writes and fragment reads).  The kernel is persistent and its K-loop FLAT over (tile, K-step):
+// registers hold step g + 1 while step g is multiplied and the loads of step g + 2 are in flight, across tile
+// boundaries too, so a tile's first K-steps arrive under the previous tile's last ones and only the accumulator flush
+// interrupts the matrix work.  Scores go out as 128-byte row segments straight from the accumulators (an accumulator
+// register is 32 consecutive documents of one query).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MQ_Q = 64, MQ_D = 256, MQ_BK = 16, MQ_STRIDE = MQ_BK + 4;
+constexpr int MQ_STAGE_FLOATS = (MQ_Q + MQ_D) * MQ_STRIDE;
+constexpr int MQ_LDS_BYTES = (2 * MQ_STAGE_FLOATS + 2 * MQ_D + MQ_Q) * 4;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* __restrict__ queries, int nq,
+                                                                  const float* __restrict__ corpus, int64_t n_docs, int dim,
+                                                                  const float* __restrict__ qn2, float* __restrict__ scores,
+                                                                  int64_t stride, int64_t n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                                   // [2][64][20]   (stage s at + s * MQ_STAGE_FLOATS)
+    float* sD = smem + MQ_Q * MQ_STRIDE;                // [2][256][20]
+    float* sDn = smem + 2 * MQ_STAGE_FLOATS;            // [2][256]: ||doc||^2 of a tile, by tile parity
+    float* sQn = sDn + 2 * MQ_D;                        // [64]: sqrt(||q||^2)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int nk = dim / MQ_BK;
+    int64_t my_tiles = 0;
+    if ((int64_t)blockIdx.x < n_tiles) my_tiles = (n_tiles - 1 - blockIdx.x) / gridDim.x + 1;
+    if (my_tiles == 0) return;
+    const int64_t steps = my_tiles * nk;
+
+    // staging: thread -> (row, 16-byte column); lanes 0-3 take row r, lanes 4-7 row r + 4 (see gemm_nt_f32_mfma_ln)
+    const int ld_grp = tid >> 3;
+    const int ld_row = (ld_grp >> 2) * 8 + (ld_grp & 3) + 4 * ((tid >> 2) & 1), ld_c4 = tid & 3;
+    const int st_off = ld_row * MQ_STRIDE + ld_c4 * 4;
+    auto rsrc = [](const float* p, int64_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+    };
+    auto ld16 = [](__amdgpu_buffer_rsrc_t r, uint32_t off, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
+    };
+    const __amdgpu_buffer_rsrc_t rQ = rsrc(queries, (int64_t)nq * dim * 4);   // rows past nq: zeros
+    const uint32_t offQ = (uint32_t)(((int64_t)ld_row * dim + ld_c4 * 4) * 4);
+    uint32_t offD[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offD[i] = (uint32_t)(((int64_t)(ld_row + 64 * i) * dim + ld_c4 * 4) * 4);
+
+    // the staging side of the flat loop runs two steps ahead of the matrix side
+    int64_t s_tile = blockIdx.x;  // tile of the step to be requested next
+    int s_k = 0, s_par = 0;       // its K-step; parity of the tile whose rows sit in the registers
+    auto tile_rsrc = [&](int64_t tile) {
+        const int64_t d0 = tile * MQ_D;
+        const int64_t rows = n_docs - d0 < MQ_D ? n_docs - d0 : MQ_D;   // documents past n_docs: zeros
+        return rsrc(corpus + d0 * dim, rows * dim * 4);
+    };
+    __amdgpu_buffer_rsrc_t rD = tile_rsrc(s_tile);
+    f32x4 gq, gd[4];
+    auto request = [&]() {  // the next step's rows -> registers
+        const int soff = s_k * MQ_BK * 4;
+        gq = ld16(rQ, offQ, soff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gd[i] = ld16(rD, offD[i], soff);
+        if (++s_k == nk) {
+            s_k = 0;
+            s_tile += gridDim.x;
+            if (s_tile < n_tiles) rD = tile_rsrc(s_tile);
+        }
+    };
+    float sumsq[4] = {0.f, 0.f, 0.f, 0.f};
+    int st_k = 0;  // K-step of the rows in the registers
+    auto store = [&](int stage) {  // registers -> LDS stage; the documents' squared norms on the way
+        *reinterpret_cast<f32x4*>(sQ + stage * MQ_STAGE_FLOATS + st_off) = gq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(sD + stage * MQ_STAGE_FLOATS + st_off + 64 * i * MQ_STRIDE) = gd[i];
+            sumsq[i] = fmaf(gd[i][0], gd[i][0], sumsq[i]);
+            sumsq[i] = fmaf(gd[i][1], gd[i][1], sumsq[i]);
+            sumsq[i] = fmaf(gd[i][2], gd[i][2], sumsq[i]);
+            sumsq[i] = fmaf(gd[i][3], gd[i][3], sumsq[i]);
+        }
+        if (++st_k == nk) {  // the tile's last K-step: its norms are complete
+            st_k = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = sumsq[i];
+                v += __shfl_xor(v, 1, kWave);
+                v += __shfl_xor(v, 2, kWave);
+                if (ld_c4 == 0) sDn[s_par * MQ_D + ld_row + 64 * i] = v;
+                sumsq[i] = 0.0f;
+            }
+            s_par ^= 1;
+        }
+    };
+
+    if (tid < MQ_Q) sQn[tid] = tid < nq ? sqrtf(qn2[tid]) : 0.0f;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int a_off = l31 * MQ_STRIDE + half * 4;                 // query rows 0..31 (+32 for the second tile)
+    const int b_off = (wid * 64 + l31) * MQ_STRIDE + half * 4;    // this wave's documents
+    struct Frag {
+        f32x4 a0, a1, b0, b1;
+    };
+    auto read_frag = [&](Frag& f, int stage, int kk) {
+        const float* pa = sQ + stage * MQ_STAGE_FLOATS + a_off + kk * 8;
+        const float* pb = sD + stage * MQ_STAGE_FLOATS + b_off + kk * 8;
+        f.a0 = *reinterpret_cast<const f32x4*>(pa);
+        f.a1 = *reinterpret_cast<const f32x4*>(pa + 32 * MQ_STRIDE);
+        f.b0 = *reinterpret_cast<const f32x4*>(pb);
+        f.b1 = *reinterpret_cast<const f32x4*>(pb + 32 * MQ_STRIDE);
+    };
+    auto mfma16 = [&](const Frag& f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[c], f.b0[c], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[c], f.b1[c], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[c], f.b0[c], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[c], f.b1[c], acc[1][1], 0, 0, 0);
+        }
+    };
+
+    // prologue: step 0 -> LDS stage 0, step 1 in flight in the registers, fragments kk = 0 of step 0
+    request();
+    store(0);
+    if (steps > 1) request();
+    __syncthreads();
+    Frag fr[2];
+    read_frag(fr[0], 0, 0);
+
+    int64_t c_tile = blockIdx.x;  // tile the matrix side is on
+    int c_k = 0, c_par = 0;
+    for (int64_t g = 0; g < steps; ++g) {
+        const int cur = (int)(g & 1);
+        // phase 0: fragments of the second half of this step; step g + 1 -> the other LDS stage; request step g + 2
+        read_frag(fr[1], cur, 1);
+        if (g + 1 < steps) store(cur ^ 1);
+        if (g + 2 < steps) request();
+        mfma16(fr[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 4 fragment reads first
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {                       // then a staging piece every few MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA x 2
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 1: everyone has read stage cur and written stage cur ^ 1
+        __syncthreads();
+        if (g + 1 < steps) read_frag(fr[0], cur ^ 1, 0);
+        mfma16(fr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++c_k == nk) {
+            // the tile is complete: cosines out, accumulators cleared
+            const int64_t d_base = c_tile * MQ_D + wid * 64 + l31;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t d = d_base + j * 32;
+                const float dn2 = sDn[c_par * MQ_D + wid * 64 + j * 32 + l31];
+                const float dn = sqrtf(dn2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int q = i * 32 + acc_row(r, half);
+                        const float qn = sQn[q];
+                        const float dot = acc[i][j][r];
+                        float v;
+                        if (MODE == 0) {
+                            v = dot / fmaxf(qn * dn, 1e-9f);          // vector.rs:131-148
+                        } else {
+                            v = dn < 1e-9f ? 0.0f : dot / (qn * dn);  // segment.rs:355-371
+                        }
+                        if (q < nq && d < n_docs) scores[(int64_t)q * stride + d] = v;
+                        acc[i][j][r] = 0.0f;
+                    }
+            }
+            c_k = 0;
+            c_par ^= 1;
+            c_tile += gridDim.x;
+        }
+    }
+}
+
 // One streaming pass over the corpus per group of SCAN_NQ queries.
 hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
                        float* scores, int64_t score_stride, hipStream_t stream);
 
-// Many queries: the dot products are a [nq, dim] x [n_docs, dim]^T product, so the corpus is read once
-// by the matrix-core GEMM (queries as the row operand) instead of once per 4 queries; row norms come
-// from one streaming pass, then an element-wise pass turns dots into cosines in place.
-hipError_t scan_gemm(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
+// Many queries: blocks of 64 through the fused matrix-core scan (one corpus read per block).
+hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
                      float* scores, hipStream_t stream)
 {
-    float* tmp = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), (size_t)(n_docs + nq + 8) * sizeof(float), stream);
+    float* qn2 = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&qn2), (size_t)(nq + 8) * sizeof(float), stream);
     if (e != hipSuccess) return e;
-    float* dn2 = tmp;
-    float* qn2 = tmp + ((n_docs + 3) / 4) * 4;
-    const int64_t n_main = n_docs / 128 * 128;
-    e = scan_passes(corpus, 1, corpus, n_docs, dim, 2, dn2, n_docs, stream);      // row norms (query unused)
-    if (e == hipSuccess) e = scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);
-    for (int q0 = 0; q0 < nq && e == hipSuccess; q0 += 128) {
-        const int m = nq - q0 < 128 ? nq - q0 : 128;
-        e = launch_gemm(queries + (int64_t)q0 * dim, dim, corpus, nullptr, nullptr, 0, scores + (int64_t)q0 * n_docs,
-                        n_docs, m, (int)n_main, dim, EPI_BIAS, stream);
-    }
-    if (e == hipSuccess) {
-        const int64_t n4 = n_main / 4;
-        int64_t bx = (n4 + 255) / 256;
-        if (bx > 4096) bx = 4096;
-        hipLaunchKernelGGL(cosine_finish_kernel, dim3((unsigned)bx, (unsigned)nq), dim3(256), 0, stream, scores, n_docs,
-                           qn2, dn2, n4, mode);
+    e = scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);  // squared norms of the queries (query operand unused)
+    const int64_t n_tiles = (n_docs + MQ_D - 1) / MQ_D;
+    const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 256 * 2);  // the workgroups the chip holds at once (two per CU)
+    for (int q0 = 0; q0 < nq && e == hipSuccess; q0 += MQ_Q) {
+        const int m = nq - q0 < MQ_Q ? nq - q0 : MQ_Q;
+        if (mode == 0)
+            hipLaunchKernelGGL(cosine_scan_mfma_kernel<0>, dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, m,
+                               corpus, n_docs, dim, qn2 + q0, scores + (int64_t)q0 * n_docs, n_docs, n_tiles);
+        else
+            hipLaunchKernelGGL(cosine_scan_mfma_kernel<1>, dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, m,
+                               corpus, n_docs, dim, qn2 + q0, scores + (int64_t)q0 * n_docs, n_docs, n_tiles);
         e = hipGetLastError();
     }
-    if (e == hipSuccess && n_main < n_docs)  // the < 128 leftover documents
-        e = scan_passes(queries, nq, corpus + n_main * dim, n_docs - n_main, dim, mode, scores + n_main, n_docs, stream);
-    const hipError_t fe = hipFreeAsync(tmp, stream);
+    const hipError_t fe = hipFreeAsync(qn2, stream);
     return e != hipSuccess ? e : fe;
 }
 
@@ -544,10 +720,10 @@ hipError_t launch_cosine_scores(const float* queries, int nq, const float* corpu
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) &&
                            ((reinterpret_cast<uintptr_t>(queries) & 15) == 0) &&
                            ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
-    // Crossover: a streaming pass per 4 queries costs about as much as the GEMM route from ~20 queries on.
-    if (nq >= 20 && aligned16 && dim % 32 == 0 && n_docs % 4 == 0 && n_docs >= 128 && n_docs < (int64_t)INT32_MAX &&
+    // Crossover: a streaming pass serves 4 queries, the matrix-core scan 64 at about the cost of two passes.
+    if (nq >= 20 && aligned16 && dim % MQ_BK == 0 && (int64_t)MQ_D * dim * 4 < ((int64_t)1 << 31) && (mode == 0 || mode == 1) &&
         !tune::scan_streaming_only())
-        return scan_gemm(queries, nq, corpus, n_docs, dim, mode, scores, stream);
+        return scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream);
     return scan_passes(queries, nq, corpus, n_docs, dim, mode, scores, n_docs, stream);
 }
 
