@@ -518,19 +518,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
     int kt = 0;
     for (; kt + 2 < nk; ++kt) step(TT{}, TT{}, kt);
     if (kt + 1 < nk) step(TT{}, FF{}, kt++);
-    step(FF{}, FF{}, kt);
 
-    // ---- epilogue ----
+    // The epilogue's residual rows.  Round 0's are requested HERE, before the last K-step (whose staging registers are
+    // idle: nothing is left to stage), so their round trip runs under that step's MFMAs instead of in front of the
+    // epilogue; round 1's are requested once round 0's accumulators have left their registers for LDS.
     constexpr int OS = T::OUT_STRIDE, NV = T::V4_PER_THREAD;
     const int e_row = tid >> 3, e_t8 = tid & 7;
-    f32x4 res[2][NV];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    f32x4 res[NV];
+    auto load_residual = [&](int i) {
         int64_t m = m0 + i * 32 + e_row;
         m = m < M ? m : M - 1;
 #pragma unroll
-        for (int q = 0; q < NV; ++q) res[i][q] = *reinterpret_cast<const f32x4*>(R + m * ldr + (e_t8 + 8 * q) * 4);
-    }
+        for (int q = 0; q < NV; ++q) res[q] = *reinterpret_cast<const f32x4*>(R + m * ldr + (e_t8 + 8 * q) * 4);
+    };
+    load_residual(0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(FF{}, FF{}, kt);
+
+    // ---- epilogue ----
     const float inv_n = 1.0f / (float)BN;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -548,9 +553,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
             const int c = (e_t8 + 8 * q) * 4;
             x[q] = *reinterpret_cast<const f32x4*>(smem + e_row * OS + c);
             if (bias) x[q] += *reinterpret_cast<const f32x4*>(bias + c);
-            x[q] += res[i][q];
+            x[q] += res[q];
             s += (x[q][0] + x[q][1]) + (x[q][2] + x[q][3]);
         }
+        if (i == 0) load_residual(1);  // (R == Y in place: round 1's rows are not written before the second round's stores)
         s += __shfl_xor(s, 1, kWave);
         s += __shfl_xor(s, 2, kWave);
         s += __shfl_xor(s, 4, kWave);

@@ -192,15 +192,16 @@ __global__ __launch_bounds__(256) void embed_generic_kernel(
 // a hidden row is coalesced.  mask is the u32 attention mask (traits.rs:71
 // converts it with `as f32`).
 // ---------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
+template <int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void pool_kernel(const float* __restrict__ hs,
                                                    const uint32_t* __restrict__ mask, int seq,
                                                    int hidden, int normalize, const int32_t* __restrict__ cu,
                                                    float* __restrict__ out)
 {
-    __shared__ float red[4];
-    __shared__ int red_last[4];
-    __shared__ f32x4 part[256];
+    constexpr int NW = THREADS / 64;
+    __shared__ float red[NW];
+    __shared__ int red_last[NW];
+    __shared__ f32x4 part[THREADS];
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     // packed rows: sentence b is rows cu[b] .. cu[b+1] of hs, every one of them a kept token
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
     // at once (mask values are 0 / 1: the float sum is exact in any order)
     float cnt = 0.0f;
     int last = 0;
-    for (int s = tid; s < seq; s += 256) {
+    for (int s = tid; s < seq; s += THREADS) {
         const float mv = mrow ? (float)mrow[s] : 1.0f;
         cnt += mv;
         if (mv > 0.0f) last = s;
@@ -225,15 +226,20 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
         red_last[tid >> 6] = last;
     }
     __syncthreads();
-    cnt = (red[0] + red[1]) + (red[2] + red[3]);
-    last = max(max(red_last[0], red_last[1]), max(red_last[2], red_last[3]));
+    cnt = 0.0f;
+    last = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {   // (mask values are 0 / 1: exact in any order)
+        cnt += red[w];
+        last = max(last, red_last[w]);
+    }
     __syncthreads();
 
     const int nv4 = hidden >> 2;
     if (MODE == POOL_MEAN && (hidden & 3) == 0 && nv4 <= 256) {
-        // 16-byte columns; with hidden = 384 two row groups share the block (192 lanes busy), each summing every
-        // second row; the groups' partial sums meet in LDS and are added in group order.
-        const int groups = 256 / nv4;
+        // 16-byte columns; with hidden = 384 a 256-thread block holds two row groups (192 lanes busy), a 1024-thread block
+        // ten, each summing every groups-th row; the groups' partial sums meet in LDS and are added in group order.
+        const int groups = THREADS / nv4;
         const int c4 = tid % nv4, g = tid / nv4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         if (g < groups) {
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
             sq = wave_sum(sq);
             if ((tid & 63) == 0) red[tid >> 6] = sq;
             __syncthreads();
+            // (only group 0 holds non-zero squares: waves 0 .. ceil(nv4 / 64) - 1; the first four cover hidden <= 1024)
             const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
             if (norm > 0.0f) a = a / norm;  // traits.rs:529-536: divide only when the norm is > 0
         }
@@ -279,12 +286,12 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
         return;
     }
 
-    constexpr int MAXC = 4;  // hidden <= 1024
+    constexpr int MAXC = 1024 / THREADS;  // hidden <= 1024
     float acc[MAXC];
     float sq = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
-        const int c = tid + j * 256;
+        const int c = tid + j * THREADS;
         acc[j] = 0.0f;
         if (c >= hidden) continue;
         if (MODE == POOL_MEAN) {
@@ -317,7 +324,10 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
         sq = wave_sum(sq);
         if ((tid & 63) == 0) red[tid >> 6] = sq;
         __syncthreads();
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        float n2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) n2 += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+        const float norm = sqrtf(n2);
         // traits.rs:529-536: divide only when the norm is > 0
         if (norm > 0.0f) {
 #pragma unroll
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hs,
     }
 #pragma unroll
     for (int j = 0; j < MAXC; ++j) {
-        const int c = tid + j * 256;
+        const int c = tid + j * THREADS;
         if (c < hidden) out[b * hidden + c] = acc[j];
     }
 }
@@ -544,26 +554,23 @@ hipError_t launch_pool(const float* hidden_states, const uint32_t* mask, int64_t
 {
     if (batch <= 0) return hipSuccess;
     if (hidden > 1024 || seq <= 0) return hipErrorInvalidValue;
-    dim3 grid((unsigned)batch), block(256);
+    // A handful of sentences is a latency chain per workgroup (one sentence each): 1024 threads then split a sentence's
+    // rows ten ways instead of two (20 -> 7 us for a call of 1 .. 32 sentences); large batches are HBM-bound either way.
+    const bool wide = batch < 2048;
+    dim3 grid((unsigned)batch);
+#define KJ_POOL(MODE_)                                                                                                       \
+    if (wide)                                                                                                                \
+        hipLaunchKernelGGL((pool_kernel<MODE_, 1024>), grid, dim3(1024), 0, stream, hidden_states, mask, seq, hidden, normalize, cu, out); \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((pool_kernel<MODE_, 256>), grid, dim3(256), 0, stream, hidden_states, mask, seq, hidden, normalize, cu, out)
     switch (mode) {
-    case POOL_MEAN:
-        hipLaunchKernelGGL(pool_kernel<POOL_MEAN>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, cu, out);
-        break;
-    case POOL_CLS:
-        hipLaunchKernelGGL(pool_kernel<POOL_CLS>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, cu, out);
-        break;
-    case POOL_MAX:
-        hipLaunchKernelGGL(pool_kernel<POOL_MAX>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, cu, out);
-        break;
-    case POOL_LAST:
-        hipLaunchKernelGGL(pool_kernel<POOL_LAST>, grid, block, 0, stream, hidden_states, mask, seq,
-                           hidden, normalize, cu, out);
-        break;
+    case POOL_MEAN: KJ_POOL(POOL_MEAN); break;
+    case POOL_CLS: KJ_POOL(POOL_CLS); break;
+    case POOL_MAX: KJ_POOL(POOL_MAX); break;
+    case POOL_LAST: KJ_POOL(POOL_LAST); break;
     default: return hipErrorInvalidValue;
     }
+#undef KJ_POOL
     return hipGetLastError();
 }
 
