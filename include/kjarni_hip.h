@@ -363,6 +363,9 @@ KjarniErrorCode kjarni_hip_decoder_dims(const KjarniHipDecoder* decoder, int32_t
 KjarniErrorCode kjarni_hip_decoder_reset(KjarniHipDecoder* decoder); /* empty KV cache */
 /* Prompt projections that took the 128 x 128-tile GEMM route since load (0 on NULL): a route counter for tests. */
 uint64_t kjarni_hip_decoder_tile_gemm_calls(const KjarniHipDecoder* decoder);
+/* kjarni_hip_decoder_generate with a repetition penalty / n-gram ban: processors on the device (default) or on a host copy
+ * of the logits (0), as kjarni_hip_chat_set_device_sampling. */
+void kjarni_hip_decoder_set_device_sampling(KjarniHipDecoder* decoder, int32_t on);
 /* CpuDecoder::forward + final norm + lm head (llama/cpu_decoder.rs:196-219): appends n tokens to the cache;
  * the prompt is processed 8 rows at a time and hidden_out receives the final-normed rows of the LAST block,
  * f32 [((n-1) mod 8) + 1, hidden]; logits_out f32 [vocab] of the last position.  Either may be NULL. */
@@ -407,6 +410,14 @@ KjarniErrorCode kjarni_chat_template_apply(int32_t template_kind, const int32_t*
  * the no-repeat-n-gram ban (:29-57, 0 = off) in place. */
 KjarniErrorCode kjarni_sampling_distribution(const float* logits, size_t vocab, float temperature, int64_t top_k, float top_p, float min_p,
                                              float* probs_out);
+/* The same distribution decided from CANDIDATES only -- every token whose logit is within `tau` of the maximum, the
+ * maximum, and the sum of exp(logit - max) over the vocabulary in a non-index order -- which is what the decode loop's
+ * device kernels hand to the host per sampled token instead of 4 x vocab bytes of logits.  *decided = 0 when the
+ * candidates do not decide it (a filter reaches past them, or a top-p crossing lies within the rounding of the sum):
+ * the loop then fetches the logits and runs kjarni_sampling_distribution's path.  Host-side emulation for parity tests. */
+KjarniErrorCode kjarni_sampling_distribution_candidates(const float* logits, size_t vocab, float tau, float temperature, int64_t top_k,
+                                                        float top_p, float min_p, float* probs_out, int32_t* decided,
+                                                        size_t* n_candidates);
 uint32_t kjarni_sample_from_probs(const float* probs, size_t vocab, float uniform);
 KjarniErrorCode kjarni_logits_process(float* logits, size_t vocab, const uint32_t* tokens, size_t n_tokens, float repetition_penalty,
                                       size_t no_repeat_ngram);
@@ -439,6 +450,12 @@ KjarniErrorCode kjarni_hip_chat_format_prompt(const KjarniChat* chat, const int3
 KjarniErrorCode kjarni_hip_chat_encode(const KjarniChat* chat, const char* prompt, const KjarniGenerationConfig* runtime, uint32_t* ids_out,
                                        size_t capacity, size_t* n_out);
 void kjarni_hip_chat_seed(KjarniChat* chat, uint64_t seed);
+/* Sampled tokens and the logits processors: by default everything that is O(vocab) runs on the device and the host
+ * decides on a candidate list (a 32-byte header + a few hundred (token, logit) pairs per token); 0 = the logits travel
+ * to the host for every token, which is the checker the tests compare with -- same tokens for the same seed.  The
+ * counters: tokens decided from candidates / tokens that needed the logits after all. */
+void kjarni_hip_chat_set_device_sampling(KjarniChat* chat, int32_t on);
+void kjarni_hip_chat_sampling_counters(KjarniChat* chat, uint64_t* from_candidates, uint64_t* from_logits);
 
 #ifdef __cplusplus
 }

@@ -375,6 +375,8 @@ SIGNATURES = {
     "kjarni_bpe_tokenizer_pre_tokenize": (c_int32, [c_void_p, c_char_p, POINTER(KjarniStringArray)]),
     "kjarni_chat_template_apply": (c_int32, [c_int32, POINTER(c_int32), POINTER(c_char_p), c_size_t, POINTER(c_void_p)]),
     "kjarni_sampling_distribution": (c_int32, [_f32p, c_size_t, c_float, c_int64, c_float, c_float, _f32p]),
+    "kjarni_sampling_distribution_candidates": (c_int32, [_f32p, c_size_t, c_float, c_float, c_int64, c_float, c_float, _f32p,
+                                                        POINTER(c_int32), POINTER(c_size_t)]),
     "kjarni_sample_from_probs": (C.c_uint32, [_f32p, c_size_t, c_float]),
     "kjarni_logits_process": (c_int32, [_f32p, c_size_t, _u32p, c_size_t, c_float, c_size_t]),
     "kjarni_generation_resolve": (c_int32, [c_char_p, c_size_t, c_char_p, c_int32, POINTER(KjarniGenerationConfig),
@@ -383,12 +385,15 @@ SIGNATURES = {
     "kjarni_hip_chat_format_prompt": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_char_p), c_size_t, c_char_p, POINTER(c_void_p)]),
     "kjarni_hip_chat_encode": (c_int32, [c_void_p, c_char_p, POINTER(KjarniGenerationConfig), _u32p, c_size_t, POINTER(c_size_t)]),
     "kjarni_hip_chat_seed": (None, [c_void_p, C.c_uint64]),
+    "kjarni_hip_chat_set_device_sampling": (None, [c_void_p, c_int32]),
+    "kjarni_hip_chat_sampling_counters": (None, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "kjarni_hip_decoder_load": (c_int32, [c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "kjarni_hip_decoder_free": (None, [c_void_p]),
     "kjarni_hip_decoder_dims": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                           POINTER(c_int32), POINTER(C.c_uint64)]),
     "kjarni_hip_decoder_reset": (c_int32, [c_void_p]),
     "kjarni_hip_decoder_tile_gemm_calls": (c_uint64, [c_void_p]),
+    "kjarni_hip_decoder_set_device_sampling": (None, [c_void_p, c_int32]),
     "kjarni_hip_decoder_forward": (c_int32, [c_void_p, _u32p, c_int32, _f32p, _f32p]),
     "kjarni_hip_decoder_generate": (c_int32, [c_void_p, _u32p, c_size_t, c_size_t, c_float, c_int32, KjarniTokenCallbackFn, c_void_p,
                                               _u32p, c_size_t, POINTER(c_size_t)]),

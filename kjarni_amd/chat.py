@@ -172,6 +172,16 @@ class Chat:
     def seed(self, seed: int):
         lib().kjarni_hip_chat_seed(self._handle, seed)
 
+    def set_device_sampling(self, on: bool):
+        """Sampling / logits processors with the O(vocab) work on the device (default) or on a host copy of the logits."""
+        lib().kjarni_hip_chat_set_device_sampling(self._handle, 1 if on else 0)
+
+    def sampling_counters(self):
+        """(tokens decided from the device's candidates, tokens that needed the full logits)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        lib().kjarni_hip_chat_sampling_counters(self._handle, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
 
 class ChatConversation:
     def __init__(self, chat: Chat):
@@ -255,6 +265,21 @@ def sampling_distribution(logits, temperature: float = 1.0, top_k: Optional[int]
                                                    -1.0 if top_p is None else top_p, -1.0 if min_p is None else min_p,
                                                    out.ctypes.data_as(f)))
     return out
+
+
+def sampling_distribution_candidates(logits, tau: float, temperature: float = 1.0, top_k: Optional[int] = None,
+                                     top_p: Optional[float] = None, min_p: Optional[float] = None):
+    """The distribution decided from the candidates within `tau` of the maximum (what the device hands to the decode loop).
+    Returns (probs or None when the candidates do not decide it, number of candidates)."""
+    lg = np.ascontiguousarray(logits, np.float32)
+    out = np.zeros_like(lg)
+    f = C.POINTER(C.c_float)
+    decided, n = C.c_int32(0), C.c_size_t(0)
+    check_error(lib().kjarni_sampling_distribution_candidates(lg.ctypes.data_as(f), lg.size, tau, temperature,
+                                                              -1 if top_k is None else top_k, -1.0 if top_p is None else top_p,
+                                                              -1.0 if min_p is None else min_p, out.ctypes.data_as(f),
+                                                              C.byref(decided), C.byref(n)))
+    return (out if decided.value else None), int(n.value)
 
 
 def sample_from_probs(probs, uniform: float) -> int:

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 
 #include "host_util.h"
 #include "../../include/kjarni_hip.h"
@@ -381,6 +382,45 @@ KJARNI_EXPORT KjarniErrorCode kjarni_sampling_distribution(const float* logits, 
     });
 }
 
+// The candidate form of the same distribution (what the decode loop uses: the device hands over every token within `tau`
+// of the maximum + the maximum + the sum of exp over the vocabulary; sampling.h).  Here the device's part is emulated on
+// the host (sum accumulated in double: a different rounding order, as on the device), so the CPU suite can hold the
+// candidate form to the full one.  *decided = 0: the candidates do not decide the distribution (probs_out untouched).
+KJARNI_EXPORT KjarniErrorCode kjarni_sampling_distribution_candidates(const float* logits, size_t vocab, float tau, float temperature,
+                                                                      int64_t top_k, float top_p, float min_p, float* probs_out,
+                                                                      int32_t* decided, size_t* n_candidates)
+{
+    if (!logits || !probs_out || !decided) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_UNKNOWN, [&] {
+        SamplingParams p;
+        p.temperature = temperature;
+        p.top_k = top_k;
+        p.top_p = top_p;
+        p.min_p = min_p;
+        float mx = -std::numeric_limits<float>::infinity();
+        for (size_t i = 0; i < vocab; ++i) mx = std::max(mx, logits[i]);
+        const float floor = mx - tau;
+        double sum = 0.0;
+        std::vector<uint32_t> cid;
+        std::vector<float> cval;
+        for (size_t i = vocab; i-- > 0;) {  // (descending ids: the candidate list arrives in no particular order)
+            sum += (double)std::exp(logits[i] - mx);
+            if (logits[i] >= floor) {
+                cid.push_back((uint32_t)i);
+                cval.push_back(logits[i]);
+            }
+        }
+        if (n_candidates) *n_candidates = cid.size();
+        std::vector<uint32_t> ids;
+        std::vector<float> probs;
+        *decided = sampling_distribution_candidates(cid.data(), cval.data(), cid.size(), mx, floor, (float)sum, vocab, p, ids, probs) ? 1 : 0;
+        if (*decided) {
+            std::fill(probs_out, probs_out + vocab, 0.0f);
+            for (size_t i = 0; i < ids.size(); ++i) probs_out[ids[i]] = probs[i];
+        }
+    });
+}
+
 KJARNI_EXPORT uint32_t kjarni_sample_from_probs(const float* probs, size_t vocab, float uniform)
 {
     if (!probs || vocab == 0) return 0;
@@ -490,4 +530,15 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_chat_encode(const KjarniChat* chat, con
 KJARNI_EXPORT void kjarni_hip_chat_seed(KjarniChat* chat, uint64_t seed)
 {
     if (chat) chat->inner->reseed(seed);
+}
+
+KJARNI_EXPORT void kjarni_hip_chat_set_device_sampling(KjarniChat* chat, int32_t on)
+{
+    if (chat) chat->inner->model().set_device_sampling(on != 0);
+}
+
+KJARNI_EXPORT void kjarni_hip_chat_sampling_counters(KjarniChat* chat, uint64_t* from_candidates, uint64_t* from_logits)
+{
+    if (from_candidates) *from_candidates = chat ? chat->inner->model().tokens_from_candidates() : 0;
+    if (from_logits) *from_logits = chat ? chat->inner->model().tokens_from_logits() : 0;
 }

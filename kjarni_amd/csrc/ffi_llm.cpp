@@ -49,6 +49,11 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_decoder_dims(const KjarniHipDecoder* d,
 
 KJARNI_EXPORT uint64_t kjarni_hip_decoder_tile_gemm_calls(const KjarniHipDecoder* d) { return d ? d->model->tile_gemm_calls() : 0; }
 
+KJARNI_EXPORT void kjarni_hip_decoder_set_device_sampling(KjarniHipDecoder* d, int32_t on)
+{
+    if (d) d->model->set_device_sampling(on != 0);
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_decoder_reset(KjarniHipDecoder* d)
 {
     if (!d) return KJARNI_ERROR_NULL_POINTER;

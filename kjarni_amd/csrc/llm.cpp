@@ -108,6 +108,7 @@ void* LlmModel::upload_weight(const std::vector<float>& host)
 LlmModel::~LlmModel()
 {
     if (host_logits_) (void)hipHostFree(host_logits_);
+    if (samp_host_) (void)hipHostFree(samp_host_);
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (graph_) (void)hipGraphExecDestroy(graph_);
@@ -519,7 +520,119 @@ std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, co
     const float repetition_penalty = opt.repetition_penalty;
     const int no_repeat_ngram = opt.no_repeat_ngram;
 
+    if ((opt.sample || repetition_penalty != 1.0f || no_repeat_ngram > 0) && device_sampling_) {
+        // Logits processors and sampling (generator.rs:331-343), with everything that is O(vocab) on the device
+        // (llm_kernels.hip): the processors edit the logits where the vocabulary head left them; for a sampled token three
+        // small launches cut the vocabulary down to the candidates within reach of the filters and sum the exponentials,
+        // and the host receives a 32-byte header + a few hundred (token, logit) pairs instead of 4 x vocab bytes.  It
+        // finishes top-k / top-p / min-p / temperature / the draw on them exactly as the reference does on the full array
+        // (sampling.cpp); when the candidates cannot decide (rare: a crossing within the rounding of the device's sum, a
+        // nearly flat distribution) it fetches the logits -- already processed -- and runs the full-array path.
+        const size_t vocab = (size_t)cfg_.vocab;
+        const size_t out_bytes = sizeof(SampleHeader) + (size_t)kCandCap * sizeof(SampleCandidate);
+        if (!samp_scratch_) {
+            samp_scratch_ = dalloc((sample_scratch_bytes() + 3) / 4);
+            hip_check(hipMemset(samp_scratch_, 0, sample_scratch_bytes()), "memset");
+            samp_out_ = reinterpret_cast<uint8_t*>(dalloc((out_bytes + 3) / 4));
+            hip_check(hipMemset(samp_out_, 0, out_bytes), "memset");
+            hip_check(hipHostMalloc((void**)&samp_host_, out_bytes, hipHostMallocDefault), "hipHostMalloc");
+            samp_tokens_ = reinterpret_cast<int32_t*>(dalloc((size_t)cache_cap_ + 16));
+            samp_distinct_ = reinterpret_cast<int32_t*>(dalloc((size_t)cache_cap_ + 16));
+            samp_counts_ = reinterpret_cast<int*>(dalloc(vocab));
+            samp_ndistinct_ = reinterpret_cast<int*>(dalloc(4));
+        }
+        if (opt.sample && !host_logits_)
+            hip_check(hipHostMalloc((void**)&host_logits_, vocab * sizeof(float), hipHostMallocDefault), "hipHostMalloc");
+        SampleHeader* header_dev = reinterpret_cast<SampleHeader*>(samp_out_);
+        SampleCandidate* cand_dev = reinterpret_cast<SampleCandidate*>(samp_out_ + sizeof(SampleHeader));
+        const SampleHeader* header = reinterpret_cast<const SampleHeader*>(samp_host_);
+        const SampleCandidate* cand = reinterpret_cast<const SampleCandidate*>(samp_host_ + sizeof(SampleHeader));
+        const bool processors = repetition_penalty != 1.0f || no_repeat_ngram > 0;
+        if (processors) {  // the history so far = the prompt
+            hip_check(hipMemsetAsync(samp_counts_, 0, vocab * sizeof(int), stream_), "memset counts");
+            hip_check(hipMemsetAsync(samp_ndistinct_, 0, sizeof(int), stream_), "memset");
+            hip_check(hipMemcpyAsync(samp_tokens_, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_), "H2D history");
+            hip_check(launch_token_counts(samp_tokens_, (int)all.size(), (int)vocab, samp_counts_, samp_distinct_, samp_ndistinct_, stream_),
+                      "token counts");
+        }
+        std::vector<float> probs, cvals;
+        std::vector<uint32_t> ids, cids;
+        hipGraphExec_t exec = nullptr;
+        int skip_candidates = 0;
+        for (size_t step = 0; step < max_new_tokens; ++step) {
+            if (all.size() >= context_limit) break;
+            if (processors)
+                hip_check(launch_logits_processors(logits_, (int)vocab, samp_tokens_, (int)all.size(), samp_counts_, samp_distinct_,
+                                                   samp_ndistinct_, repetition_penalty, no_repeat_ngram, stream_), "logits processors");
+            uint32_t next;
+            if (opt.sample) {
+                // A distribution the candidates could not decide (nearly flat: top-p reaches through most of the vocabulary) rarely
+                // becomes decidable on the next token: after a miss the cut is not attempted for a few tokens.
+                const bool attempt = skip_candidates == 0;
+                if (!attempt) --skip_candidates;
+                const size_t first = sizeof(SampleHeader) + (size_t)kCandFirst * sizeof(SampleCandidate);
+                if (attempt) {
+                    hip_check(launch_sample_candidates(logits_, (int)vocab, opt.sampling.top_k, opt.sampling.top_p, opt.sampling.min_p,
+                                                       samp_scratch_, header_dev, cand_dev, kCandCap, stream_), "sample candidates");
+                    hip_check(hipMemcpyAsync(samp_host_, samp_out_, first, hipMemcpyDeviceToHost, stream_), "D2H candidates");
+                    hip_check(hipStreamSynchronize(stream_), "sync");
+                }
+                bool decided = false;
+                if (attempt && !header->overflow && header->count <= (uint32_t)kCandCap) {
+                    const size_t n = header->count;
+                    if (n > (size_t)kCandFirst) {
+                        hip_check(hipMemcpyAsync(samp_host_ + first, samp_out_ + first, (n - kCandFirst) * sizeof(SampleCandidate),
+                                                 hipMemcpyDeviceToHost, stream_), "D2H candidates");
+                        hip_check(hipStreamSynchronize(stream_), "sync");
+                    }
+                    cids.resize(n);
+                    cvals.resize(n);
+                    for (size_t i = 0; i < n; ++i) {
+                        cids[i] = cand[i].token;
+                        cvals[i] = cand[i].logit;
+                    }
+                    decided = sampling_distribution_candidates(cids.data(), cvals.data(), n, header->mx, header->floor, header->sum, vocab,
+                                                               opt.sampling, ids, probs);
+                }
+                if (decided) {
+                    ++tokens_from_candidates_;
+                } else {
+                    ++tokens_from_logits_;
+                    if (attempt) skip_candidates = 8;
+                    hip_check(hipMemcpyAsync(host_logits_, logits_, vocab * sizeof(float), hipMemcpyDeviceToHost, stream_), "D2H logits");
+                    hip_check(hipStreamSynchronize(stream_), "sync");
+                    sampling_distribution(host_logits_, vocab, opt.sampling, ids, probs);  // (the processors already ran, on the device)
+                }
+                next = sample_from_distribution(ids, probs, opt.uniform(), vocab);
+            } else {  // greedy on processed logits: the device's argmax (last maximum wins), four bytes back
+                enqueue_argmax(false);
+                int32_t t = 0;
+                hip_check(hipMemcpyAsync(&t, token_, sizeof(t), hipMemcpyDeviceToHost, stream_), "D2H token");
+                hip_check(hipStreamSynchronize(stream_), "sync");
+                next = (uint32_t)t;
+                ++tokens_from_candidates_;
+            }
+            if (is_stop(next)) break;
+            all.push_back(next);
+            out.push_back(next);
+            if (on_token && !on_token(next)) break;
+            if (all.size() >= context_limit) break;
+            if (!exec) exec = step_graph();
+            const int32_t tok = (int32_t)next;
+            hip_check(hipMemcpyAsync(token_, &tok, sizeof(tok), hipMemcpyHostToDevice, stream_), "H2D token");
+            if (processors) {
+                int32_t* slot = samp_tokens_ + (all.size() - 1);
+                hip_check(hipMemcpyAsync(slot, &tok, sizeof(tok), hipMemcpyHostToDevice, stream_), "H2D history");
+                hip_check(launch_token_counts(slot, 1, (int)vocab, samp_counts_, samp_distinct_, samp_ndistinct_, stream_), "token counts");
+            }
+            hip_check(hipGraphLaunch(exec, stream_), "graph launch");
+            cache_len_ += 1;
+        }
+        return out;
+    }
+
     if (opt.sample || repetition_penalty != 1.0f || no_repeat_ngram > 0) {
+        // (device sampling switched off: the checker path of the tests)
         // Logits processors and sampling work on the host copy of the logits (generator.rs:331-343): one pass per token.
         // The logits land in a pinned host buffer (one async copy per token at full PCIe rate).
         if (!host_logits_) hip_check(hipHostMalloc((void**)&host_logits_, (size_t)cfg_.vocab * sizeof(float), hipHostMallocDefault), "hipHostMalloc");

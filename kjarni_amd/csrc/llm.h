@@ -62,6 +62,12 @@ public:
     // Prompt projections that ran the encoder's 128 x 128-tile GEMM since load (the other route is the 64 x 64 prompt kernel):
     // lets a test assert which route a geometry took.
     uint64_t tile_gemm_calls() const { return tile_gemm_calls_; }
+    // Sampled decoding / logits processors: the O(vocab) work runs on the device and the host decides on a candidate list
+    // (default); off = the logits travel to the host every token (the checker in tests).  The counters say how many tokens
+    // were decided from candidates and how many needed the logits after all.
+    void set_device_sampling(bool on) { device_sampling_ = on; }
+    uint64_t tokens_from_candidates() const { return tokens_from_candidates_; }
+    uint64_t tokens_from_logits() const { return tokens_from_logits_; }
 
     void reset();  // empty KV cache
     // Appends n tokens (any n: processed 8 rows at a time); the logits of the last position stay on the device.
@@ -113,6 +119,15 @@ private:
     float* pw32_ = nullptr;    // f32 copy of the weight matrix a long prompt's GEMM is working on (bf16 checkpoints)
     float* psplit_ = nullptr;  // K-slice partial tiles of the prompt GEMMs (short prompts)
     float* host_logits_ = nullptr;  // pinned
+    // sampled decoding on the device (allocated on first use): candidate header + list and its pinned mirror, the token
+    // history with per-token counts and the list of distinct tokens (logits processors)
+    static constexpr int kCandCap = 4096, kCandFirst = 512;
+    void* samp_scratch_ = nullptr;
+    uint8_t *samp_out_ = nullptr, *samp_host_ = nullptr;
+    int32_t *samp_tokens_ = nullptr, *samp_distinct_ = nullptr;
+    int *samp_counts_ = nullptr, *samp_ndistinct_ = nullptr;
+    bool device_sampling_ = true;
+    uint64_t tokens_from_candidates_ = 0, tokens_from_logits_ = 0;
     int prefill_cap_ = 0;
     uint64_t tile_gemm_calls_ = 0;
     hipStream_t stream_ = nullptr;

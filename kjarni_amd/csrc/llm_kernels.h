@@ -79,4 +79,28 @@ hipError_t launch_llm_embed(const uint32_t* ids, int n, int hidden, int vocab, c
 hipError_t launch_argmax(const float* logits, int vocab, unsigned long long* best_scratch, int32_t* out, int32_t* history, int* count,
                          int* pos, hipStream_t stream);
 
+// ---- sampled decoding: the O(vocab) part on the device (llm_kernels.hip) ----------------------------------------------
+struct SampleHeader {   // 32 bytes, device memory mirrored to the host per sampled token
+    float mx;           // maximum logit
+    float sum;          // sum of exp(logit - mx) over the vocabulary (deterministic, not in index order)
+    float floor;        // every token with logit >= floor is in the candidate list
+    uint32_t count;     // candidates appended (may exceed the capacity: then overflow is set)
+    uint32_t overflow;  // 1: the list is not usable (too long, or no cut could be placed) -- fetch the logits
+    uint32_t pad[3];
+};
+struct SampleCandidate {
+    uint32_t token;
+    float logit;
+};
+size_t sample_scratch_bytes();   // zero-initialised device scratch of launch_sample_candidates
+// top_k < 0 / top_p < 0 / min_p < 0: that filter is off (as SamplingParams).
+hipError_t launch_sample_candidates(const float* logits, int vocab, int64_t top_k, float top_p, float min_p, void* scratch,
+                                    SampleHeader* header, SampleCandidate* candidates, int capacity, hipStream_t stream);
+// Logits processors on the device.  State: counts[vocab] (occurrences of each token in the history), distinct[] (the tokens
+// with a non-zero count) and *n_distinct, all zero-initialised and advanced by launch_token_counts for every token that
+// joins the history; tokens[len] is the history itself, in order.
+hipError_t launch_token_counts(const int32_t* tokens, int n, int vocab, int* counts, int32_t* distinct, int* n_distinct, hipStream_t stream);
+hipError_t launch_logits_processors(float* logits, int vocab, const int32_t* tokens, int len, const int* counts, const int32_t* distinct,
+                                    const int* n_distinct, float repetition_penalty, int no_repeat_ngram, hipStream_t stream);
+
 }  // namespace kjarni

@@ -8,6 +8,7 @@
 //   layer     cpu/decoder/rope_decoder_layer.rs:18-41, cpu/decoder/decoder_attention.rs:44-170,
 //             cpu/feedforward/swiglu.rs:32-57
 //   greedy    common/sampling.rs:83-88
+#include <algorithm>
 #include <atomic>
 
 #include "device_utils.h"
@@ -1732,6 +1733,186 @@ hipError_t launch_llm_embed(const uint32_t* ids, int n, int hidden, int vocab, c
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sampled decoding: what of sample_token (common/sampling.rs:81-114) and of the logits processors (:8-57) is O(vocab) runs
+// here, on the logits where the vocabulary head left them; the host gets a few hundred (token, logit) pairs instead of
+// 4 x vocab bytes and finishes the filters on them exactly (sampling.cpp, sampling_distribution_candidates).
+//
+//   logits processors: repetition penalty once per occurrence of every past token (counts per token + the list of distinct
+//     tokens are kept on the device, updated by one tiny kernel per new token); no-repeat-n-gram bans by one thread per
+//     window of the history.
+//   sample_max:     per-workgroup maxima (the first launch also clears the histogram of the previous token);
+//   sample_hist:    m = max; histogram of (m - logit) in bins of 1/8 (count and exp mass per bin); per-workgroup sums of
+//                   exp(logit - m), each in a fixed order (the total is deterministic, but not the reference's index order:
+//                   the host treats it as such);
+//   sample_compact: every workgroup derives the cut `tau` from the histogram -- the distance below the maximum that holds
+//                   top_k tokens and top_p of the mass, two bins of margin, and ln(1 / min_p) when min_p filters the whole
+//                   vocabulary -- then appends every token with logit >= m - tau to the candidate list.
+// A list longer than its capacity, or a cut the histogram cannot place, is reported in the header and the host falls back
+// to fetching the logits.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SAMPLE_BLOCKS = 64, SAMPLE_BINS = 512;
+
+struct SampleScratch {                 // device memory, zero-initialised once
+    float part_max[SAMPLE_BLOCKS];
+    float part_sum[SAMPLE_BLOCKS];
+    unsigned hist_count[SAMPLE_BINS + 1];
+    float hist_mass[SAMPLE_BINS + 1];
+};
+
+__global__ __launch_bounds__(256) void sample_max_kernel(const float* __restrict__ logits, int vocab, SampleScratch* __restrict__ sc,
+                                                         SampleHeader* __restrict__ header)
+{
+    __shared__ float red[4];
+    float m = -INFINITY;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vocab; i += gridDim.x * 256) m = fmaxf(m, logits[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) sc->part_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // (the histogram and the candidate counter of the previous token are dead by now)
+    for (int b = blockIdx.x * 256 + threadIdx.x; b <= SAMPLE_BINS; b += gridDim.x * 256) {
+        sc->hist_count[b] = 0u;
+        sc->hist_mass[b] = 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        header->count = 0u;
+        header->overflow = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_hist_kernel(const float* __restrict__ logits, int vocab, SampleScratch* __restrict__ sc)
+{
+    __shared__ unsigned h_count[SAMPLE_BINS + 1];
+    __shared__ float h_mass[SAMPLE_BINS + 1];
+    __shared__ float red[4];
+    for (int b = threadIdx.x; b <= SAMPLE_BINS; b += 256) {
+        h_count[b] = 0u;
+        h_mass[b] = 0.0f;
+    }
+    float m = -INFINITY;
+    for (int b = 0; b < SAMPLE_BLOCKS; ++b) m = fmaxf(m, sc->part_max[b]);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < vocab; i += gridDim.x * 256) {
+        const float v = logits[i];
+        const float e = expf(v - m);
+        const float d = (m - v) * 8.0f;
+        const int bin = d < (float)SAMPLE_BINS ? (int)d : SAMPLE_BINS;  // (NaN and -inf land in the last bin)
+        sum += e;
+        atomicAdd(&h_count[bin], 1u);
+        atomicAdd(&h_mass[bin], e);
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) sc->part_sum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int b = threadIdx.x; b <= SAMPLE_BINS; b += 256) {
+        if (h_count[b]) {
+            atomicAdd(&sc->hist_count[b], h_count[b]);
+            atomicAdd(&sc->hist_mass[b], h_mass[b]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_compact_kernel(const float* __restrict__ logits, int vocab, long long top_k, float top_p,
+                                                             float min_p, const SampleScratch* __restrict__ sc,
+                                                             SampleHeader* __restrict__ header, SampleCandidate* __restrict__ cand, int cap)
+{
+    __shared__ float s_floor;
+    __shared__ int s_all;
+    if (threadIdx.x == 0) {
+        float m = -INFINITY, sum = 0.0f;
+        for (int b = 0; b < SAMPLE_BLOCKS; ++b) m = fmaxf(m, sc->part_max[b]);
+        for (int b = 0; b < SAMPLE_BLOCKS; ++b) sum += sc->part_sum[b];
+        // the cut: enough tokens for top-k, enough mass for top-p (the histogram's masses are summed in no fixed order:
+        // a relative margin on top of the two bins), everything min-p can keep when it filters the whole vocabulary
+        const bool k_on = top_k >= 0 && top_k < (long long)vocab;  // (top_k >= vocab filters nothing)
+        const double need_count = k_on ? (double)top_k : 1.0;
+        const double need_mass = top_p >= 0.0f ? (double)top_p * (double)sum * 1.001 : 0.0;
+        double cnt = 0.0, mass = 0.0;
+        float tau = INFINITY;
+        for (int b = 0; b < SAMPLE_BINS; ++b) {
+            cnt += (double)sc->hist_count[b];
+            mass += (double)sc->hist_mass[b];
+            if (cnt >= need_count && mass > need_mass) {
+                tau = (float)(b + 2) / 8.0f;
+                break;
+            }
+        }
+        const bool minp_on_all = min_p >= 0.0f && !k_on && !(top_p >= 0.0f && top_p < 1.0f);
+        if (minp_on_all) tau = min_p > 0.0f ? fmaxf(tau, -logf(min_p) + 0.25f) : INFINITY;
+        s_all = !(tau < 1e30f) || !(m > -INFINITY) || !(m < INFINITY);
+        s_floor = m - tau;
+        if (blockIdx.x == 0) {
+            header->mx = m;
+            header->sum = sum;
+            header->floor = s_all ? -INFINITY : m - tau;
+        }
+    }
+    __syncthreads();
+    if (s_all) {  // no usable cut: the host takes the logits
+        if (blockIdx.x == 0 && threadIdx.x == 0) header->overflow = 1u;
+        return;
+    }
+    const float floor = s_floor;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * 256; i0 < vocab; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        const float v = i < vocab ? logits[i] : -INFINITY;
+        const bool keep = i < vocab && v >= floor;
+        const unsigned long long bits = __ballot(keep);
+        if (bits == 0ull) continue;
+        unsigned base = 0u;
+        if (lane == 0) base = atomicAdd(&header->count, (unsigned)__popcll(bits));
+        base = __shfl(base, 0, kWave);
+        if (keep) {
+            const unsigned slot = base + (unsigned)__popcll(bits & ((1ull << lane) - 1ull));
+            if (slot < (unsigned)cap) cand[slot] = SampleCandidate{(uint32_t)i, v};
+            else header->overflow = 1u;
+        }
+    }
+}
+
+// counts[t] += 1 for each of the n tokens; a token seen for the first time joins the list of distinct tokens
+__global__ __launch_bounds__(256) void token_counts_kernel(const int32_t* __restrict__ tokens, int n, int vocab, int* __restrict__ counts,
+                                                           int32_t* __restrict__ distinct, int* __restrict__ n_distinct)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int t = tokens[i];
+    if (t < 0 || t >= vocab) return;
+    if (atomicAdd(&counts[t], 1) == 0) distinct[atomicAdd(n_distinct, 1)] = t;
+}
+
+// apply_repetition_penalty (sampling.rs:8-27 / generator.rs:331-337): s < 0 ? s * penalty : s / penalty, once per OCCURRENCE
+// of the token in the history, in sequence (each application rounds)
+__global__ __launch_bounds__(256) void repetition_penalty_kernel(float* __restrict__ logits, const int* __restrict__ counts,
+                                                                 const int32_t* __restrict__ distinct,
+                                                                 const int* __restrict__ n_distinct, float penalty)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= *n_distinct) return;
+    const int t = distinct[j];
+    float s = logits[t];
+    for (int c = counts[t]; c > 0; --c) s = s < 0.0f ? __fmul_rn(s, penalty) : __fdiv_rn(s, penalty);
+    logits[t] = s;
+}
+
+// apply_no_repeat_ngram (sampling.rs:29-57): every window of the history whose first n - 1 tokens equal the last n - 1 bans
+// its n-th token
+__global__ __launch_bounds__(256) void no_repeat_ngram_kernel(float* __restrict__ logits, int vocab, const int32_t* __restrict__ tokens,
+                                                              int len, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i + n > len) return;
+    const int32_t* tail = tokens + len - (n - 1);
+    for (int k = 0; k < n - 1; ++k)
+        if (tokens[i + k] != tail[k]) return;
+    const int banned = tokens[i + n - 1];
+    if (banned >= 0 && banned < vocab) logits[banned] = -INFINITY;
+}
+
 hipError_t launch_argmax(const float* logits, int vocab, unsigned long long* best_scratch, int32_t* out, int32_t* history, int* count,
                          int* pos, hipStream_t stream)
 {
@@ -1739,6 +1920,40 @@ hipError_t launch_argmax(const float* logits, int vocab, unsigned long long* bes
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(argmax_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, logits, vocab, best_scratch);
     hipLaunchKernelGGL(argmax_finalize_kernel, dim3(1), dim3(1), 0, stream, best_scratch, out, history, count, pos);
+    return hipGetLastError();
+}
+
+
+size_t sample_scratch_bytes() { return sizeof(SampleScratch); }
+
+hipError_t launch_sample_candidates(const float* logits, int vocab, int64_t top_k, float top_p, float min_p, void* scratch,
+                                    SampleHeader* header, SampleCandidate* candidates, int capacity, hipStream_t stream)
+{
+    SampleScratch* sc = static_cast<SampleScratch*>(scratch);
+    hipLaunchKernelGGL(sample_max_kernel, dim3(SAMPLE_BLOCKS), dim3(256), 0, stream, logits, vocab, sc, header);
+    hipLaunchKernelGGL(sample_hist_kernel, dim3(SAMPLE_BLOCKS), dim3(256), 0, stream, logits, vocab, sc);
+    hipLaunchKernelGGL(sample_compact_kernel, dim3(SAMPLE_BLOCKS), dim3(256), 0, stream, logits, vocab, (long long)top_k, top_p, min_p, sc,
+                       header, candidates, capacity);
+    return hipGetLastError();
+}
+
+hipError_t launch_token_counts(const int32_t* tokens, int n, int vocab, int* counts, int32_t* distinct, int* n_distinct, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(token_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tokens, n, vocab, counts, distinct,
+                       n_distinct);
+    return hipGetLastError();
+}
+
+hipError_t launch_logits_processors(float* logits, int vocab, const int32_t* tokens, int len, const int* counts, const int32_t* distinct,
+                                    const int* n_distinct, float repetition_penalty, int no_repeat_ngram, hipStream_t stream)
+{
+    if (repetition_penalty != 1.0f && len > 0)
+        hipLaunchKernelGGL(repetition_penalty_kernel, dim3((unsigned)((std::min(len, vocab) + 255) / 256)), dim3(256), 0, stream, logits,
+                           counts, distinct, n_distinct, repetition_penalty);
+    if (no_repeat_ngram > 0 && len + 1 >= no_repeat_ngram && len >= no_repeat_ngram)
+        hipLaunchKernelGGL(no_repeat_ngram_kernel, dim3((unsigned)((len - no_repeat_ngram + 1 + 255) / 256)), dim3(256), 0, stream, logits,
+                           vocab, tokens, len, no_repeat_ngram);
     return hipGetLastError();
 }
 

@@ -236,23 +236,45 @@ std::vector<uint32_t> sorted_prefix(const float* vals, size_t n, float mx, float
     }
 }
 
-}  // namespace
 
-void sampling_distribution(const float* logits, size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs)
+// sample_token's filters over a VIEW of the vocabulary: either all of it (`complete`: n = vocab, position = token id), or
+// the candidate list the device cut out of it (llm_kernels.hip, sample_candidates): every token whose logit is >= `floor`,
+// in ascending id order, with the maximum `mx` and the sum of exp(logit - mx) over the WHOLE vocabulary (`sum`, summed
+// in tree order on the device: never `exact`) supplied alongside.  Everything outside the list sorts after everything
+// inside it, so the list's own sort order is an exact prefix of the reference's; a filter that needs more than the list
+// holds, or whose decision hangs on the rounding order of that sum, returns false and the caller fetches the logits.
+struct VocabView {
+    const float* vals;       // logits of the view's positions
+    size_t n;
+    const uint32_t* tokens;  // null: position == token id
+    bool complete;
+    float mx;                // maximum over the whole vocabulary
+    float floor;             // candidates: every token outside the view has a logit < floor
+    float sum;               // candidates: sum of exp(logit - mx) over the whole vocabulary (not in index order)
+};
+
+bool sampling_distribution_view(const VocabView& view, size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids,
+                                std::vector<float>& probs)
 {
-    // Survivors: everything (`all`, values read straight from `logits`) until a filter shrinks the set to (ids, vals).
+    // Survivors: everything (`all`, values read straight from the view) until a filter shrinks the set to (ids, vals).
+    const float* logits = view.vals;
+    const size_t n_view = view.n;
     bool all = true, have_exps = false;
     float exps_sum = 0.0f;
     std::vector<float> vals, exps;
     ids.clear();
     probs.clear();
-    if (vocab == 0) return;
-    const float mx_all = vec_max(logits, vocab);
-    auto shrink_from_all = [&](std::vector<uint32_t>& positions) {  // positions index `logits`
+    if (vocab == 0) return true;
+    const float mx_all = view.mx;
+    auto token_of = [&](uint32_t pos) { return view.tokens ? view.tokens[pos] : pos; };
+    auto shrink_from_all = [&](std::vector<uint32_t>& positions) {  // positions index the view
         std::sort(positions.begin(), positions.end());
-        ids = positions;
-        vals.resize(ids.size());
-        for (size_t i = 0; i < ids.size(); ++i) vals[i] = logits[ids[i]];
+        ids.resize(positions.size());
+        vals.resize(positions.size());
+        for (size_t i = 0; i < positions.size(); ++i) {
+            ids[i] = token_of(positions[i]);
+            vals[i] = logits[positions[i]];
+        }
         all = false;
     };
     auto shrink = [&](std::vector<uint32_t>& positions) {  // positions index (ids, vals)
@@ -266,10 +288,19 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
         ids.swap(nid);
         vals.swap(nval);
     };
+    // exp(logit - mx) over the view and the sum over the whole vocabulary
+    auto view_exps = [&](bool& exact) {
+        exps.resize(n_view);
+        if (view.complete) return vec_exp_sum(logits, n_view, mx_all, 1.0f, exps.data(), exact);
+        exp_scalar(logits, n_view, mx_all, 1.0f, exps.data());
+        exact = false;
+        return view.sum;
+    };
 
     if (p.top_k >= 0 && (size_t)p.top_k < vocab) {  // top_k_filtering
         const size_t k = (size_t)p.top_k;
-        std::vector<uint32_t> order = sorted_prefix(logits, vocab, mx_all, tau_for_count(logits, vocab, mx_all, k),
+        if (!view.complete && n_view < k) return false;
+        std::vector<uint32_t> order = sorted_prefix(logits, n_view, mx_all, tau_for_count(logits, n_view, mx_all, k),
                                                     [&](const std::vector<uint32_t>& c) { return c.size() >= k; });
         order.resize(std::min(order.size(), k));
         shrink_from_all(order);
@@ -278,9 +309,8 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
         size_t cut = 0;
         bool found = false;
         if (all) {
-            exps.resize(vocab);
             bool exact = false;
-            float sum = vec_exp_sum(logits, vocab, mx_all, 1.0f, exps.data(), exact);
+            float sum = view_exps(exact);
             have_exps = true;
             exps_sum = sum;
             std::vector<uint32_t> order;
@@ -309,18 +339,20 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
                 } else {
                     // a peaked distribution crosses p within a few units of the maximum: one cheap threshold pass; otherwise
                     // the histogram picks the threshold
-                    order = sorted_prefix(logits, vocab, mx_all, 6.0f, [&](const std::vector<uint32_t>& c) { return scan(c) || true; });
+                    order = sorted_prefix(logits, n_view, mx_all, 6.0f, [&](const std::vector<uint32_t>& c) { return scan(c) || true; });
                 }
                 if (!found) {
-                    const float tau0 = tau_for_mass(logits, exps.data(), vocab, mx_all, (double)p.top_p * (double)sum);
-                    order = sorted_prefix(logits, vocab, mx_all, tau0, scan);
+                    const float tau0 = tau_for_mass(logits, exps.data(), n_view, mx_all, (double)p.top_p * (double)sum);
+                    order = sorted_prefix(logits, n_view, mx_all, tau0, scan);
                     if (!found) {
                         scan(order);
-                        if (!found && !exact && order.size() == vocab) ambiguous = true;  // total mass within rounding of p
+                        if (!found && !view.complete) return false;  // the crossing lies beyond the candidates
+                        if (!found && !exact && order.size() == n_view) ambiguous = true;  // total mass within rounding of p
                     }
                 }
                 if (!ambiguous) break;
-                sum = running_sum(exps.data(), vocab);
+                if (!view.complete) return false;  // the in-order sum needs every logit
+                sum = running_sum(exps.data(), n_view);
                 exps_sum = sum;
                 exact = true;
             }
@@ -356,17 +388,17 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
         if (all) {
             float sum = exps_sum;
             if (!have_exps) {
-                exps.resize(vocab);
                 bool exact = false;
-                sum = vec_exp_sum(logits, vocab, mx_all, 1.0f, exps.data(), exact);
+                sum = view_exps(exact);
             }
             const float scale = sum > 0.0f ? 1.0f / sum : 1.0f;
             const float max_prob = std::max(0.0f, 1.0f * scale);  // exp(0) * scale
             const float cutoff = max_prob * p.min_p;
             // prob >= cutoff  <=>  logit >= max + ln(min_p) up to rounding: gather with slack, decide exactly
             const float slack = p.min_p > 0.0f ? -std::log(p.min_p) + 1e-3f : std::numeric_limits<float>::infinity();
+            if (!view.complete && !(view.floor <= mx_all - slack)) return false;  // survivors may lie outside the candidates
             std::vector<uint32_t> pos;
-            for (size_t i = 0; i < vocab; ++i)
+            for (size_t i = 0; i < n_view; ++i)
                 if (!(logits[i] < mx_all - slack) && !(exps[i] * scale < cutoff)) pos.push_back((uint32_t)i);
             if (pos.size() < vocab) shrink_from_all(pos);
         } else if (!vals.empty()) {
@@ -382,6 +414,7 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
     }
     const float temp = p.temperature < 1e-5f ? 1.0f : p.temperature;
     if (all) {  // temperature only: the whole vocabulary is the distribution
+        if (!view.complete) return false;
         ids.resize(vocab);
         for (size_t i = 0; i < vocab; ++i) ids[i] = (uint32_t)i;
         probs.resize(vocab);
@@ -392,10 +425,44 @@ void sampling_distribution(const float* logits, size_t vocab, const SamplingPara
             const float scale = 1.0f / sum;
             for (float& q : probs) q *= scale;
         }
-        return;
+        return true;
     }
     for (float& v : vals) v /= temp;
     softmax(vals, probs);
+    return true;
+}
+
+}  // namespace
+
+void sampling_distribution(const float* logits, size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs)
+{
+    ids.clear();
+    probs.clear();
+    if (vocab == 0) return;
+    const VocabView view{logits, vocab, nullptr, true, vec_max(logits, vocab), kNegInf, 0.0f};
+    (void)sampling_distribution_view(view, vocab, p, ids, probs);
+}
+
+bool sampling_distribution_candidates(const uint32_t* cand_ids, const float* cand_vals, size_t n_cand, float mx, float floor, float sum,
+                                      size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs)
+{
+    ids.clear();
+    probs.clear();
+    if (vocab == 0) return true;
+    if (n_cand == 0 || !std::isfinite(mx) || !(sum > 0.0f)) return false;
+    if (n_cand >= vocab) return false;  // nothing was cut: the plain path is the same work
+    // ascending token id = the vocabulary's position order (the reference's sort is stable in it)
+    std::vector<uint32_t> order(n_cand);
+    for (size_t i = 0; i < n_cand; ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cand_ids[a] < cand_ids[b]; });
+    std::vector<uint32_t> tok(n_cand);
+    std::vector<float> val(n_cand);
+    for (size_t i = 0; i < n_cand; ++i) {
+        tok[i] = cand_ids[order[i]];
+        val[i] = cand_vals[order[i]];
+    }
+    const VocabView view{val.data(), n_cand, tok.data(), false, mx, floor, sum};
+    return sampling_distribution_view(view, vocab, p, ids, probs);
 }
 
 uint32_t sample_from_distribution(const std::vector<uint32_t>& ids, const std::vector<float>& probs, float uniform, size_t vocab)

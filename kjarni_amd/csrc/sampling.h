@@ -42,6 +42,12 @@ inline void sampling_distribution(const std::vector<float>& logits, const Sampli
 {
     sampling_distribution(logits.data(), logits.size(), p, ids, probs);
 }
+// The same distribution from what the device hands over instead of the logits (llm_kernels.hip, launch_sample_candidates):
+// every token with a logit >= floor (ids / values in any order), the maximum mx and the sum of exp(logit - mx) over the
+// whole vocabulary.  False: these candidates do not decide it (a filter reaches past them, or a top-p crossing is within
+// the rounding of the device's sum) -- fetch the logits and call sampling_distribution().
+bool sampling_distribution_candidates(const uint32_t* cand_ids, const float* cand_vals, size_t n_cand, float mx, float floor, float sum,
+                                      size_t vocab, const SamplingParams& p, std::vector<uint32_t>& ids, std::vector<float>& probs);
 // sample_from_probs over the full vocabulary: first index whose running sum reaches `uniform`, else vocab - 1.
 uint32_t sample_from_distribution(const std::vector<uint32_t>& ids, const std::vector<float>& probs, float uniform, size_t vocab);
 

@@ -29,6 +29,9 @@ class HipDecoder:
     def reset(self):
         check_error(lib().kjarni_hip_decoder_reset(self._h))
 
+    def set_device_sampling(self, on: bool):
+        lib().kjarni_hip_decoder_set_device_sampling(self._h, 1 if on else 0)
+
     def tile_gemm_calls(self) -> int:
         """Prompt projections that took the 128 x 128-tile GEMM route since load."""
         return int(lib().kjarni_hip_decoder_tile_gemm_calls(self._h))

@@ -249,3 +249,55 @@ def test_logits_processors_match_oracle():
                 apply_no_repeat_ngram(want, toks, n)
             got = kc.logits_process(lg, toks, pen, n)
             assert np.array_equal(got, np.asarray(want, np.float32)), (toks, pen, n)
+
+
+# ---- the candidate form of the sampler (what the decode loop uses: the device cuts the vocabulary down to the tokens within
+# ---- tau of the maximum and sums the exponentials; kjarni_amd/csrc/sampling.cpp, sampling_distribution_candidates)
+def _logit_sets():
+    rng = np.random.default_rng(7)
+    yield "peaked", (rng.standard_normal(5000) * 2.5).astype(np.float32)
+    yield "flat", (rng.standard_normal(5000) * 0.05).astype(np.float32)
+    big = (rng.standard_normal(128256) * 1.5).astype(np.float32)
+    big[[17, 4000, 99999]] += np.float32(9.0)
+    yield "vocab-128k", big
+    ties = np.round(rng.standard_normal(3000) * 2).astype(np.float32)      # many exact ties: the stable order matters
+    yield "ties", ties
+    lone = np.full(2000, -30.0, np.float32)
+    lone[123] = 5.0
+    yield "one-token", lone
+
+
+@pytest.mark.parametrize("params", [dict(top_k=40, top_p=0.9, min_p=0.05, temperature=0.7), dict(top_p=0.9, min_p=0.05, temperature=0.6),
+                                    dict(top_k=50, top_p=0.9, min_p=0.1, temperature=0.7), dict(top_k=5), dict(top_p=0.5),
+                                    dict(min_p=0.2, temperature=1.3), dict(top_p=0.999, temperature=0.3), dict(top_k=1),
+                                    dict(temperature=0.8)])
+def test_candidate_form_equals_the_full_sampler_or_declines(params):
+    """Whenever the candidates decide the distribution it is the full sampler's, bit for bit; when they cannot (a filter
+    reaches past them, temperature only, a crossing within the rounding of the sum) the call says so."""
+    from kjarni_amd import chat as K
+    decided_some = False
+    for name, logits in _logit_sets():
+        full = K.sampling_distribution(logits, **params)
+        for tau in (0.5, 3.0, 8.0, 20.0, 60.0):
+            got, n = K.sampling_distribution_candidates(logits, tau, **params)
+            assert 1 <= n <= logits.size
+            if got is None:
+                continue
+            decided_some = True
+            assert np.array_equal(got, full), (name, tau, params)
+    only_temperature = not any(k in params for k in ("top_k", "top_p", "min_p"))
+    assert decided_some != only_temperature       # temperature only needs the whole vocabulary: always declined
+
+
+def test_candidate_form_declines_what_it_cannot_decide():
+    from kjarni_amd import chat as K
+    rng = np.random.default_rng(3)
+    logits = (rng.standard_normal(4000) * 0.1).astype(np.float32)     # nearly flat: top-p 0.9 needs ~90 % of the vocabulary
+    got, n = K.sampling_distribution_candidates(logits, 0.05, top_p=0.9)
+    assert got is None and n < 4000
+    got, _ = K.sampling_distribution_candidates(logits, 0.05, top_k=3000)
+    assert got is None                                                # fewer candidates than k
+    got, _ = K.sampling_distribution_candidates(logits, 1.0, min_p=0.01)
+    assert got is None                                                # ln(1 / 0.01) = 4.6 > tau: survivors may lie outside
+    got, n = K.sampling_distribution_candidates(logits, 50.0, top_p=0.9)
+    assert got is None and n == 4000                                  # nothing was cut: the plain path is the same work

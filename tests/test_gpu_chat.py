@@ -340,3 +340,51 @@ def test_mistral_chat(tmp_path):
     pieces = []
     chat.stream("Hello there", lambda t: pieces.append(t) or True, g)
     assert pieces == [t for _, t in o.stream(prompt, ov)]
+
+
+# ---- sampling with the O(vocab) work on the device (llm_kernels.hip: processors, candidate cut) against the same loop on
+# ---- a host copy of the logits (the checker): same seed, same tokens
+@pytest.fixture(scope="module")
+def peaked_chat(tmp_path_factory):
+    """The llama fixture with its final norm scaled 8x: a peaked next-token distribution (as a trained model's), so that
+    the candidates within reach of top-p / min-p are a small part of the vocabulary."""
+    from safetensors.numpy import save_file
+
+    from kjarni_amd.chat import Chat
+    tmp = tmp_path_factory.mktemp("chat_peaked")
+    d, cfg, tensors = _make(tmp, "llama", synth.LLAMA_TEST, "llama3", vocab_size=720, bos_token_id=LLAMA_SPECIAL["bos"],
+                            eos_token_id=[LLAMA_SPECIAL["end_of_text"], LLAMA_SPECIAL["eom"], LLAMA_SPECIAL["eot"]])
+    tensors = dict(tensors)
+    tensors["model.norm.weight"] = (tensors["model.norm.weight"] * np.float32(8.0)).astype(np.float32)
+    save_file({k: np.ascontiguousarray(v) for k, v in tensors.items()}, os.path.join(d, "model.safetensors"))
+    return Chat("llama3.2-1b-instruct", model_path=d)
+
+
+@pytest.mark.parametrize("which", ["peaked", "flat"])
+def test_device_sampling_equals_host_sampling(llama_chat, peaked_chat, which):
+    from kjarni_amd.chat import GenerationConfig
+    chat = peaked_chat if which == "peaked" else llama_chat
+    cfgs = [GenerationConfig(max_new_tokens=40),                                                    # top-p 0.9 + min-p 0.05, T 0.6
+            GenerationConfig(max_new_tokens=40, temperature=0.7, top_k=40, top_p=0.9, min_p=0.05),
+            GenerationConfig(max_new_tokens=40, temperature=1.5, top_k=5, top_p=0.95, min_p=0.0, repetition_penalty=1.3),
+            GenerationConfig(max_new_tokens=40, temperature=1.0, top_p=0.8, repetition_penalty=1.15),
+            GenerationConfig(max_new_tokens=40, temperature=0.9, min_p=0.1),
+            GenerationConfig(max_new_tokens=40, temperature=1.2),                                   # temperature only: needs the logits
+            GenerationConfig(max_new_tokens=30, do_sample=False, repetition_penalty=1.4)]
+    before = chat.sampling_counters()
+    for g in cfgs:
+        for seed in (3, 4):
+            runs = []
+            for on in (True, False):
+                chat.set_device_sampling(on)
+                chat.seed(seed)
+                pieces = []
+                chat.stream("Tell me about sampling.", lambda t: pieces.append(t) or True, g)
+                runs.append(pieces)
+            chat.set_device_sampling(True)
+            assert runs[0] == runs[1], (which, g, seed)
+            assert len(runs[0]) > 0
+    cand, full = (a - b for a, b in zip(chat.sampling_counters(), before))
+    assert cand + full > 0
+    if which == "peaked":
+        assert cand > 3 * full      # the candidates decide nearly every token; temperature-only always needs the logits

@@ -67,6 +67,15 @@ def test_greedy_generation_matches_oracle(tmp_path):
     _check(gpu.generate(prompt, 25, repetition_penalty=1.3, no_repeat_ngram=2), exp, trace)
     exp, trace = orc.generate(prompt, 25, repetition_penalty=1.7, return_logits=True)
     _check(gpu.generate(prompt, 25, repetition_penalty=1.7), exp, trace)
+    # the processors run on the device by default (counts per token + n-gram windows, llm_kernels.hip); on a host copy of the
+    # logits (the checker) the tokens are the same -- repeated tokens in the prompt (9, 9) are penalised once per occurrence
+    for kw in (dict(repetition_penalty=1.3, no_repeat_ngram=2), dict(repetition_penalty=1.7), dict(no_repeat_ngram=1),
+               dict(repetition_penalty=0.8, no_repeat_ngram=3)):
+        on_device = gpu.generate(prompt, 30, **kw)
+        gpu.set_device_sampling(False)
+        on_host = gpu.generate(prompt, 30, **kw)
+        gpu.set_device_sampling(True)
+        assert on_device == on_host, kw
 
 
 def test_stop_tokens_and_context_limit(tmp_path):
