@@ -519,10 +519,12 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int nk = dim / MQ_BK;
-    int64_t my_tiles = 0;
-    if ((int64_t)blockIdx.x < n_tiles) my_tiles = (n_tiles - 1 - blockIdx.x) / gridDim.x + 1;
-    if (my_tiles == 0) return;
-    const int64_t steps = my_tiles * nk;
+    // (tile and step counts fit 32 bits: a workgroup's share of at most 2^31 / 256 tiles; scalar registers are scarce here --
+    // two buffer descriptors and the loop state -- and every spilled one is a v_readlane in the K-loop)
+    const int nt = (int)n_tiles, grid = (int)gridDim.x;
+    if ((int)blockIdx.x >= nt) return;
+    const int my_tiles = (nt - 1 - (int)blockIdx.x) / grid + 1;
+    const int steps = my_tiles * nk;
 
     // staging: thread -> (row, 16-byte column); lanes 0-3 take row r, lanes 4-7 row r + 4 (see gemm_nt_f32_mfma_ln)
     const int ld_grp = tid >> 3;
@@ -541,10 +543,10 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     for (int i = 0; i < 4; ++i) offD[i] = (uint32_t)(((int64_t)(ld_row + 64 * i) * dim + ld_c4 * 4) * 4);
 
     // the staging side of the flat loop runs two steps ahead of the matrix side
-    int64_t s_tile = blockIdx.x;  // tile of the step to be requested next
-    int s_k = 0, s_par = 0;       // its K-step; parity of the tile whose rows sit in the registers
-    auto tile_rsrc = [&](int64_t tile) {
-        const int64_t d0 = tile * MQ_D;
+    int s_tile = (int)blockIdx.x;  // tile of the step to be requested next
+    int s_k = 0, s_par = 0;        // its K-step; parity of the tile whose rows sit in the registers
+    auto tile_rsrc = [&](int tile) {
+        const int64_t d0 = (int64_t)tile * MQ_D;
         const int64_t rows = n_docs - d0 < MQ_D ? n_docs - d0 : MQ_D;   // documents past n_docs: zeros
         return rsrc(corpus + d0 * dim, rows * dim * 4);
     };
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
         for (int i = 0; i < 4; ++i) gd[i] = ld16(rD, offD[i], soff);
         if (++s_k == nk) {
             s_k = 0;
-            s_tile += gridDim.x;
-            if (s_tile < n_tiles) rD = tile_rsrc(s_tile);
+            s_tile += grid;
+            if (s_tile < nt) rD = tile_rsrc(s_tile);
         }
     };
     float sumsq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -628,10 +630,10 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     Frag fr[2];
     read_frag(fr[0], 0, 0);
 
-    int64_t c_tile = blockIdx.x;  // tile the matrix side is on
+    int c_tile = (int)blockIdx.x;  // tile the matrix side is on
     int c_k = 0, c_par = 0;
-    for (int64_t g = 0; g < steps; ++g) {
-        const int cur = (int)(g & 1);
+    for (int g = 0; g < steps; ++g) {
+        const int cur = g & 1;
         // phase 0: fragments of the second half of this step; step g + 1 -> the other LDS stage; request step g + 2
         read_frag(fr[1], cur, 1);
         if (g + 1 < steps) store(cur ^ 1);
@@ -652,13 +654,17 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
         mfma16(fr[1]);
         __builtin_amdgcn_sched_barrier(0);
         if (++c_k == nk) {
-            // the tile is complete: cosines out, accumulators cleared
-            const int64_t d_base = c_tile * MQ_D + wid * 64 + l31;
+            // The tile is complete: cosines out, accumulators cleared.  dot / den as one v_rcp_f32 + a Newton step on the
+            // quotient (r = 1 / den to 1 ulp, v = dot r, v += (dot - den v) r): the IEEE division sequence without its
+            // range scaling, which den = ||q|| ||doc|| never needs; 6 vector instructions per score instead of 15 -- the
+            // f32 MFMAs do not hide vector work.
+            const int64_t d_base = (int64_t)c_tile * MQ_D + wid * 64 + l31;
+            const bool whole = nq == MQ_Q && (int64_t)(c_tile + 1) * MQ_D <= n_docs;  // no row or column of the tile is cut
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int64_t d = d_base + j * 32;
-                const float dn2 = sDn[c_par * MQ_D + wid * 64 + j * 32 + l31];
-                const float dn = sqrtf(dn2);
+                const float dn = sqrtf(sDn[c_par * MQ_D + wid * 64 + j * 32 + l31]);
+                float* out = scores + d;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -666,19 +672,18 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                         const int q = i * 32 + acc_row(r, half);
                         const float qn = sQn[q];
                         const float dot = acc[i][j][r];
-                        float v;
-                        if (MODE == 0) {
-                            v = dot / fmaxf(qn * dn, 1e-9f);          // vector.rs:131-148
-                        } else {
-                            v = dn < 1e-9f ? 0.0f : dot / (qn * dn);  // segment.rs:355-371
-                        }
-                        if (q < nq && d < n_docs) scores[(int64_t)q * stride + d] = v;
+                        const float den = MODE == 0 ? fmaxf(qn * dn, 1e-9f) : qn * dn;   // vector.rs:131-148 | segment.rs:355-371
+                        const float rc = __builtin_amdgcn_rcpf(den);
+                        float v = dot * rc;
+                        v = fmaf(fmaf(-den, v, dot), rc, v);
+                        if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
+                        if (whole || (q < nq && d < n_docs)) out[(int64_t)q * stride] = v;
                         acc[i][j][r] = 0.0f;
                     }
             }
             c_k = 0;
             c_par ^= 1;
-            c_tile += gridDim.x;
+            c_tile += grid;
         }
     }
 }
