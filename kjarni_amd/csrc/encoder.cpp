@@ -794,7 +794,7 @@ void EncoderModel::plan_packing(Workspace& ws, const uint32_t* mask_dev, const u
     if (total == batch * seq) return;  // nothing is padded
 
     // chunks: maximal runs of whole sentences within chunk_tokens_ packed rows (a row index must also fit 31 bits)
-    const int64_t cap = std::max<int64_t>(chunk_tokens_, seq);
+    const int64_t cap = std::min<int64_t>(std::max<int64_t>(chunk_tokens_, seq), ((int64_t)1 << 31) - seq - 1);  // (cu is 32-bit)
     const int64_t max_nb = std::max<int64_t>(1, ((int64_t)1 << 31) / seq - 1);
     plan.cu.reserve((size_t)batch + 64);
     for (int64_t b = 0; b < batch;) {
