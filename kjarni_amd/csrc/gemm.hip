@@ -71,7 +71,7 @@ struct Tile {
     static constexpr int PIECES_PER_PHASE = (PIECES + NKK - 2) / (NKK - 1);  // spread over the phases before the barrier
     // Epilogue staging rows per wave per round: as many as fit in this tile's LDS.
     static constexpr int EPI_ROWS = (LDS_BYTES >= 4 * 64 * EPI_STRIDE * 4) ? 64 : 32;
-    static constexpr int WAVES_PER_SIMD = 2;
+    static constexpr int WAVES_PER_SIMD = BKT == 16 ? 3 : 2;  // workgroups per CU (BK = 16: 40 KiB of LDS each, tuning build only)
 };
 
 // silu_scalar, activations.rs:74-82
@@ -1066,6 +1066,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
     if (aligned) {
 #ifdef KJARNI_TUNING
         if (tune::tiles_without_epilogue()) return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+#ifdef KJARNI_TUNING
+        if (tune::tiles_bk16_three_per_cu() && K % 16 == 0) return launch_tiled<EPI, 16, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+#endif
 #endif
         return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
