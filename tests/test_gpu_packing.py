@@ -182,3 +182,46 @@ def test_other_head_widths_and_rope(tmp_path):
             assert float(np.abs(packed - ref).max()) < TOL, (name, B, S)
             assert float(np.abs(packed - padded).max()) < 1e-5, (name, B, S)
         enc.close()
+
+
+def test_random_masks_packed_equals_padded(minilm, cross):
+    """Seeded sweep: random batch sizes, padded lengths and mask patterns (right padding, holes, full rows, a one-token
+    sentence), embed with a random pooling mode and rerank logits: the packed layout against the padded one."""
+    rng = np.random.default_rng(2024)
+    enc, _ = minilm
+    cenc, _ = cross
+    for case in range(30):
+        B = int(rng.choice([1, 2, 3, 9, 33, 64, 65, 130, 700]))
+        S = int(rng.choice([2, 7, 16, 33, 64, 100, 128, 129, 200, 384]))
+        if B * S > 60000:
+            B = max(1, 60000 // S)
+        ids, mask = synth.synthetic_ids(B, S, seed=case, ragged=True)
+        kind = case % 3
+        if kind == 1:                                  # holes
+            holes = rng.random(mask.shape) < 0.3
+            holes[:, 0] = False
+            mask[holes] = 0
+        elif kind == 2:                                # a mix of full rows and one-token rows
+            mask[::3] = 1
+            ids[::3][ids[::3] == 0] = 1999
+            if B > 1:
+                mask[1, 1:] = 0
+        pooling = ["mean", "cls", "max", "last_token"][case % 4]
+        packed, padded = both_layouts(enc, lambda: enc.embed(ids, mask, pooling=pooling, normalize=bool(case & 1)))
+        assert np.isfinite(packed).all()
+        assert float(np.abs(packed - padded).max()) < 1e-5, (case, B, S, pooling)
+        types = (rng.random(mask.shape) < 0.5).astype(np.uint32)
+        packed, padded = both_layouts(cenc, lambda: cenc.logits(ids, mask, types))
+        assert float(np.abs(packed - padded).max()) < 1e-5, (case, B, S)
+
+
+def test_out_of_vocabulary_ids_on_packed_rows(minilm):
+    """ids >= vocab leave zero rows before the embedding LayerNorm (embeddings/mod.rs:232-236), also when the row is found
+    through tok_src."""
+    enc, orc = minilm
+    ids, mask = synth.synthetic_ids(12, 40, seed=77, ragged=True)
+    ids[3, 2] = 40000
+    ids[7, 1] = 2 ** 31
+    packed, padded = both_layouts(enc, lambda: enc.embed(ids, mask))
+    ref = orc.embed_batch(ids, mask)
+    assert float(np.abs(packed - ref).max()) < TOL and float(np.abs(packed - padded).max()) < 1e-5
