@@ -554,6 +554,7 @@ std::vector<uint32_t> LlmModel::generate(const std::vector<uint32_t>& prompt, co
             hip_check(hipMemcpyAsync(samp_tokens_, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_), "H2D history");
             hip_check(launch_token_counts(samp_tokens_, (int)all.size(), (int)vocab, samp_counts_, samp_distinct_, samp_ndistinct_, stream_),
                       "token counts");
+            hip_check(hipStreamSynchronize(stream_), "sync");  // (`all` grows below: the copy must have read it)
         }
         std::vector<float> probs, cvals;
         std::vector<uint32_t> ids, cids;
