@@ -90,14 +90,18 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("n,dim,nq,mode", [(5000, 384, 33, 0), (4100, 384, 64, 1), (1028, 768, 21, 0),
-                                           (2051, 384, 40, 0), (3000, 100, 25, 1), (640, 384, 130, 0)])
+                                           (2051, 384, 40, 0), (3000, 100, 25, 1), (640, 384, 130, 0),
+                                           # the fused matrix-core scan at its edges: 20 queries (its first size), exactly 64, 65
+                                           # (two passes), document counts around the 256-document tile, the narrowest / widest rows
+                                           (257, 384, 20, 0), (255, 16, 64, 1), (1000, 1024, 65, 0), (513, 32, 130, 1),
+                                           (12, 384, 64, 0), (70_000, 384, 64, 0)])
 def test_many_queries_gemm_route_matches_streaming_and_oracle(n, dim, nq, mode):
-    """From 20 queries on the dot products go through the matrix-core GEMM (corpus read once); shapes
-    it does not take (n % 4 != 0, dim % 32 != 0) fall back to the streaming passes.  Both must agree
-    with the oracle, zero rows and zero queries included."""
+    """From 20 queries on, blocks of 64 go through the fused matrix-core scan (corpus read once per block, document norms
+    and cosines in the same launch); row widths it does not take (dim % 16 != 0) fall back to the streaming passes.
+    Both must agree with the oracle, zero rows and zero queries included."""
     import kjarni_amd
     corpus = _unit_rows(n, dim, seed=n) * np.float32(0.5)
-    corpus[11] = 0.0
+    corpus[min(11, n - 1)] = 0.0
     queries = _unit_rows(nq, dim, seed=nq + 1) * np.float32(3.0)
     queries[2] = 0.0
     k = 12
