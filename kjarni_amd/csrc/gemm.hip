@@ -375,12 +375,15 @@ struct LnTile {
     static constexpr int OUT_STRIDE = BN + 32;
     static constexpr int OUT_FLOATS = 32 * OUT_STRIDE;
     static constexpr int LDS_FLOATS = 2 * STAGE_FLOATS > OUT_FLOATS ? 2 * STAGE_FLOATS : OUT_FLOATS;
-    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    // + bias | gamma | beta: the epilogue's per-column vectors wait in LDS from the start of the tile (3 x 1.5 KiB for 384 columns;
+    // two workgroups still fit a CU) instead of being 72 global loads per thread per tile in front of the statistics
+    static constexpr int PARAM_FLOATS = 3 * BN;
+    static constexpr int LDS_BYTES = (LDS_FLOATS + PARAM_FLOATS) * 4;
     static constexpr int B_LOADS = BN * (BK / 4) / 256;  // 16-byte loads per thread per K-step for W (A: one)
     static constexpr int V4_PER_THREAD = BN / 4 / 8;     // epilogue: 8 lanes per row
 };
 
-template <int NT>
+template <int NT, bool PARAMS_IN_LDS>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* R, int64_t ldr, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -402,6 +405,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
     const int64_t xcd = wg % 8, slot = wg / 8;
     const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const int64_t m0 = bid * BM;
+    float* sP = smem + T::LDS_FLOATS;  // [bias | gamma | beta][BN]
+    if (PARAMS_IN_LDS) {
+        // (its own region: no hazard with the operand stages; the K-loop's barriers order it before the epilogue)
+        for (int q = tid; q < 3 * BN / 4; q += 256) {
+            const int which = q / (BN / 4), c = (q - which * (BN / 4)) * 4;
+            const float* src = which == 0 ? bias : which == 1 ? gamma : beta;
+            *reinterpret_cast<f32x4*>(sP + which * BN + c) = src ? *reinterpret_cast<const f32x4*>(src + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     // staging: thread -> (row, 16-byte column) of the [rows][BK] operand tiles, through buffer descriptors (scalar
     // K offset, constant 32-bit lane offsets: no vector address arithmetic in the K-loop; rows past M read as zeros)
@@ -552,7 +564,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
         for (int q = 0; q < NV; ++q) {
             const int c = (e_t8 + 8 * q) * 4;
             x[q] = *reinterpret_cast<const f32x4*>(smem + e_row * OS + c);
-            if (bias) x[q] += *reinterpret_cast<const f32x4*>(bias + c);
+            if (PARAMS_IN_LDS) x[q] += *reinterpret_cast<const f32x4*>(sP + c);
+            else if (bias) x[q] += *reinterpret_cast<const f32x4*>(bias + c);
             x[q] += res[q];
             s += (x[q][0] + x[q][1]) + (x[q][2] + x[q][3]);
         }
@@ -578,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 const int c = (e_t8 + 8 * q) * 4;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+                const f32x4 g = *reinterpret_cast<const f32x4*>((PARAMS_IN_LDS ? sP + BN : gamma) + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>((PARAMS_IN_LDS ? sP + 2 * BN : beta) + c);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (x[q][e] - mean) * inv_std * g[e] + b[e];
@@ -602,15 +615,27 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (T::LDS_BYTES > 64 * 1024 && !attr_set[dev & 63]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma_ln<NT>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma_ln<NT, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return e;
+#ifdef KJARNI_TUNING
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma_ln<NT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+#endif
         attr_set[dev & 63] = true;
     }
     const int64_t total = (M + T::BM - 1) / T::BM;
     // (a grid of the 512 resident workgroups measured +0.6 % on the K = 384 shape and -0.6 % on K = 1536: one workgroup per tile)
     dim3 grid((unsigned)(tune::persistent_layernorm_tiles() ? std::min<int64_t>(total, 256 * 2) : total));
-    hipLaunchKernelGGL((gemm_nt_f32_mfma_ln<NT>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias, R, ldr,
+#ifdef KJARNI_TUNING
+    if (tune::layernorm_params_from_global()) {
+        hipLaunchKernelGGL((gemm_nt_f32_mfma_ln<NT, false>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias, R, ldr,
+                           gamma, beta, eps, Y, ldy, M, K, total);
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL((gemm_nt_f32_mfma_ln<NT, true>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias, R, ldr,
                        gamma, beta, eps, Y, ldy, M, K, total);
     return hipGetLastError();
 }

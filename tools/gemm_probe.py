@@ -85,6 +85,32 @@ def bk16():
     ops.set_gemm_variant(0)
 
 
+def lnparams():
+    """Fused LayerNorm GEMM: bias / gamma / beta from LDS (default) against global loads in the epilogue (tuning variant 14)."""
+    if not ops.has_tuning():
+        return
+    m, n = 262144, 384
+    for name, k in (("out+ln", 384), ("fc2+ln", 1536)):
+        x = rng.standard_normal((m, k), dtype=np.float32)
+        w = (rng.standard_normal((n, k), dtype=np.float32) * 0.05).astype(np.float32)
+        b = rng.standard_normal(n, dtype=np.float32)
+        r = rng.standard_normal((m, n), dtype=np.float32)
+        g = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+        beta = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        fl = 2.0 * m * n * k
+        ref = None
+        for _ in range(3):
+            for variant in (0, 14):
+                ops.set_gemm_variant(variant)
+                y, ms = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12, iters=iters_for(fl))
+                if ref is None:
+                    ref = y
+                tf = fl / (ms * 1e-3) / 1e12
+                print(f"{name} {'params in LDS   ' if variant == 0 else 'params from global'} {ms:8.4f} ms {tf:7.2f} TFLOP/s "
+                      f"({tf / PEAK * 100:5.1f}% peak) max diff vs first {float(np.abs(y - ref).max()):.1e}", flush=True)
+    ops.set_gemm_variant(0)
+
+
 def attn():
     B, S, heads, d = 1024, 128, 12, 32
     qkv = rng.standard_normal((B, S, 3 * heads * d), dtype=np.float32)
@@ -151,6 +177,8 @@ if __name__ == "__main__":
         attn()
     if "bk16" in what:
         bk16()
+    if "lnparams" in what:
+        lnparams()
     if "prio" in what:
         prio()
     if "persist" in what:
