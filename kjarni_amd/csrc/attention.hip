@@ -362,25 +362,35 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         }
     };
     // Q fragments (B operand of S^T = K Q^T) and the keep-bits of keys 0..63 / 64..127.
+    // The mask words of an item's sentence (keys lane and lane + 64) are REQUESTED with its K / V rows, a whole item ahead, and
+    // turned into the two 64-bit keep sets only at the end of the iteration: a ballot right behind the request would wait
+    // for it -- and, the vector-memory counter being in order, for the K / V / Q prefetch in front of it -- in the middle
+    // of the item (round 3: that wait sat between the score tiles and the softmax of every item of a masked call).
+    uint32_t mask_w0 = 1u, mask_w1 = 1u;
+    auto request_mask = [&](int b) {
+        if (VARLEN || mask == nullptr) return;
+        // rows past `seq` are never requested: their bits are cleared by the lane tests at the ballot
+        const int64_t base = (int64_t)b * seq;
+        mask_w0 = lane < seq ? __builtin_nontemporal_load(mask + base + lane) : 0u;
+        mask_w1 = lane + 64 < seq ? __builtin_nontemporal_load(mask + base + lane + 64) : 0u;
+    };
+    auto ballot_mask = [&]() {
+        if (VARLEN) return;
+        keep_lo = __ballot(lane < seq && mask_w0 != 0u);
+        keep_hi = __ballot(lane + 64 < seq && mask_w1 != 0u);
+    };
     auto prefetch_q = [&](int b, int h) {  // (after prefetch_kv of the same item: pre_row0 / pre_len are its rows)
         const __amdgpu_buffer_rsrc_t rq = rsrc(qkv + pre_row0 * row_stride + h * D, span_in_of(pre_len));
 #pragma unroll
         for (int kk = 0; kk < D / 8; ++kk) qf[kk] = ld16(rq, off_q, kk * 32);
-        if (!VARLEN) {
-            bool k0 = lane < seq, k1 = lane + 64 < seq;
-            if (mask != nullptr) {
-                if (k0) k0 = mask[(int64_t)b * seq + lane] != 0u;
-                if (k1) k1 = mask[(int64_t)b * seq + lane + 64] != 0u;
-            }
-            keep_lo = __ballot(k0);
-            keep_hi = __ballot(k1);
-        }
     };
 
     int64_t item = blockIdx.x;
     if (item < n_items) {
         prefetch_kv(cur_b, cur_h);
+        request_mask(cur_b);
         prefetch_q(cur_b, cur_h);
+        ballot_mask();
     }
     int64_t cur_row0 = pre_row0;  // rows of the item the loop body computes
     int cur_len = pre_len;
@@ -395,9 +405,12 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         for (int r = 0; r < 16; ++r) o_pend[dt][r] = 0.0f;
     const float* pend_base = nullptr;
     int pend_len = seq;
+    // (no branch around the stores: before the first item the descriptor has no extent and the hardware drops them.  The item
+    // loop is kept free of data-dependent branches around memory operations on purpose -- the compiler counts outstanding
+    // vector-memory operations exactly only along straight-line code; at a join it falls back to "wait for everything",
+    // which made every item wait for the NEXT item's K / V prefetch before its score tiles were done, rounds 1-2.)
     auto flush = [&]() {
-        if (pend_base == nullptr) return;
-        const __amdgpu_buffer_rsrc_t ro = rsrc(pend_base, span_out_of(pend_len));
+        const __amdgpu_buffer_rsrc_t ro = rsrc(pend_base != nullptr ? pend_base : ctx, pend_base != nullptr ? span_out_of(pend_len) : 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (DIAG != 3 || o_pend[0][r] == 123456.789f) {
@@ -426,9 +439,16 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         const int64_t next = item + gridDim.x;
         int nb = cur_b, nh = cur_h;
         advance(nb, nh);
+        if (next >= n_items) {  // the last item of this workgroup requests itself again: the loop body stays branch-free
+            nb = cur_b;
+            nh = cur_h;
+        }
         __syncthreads();
         flush();                                               // the previous item's outputs
-        if (next < n_items && DIAG != 4) prefetch_kv(nb, nh);  // in flight during this item's MFMAs + softmax
+        if (DIAG != 4) {  // in flight during this item's MFMAs + softmax
+            prefetch_kv(nb, nh);
+            request_mask(nb);
+        }
 
         const int len = cur_len;                                       // (VARLEN: this sentence's; else seq)
         const int nkt = VARLEN ? ((len + 31) >> 5) : 4;                // 32-key tiles that hold keys
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
 
         // Q fragments and mask bits of this item are consumed: fetch the next item's.
         const unsigned long long cur_lo = keep_lo, cur_hi = keep_hi;
-        if (next < n_items && DIAG != 4) prefetch_q(nb, nh);
+        if (DIAG != 4) prefetch_q(nb, nh);
 
         // scale (after the dot product, as the reference) then mask overwrite.
         const unsigned long long valid_lo = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
@@ -565,6 +585,7 @@ __global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __r
         pend_len = len;
 #pragma unroll
         for (int dt = 0; dt < D / 32; ++dt) o_pend[dt] = o[dt];
+        if (DIAG != 4) ballot_mask();  // the next item's keep sets, from words requested an item ago
         cur_b = nb;
         cur_h = nh;
         cur_row0 = pre_row0;
