@@ -891,6 +891,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // The epilogue's bias value is requested HERE, in front of the K-loop: requested in the epilogue it sits behind the next
+        // pair's operand tiles (already in flight by then) in the in-order vector-memory counter, and the first store of every
+        // tile waited for that whole prefetch.
+        float bv = 0.0f;
+        if (!PARTIAL && bias != nullptr) {
+            const int bcol = cur_pair.n0 + wc * 32 + l31;
+            bv = bias[bcol < N ? bcol : N - 1];
+        }
         store(0);
         __syncthreads();
         // (a second K-step of global loads in flight measured no faster at 4 096 rows and 7 % slower at 1 024)
@@ -923,7 +931,6 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__
                     if (row < M) out[(int64_t)row * N + col] = acc[r];
                 }
             } else {
-                const float bv = bias ? bias[col] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = done.m0 + wr * 32 + acc_row(r, half);
