@@ -69,9 +69,7 @@ struct Tile {
     static constexpr int ROWS_PER_PASS = 256 / V4_PER_ROW;
     static constexpr int PIECES = 2 * LOADS;                  // 16-byte loads per thread per K-step (A then W)
     static constexpr int PIECES_PER_PHASE = (PIECES + NKK - 2) / (NKK - 1);  // spread over the phases before the barrier
-    // Epilogue staging rows per wave per round: as many as fit in this tile's LDS.
-    static constexpr int EPI_ROWS = (LDS_BYTES >= 4 * 64 * EPI_STRIDE * 4) ? 64 : 32;
-    static constexpr int WAVES_PER_SIMD = BKT == 16 ? 3 : 2;  // workgroups per CU (BK = 16: 40 KiB of LDS each, tuning build only)
+    static constexpr int WAVES_PER_SIMD = 2;  // workgroups per CU
 };
 
 // silu_scalar, activations.rs:74-82
@@ -295,9 +293,14 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
         continue;
     }
 
-    // Epilogue through LDS (wave-private region, LDS operations of one wave execute in order).
-    constexpr int EROWS = T::EPI_ROWS;  // 64: one round; 32: two rounds
-    float* sw = smem + wid * (EROWS * EPI_STRIDE);
+    // Epilogue through LDS (wave-private region, LDS operations of one wave execute in order), 32 rows per round.  The regions
+    // lie in the SECOND stage of the operand tiles (waves 0 / 1 in A's, waves 2 / 3 in B's: 2 x 32 x 68 floats fit a 128 x 36
+    // stage), which nobody reads after the barrier of the last K-step and which the next tile does not write before its
+    // own prologue barrier: a wave that is done goes straight on to request and stage the next tile's first operands (into
+    // the FIRST stage) while slower waves are still in their epilogue -- no barrier closes a tile.
+    constexpr int EROWS = 32;
+    static_assert(2 * EROWS * EPI_STRIDE <= TILE_FLOATS, "two waves' epilogue regions must fit one operand stage");
+    float* sw = (wid < 2 ? sA : sB) + TILE_FLOATS + (wid & 1) * (EROWS * EPI_STRIDE);
     const int e_row = lane >> 4, e_c4 = lane & 15;
     const int n = n0 + wc * 64 + e_c4 * 4;
 #pragma unroll
@@ -343,7 +346,6 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
             if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
         }
     }
-    __syncthreads();  // the epilogue's LDS staging overlaps the operand tiles of the next tile
     }
 }
 
@@ -810,7 +812,7 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     // chip holds at once measured +2.2 % (QKV shape: no dispatch between a workgroup's tiles); with the GELU epilogue -1.1 %
     // (the barrier that ends a tile waits for the slowest wave's epilogue), so those launch one workgroup per tile.
     const int64_t resident = (int64_t)256 * T::WAVES_PER_SIMD;
-    const bool persistent = EPI == EPI_BIAS && !tune::no_persistent_tile_loop();
+    const bool persistent = !tune::no_persistent_tile_loop();
     dim3 grid((unsigned)(persistent ? std::min(total, resident) : total));
     hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
                        R, ldr, Y, ldy, M, N, K, n_tiles, total);
@@ -1098,9 +1100,6 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
     if (aligned) {
 #ifdef KJARNI_TUNING
         if (tune::tiles_without_epilogue()) return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-#ifdef KJARNI_TUNING
-        if (tune::tiles_bk16_three_per_cu() && K % 16 == 0) return launch_tiled<EPI, 16, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-#endif
 #endif
         return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }

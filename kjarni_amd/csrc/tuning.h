@@ -12,7 +12,6 @@
 //   10  plain-epilogue 128 x 128 tiles without the persistent tile loop
 //   11  fused LayerNorm tiles as a persistent launch (two workgroups per CU)
 //   14  fused LayerNorm tiles read bias / gamma / beta from global memory in the epilogue (rounds 1-2) instead of from LDS
-//   12  128 x 128 tiles with BK = 16 and three workgroups per CU (round 3: measured below the BK = 32 form)
 // attention variant (kjarni_hip_set_attention_variant):
 //    1  never the persistent pipelined kernel (d = 32, seq <= 128)
 //   11..16  knock-out diagnostics of the pipelined kernel (its DIAG template parameter 1..6)
@@ -45,7 +44,6 @@ inline bool mid_one_workgroup_per_tile() { return gemm() == 5; }
 inline bool no_few_rows_route() { return gemm() == 6; }
 inline bool no_mid_route() { return gemm() == 7; }
 inline bool tiles_without_epilogue() { return gemm() == 9; }
-inline bool tiles_bk16_three_per_cu() { return gemm() == 12; }
 inline bool layernorm_params_from_global() { return gemm() == 14; }
 inline bool no_persistent_tile_loop() { return gemm() == 10; }
 inline bool persistent_layernorm_tiles() { return gemm() == 11; }

@@ -62,29 +62,6 @@ def persist():
     ops.set_gemm_variant(0)
 
 
-def bk16():
-    """128 x 128 tiles, BK = 32 with two workgroups per CU (default) against BK = 16 with three (tuning variant 12)."""
-    if not ops.has_tuning():
-        return
-    m = 262144
-    for name, k, n, epi in (("qkv ", 384, 1152, ops.EPI_BIAS), ("fc1 ", 384, 1536, ops.EPI_BIAS_GELU), ("k1536", 1536, 1536, ops.EPI_BIAS)):
-        x = rng.standard_normal((m, k), dtype=np.float32)
-        w = (rng.standard_normal((n, k), dtype=np.float32) * 0.05).astype(np.float32)
-        b = rng.standard_normal(n, dtype=np.float32)
-        fl = 2.0 * m * n * k
-        ref = None
-        for _ in range(3):
-            for variant in (0, 12):
-                ops.set_gemm_variant(variant)
-                y, ms = ops.linear(x, w, b, None, epi, iters=iters_for(fl))
-                if ref is None:
-                    ref = y
-                tf = fl / (ms * 1e-3) / 1e12
-                print(f"gemm {name} epi={epi} {'BK32 x 2 WG' if variant == 0 else 'BK16 x 3 WG'} {ms:8.4f} ms {tf:7.2f} TFLOP/s "
-                      f"({tf / PEAK * 100:5.1f}% peak) max diff vs first {float(np.abs(y - ref).max()):.1e}", flush=True)
-    ops.set_gemm_variant(0)
-
-
 def lnparams():
     """Fused LayerNorm GEMM: bias / gamma / beta from LDS (default) against global loads in the epilogue (tuning variant 14)."""
     if not ops.has_tuning():
@@ -175,8 +152,6 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["fused", "sweep"]
     if "attn" in what:
         attn()
-    if "bk16" in what:
-        bk16()
     if "lnparams" in what:
         lnparams()
     if "prio" in what:
