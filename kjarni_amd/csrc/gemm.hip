@@ -298,9 +298,14 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     // stage), which nobody reads after the barrier of the last K-step and which the next tile does not write before its
     // own prologue barrier: a wave that is done goes straight on to request and stage the next tile's first operands (into
     // the FIRST stage) while slower waves are still in their epilogue -- no barrier closes a tile.
-    constexpr int EROWS = 32;
-    static_assert(2 * EROWS * EPI_STRIDE <= TILE_FLOATS, "two waves' epilogue regions must fit one operand stage");
-    float* sw = (wid < 2 ? sA : sB) + TILE_FLOATS + (wid & 1) * (EROWS * EPI_STRIDE);
+    // That is the plain epilogue's scheme (the persistent launch: QKV +0.5 %).  Epilogues with arithmetic (GELU, ...) run one
+    // workgroup per tile and keep ONE round of 64 rows over the whole operand area: sixteen independent 16-byte pieces per
+    // thread in flight through the activation instead of eight (FC1 + GELU measured 1.7 % slower in two rounds).
+    constexpr bool kSplitRounds = EPI == EPI_BIAS;
+    constexpr int EROWS = kSplitRounds ? 32 : 64;
+    static_assert(2 * 32 * EPI_STRIDE <= TILE_FLOATS, "two waves' epilogue regions must fit one operand stage");
+    static_assert(4 * 64 * EPI_STRIDE * 4 <= T::LDS_BYTES, "the one-round epilogue needs the whole operand area");
+    float* sw = kSplitRounds ? (wid < 2 ? sA : sB) + TILE_FLOATS + (wid & 1) * (EROWS * EPI_STRIDE) : smem + wid * (EROWS * EPI_STRIDE);
     const int e_row = lane >> 4, e_c4 = lane & 15;
     const int n = n0 + wc * 64 + e_c4 * 4;
 #pragma unroll
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
             if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
         }
     }
+    if (!kSplitRounds) __syncthreads();  // (the one-round staging overlaps the first operand stage of a next tile)
     }
 }
 
@@ -812,7 +818,7 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     // chip holds at once measured +2.2 % (QKV shape: no dispatch between a workgroup's tiles); with the GELU epilogue -1.1 %
     // (the barrier that ends a tile waits for the slowest wave's epilogue), so those launch one workgroup per tile.
     const int64_t resident = (int64_t)256 * T::WAVES_PER_SIMD;
-    const bool persistent = !tune::no_persistent_tile_loop();
+    const bool persistent = EPI == EPI_BIAS && !tune::no_persistent_tile_loop();  // (GELU in the pipeline: 1.7 % slower as a persistent launch, r03l)
     dim3 grid((unsigned)(persistent ? std::min(total, resident) : total));
     hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
                        R, ldr, Y, ldy, M, N, K, n_tiles, total);
