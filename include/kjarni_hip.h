@@ -75,7 +75,10 @@ KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64
 /* Ragged batches: embed / logits run the layers over the kept tokens only (mask != 0) when a call has padding, every
  * sentence keeps its token 0 and the mask holds only 0 / 1 -- a padded token is observable through neither output
  * (pooling skips it, pooling/mod.rs:11-33; as a key its score is overwritten, utils/masks.rs:4-36).  On by default;
- * 0 makes every call take the padded layout (what hidden_states always does).  Results agree to rounding (<= 1e-6). */
+ * 0 makes every call take the padded layout (what hidden_states always does).  Results agree to rounding (<= 1e-6).
+ * With packing on, a device-pointer embed / logits call of more than one sentence synchronises `stream` once before the
+ * layers are enqueued (4 bytes per sentence come back to place the chunks), so it cannot be captured into a HIP graph;
+ * turn packing off for that. */
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
 /* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
