@@ -279,8 +279,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // VARLEN (packed rows of a ragged batch): item (b, h) is rows cu[b] .. cu[b+1], every key a kept token -- no mask; a wave
 // whose 32 queries lie past the sentence's end, and 32-key tiles past it, are skipped (wave-uniform branches), so an
 // item costs ceil(len / 32)^2 / 16 of a 128-token one.
+// (head_dim 64: K + V^T of an item are 69 KB of LDS, so two workgroups fit a CU whatever the registers say -- at three the
+// 168-register budget spilled 109 VGPRs into the item loop; rounds 1-3 ran BERT-base shaped models that way at 66 TFLOP/s)
 template <int D, int DIAG, bool VARLEN>
-__global__ __launch_bounds__(256, 3) void attention_pipe_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(const float* __restrict__ qkv,
                                                                 const uint32_t* __restrict__ mask,
                                                                 int64_t n_items, int seq, int heads,
                                                                 float scale, float mask_value,
@@ -662,17 +664,29 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         attr_set[dev & 63] = true;
     }
     const float scale = 1.0f / sqrtf((float)D);  // encoder_self_attention.rs:43
-    if (D == 32 && seq <= KCHUNK && !tune::no_pipelined_attention()) {
+    if (seq <= KCHUNK && !tune::no_pipelined_attention()) {
         const int64_t n_items = batch * heads;
-        // Three resident workgroups per CU (35.8 KiB of LDS and <= 168 VGPRs each): the third hides what two leave
-        // exposed of the K / V / Q streams' latency (measured 274 -> 264 us per launch of 12 288 items).
-        int64_t max_blocks = 256 * 3;
+        // head_dim 32: three resident workgroups per CU (35.8 KiB of LDS and <= 168 VGPRs each): the third hides what two
+        // leave exposed of the K / V / Q streams' latency (measured 274 -> 264 us per launch of 12 288 items).
+        // head_dim 64: 68.6 KiB of LDS per workgroup -- two per CU, and the kernel is compiled for that (<= 256 VGPRs).
+        constexpr int kResident = D >= 64 ? 2 : 3;
+        int64_t max_blocks = 256 * kResident;
         if (tune::attention_two_workgroups_per_cu()) max_blocks = 256 * 2;
         const unsigned grid = (unsigned)(n_items < max_blocks ? n_items : max_blocks);
-        // (AttnSmem<32>::BYTES = 35.8 KiB: below the 64 KiB opt-in threshold)
-        static_assert(D != 32 || SM::BYTES <= 64 * 1024, "the pipelined kernel would need the dynamic-LDS opt-in");
+        if (SM::BYTES > 64 * 1024) {  // the dynamic-LDS opt-in, once per device and kernel
+            static bool pipe_attr_set[64] = {};
+            if (!pipe_attr_set[dev & 63]) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+                if (e != hipSuccess) return e;
+                pipe_attr_set[dev & 63] = true;
+            }
+        }
 #ifdef KJARNI_TUNING
-        switch (tune::attention_knockout() + 10) {
+        switch (D == 32 ? tune::attention_knockout() + 10 : 0) {  // (the knock-outs are measured on the headline shape)
         case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
         case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
         case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();

@@ -154,12 +154,14 @@ def test_fused_layernorm_projection_on_large_calls(m, k):
     assert float(np.abs(got - ref).max()) < OP_TOL * max(1.0, float(np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("B,S", [(200, 128), (200, 100), (200, 37), (1100, 128), (70, 128)])
-def test_attention_on_the_item_loop(B, S):
-    """d = 32, S <= 128 and more than 768 (sentence, head) items: the persistent kernel with prefetch and deferred stores;
-    70 x 12 = 840 items is the first size past one item per workgroup."""
+@pytest.mark.parametrize("B,S,d", [(200, 128, 32), (200, 100, 32), (200, 37, 32), (1100, 128, 32), (70, 128, 32),
+                                   (120, 128, 64), (120, 77, 64), (43, 128, 64), (300, 19, 64)])
+def test_attention_on_the_item_loop(B, S, d):
+    """S <= 128 and more (sentence, head) items than resident workgroups (768 at d = 32, 512 at d = 64): the persistent
+    kernel with prefetch and deferred stores; 70 x 12 = 840 (43 x 12 = 516) items is the first size past one item per
+    workgroup."""
     from kjarni_amd import ops
-    heads, d = 12, 32
+    heads = 12
     H = heads * d
     rng = np.random.default_rng(B + S)
     qkv = rng.standard_normal((B, S, 3 * H)).astype(np.float32)

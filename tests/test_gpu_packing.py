@@ -162,8 +162,9 @@ def test_device_pointer_calls_pack_too(minilm):
 
 
 def test_other_head_widths_and_rope(tmp_path):
-    """d = 64 heads (DistilBERT-base shape, the general attention kernel), a toy head width (the any-width kernel), and
-    Nomic's RoPE (positions of packed rows come from their padded index)."""
+    """d = 64 heads (DistilBERT-base shape: the pipelined kernel at two workgroups per CU up to 128 tokens -- 300 sentences x
+    2 heads is more items than its 512 workgroups -- the general kernel above), a toy head width (the any-width kernel),
+    and Nomic's RoPE (positions of packed rows come from their padded index)."""
     import kjarni_amd
     cases = [("distil", lambda d: synth.distilbert_sentiment(d, dim=128, n_layers=2, n_heads=2, hidden_dim=256)),
              ("toy", lambda d: synth.minilm_embedder(d, seed=4, hidden_size=48, num_hidden_layers=2, num_attention_heads=4,
@@ -175,7 +176,7 @@ def test_other_head_widths_and_rope(tmp_path):
         enc = kjarni_amd.HipEncoder(d, 0)
         orc = O.OracleModel(t, cfg)
         vocab = cfg.get("vocab_size", 30522)
-        for B, S in ((7, 40), (5, 150)):
+        for B, S in ((7, 40), (5, 150), (300, 100)):
             ids, mask = synth.synthetic_ids(B, S, vocab=vocab, seed=B + S, ragged=True)
             packed, padded = both_layouts(enc, lambda: enc.embed(ids, mask))
             ref = orc.embed_batch(ids, mask)

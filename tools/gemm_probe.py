@@ -88,8 +88,8 @@ def lnparams():
     ops.set_gemm_variant(0)
 
 
-def attn():
-    B, S, heads, d = 1024, 128, 12, 32
+def attn(d=32):
+    B, S, heads = 1024, 128, 12
     qkv = rng.standard_normal((B, S, 3 * heads * d), dtype=np.float32)
     for ragged in (False, True):
         mask = np.ones((B, S), np.uint32)
@@ -98,7 +98,7 @@ def attn():
                 mask[b, rng.integers(16, S + 1):] = 0
         names = {0: "kernel", 11: "no softmax", 12: "no LDS staging", 13: "no output stores", 14: "no prefetch", 15: "memory only", 20: "2 WG per CU", 16: "nt loads"}
         for _ in range(2):
-            for variant in ((0, 20, 16, 11, 13, 14, 15) if ops.has_tuning() and not ragged else (0,)):
+            for variant in ((0, 20, 16, 11, 13, 14, 15) if ops.has_tuning() and not ragged and d == 32 else (0,)):
                 if ops.has_tuning():
                     ops.set_attention_variant(variant)
                 ctx, ms = ops.attention(qkv, mask, heads, iters=1500)
@@ -152,6 +152,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["fused", "sweep"]
     if "attn" in what:
         attn()
+    if "attn64" in what:
+        attn(64)
     if "lnparams" in what:
         lnparams()
     if "prio" in what:
