@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 // item costs ceil(len / 32)^2 / 16 of a 128-token one.
 // (head_dim 64: K + V^T of an item are 69 KB of LDS, so two workgroups fit a CU whatever the registers say -- at three the
 // 168-register budget spilled 109 VGPRs into the item loop; rounds 1-3 ran BERT-base shaped models that way at 66 TFLOP/s)
-template <int D, int DIAG, bool VARLEN>
+// MODE 2 (padded rows, seq <= 96: one sentence, short batches): the mask as MODE 0, the 32-key tiles and waves past `seq` skipped
+// as MODE 1 -- a 28-token item is 32 MFMAs on one wave instead of 256 on each of four.
+template <int D, int DIAG, int MODE>
 __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(const float* __restrict__ qkv,
                                                                 const uint32_t* __restrict__ mask,
                                                                 int64_t n_items, int seq, int heads,
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
                                                                 float* __restrict__ ctx)
 {
     using SM = AttnSmem<D>;
+    constexpr bool VARLEN = MODE == 1, TRIM = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sK = smem;
     float* sVt = smem + SM::K_FLOATS;
@@ -453,12 +456,12 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         }
 
         const int len = cur_len;                                       // (VARLEN: this sentence's; else seq)
-        const int nkt = VARLEN ? ((len + 31) >> 5) : 4;                // 32-key tiles that hold keys
-        const bool wave_on = !VARLEN || wid * 32 < len;                // wave-uniform: do this wave's queries exist
+        const int nkt = TRIM ? ((len + 31) >> 5) : 4;                  // 32-key tiles that hold keys
+        const bool wave_on = !TRIM || wid * 32 < len;                  // wave-uniform: do this wave's queries exist
         f32x16 s[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (VARLEN && !(wave_on && kt < nkt)) continue;
+            if (TRIM && !(wave_on && kt < nkt)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
             const float* pk = sK + (kt * 32 + l31) * SM::K_STRIDE + half * 4;
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
             const bool all_valid = len >= KCHUNK;  // wave-uniform
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                if (VARLEN && kt != nkt - 1) continue;  // only the last tile that holds keys is partial
+                if (VARLEN ? kt != nkt - 1 : (TRIM && kt >= nkt)) continue;  // packed rows: only the last tile that holds keys is partial
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         float cmax = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (VARLEN && kt >= nkt) continue;
+            if (TRIM && kt >= nkt) continue;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) cmax = fmaxf(fmaxf(cmax, s[kt][r]), s[kt][r + 1]);
         }
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (VARLEN && kt >= nkt) continue;
+            if (TRIM && kt >= nkt) continue;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 t = __builtin_elementwise_fma(f32x2{s[kt][r], s[kt][r + 1]}, c1v, negv);
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
             const f32x2 invv = {inv, inv};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                if (VARLEN && kt >= nkt) continue;
+                if (TRIM && kt >= nkt) continue;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const f32x2 pr = f32x2{s[kt][r], s[kt][r + 1]} * invv;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
             const float* pv = sVt + (dt * 32 + l31) * SM::VT_STRIDE + half * 4;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                if (VARLEN && !(wave_on && kt < nkt)) continue;
+                if (TRIM && !(wave_on && kt < nkt)) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 vf = *reinterpret_cast<const f32x4*>(pv + kt * 32 + g * 8);
@@ -676,10 +679,13 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         if (SM::BYTES > 64 * 1024) {  // the dynamic-LDS opt-in, once per device and kernel
             static bool pipe_attr_set[64] = {};
             if (!pipe_attr_set[dev & 63]) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, true>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, 1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
                 if (e == hipSuccess)
-                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, false>),
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pipe_kernel<D, 0, 2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
                 if (e != hipSuccess) return e;
                 pipe_attr_set[dev & 63] = true;
@@ -687,20 +693,23 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         }
 #ifdef KJARNI_TUNING
         switch (D == 32 ? tune::attention_knockout() + 10 : 0) {  // (the knock-outs are measured on the headline shape)
-        case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
-        case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
-        case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
-        case 16: hipLaunchKernelGGL((attention_pipe_kernel<D, 6, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
-        case 15: hipLaunchKernelGGL((attention_pipe_kernel<D, 5, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
-        case 14: hipLaunchKernelGGL((attention_pipe_kernel<D, 4, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 11: hipLaunchKernelGGL((attention_pipe_kernel<D, 1, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 12: hipLaunchKernelGGL((attention_pipe_kernel<D, 2, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 13: hipLaunchKernelGGL((attention_pipe_kernel<D, 3, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 16: hipLaunchKernelGGL((attention_pipe_kernel<D, 6, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 15: hipLaunchKernelGGL((attention_pipe_kernel<D, 5, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
+        case 14: hipLaunchKernelGGL((attention_pipe_kernel<D, 4, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items, seq, heads, scale, mask_value, nullptr, ctx); return hipGetLastError();
         default: break;
         }
 #endif
         if (cu)
-            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, true>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, nullptr, n_items,
+            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, 1>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, nullptr, n_items,
                                seq, heads, scale, mask_value, cu, ctx);
+        else if (seq <= 96 && !tune::no_short_attention())  // at least one 32-key tile and one wave of every item are empty
+            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, 2>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
+                               seq, heads, scale, mask_value, nullptr, ctx);
         else
-            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, false>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
+            hipLaunchKernelGGL((attention_pipe_kernel<D, 0, 0>), dim3(grid), dim3(256), SM::BYTES, stream, qkv, mask, n_items,
                                seq, heads, scale, mask_value, nullptr, ctx);
         return hipGetLastError();
     }

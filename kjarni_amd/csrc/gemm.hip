@@ -658,7 +658,11 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
 // residual and 128-byte row-segment stores.  An output's arithmetic -- a k-ordered MFMA chain per K slice, then the
 // sixteen partials in order -- does not depend on M, so a row's result is the same in any batch of up to 64 rows (the kernel itself takes up to 128;
 // from 65 rows the 64 x 64-tile route below is faster: 0.47 ms against 0.65 ms for a 128-token forward).
-template <int EPI, int MT>
+// SLICED (the residual + LayerNorm projections with a long K, FC2): blockIdx.y is one of gridDim.y K slices of K floats each
+// (W rows ldw = gridDim.y * K apart), and the workgroup leaves its 32 columns of that slice's partial sums in slab blockIdx.y of
+// Y ([gridDim.y][M][N], no epilogue) for mid_reduce_ln_kernel: 4 x N / 32 workgroups instead of N / 32 -- a workgroup's MFMAs
+// run on ONE CU however its K is dealt over the waves, and FC2 on 12 CUs was 13 us of matrix time and round trips.
+template <int EPI, int MT, bool SLICED = false>
 __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restrict__ A, int64_t lda,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
                                                             const float* R, int64_t ldr, float* Y, int64_t ldy, int M, int N,
@@ -671,14 +675,20 @@ __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restri
     const int l31 = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32;
     const int ks = K / WAVES;  // this wave's K slice (a multiple of 8)
+    const int64_t ldw = SLICED ? (int64_t)K * gridDim.y : K;
+    if (SLICED) {
+        A += (int64_t)blockIdx.y * K;
+        W += (int64_t)blockIdx.y * K;
+        Y += (int64_t)blockIdx.y * M * N;
+    }
     const __amdgpu_buffer_rsrc_t rA =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((((int64_t)M - 1) * lda + K) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * K), 0,
-                                                                        (int)((int64_t)32 * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * ldw), 0,
+                                                                        (int)(((int64_t)31 * ldw + K) * 4), 0x00020000);
     uint32_t offA[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) offA[mt] = (uint32_t)(((int64_t)(mt * 32 + l31) * lda + half * 4) * 4);
-    const uint32_t offW = (uint32_t)(((int64_t)l31 * K + half * 4) * 4);
+    const uint32_t offW = (uint32_t)(((int64_t)l31 * ldw + half * 4) * 4);
     auto ld16 = [](__amdgpu_buffer_rsrc_t r, uint32_t off, int soff) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
     };
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restri
     }
     float* mine = smem + wid * (32 * 32);
     const int n = n0 + (tid & 31);
-    const float bv = bias ? bias[n] : 0.0f;
+    const float bv = (!SLICED && bias) ? bias[n] : 0.0f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (mt > 0) __syncthreads();  // the previous tile's partials have been summed
@@ -722,10 +732,14 @@ __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restri
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) v += smem[w * (32 * 32) + tid];
         if (m < M) {
-            v += bv;
-            if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)m * ldr + n];
-            if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)m * ldr + n]);
-            Y[(int64_t)m * ldy + n] = epilogue<EPI>(v);
+            if (SLICED) {
+                Y[(int64_t)m * N + n] = v;
+            } else {
+                v += bv;
+                if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)m * ldr + n];
+                if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)m * ldr + n]);
+                Y[(int64_t)m * ldy + n] = epilogue<EPI>(v);
+            }
         }
     }
 }
@@ -1118,8 +1132,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
 }  // namespace
 
 // Rows from which the residual + LayerNorm GEMMs take the K-sliced route: with a long K (>= 1024: the FC2 shape) from the
-// first row -- the few-rows kernel has N / 32 = 12 workgroups there, each with a 12-step serial K chain (17 us for one
-// sentence, + 4 us of LayerNorm launch; sliced + reduce: 13 us) -- otherwise from kFewRowsMax + 1.
+// first row -- unsliced, the few-rows kernel has N / 32 = 12 workgroups there, and a workgroup's MFMAs run on one CU however
+// its K is dealt over the waves (13 us for one sentence, + 5 us of LayerNorm launch; four slices of the same kernel on
+// 48 CUs + the LayerNorm reduce: 10.5 us) -- otherwise from kFewRowsMax + 1.
 inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 : kFewRowsMax + 1; }
 
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
@@ -1151,6 +1166,20 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         if ((size_t)ksplit * M * N <= scratch.floats) {
             const int m_tiles = ((int)M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
             const int total = m_tiles * n_tiles * ksplit;
+            // up to 64 rows: the slices' partial tiles from the few-rows kernel (K over the sixteen waves of a workgroup: a
+            // 3-step chain per wave instead of the tile kernel's 12-step one -- FC2 + LayerNorm of one sentence 15.5 -> 10.5 us)
+            const int k_len = K / ksplit;
+            if (M <= kFewRowsMax && ksplit > 1 && N % 32 == 0 && k_len % 128 == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
+                (int64_t)32 * K * 4 < ((int64_t)1 << 31) && !tune::no_few_rows_route() && !tune::no_few_rows_k_slices()) {
+                const dim3 sgrid((unsigned)(N / 32), (unsigned)ksplit);
+                constexpr int LDS = 16 * 32 * 32 * 4;
+                if (M <= 32)
+                    hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI_BIAS, 1, true>), sgrid, dim3(1024), LDS, stream, A, lda, W, nullptr, nullptr, 0,
+                                       scratch.p, N, (int)M, N, k_len);
+                else
+                    hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI_BIAS, 2, true>), sgrid, dim3(1024), LDS, stream, A, lda, W, nullptr, nullptr, 0,
+                                       scratch.p, N, (int)M, N, k_len);
+            } else
             hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : kMidResident)),
                                dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p, n_tiles, total);
             const dim3 rgrid((unsigned)((M + 3) / 4));
@@ -1166,7 +1195,10 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         }
     }
     if (!R || !gamma || !beta) return hipErrorInvalidValue;
-    if (!gemm_residual_layernorm_supported(N, K) || lda % 4 || ldr % 4 || ldy % 4 ||
+    // a handful of rows and a short K: the few-rows projection + a LayerNorm launch (the 64-row tiles would be one workgroup
+    // walking all of K alone: 38 us for out-proj at 28 rows against 11)
+    const bool few_rows_pair = M <= kFewRowsMax && ldy == N && aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route();
+    if (few_rows_pair || !gemm_residual_layernorm_supported(N, K) || lda % 4 || ldr % 4 || ldy % 4 ||
         (int64_t)64 * lda * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31 ||
         !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y)) {
         // Neither fused form takes this call (an output pointer that is 4- but not 16-byte aligned, a row width the

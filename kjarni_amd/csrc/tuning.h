@@ -12,10 +12,12 @@
 //   10  plain-epilogue 128 x 128 tiles without the persistent tile loop
 //   11  fused LayerNorm tiles as a persistent launch (two workgroups per CU)
 //   14  fused LayerNorm tiles read bias / gamma / beta from global memory in the epilogue (rounds 1-2) instead of from LDS
+//   15  residual projection + LayerNorm of up to 64 rows with a long K: the 64 x 64-tile K slices instead of the few-rows kernel's
 // attention variant (kjarni_hip_set_attention_variant):
-//    1  never the persistent pipelined kernel (d = 32, seq <= 128)
+//    1  never the persistent pipelined kernel (seq <= 128)
 //   11..16  knock-out diagnostics of the pipelined kernel (its DIAG template parameter 1..6)
 //   20  two resident workgroups per CU instead of three
+//   21  padded calls of seq <= 96 on the full 128-key kernel (no skipping of empty key tiles and waves)
 // cosine variant (kjarni_hip_set_cosine_variant):
 //    1  streaming passes only (no GEMM route for many queries)
 #pragma once
@@ -47,10 +49,12 @@ inline bool tiles_without_epilogue() { return gemm() == 9; }
 inline bool layernorm_params_from_global() { return gemm() == 14; }
 inline bool no_persistent_tile_loop() { return gemm() == 10; }
 inline bool persistent_layernorm_tiles() { return gemm() == 11; }
+inline bool no_few_rows_k_slices() { return gemm() == 15; }
 
 inline bool no_pipelined_attention() { return attention() == 1; }
 inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }
 inline bool attention_two_workgroups_per_cu() { return attention() == 20; }
+inline bool no_short_attention() { return attention() == 21; }
 
 inline bool scan_streaming_only() { return cosine() == 1; }
 

@@ -46,7 +46,11 @@ def test_linear_all_epilogues(m, k, n):
 
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (63, 384, 384), (64, 1536, 384), (65, 384, 384), (300, 1536, 384),
                                    (1000, 16, 384), (129, 256, 256), (200, 1024, 256), (77, 768, 768), (40, 100, 60),
-                                   (1000, 3072, 768), (8192, 1536, 384), (8193, 1536, 384), (8400, 384, 384), (700, 4096, 1024)])
+                                   (1000, 3072, 768), (8192, 1536, 384), (8193, 1536, 384), (8400, 384, 384), (700, 4096, 1024),
+                                   # up to 64 rows with a long K: the few-rows kernel's K slices (one and two row tiles,
+                                   # the last rows of each), then the LayerNorm reduce
+                                   (1, 1536, 384), (28, 1536, 384), (32, 1536, 384), (33, 1536, 384), (28, 3072, 768),
+                                   (64, 4096, 1024), (17, 1024, 256)])
 @pytest.mark.parametrize("eps", [1e-12, 1e-5])
 def test_residual_projection_with_fused_layernorm(m, k, n, eps):
     """out-proj / FC2 + residual + LayerNorm of the post-norm layer (encoder_layer.rs:129-147, 155-176) as ONE kernel
