@@ -656,11 +656,12 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     const double f_fc1 = 2.0 * Td * Hd * Id, b_fc1 = 4.0 * (Td * Hd + Hd * Id + Td * Id);
     const double f_fc2 = 2.0 * Td * Hd * Id, b_fc2 = 4.0 * (Td * Id + Hd * Id + 2 * Td * Hd);
     const double b_ln = 8.0 * Td * Hd;
-    // Up to 128 tokens the projections take the few-rows kernel (K split over the waves of a workgroup, gemm.hip) and
-    // LayerNorm stays its own small launch; beyond that the residual projections carry it in their epilogue.
+    // Up to gemm_few_rows_max() tokens the projections take the few-rows kernel (K split over the waves of a workgroup,
+    // gemm.hip) and LayerNorm stays its own small launch (after FC2: the reduce of its K slices); beyond that the residual
+    // projections carry it in their epilogue.
     const GemmScratch sc{ws.split, ws.split_floats};
-    // (up to 64 rows: the few-rows projection kernel + a LayerNorm launch)
-    const bool fused_ln = T > 64 && (fuse_layernorm() || (gemm_mid_layernorm_supported(T, H, H) && gemm_mid_layernorm_supported(T, H, I)));
+    const int64_t few = gemm_few_rows_max();
+    const bool fused_ln = T > few && (fuse_layernorm() || (gemm_mid_layernorm_supported(T, H, H) && gemm_mid_layernorm_supported(T, H, I)));
 
     hipEvent_t pe = prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));
     hip_check(launch_embed_layernorm(ids, type_ids, word_, pos_, type_, emb_ln_g_, emb_ln_b_, cfg_.eps, T,
@@ -673,7 +674,7 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     auto residual_ln = [&](int kind, const float* A, int K, const float* W, const float* b, const float* g,
                            const float* beta, double flops, double bytes, const char* what) {
         // (a handful of rows: only the long-K projection takes the fused route -- K slices + a LayerNorm reduce)
-        if (fused_ln || (T <= 64 && gemm_mid_layernorm_supported(T, H, K))) {
+        if (fused_ln || (T <= few && gemm_mid_layernorm_supported(T, H, K))) {
             hipEvent_t e = prof_start(kind, stream, flops, bytes);
             hip_check(launch_gemm_residual_layernorm(A, K, W, b, hidden, H, g, beta, cfg_.eps, hidden, H, T, H, K,
                                                      stream, sc), what);

@@ -649,15 +649,19 @@ hipError_t launch_ln_tiled(const float* A, int64_t lda, const float* W, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Few rows (M <= kFewRowsMax = 64: one sentence to classify, a handful to embed -- BASELINE.json configs[0]).  The tiled kernels
+// Few rows (M <= kFewRowsMax = 256: one sentence to classify or embed, a handful -- BASELINE.json configs[0]).  The tiled kernels
 // above are sized for 10^5 rows; at M = 28 they run N / 128 workgroups that each walk the whole K dimension alone
-// (25-124 us per launch, 3-12 of the 256 CUs busy).  Here a workgroup of 16 waves owns 32 output columns for ALL rows
-// and splits K sixteen ways.  No operand staging: a wave's MFMA fragments come straight from global memory through
-// buffer descriptors (rows >= M read as zeros) -- every weight element is needed by exactly one wave.  Per 32-row
-// tile the sixteen partial tiles meet in LDS (64 KiB) and are summed in wave order, then bias / activation /
-// residual and 128-byte row-segment stores.  An output's arithmetic -- a k-ordered MFMA chain per K slice, then the
-// sixteen partials in order -- does not depend on M, so a row's result is the same in any batch of up to 64 rows (the kernel itself takes up to 128;
-// from 65 rows the 64 x 64-tile route below is faster: 0.47 ms against 0.65 ms for a 128-token forward).
+// (25-124 us per launch, 3-12 of the 256 CUs busy).  Here a workgroup of 16 waves owns 32 output columns of a group of 32
+// (or 64) rows and splits K sixteen ways; a call is N / 32 x ceil(M / 32) such workgroups (blockIdx.z = the row group).  No
+// operand staging: a wave's MFMA fragments come straight from global memory through buffer descriptors (rows >= M read
+// as zeros) -- within a row group every weight element is needed by exactly one wave.  Per 32-row tile the sixteen partial
+// tiles meet in LDS (64 KiB) and are summed in wave order, then bias / activation / residual and 128-byte row-segment
+// stores.  An output's arithmetic -- a k-ordered MFMA chain per K slice, then the sixteen partials in order -- does not
+// depend on M or on the row's place in the call, so a row's result is the same in any call of up to kFewRowsMax rows.
+// Why rows over the grid and not more rows per workgroup: a workgroup's MFMAs run on ONE CU however its K is dealt over the
+// waves (32 columns x 128 rows x K = 384: 5.1 us of matrix time), and a call this small leaves most of the 256 CUs idle --
+// one 128-token sentence went 0.445 -> 0.333 ms when its four row tiles became four workgroups; from ~400 rows the
+// 64 x 64-tile route below is faster (512 rows: 0.455 against 0.492 ms; measured with tools/few_rows_sweep.sh).
 // SLICED (the residual + LayerNorm projections with a long K, FC2): blockIdx.y is one of gridDim.y K slices of K floats each
 // (W rows ldw = gridDim.y * K apart), and the workgroup leaves its 32 columns of that slice's partial sums in slab blockIdx.y of
 // Y ([gridDim.y][M][N], no epilogue) for mid_reduce_ln_kernel: 4 x N / 32 workgroups instead of N / 32 -- a workgroup's MFMAs
@@ -680,6 +684,16 @@ __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restri
         A += (int64_t)blockIdx.y * K;
         W += (int64_t)blockIdx.y * K;
         Y += (int64_t)blockIdx.y * M * N;
+        ldy = N;
+    }
+    // blockIdx.z: which group of MT * 32 rows (a call of a few hundred rows is that many independent few-rows problems: every
+    // workgroup still has one CU's matrix pipes for its 32 columns x MT * 32 rows, and there are CUs to spare)
+    {
+        const int m0 = blockIdx.z * (MT * 32);
+        A += (int64_t)m0 * lda;
+        if (R) R += (int64_t)m0 * ldr;
+        Y += (int64_t)m0 * ldy;
+        M = M - m0 < MT * 32 ? M - m0 : MT * 32;
     }
     const __amdgpu_buffer_rsrc_t rA =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((((int64_t)M - 1) * lda + K) * 4), 0x00020000);
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_f32_skinny(const float* __restri
         for (int w = 0; w < WAVES; ++w) v += smem[w * (32 * 32) + tid];
         if (m < M) {
             if (SLICED) {
-                Y[(int64_t)m * N + n] = v;
+                Y[(int64_t)m * ldy + n] = v;
             } else {
                 v += bv;
                 if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)m * ldr + n];
@@ -748,14 +762,16 @@ template <int EPI>
 hipError_t launch_skinny(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr,
                          float* Y, int64_t ldy, int M, int N, int K, hipStream_t stream)
 {
-    const dim3 grid((unsigned)(N / 32));
     constexpr int LDS = 16 * 32 * 32 * 4;  // 64 KiB
-    if (M <= 32)
-        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 1>), grid, dim3(1024), LDS, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K);
-    else if (M <= 64)
-        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 2>), grid, dim3(1024), LDS, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K);
-    else
-        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 4>), grid, dim3(1024), LDS, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K);
+    // one 32-row tile per workgroup while that leaves the chip room (<= 2 workgroups per CU), else two
+    const int z1 = (M + 31) / 32;
+    if ((int64_t)z1 * (N / 32) <= 512 || M <= 32) {
+        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 1>), dim3((unsigned)(N / 32), 1, (unsigned)z1), dim3(1024), LDS, stream, A, lda, W, bias,
+                           R, ldr, Y, ldy, M, N, K);
+    } else {
+        hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI, 2>), dim3((unsigned)(N / 32), 1, (unsigned)((M + 63) / 64)), dim3(1024), LDS, stream, A,
+                           lda, W, bias, R, ldr, Y, ldy, M, N, K);
+    }
     return hipGetLastError();
 }
 
@@ -839,7 +855,7 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     return hipGetLastError();
 }
 
-// ---- Calls of 65 .. 8192 rows (the reference's default batch is 32 sentences) --------------------------------------------
+// ---- Calls of 257 .. 8192 rows (the reference's default batch is 32 sentences) -------------------------------------------
 // The large-batch tiles (128 x 128, and 64 x 384 for the fused LayerNorm) are sized for 10^5 rows: at 4 096 rows the
 // 384-wide GEMMs are 64 workgroups on 256 CUs, each with the whole K-loop serial (FC2 + LN: 150 us of a 320 us layer).
 // Here: 64 x 64 tiles, four waves of one 32 x 32 MFMA tile, BK = 32, LDS double buffer; narrow outputs with a long K
@@ -1048,12 +1064,14 @@ __global__ __launch_bounds__(256) void mid_reduce_ln_kernel(const float* __restr
     }
 }
 
-constexpr int64_t kFewRowsMax = 64, kMidMaxRows = 8192;
+constexpr int64_t kFewRowsMax = 256, kMidMaxRows = 8192;
+inline int64_t few_rows_max() { return tune::few_rows_max_override() > 0 ? tune::few_rows_max_override() : kFewRowsMax; }
 constexpr int kMidResident = 256 * 4;  // workgroups of gemm_nt_f32_mid the chip holds at once (36 KiB of LDS each)
 
 inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
-                         const float* bias, const float* R, int64_t min_rows = kFewRowsMax + 1)
+                         const float* bias, const float* R, int64_t min_rows = -1)
 {
+    if (min_rows < 0) min_rows = few_rows_max() + 1;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return M >= min_rows && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
            al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && !tune::no_mid_route();
@@ -1090,8 +1108,8 @@ inline bool aligned6(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t 
     (void)Y;
     (void)bias;
     (void)R;
-    return M <= 128 && N % 32 == 0 && K % 128 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
-           (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (int64_t)128 * lda * 4 < ((int64_t)1 << 31) &&
+    return M <= few_rows_max() && N % 32 == 0 && K % 128 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
            (int64_t)32 * K * 4 < ((int64_t)1 << 31);
 }
 
@@ -1135,7 +1153,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
 // first row -- unsliced, the few-rows kernel has N / 32 = 12 workgroups there, and a workgroup's MFMAs run on one CU however
 // its K is dealt over the waves (13 us for one sentence, + 5 us of LayerNorm launch; four slices of the same kernel on
 // 48 CUs + the LayerNorm reduce: 10.5 us) -- otherwise from kFewRowsMax + 1.
-inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 : kFewRowsMax + 1; }
+inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 : few_rows_max() + 1; }
+
+int64_t gemm_few_rows_max() { return few_rows_max(); }
 
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
 {
@@ -1169,16 +1189,17 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
             // up to 64 rows: the slices' partial tiles from the few-rows kernel (K over the sixteen waves of a workgroup: a
             // 3-step chain per wave instead of the tile kernel's 12-step one -- FC2 + LayerNorm of one sentence 15.5 -> 10.5 us)
             const int k_len = K / ksplit;
-            if (M <= kFewRowsMax && ksplit > 1 && N % 32 == 0 && k_len % 128 == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
+            if (M <= few_rows_max() && ksplit > 1 && N % 32 == 0 && k_len % 128 == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
                 (int64_t)32 * K * 4 < ((int64_t)1 << 31) && !tune::no_few_rows_route() && !tune::no_few_rows_k_slices()) {
-                const dim3 sgrid((unsigned)(N / 32), (unsigned)ksplit);
                 constexpr int LDS = 16 * 32 * 32 * 4;
-                if (M <= 32)
-                    hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI_BIAS, 1, true>), sgrid, dim3(1024), LDS, stream, A, lda, W, nullptr, nullptr, 0,
-                                       scratch.p, N, (int)M, N, k_len);
+                const int z1 = ((int)M + 31) / 32;
+                if ((int64_t)z1 * (N / 32) * ksplit <= 512 || M <= 32)
+                    hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI_BIAS, 1, true>), dim3((unsigned)(N / 32), (unsigned)ksplit, (unsigned)z1),
+                                       dim3(1024), LDS, stream, A, lda, W, nullptr, nullptr, 0, scratch.p, N, (int)M, N, k_len);
                 else
-                    hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI_BIAS, 2, true>), sgrid, dim3(1024), LDS, stream, A, lda, W, nullptr, nullptr, 0,
-                                       scratch.p, N, (int)M, N, k_len);
+                    hipLaunchKernelGGL((gemm_nt_f32_skinny<EPI_BIAS, 2, true>),
+                                       dim3((unsigned)(N / 32), (unsigned)ksplit, (unsigned)(((int)M + 63) / 64)), dim3(1024), LDS, stream, A, lda,
+                                       W, nullptr, nullptr, 0, scratch.p, N, (int)M, N, k_len);
             } else
             hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : kMidResident)),
                                dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p, n_tiles, total);
@@ -1197,7 +1218,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
     if (!R || !gamma || !beta) return hipErrorInvalidValue;
     // a handful of rows and a short K: the few-rows projection + a LayerNorm launch (the 64-row tiles would be one workgroup
     // walking all of K alone: 38 us for out-proj at 28 rows against 11)
-    const bool few_rows_pair = M <= kFewRowsMax && ldy == N && aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route();
+    const bool few_rows_pair = M <= few_rows_max() && ldy == N && aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route();
     if (few_rows_pair || !gemm_residual_layernorm_supported(N, K) || lda % 4 || ldr % 4 || ldy % 4 ||
         (int64_t)64 * lda * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31 ||
         !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y)) {

@@ -46,7 +46,7 @@ hipError_t launch_layernorm(const float* in, const float* gamma, const float* be
 
 // R4/R5/R9: fp32 MFMA GEMM with fused epilogue.  A rows are `lda` floats apart
 // (lets the head GEMM read CLS rows in place), R/Y rows ldr/ldy apart.
-// scratch (optional): a slab the call may use for partial tiles -- calls of 65 .. 8192 rows then take quarter-size tiles
+// scratch (optional): a slab the call may use for partial tiles -- calls of 257 .. 8192 rows then take quarter-size tiles
 // with K slices (gemm.hip, "calls of a few hundred to a few thousand rows") instead of the large-batch tiles.
 struct GemmScratch {
     float* p = nullptr;
@@ -60,8 +60,11 @@ hipError_t launch_gemm(const float* A, int64_t lda, const float* W, const float*
 // (cpu/encoder/encoder_layer.rs:129-147, 155-176).  Row widths the kernel covers: see ..._supported();
 // anything else returns hipErrorInvalidValue and the caller runs launch_gemm + launch_layernorm.
 bool gemm_residual_layernorm_supported(int N, int K);
-// With a scratch slab of gemm_scratch_floats(rows, N) floats, calls of 65 .. 8192 rows also take any N <= 1024:
+// With a scratch slab of gemm_scratch_floats(rows, N) floats, calls of 257 .. 8192 rows (and up to 256 with a long K) also take any N <= 1024:
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K);
+// Calls of up to this many rows take the few-rows kernel (K over the waves of a workgroup; LayerNorm a launch of its own
+// unless the K-sliced route above applies).
+int64_t gemm_few_rows_max();
 size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n);
 hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
                                           const float* R, int64_t ldr, const float* gamma, const float* beta, float eps,

@@ -13,6 +13,7 @@
 //   11  fused LayerNorm tiles as a persistent launch (two workgroups per CU)
 //   14  fused LayerNorm tiles read bias / gamma / beta from global memory in the epilogue (rounds 1-2) instead of from LDS
 //   15  residual projection + LayerNorm of up to 64 rows with a long K: the 64 x 64-tile K slices instead of the few-rows kernel's
+// 1000 + r  the few-rows kernel takes calls of up to r rows (sweeps of the few-rows / 64 x 64-tile crossover)
 // attention variant (kjarni_hip_set_attention_variant):
 //    1  never the persistent pipelined kernel (seq <= 128)
 //   11..16  knock-out diagnostics of the pipelined kernel (its DIAG template parameter 1..6)
@@ -50,6 +51,7 @@ inline bool layernorm_params_from_global() { return gemm() == 14; }
 inline bool no_persistent_tile_loop() { return gemm() == 10; }
 inline bool persistent_layernorm_tiles() { return gemm() == 11; }
 inline bool no_few_rows_k_slices() { return gemm() == 15; }
+inline int few_rows_max_override() { return gemm() >= 1000 ? gemm() - 1000 : 0; }  // (measurements: 1000 + rows)
 
 inline bool no_pipelined_attention() { return attention() == 1; }
 inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }

@@ -37,7 +37,7 @@ def test_embedder_registry_name_and_encode_batch(embed_env):
     assert np.abs(got - ref).max() < TOL
     # HF alias, case-insensitive (registry.rs:753-766)
     emb2 = kjarni_amd.Embedder("sentence-transformers/all-MiniLM-L6-v2", cache_dir=cache)
-    # (a different call size: up to 64 tokens in all, 65 .. 8192 and more take projection kernels that sum in different orders)
+    # (a different call size: up to 256 tokens in all, 257 .. 8192 and more take projection kernels that sum in different orders)
     assert np.abs(emb2.encode_batch(TEXTS[:2]) - got[:2]).max() < 1e-6
     assert np.array_equal(emb2.encode_batch(TEXTS), got)
 

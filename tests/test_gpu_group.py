@@ -2,7 +2,7 @@
 concurrent calls on one handle.  The GPU box has one device, so the fan-out is exercised with that device listed
 twice (two replicas, two host threads, two streams) and the RCCL path with a one-rank communicator; results must be
 oracle-equal and equal to the single-replica result to rounding (1e-6): the projections pick their tile route by the
-number of token rows in a call (<= 64, 65 .. 8 192, more), so a row block of a call and the whole call
+number of token rows in a call (<= 256, 257 .. 8 192, more), so a row block of a call and the whole call
 are bit-equal only when both land in the same range."""
 import ctypes as C
 import os

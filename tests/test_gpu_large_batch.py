@@ -233,14 +233,14 @@ def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6):
 
 # ------------------------------------------------------------------------------------------------ (d)
 def test_call_size_sweep_against_the_oracle(minilm2):
-    """Seeded sweep over (sentences, padded length): the three projection routes (<= 64 tokens, 65 .. 8 192, more), both
+    """Seeded sweep over (sentences, padded length): the three projection routes (<= 256 tokens, 257 .. 8 192, more), both
     attention kernels, ragged masks."""
     enc, orc = minilm2
     rng = np.random.default_rng(0)
     worst = 0.0
     for i in range(24):
         seq = int(rng.integers(1, 160))
-        tokens = int(rng.choice([40, 64, 65, 300, 2000, 8192, 8300, 20000, 50000]))
+        tokens = int(rng.choice([40, 64, 65, 256, 257, 300, 2000, 8192, 8300, 20000, 50000]))
         b = max(1, tokens // seq)
         ids, mask = synth.synthetic_ids(b, seq, seed=100 + i, ragged=True)
         got = enc.embed(ids, mask)
@@ -258,7 +258,7 @@ def test_projection_shape_sweep_against_float64():
     from scipy.special import erf
     rng = np.random.default_rng(0)
     for i in range(60):
-        m = int(rng.choice([1, 7, 33, 64, 65, 100, 129, 500, 1000, 2049, 4096, 4100, 8192, 8193, 9000, 12000, 20000]))
+        m = int(rng.choice([1, 7, 33, 64, 65, 100, 129, 256, 257, 500, 1000, 2049, 4096, 4100, 8192, 8193, 9000, 12000, 20000]))
         if rng.random() < 0.4:
             m = int(rng.integers(1, 12000))
         n = int(rng.choice([4, 32, 60, 64, 128, 256, 384, 388, 512, 768, 1024, 1152, 1536, 2048]))

@@ -18,7 +18,8 @@ def _silu(x):
                                    (4096, 384, 1536), (8192, 384, 384), (8193, 384, 384), (8300, 1536, 384), (2000, 3072, 768)])
 def test_linear_all_epilogues(m, k, n):
     # LinearLayer::matmul shapes incl. decode (m=1), odd dims (cpu/ops/tests.rs:78-116) and M tails; the three routes:
-    # up to 64 rows (K over the waves), 65 .. 8192 rows (64 x 64 tiles, K slices for narrow outputs), more (128 x 128)
+    # up to 256 rows (K over the waves, row groups over the grid), 257 .. 8192 rows (64 x 64 tiles, K slices for narrow outputs),
+    # more (128 x 128)
     from kjarni_amd import ops
     rng = np.random.default_rng(m * 7 + n)
     x = rng.standard_normal((m, k)).astype(np.float32)
@@ -47,10 +48,10 @@ def test_linear_all_epilogues(m, k, n):
 @pytest.mark.parametrize("m,k,n", [(1, 384, 384), (63, 384, 384), (64, 1536, 384), (65, 384, 384), (300, 1536, 384),
                                    (1000, 16, 384), (129, 256, 256), (200, 1024, 256), (77, 768, 768), (40, 100, 60),
                                    (1000, 3072, 768), (8192, 1536, 384), (8193, 1536, 384), (8400, 384, 384), (700, 4096, 1024),
-                                   # up to 64 rows with a long K: the few-rows kernel's K slices (one and two row tiles,
+                                   # up to 256 rows with a long K: the few-rows kernel's K slices (one to eight row groups,
                                    # the last rows of each), then the LayerNorm reduce
                                    (1, 1536, 384), (28, 1536, 384), (32, 1536, 384), (33, 1536, 384), (28, 3072, 768),
-                                   (64, 4096, 1024), (17, 1024, 256)])
+                                   (64, 4096, 1024), (17, 1024, 256), (130, 1536, 384), (256, 1536, 384), (200, 3072, 768)])
 @pytest.mark.parametrize("eps", [1e-12, 1e-5])
 def test_residual_projection_with_fused_layernorm(m, k, n, eps):
     """out-proj / FC2 + residual + LayerNorm of the post-norm layer (encoder_layer.rs:129-147, 155-176) as ONE kernel
@@ -75,18 +76,19 @@ def test_residual_projection_with_fused_layernorm(m, k, n, eps):
 
 @pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (768, 3072), (1024, 32)])
 def test_few_rows_results_do_not_depend_on_the_batch(k, n):
-    """Up to 64 rows the projections run the split-K kernel; a row's result must be bit-identical whatever other rows
-    share the call (1, 32, 33, 50, 64 rows: one or two 32-row tiles), and oracle-equal."""
+    """Up to 256 rows the projections run the split-K kernel, one workgroup per 32 columns and group of 32 rows; a row's
+    result must be bit-identical whatever other rows share the call (1 .. 256 rows: one to eight row groups, whole and
+    partial), and oracle-equal."""
     from kjarni_amd import ops
     rng = np.random.default_rng(k + n)
-    x = rng.standard_normal((64, k)).astype(np.float32)
+    x = rng.standard_normal((256, k)).astype(np.float32)
     w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
     b = rng.standard_normal(n).astype(np.float32)
-    r = rng.standard_normal((64, n)).astype(np.float32)
+    r = rng.standard_normal((256, n)).astype(np.float32)
     full, _ = ops.linear(x, w, b, r, ops.EPI_BIAS_RESIDUAL)
     ref = O.linear(x, w, b) + r
     assert float(np.abs(full - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
-    for m in (1, 32, 33, 50):
+    for m in (1, 32, 33, 50, 64, 65, 129, 255):
         part, _ = ops.linear(x[:m], w, b, r[:m], ops.EPI_BIAS_RESIDUAL)
         assert np.array_equal(part, full[:m]), m
     gelu, _ = ops.linear(x[:7], w, b, None, ops.EPI_BIAS_GELU)
@@ -96,7 +98,7 @@ def test_few_rows_results_do_not_depend_on_the_batch(k, n):
 
 @pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (384, 1152), (3072, 768)])
 def test_mid_size_results_do_not_depend_on_the_batch(k, n):
-    """65 .. 8192 rows take 64 x 64 tiles with a K-slice count that depends on (N, K) only: a row's result is
+    """257 .. 8192 rows take 64 x 64 tiles with a K-slice count that depends on (N, K) only: a row's result is
     bit-identical whatever other rows share the call (also with the fused LayerNorm), and oracle-equal."""
     from kjarni_amd import ops
     rng = np.random.default_rng(k * 3 + n)
@@ -111,7 +113,7 @@ def test_mid_size_results_do_not_depend_on_the_batch(k, n):
     ref = O.linear(x, w, b) + r
     assert float(np.abs(full - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
     full_ln, _ = ops.linear_layer_norm(x, w, b, r, g, beta, 1e-12)
-    for m in (65, 129, 640, 1299):
+    for m in (257, 300, 640, 1299):
         part, _ = ops.linear(x[:m], w, b, r[:m], ops.EPI_BIAS_RESIDUAL)
         assert np.array_equal(part, full[:m]), m
         if n <= 1024:
