@@ -355,10 +355,12 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
 
     int64_t pre_row0 = 0;  // rows of the item whose K / V / Q were requested last
     int pre_len = seq;
-    auto prefetch_kv = [&](int b, int h) {
+    // live = false (a workgroup's last item has no successor): the same requests through descriptors without extent -- no
+    // memory traffic, nothing to wait for at the end, and still no branch around a memory operation in the item loop
+    auto prefetch_kv = [&](int b, int h, bool live) {
         item_rows(b, pre_row0, pre_len);
         const float* base = qkv + pre_row0 * row_stride + h * D;
-        const int span_in = span_in_of(pre_len);
+        const int span_in = live ? span_in_of(pre_len) : 0;
         const __amdgpu_buffer_rsrc_t rk = rsrc(base + hidden, span_in), rv = rsrc(base + 2 * hidden, span_in);
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
@@ -384,17 +386,17 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         keep_lo = __ballot(lane < seq && mask_w0 != 0u);
         keep_hi = __ballot(lane + 64 < seq && mask_w1 != 0u);
     };
-    auto prefetch_q = [&](int b, int h) {  // (after prefetch_kv of the same item: pre_row0 / pre_len are its rows)
-        const __amdgpu_buffer_rsrc_t rq = rsrc(qkv + pre_row0 * row_stride + h * D, span_in_of(pre_len));
+    auto prefetch_q = [&](int b, int h, bool live) {  // (after prefetch_kv of the same item: pre_row0 / pre_len are its rows)
+        const __amdgpu_buffer_rsrc_t rq = rsrc(qkv + pre_row0 * row_stride + h * D, live ? span_in_of(pre_len) : 0);
 #pragma unroll
         for (int kk = 0; kk < D / 8; ++kk) qf[kk] = ld16(rq, off_q, kk * 32);
     };
 
     int64_t item = blockIdx.x;
     if (item < n_items) {
-        prefetch_kv(cur_b, cur_h);
+        prefetch_kv(cur_b, cur_h, true);
         request_mask(cur_b);
-        prefetch_q(cur_b, cur_h);
+        prefetch_q(cur_b, cur_h, true);
         ballot_mask();
     }
     int64_t cur_row0 = pre_row0;  // rows of the item the loop body computes
@@ -444,14 +446,15 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         const int64_t next = item + gridDim.x;
         int nb = cur_b, nh = cur_h;
         advance(nb, nh);
-        if (next >= n_items) {  // the last item of this workgroup requests itself again: the loop body stays branch-free
+        const bool has_next = next < n_items;
+        if (!has_next) {  // the last item of this workgroup "requests" itself (VARLEN: cu[b + 1] stays in range) -- without extent
             nb = cur_b;
             nh = cur_h;
         }
         __syncthreads();
         flush();                                               // the previous item's outputs
         if (DIAG != 4) {  // in flight during this item's MFMAs + softmax
-            prefetch_kv(nb, nh);
+            prefetch_kv(nb, nh, has_next);
             request_mask(nb);
         }
 
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
 
         // Q fragments and mask bits of this item are consumed: fetch the next item's.
         const unsigned long long cur_lo = keep_lo, cur_hi = keep_hi;
-        if (DIAG != 4) prefetch_q(nb, nh);
+        if (DIAG != 4) prefetch_q(nb, nh, has_next);
 
         // scale (after the dot product, as the reference) then mask overwrite.
         const unsigned long long valid_lo = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
