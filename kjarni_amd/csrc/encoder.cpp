@@ -54,6 +54,7 @@ EncoderModel::~EncoderModel()
         for (void* p : {(void*)w->hidden, (void*)w->qkv, (void*)w->ctx, (void*)w->mid, (void*)w->feat, (void*)w->split, w->stage,
                         (void*)w->tok_src, (void*)w->cu, (void*)w->lens})
             if (p) (void)hipFree(p);
+        if (w->pin) (void)hipHostFree(w->pin);
         if (w->done) (void)hipEventDestroy(w->done);
         if (w->stream) (void)hipStreamDestroy(w->stream);
     }
@@ -945,7 +946,7 @@ void EncoderModel::logits(const uint32_t* ids, const uint32_t* mask, const uint3
 // is synchronised, so calls from other host threads (other workspaces, other streams) keep running.
 template <class F>
 void EncoderModel::run_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
-                            int seq, size_t out_floats, float* out, F&& body)
+                            int seq, size_t out_floats, float* out, bool out_written_once, F&& body)
 {
     if (batch <= 0 || seq <= 0) return;
     Lease lease(*this, nullptr, true);
@@ -959,6 +960,40 @@ void EncoderModel::run_host(const uint32_t* ids, const uint32_t* mask, const uin
     uint32_t* mask_d = reinterpret_cast<uint32_t*>(base + tok_bytes);
     uint32_t* type_d = type_ids ? reinterpret_cast<uint32_t*>(base + 2 * tok_bytes) : nullptr;
     float* out_d = reinterpret_cast<float*>(base + out_off);
+    // Small calls (one sentence is ~45 dependent launches of ~5 us: every copy command is a few percent of the call): ids |
+    // mask | types gathered in pinned host memory and sent as one copy; the output leaves through the device mapping of the
+    // same pinned buffer -- the last kernel writes it across the bus itself, so there is no copy command behind it.
+    constexpr size_t kPinnedStageBytes = 256 * 1024;
+    const size_t out_bytes = out_floats * sizeof(float);
+    if (out_off + out_bytes <= kPinnedStageBytes) {
+        if (!ws.pin) {
+            void* h = nullptr;
+            void* d = nullptr;
+            if (hipHostMalloc(&h, kPinnedStageBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                ws.pin = static_cast<uint8_t*>(h);
+                ws.pin_dev = static_cast<uint8_t*>(d);
+            } else {
+                (void)hipGetLastError();
+                if (h) (void)hipHostFree(h);
+            }
+        }
+        if (ws.pin) {
+            std::memcpy(ws.pin, ids, tok_bytes);
+            std::memcpy(ws.pin + tok_bytes, mask, tok_bytes);
+            if (type_ids) std::memcpy(ws.pin + 2 * tok_bytes, type_ids, tok_bytes);
+            hip_check(hipMemcpyAsync(base, ws.pin, in_bytes, hipMemcpyHostToDevice, st), "H2D ids | mask | types");
+            if (out_written_once) {  // (pooled embeddings, logits: written by one kernel, never read back)
+                body(ws, ids_d, mask_d, type_d, reinterpret_cast<float*>(ws.pin_dev + out_off), st);
+                hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+                std::memcpy(out, ws.pin + out_off, out_bytes);
+            } else {             // (hidden states: the output buffer is the residual stream of every layer)
+                body(ws, ids_d, mask_d, type_d, out_d, st);
+                hip_check(hipMemcpyAsync(out, out_d, out_bytes, hipMemcpyDeviceToHost, st), "D2H output");
+                hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+            }
+            return;
+        }
+    }
     hip_check(hipMemcpyAsync(ids_d, ids, tok_bytes, hipMemcpyHostToDevice, st), "H2D ids");
     hip_check(hipMemcpyAsync(mask_d, mask, tok_bytes, hipMemcpyHostToDevice, st), "H2D mask");
     if (type_ids) hip_check(hipMemcpyAsync(type_d, type_ids, tok_bytes, hipMemcpyHostToDevice, st), "H2D type ids");
@@ -970,7 +1005,7 @@ void EncoderModel::run_host(const uint32_t* ids, const uint32_t* mask, const uin
 void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                                       int64_t batch, int seq, float mask_value, float* out)
 {
-    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * seq * cfg_.hidden, out,
+    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * seq * cfg_.hidden, out, false,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
                  const int64_t per = sentences_per_chunk(seq);
                  reserve(ws, std::min(per, batch) * seq, std::min(per, batch));
@@ -985,7 +1020,7 @@ void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask,
 void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
                               int seq, PoolMode pool, bool normalize, float mask_value, float* out)
 {
-    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.hidden, out,
+    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.hidden, out, true,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
                  PackPlan plan;  // (lives until run_host has synchronised the stream)
                  plan_packing(ws, k, mask, batch, seq, st, plan);
@@ -997,7 +1032,7 @@ void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const 
                                int seq, float mask_value, float* out)
 {
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
-    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.num_labels, out,
+    run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.num_labels, out, true,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
                  PackPlan plan;
                  plan_packing(ws, k, mask, batch, seq, st, plan);

@@ -103,6 +103,10 @@ struct Workspace {
     size_t lens_cap = 0;
     void* stage = nullptr;  // ids / mask / types in, outputs back, for the host-pointer entry points
     size_t stage_bytes = 0;
+    // small host-pointer calls (one sentence, a handful): inputs gathered in pinned host memory and sent as ONE copy, outputs
+    // written by the last kernel straight into the pinned buffer (kPinnedStageBytes, device-mapped)
+    uint8_t* pin = nullptr;
+    uint8_t* pin_dev = nullptr;
     hipStream_t stream = nullptr;  // this workspace's own stream (host-pointer entry points run on it)
     hipEvent_t done = nullptr;     // recorded behind the last launch that used the buffers
     hipStream_t done_stream = nullptr;
@@ -207,7 +211,7 @@ private:
     void* reserve_stage(Workspace& ws, size_t bytes);
     template <class F>
     void run_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq,
-                  size_t out_floats, float* out, F&& body);
+                  size_t out_floats, float* out, bool out_written_once, F&& body);
     // Runs embeddings + all layers for `batch` sentences into hidden (device, [batch*seq, H]).
     // pack != null: the chunk's rows are its kept tokens only (mask is not read; hidden is [pack->tokens, H]).
     void forward_chunk(Workspace& ws, const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
