@@ -603,6 +603,136 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
     flush();
 }
 
+// ---------------------------------------------------------------------------
+// Small calls (one sentence, a handful: at most kSplitMaxItems (sentence, head) items), S <= 128.  The kernels above give an
+// item to ONE workgroup, whose 4 x 256 MFMAs run on one CU: 6.8 us of matrix time for a 128-token item while 244 CUs idle --
+// a one-sentence forward is a chain of dependent launches, so that is 6.8 us of latency per layer.  Here an item is up to
+// four workgroups (one per block of 32 queries) and a workgroup's four waves take one 32-key tile each: 16 + 16 MFMAs per
+// wave for d = 32.  A wave's K tile and its V rows are the MFMA operands as they lie in memory (K rows as 16-byte pieces, V
+// rows as 128-byte row segments: a key's d values are the B operand's 32 lanes), so nothing is staged; the waves meet in LDS
+// three times -- the per-query maxima of the four key tiles, the sums of exp, the four partial output tiles -- and the
+// normalisation by 1 / sum happens on the way out.  Padded rows and packed rows (cu) alike; the mask semantics are the
+// other kernels' (masked key: score overwritten by mask_value; key beyond the sentence: contributes exactly 0).
+// ---------------------------------------------------------------------------
+constexpr int kSplitMaxItems = 128;  // (96 items: -1.5 % per call against the item-per-workgroup kernel; 240: +2.5 %)
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_split_kernel(const float* __restrict__ qkv, const uint32_t* __restrict__ mask, int seq,
+                                                              int heads, float scale, float mask_value,
+                                                              const int32_t* __restrict__ cu, float* __restrict__ ctx)
+{
+    __shared__ float s_max[4][32], s_sum[4][32];
+    __shared__ __attribute__((aligned(16))) float s_o[4][32][D + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's key tile
+    const int l31 = lane & 31, half = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int hidden = heads * D;
+    const int64_t row_stride = 3 * (int64_t)hidden;
+    int64_t row0 = b * seq;
+    int len = seq;
+    if (cu) {
+        row0 = cu[b];
+        len = cu[b + 1] - cu[b];
+        mask = nullptr;
+    }
+    if (qb * 32 >= len) return;  // (the grid covers the longest sentence)
+    const float* q_base = qkv + row0 * row_stride + h * D;
+    const float* k_base = q_base + hidden;
+    const float* v_base = q_base + 2 * hidden;
+    const int key0 = wid * 32;
+    const bool tile_on = key0 < len;  // wave-uniform: does this wave's key tile hold keys
+
+    // Requests first: Q (B operand of S^T = K Q^T: query l31, k = 8 kk + 4 half + c), this wave's K rows (A operand: key l31, same k),
+    // its V rows (B operand of O = P V: lane supplies V[key0 + 8 g + 4 half + c][32 dt + l31]) and its 32 mask words.
+    const int q_row = qb * 32 + l31;
+    const int k_row = key0 + l31;
+    f32x4 qf[D / 8], kf[D / 8];
+    float vf[D / 32][16];
+    uint32_t mword = 1u;
+#pragma unroll
+    for (int kk = 0; kk < D / 8; ++kk) {
+        qf[kk] = q_row < len ? *reinterpret_cast<const f32x4*>(q_base + q_row * row_stride + kk * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        kf[kk] = k_row < len ? *reinterpret_cast<const f32x4*>(k_base + k_row * row_stride + kk * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = key0 + 8 * (i >> 2) + 4 * half + (i & 3);
+            vf[dt][i] = key < len ? v_base[key * row_stride + dt * 32 + l31] : 0.0f;
+        }
+    if (mask && k_row < len) mword = mask[b * seq + k_row];
+    // this tile's keys: kept (mask != 0) and existing (< len), as 32-bit sets (both halves of the wave hold the same words)
+    const unsigned keep = (unsigned)__ballot(mword != 0u && k_row < len);
+    const unsigned exist = (unsigned)__ballot(k_row < len);
+
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+    if (tile_on) {
+#pragma unroll
+        for (int kk = 0; kk < D / 8; ++kk)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kk][c], qf[kk][c], st, 0, 0, 0);
+    }
+    // scale after the dot product (as the reference), in the exp2 domain; masked key: overwritten; key beyond the sentence: -inf
+    const float c1 = scale * 1.4426950408889634f;
+    const float masked_raw = mask_value / scale;
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2) + 4 * half);
+        float v = (keep & bit) ? st[r] : masked_raw;
+        v = (exist & bit) ? v : -INFINITY;
+        st[r] = v;
+        cmax = fmaxf(cmax, v);
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32, kWave));
+    if (half == 0) s_max[wid][l31] = cmax;
+    __syncthreads();
+    const float qmax = fmaxf(fmaxf(s_max[0][l31], s_max[1][l31]), fmaxf(s_max[2][l31], s_max[3][l31]));
+    const float neg = -qmax * c1;  // (+inf for a row whose every key is -inf: exp2(-inf + inf) = NaN, as the reference)
+    float csum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[r], c1, neg));
+        st[r] = e;
+        csum += e;
+    }
+    csum += __shfl_xor(csum, 32, kWave);
+    if (half == 0) s_sum[wid][l31] = csum;
+
+    // O_w = P_w V_w: A = P (query l31, k <-> key 8 g + c (+ 4 for the upper half) of MFMA (g, c)), B = the V values requested above
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        if (tile_on) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[i], vf[dt][i], o, 0, 0, 0);
+        }
+        // accumulator row = query (reg, half), column = d (l31)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_o[wid][acc_row(r, half)][dt * 32 + l31] = o[r];
+    }
+    __syncthreads();
+    // 32 queries x D outputs: 16-byte pieces over the 256 threads, the four partial tiles added in tile order, then 1 / sum
+    constexpr int PIECES = 32 * D / 4;
+    for (int p = tid; p < PIECES; p += 256) {
+        const int q = p / (D / 4), d4 = (p % (D / 4)) * 4;
+        if (qb * 32 + q >= len) continue;
+        f32x4 a = *reinterpret_cast<const f32x4*>(&s_o[0][q][d4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) a += *reinterpret_cast<const f32x4*>(&s_o[w][q][d4]);
+        const float total = (s_sum[0][q] + s_sum[1][q]) + (s_sum[2][q] + s_sum[3][q]);
+        if (total > 0.0f) a = a * (1.0f / total);  // activations.rs:236-241: divide only when the sum is > 0
+        *reinterpret_cast<f32x4*>(ctx + (row0 + qb * 32 + q) * hidden + h * D + d4) = a;
+    }
+}
+
 // Any-head-dim fallback (head_dim not 32/64, e.g. toy models in tests): one
 // wave per (sentence, head, query); scores for the row go through LDS.
 __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __restrict__ qkv,
@@ -670,6 +800,12 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
         attr_set[dev & 63] = true;
     }
     const float scale = 1.0f / sqrtf((float)D);  // encoder_self_attention.rs:43
+    if (seq <= KCHUNK && batch * heads <= kSplitMaxItems && !tune::no_split_attention()) {
+        // a few items: each over up to four workgroups, a key tile per wave (latency, not throughput)
+        hipLaunchKernelGGL(attention_split_kernel<D>, dim3((unsigned)((seq + 31) / 32), (unsigned)heads, (unsigned)batch), dim3(256), 0, stream,
+                           qkv, mask, seq, heads, scale, mask_value, cu, ctx);
+        return hipGetLastError();
+    }
     if (seq <= KCHUNK && !tune::no_pipelined_attention()) {
         const int64_t n_items = batch * heads;
         // head_dim 32: three resident workgroups per CU (35.8 KiB of LDS and <= 168 VGPRs each): the third hides what two

@@ -18,7 +18,8 @@
 //    1  never the persistent pipelined kernel (seq <= 128)
 //   11..16  knock-out diagnostics of the pipelined kernel (its DIAG template parameter 1..6)
 //   20  two resident workgroups per CU instead of three
-//   21  padded calls of seq <= 96 on the full 128-key kernel (no skipping of empty key tiles and waves)
+//   21  padded calls of seq <= 96 on the full 128-key kernel (no skipping of empty key tiles and waves), no split kernel either
+//   22  small calls (<= 256 items) on the item-per-workgroup kernels instead of the split one (a key tile per wave)
 // cosine variant (kjarni_hip_set_cosine_variant):
 //    1  streaming passes only (no GEMM route for many queries)
 #pragma once
@@ -57,6 +58,7 @@ inline bool no_pipelined_attention() { return attention() == 1; }
 inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }
 inline bool attention_two_workgroups_per_cu() { return attention() == 20; }
 inline bool no_short_attention() { return attention() == 21; }
+inline bool no_split_attention() { return attention() == 22 || attention() == 21; }
 
 inline bool scan_streaming_only() { return cosine() == 1; }
 

@@ -89,10 +89,13 @@ def test_chunking_is_invisible(minilm):
     enc, _ = minilm
     ids, mask = synth.synthetic_ids(40, 64, seed=5, ragged=True)
     a = enc.embed(ids, mask)
-    enc.set_chunk_tokens(64 * 7)  # 7 sentences per chunk -> ragged last chunk
+    enc.set_chunk_tokens(64 * 17)  # 17 sentences per chunk -> ragged last chunk; every chunk on the same kernel routes as the whole
     b = enc.embed(ids, mask)
+    enc.set_chunk_tokens(64 * 7)   # 7 sentences = 84 (sentence, head) items: the small-call attention kernel (<= 128 items), whose
+    c = enc.embed(ids, mask)       # sums run in another order -- equal to rounding
     enc.set_chunk_tokens(16384)
     assert np.array_equal(a, b)
+    assert float(np.abs(a - c).max()) <= 1e-6
 
 
 def test_all_masked_sentence(minilm):

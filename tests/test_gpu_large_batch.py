@@ -155,7 +155,9 @@ def test_fused_layernorm_projection_on_large_calls(m, k):
 
 
 @pytest.mark.parametrize("B,S,d", [(200, 128, 32), (200, 100, 32), (200, 37, 32), (1100, 128, 32), (70, 128, 32),
-                                   (120, 128, 64), (120, 77, 64), (43, 128, 64), (300, 19, 64)])
+                                   (120, 128, 64), (120, 77, 64), (43, 128, 64), (300, 19, 64),
+                                   # one item per workgroup, past the small-call kernel's 128 items: 132, 240, 360 items
+                                   (11, 128, 32), (20, 128, 32), (30, 50, 64), (20, 90, 32)])
 def test_attention_on_the_item_loop(B, S, d):
     """S <= 128 and more (sentence, head) items than resident workgroups (768 at d = 32, 512 at d = 64): the persistent
     kernel with prefetch and deferred stores; 70 x 12 = 840 (43 x 12 = 516) items is the first size past one item per

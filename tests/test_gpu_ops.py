@@ -137,7 +137,10 @@ def test_fused_layernorm_constant_rows():
 
 @pytest.mark.parametrize("B,S,heads,d", [(2, 128, 12, 32), (3, 37, 12, 32), (2, 200, 12, 32), (1, 512, 4, 32),
                                          (2, 128, 12, 64), (2, 77, 3, 64), (1, 300, 2, 64), (2, 9, 2, 8),
-                                         (1, 1, 12, 32)])
+                                         (1, 1, 12, 32),
+                                         # up to 128 (sentence, head) items and 128 tokens: the small-call kernel (a workgroup per
+                                         # 32 queries, a 32-key tile per wave) -- its last size, partial query blocks and key tiles
+                                         (10, 128, 12, 32), (10, 97, 12, 64), (5, 33, 12, 32), (4, 64, 16, 64), (7, 31, 12, 32)])
 def test_attention_parity(B, S, heads, d):
     from kjarni_amd import ops
     rng = np.random.default_rng(B * 100 + S)
@@ -146,6 +149,8 @@ def test_attention_parity(B, S, heads, d):
     mask = np.ones((B, S), np.uint32)
     for b in range(B):
         mask[b, rng.integers(max(1, S // 2), S + 1):] = 0
+        if b % 2 and S >= 3:
+            mask[b, S // 3] = 0   # a hole, not only right padding
     q, k, v = (np.ascontiguousarray(qkv[..., i * H:(i + 1) * H]) for i in range(3))
     for mv in (O.MASK_ALLOC, O.MASK_NOALLOC):
         ref = O.attention(q, k, v, mask.astype(np.float32), heads, mask_value=mv)
