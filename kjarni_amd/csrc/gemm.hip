@@ -138,13 +138,16 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     // XCD walks one contiguous run of tiles (N fastest).  Bijective for any tile count.
     // The grid is the workgroups the chip holds at once; workgroup w takes tiles w, w + gridDim.x, ... (gridDim.x is a
     // multiple of 8 whenever it is smaller than the tile count): a finished workgroup's successor does not wait for a dispatch.
-    const int64_t nwg = total_tiles;
-    const int64_t q8 = nwg / 8, r8 = nwg % 8;
-    for (int64_t wg = blockIdx.x; wg < total_tiles; wg += gridDim.x) {
-    const int64_t xcd = wg % 8, slot = wg / 8;
-    const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int64_t m0 = (bid / n_tiles) * BM;
-    const int n0 = (int)(bid % n_tiles) * BN;
+    // (32-bit unsigned arithmetic -- the launcher holds the tile count below 2^31: a 64-bit division here is ~200 scalar
+    // instructions between a persistent workgroup's tiles)
+    const unsigned nwg = (unsigned)total_tiles;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u;
+    for (unsigned wg = blockIdx.x; wg < nwg; wg += gridDim.x) {
+    const unsigned xcd = wg & 7u, slot = wg >> 3;
+    const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const unsigned m_tile = bid / (unsigned)n_tiles;
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = (int)(bid - m_tile * (unsigned)n_tiles) * BN;
 
     // Global staging pointers; rows past M are clamped (their results are never stored).
     const int ld_row = tid / T::V4_PER_ROW, ld_c4 = tid % T::V4_PER_ROW;
@@ -844,6 +847,7 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
     const int n_tiles = N / BN;
     const int64_t m_tiles = (M + BM - 1) / BM;
     const int64_t total = m_tiles * n_tiles;
+    if (total > 0x7fffffff) return hipErrorInvalidValue;  // (the kernel's tile index is 32-bit; a chunk is <= 262 144 rows)
     // The kernel walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  With the plain epilogue a grid of the workgroups the
     // chip holds at once measured +2.2 % (QKV shape: no dispatch between a workgroup's tiles); with the GELU epilogue -1.1 %
     // (the barrier that ends a tile waits for the slowest wave's epilogue), so those launch one workgroup per tile.
@@ -867,7 +871,10 @@ constexpr int MID_BM = 64, MID_BN = 64, MID_BK = 32, MID_STRIDE = MID_BK + 4;
 
 inline int mid_ksplit(int N, int K) { return (N <= 1024 && K >= 1024 && K % (4 * MID_BK) == 0) ? 4 : 1; }
 
-template <int EPI, bool PARTIAL>
+// DIAG (tuning build only, tools/mid_probe.py with GEMM_VARIANT 21 / 22): knock-outs that show where a tile's time goes --
+// 1 no global loads in the K-loop (stale operands), 2 no MFMAs, 3 no barrier in the K-loop (and no loads), 4 no LDS stores
+// (and no loads), 5 no LDS fragment reads (and no loads), 6 nothing but the MFMAs.
+template <int EPI, bool PARTIAL, int DIAG = 0>
 __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                        const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
                                                        int64_t ldy, int M, int N, int K, int m_tiles, int ksplit,
@@ -888,15 +895,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__
     // a workgroup takes more than one pair): every XCD gets one contiguous run, COLUMN tiles fastest -- an XCD then works on
     // a block of rows against the whole weight matrix, and both (a few hundred rows of A, all of W: 1-3 MB) stay in its
     // 4 MB L2.
-    const int64_t q8 = total / 8, r8 = total % 8;
+    // (32-bit unsigned arithmetic: the 64-bit divisions this started with were ~1 us of every tile's fixed cost)
+    const unsigned q8 = (unsigned)total >> 3, r8 = (unsigned)total & 7u;
     struct Pair {
         int m0, n0, ks;
     };
-    auto pair_of = [&](int64_t w) {
-        const int64_t xcd = w % 8, slot = w / 8;
-        const int64_t bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-        const int64_t bid = bid0 / ksplit;
-        return Pair{(int)(bid / n_tiles) * MID_BM, (int)(bid % n_tiles) * MID_BN, (int)(bid0 % ksplit)};
+    auto pair_of = [&](unsigned w) {
+        const unsigned xcd = w & 7u, slot = w >> 3;
+        const unsigned bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        const unsigned bid = bid0 / (unsigned)ksplit;
+        const unsigned mt = bid / (unsigned)n_tiles;
+        return Pair{(int)mt * MID_BM, (int)(bid - mt * (unsigned)n_tiles) * MID_BN, (int)(bid0 - bid * (unsigned)ksplit)};
     };
     const float *a_ptr[2], *b_ptr[2];
     f32x4 ga[2], gb[2];
@@ -925,7 +934,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__
     Pair cur_pair = pair_of(blockIdx.x);
     point_at(cur_pair);
     load(0);
-    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    for (unsigned w = blockIdx.x; w < (unsigned)total; w += gridDim.x) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -940,21 +949,38 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_mid(const float* __restrict__
         store(0);
         __syncthreads();
         // (a second K-step of global loads in flight measured no faster at 4 096 rows and 7 % slower at 1 024)
+        // Within a K-step the wave pipelines itself: the fragments of group kk + 1 are requested from LDS before the four MFMAs of
+        // group kk, the staging stores of the next step sit between the third and the fourth group.  (Left to the compiler the
+        // step was reads -> wait -> 8 MFMAs -> reads -> wait -> 8 MFMAs -> stores -> barrier, and knock-outs showed that LDS / barrier
+        // time ADDED to the matrix time -- 17.7 us without MFMAs + 23 us of MFMAs = the 43 us of the QKV launch at 4 096 rows: the
+        // other resident workgroups' waves do not fill those gaps.)
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) load((kt + 1) * MID_BK);
+            const bool more = kt + 1 < nk;
+            if (more && (DIAG == 0 || DIAG == 2)) load((kt + 1) * MID_BK);
+            f32x4 a[2], b[2];
+            if (DIAG < 5 || kt == 0) {
+                a[0] = *reinterpret_cast<const f32x4*>(&sA[cur][fa]);
+                b[0] = *reinterpret_cast<const f32x4*>(&sB[cur][fb]);
+            }
 #pragma unroll
             for (int kk = 0; kk < MID_BK / 8; ++kk) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[cur][fa + kk * 8]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&sB[cur][fb + kk * 8]);
+                if (kk + 1 < MID_BK / 8 && (DIAG < 5 || kt == 0)) {
+                    a[(kk + 1) & 1] = *reinterpret_cast<const f32x4*>(&sA[cur][fa + (kk + 1) * 8]);
+                    b[(kk + 1) & 1] = *reinterpret_cast<const f32x4*>(&sB[cur][fb + (kk + 1) * 8]);
+                }
+                if (kk == MID_BK / 8 - 1 && more && DIAG != 4 && DIAG != 6) store(cur ^ 1);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
+                for (int c = 0; c < 4; ++c) {
+                    if (DIAG == 2) acc[c] += a[kk & 1][c] * b[kk & 1][c];
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][c], b[kk & 1][c], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (keeps the groups in this order)
             }
-            if (kt + 1 < nk) store(cur ^ 1);
-            __syncthreads();
+            if (DIAG != 3 && DIAG != 6) __syncthreads();
         }
         const Pair done = cur_pair;
-        if (w + gridDim.x < total) {
+        if (w + gridDim.x < (unsigned)total) {
             cur_pair = pair_of(w + gridDim.x);
             point_at(cur_pair);
             load(0);
@@ -1085,8 +1111,23 @@ hipError_t launch_mid(const float* A, int64_t lda, const float* W, const float* 
     int ksplit = mid_ksplit(N, K);
     if (ksplit > 1 && (size_t)ksplit * M * N > scratch.floats) ksplit = 1;
     const int total = m_tiles * n_tiles * ksplit;
-    const dim3 grid((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : kMidResident));
+    const dim3 grid((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : (tune::mid_grid_override() > 0 ? tune::mid_grid_override() : kMidResident)));
     if (ksplit == 1) {
+#ifdef KJARNI_TUNING
+        if (tune::mid_knockout() == 1) {
+            hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, false, 1>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, 1,
+                               nullptr, n_tiles, total);
+            return hipGetLastError();
+        }
+#define KJ_MID_DIAG(D_)                                                                                                            \
+    if (tune::mid_knockout() == D_) {                                                                                               \
+        hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, false, D_>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, \
+                           1, nullptr, n_tiles, total);                                                                             \
+        return hipGetLastError();                                                                                                   \
+    }
+        KJ_MID_DIAG(2) KJ_MID_DIAG(3) KJ_MID_DIAG(4) KJ_MID_DIAG(5) KJ_MID_DIAG(6)
+#undef KJ_MID_DIAG
+#endif
         hipLaunchKernelGGL((gemm_nt_f32_mid<EPI, false>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles, 1,
                            nullptr, n_tiles, total);
         return hipGetLastError();
