@@ -81,6 +81,19 @@ KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64
  * turn packing off for that. */
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
+/* Opt-in, process-wide, default OFF (or environment KJARNI_HIP_F32_ON_BF16=1, read once at the first projection): the
+ * large-batch projections (calls of more than 8 192 token rows) compute their f32 products on the bf16 matrix cores.  Every
+ * f32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits) on its way into LDS and six of the nine
+ * cross products are accumulated in f32 -- the three dropped ones are below 2^-24 of a product, f32's own rounding --
+ * so inputs, outputs and the error level are those of f32 arithmetic (measured against float64: the same 2-4e-6 as the f32
+ * MFMA kernels, tests/test_gpu_split.py), at 1.1-1.25x their speed.  Differences: sums run in another
+ * order (results equal to the default path to rounding, not bit for bit), and a non-finite INPUT element turns its products
+ * into NaN (inf - inf in the split) where the default path keeps an infinity.  The reference computes in f32
+ * (kjarni-transformers/src/linear_layer/linear_layer.rs:160-282); whether f32 results assembled from bf16 pieces meet a
+ * deployment's precision policy is the integrator's decision, hence off by default.  Returns the previous setting. */
+int32_t kjarni_hip_set_f32_on_bf16(int32_t on);
+int32_t kjarni_hip_get_f32_on_bf16(void);
+
 /* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
  * calls may be made concurrently from any number of host threads and on any streams, as on the reference's
  * handles (its model types are Send + Sync, crates/kjarni-ffi/src/lib.rs:25-32).  The weights are immutable; each

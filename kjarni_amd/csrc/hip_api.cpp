@@ -120,6 +120,15 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* e
     return KJARNI_OK;
 }
 
+KJARNI_EXPORT int32_t kjarni_hip_set_f32_on_bf16(int32_t on)
+{
+    const int32_t before = kjarni::get_f32_on_bf16() ? 1 : 0;
+    kjarni::set_f32_on_bf16(on != 0);
+    return before;
+}
+
+KJARNI_EXPORT int32_t kjarni_hip_get_f32_on_bf16(void) { return kjarni::get_f32_on_bf16() ? 1 : 0; }
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
                                                                const uint32_t* mask_dev,
                                                                const uint32_t* type_ids_dev, int64_t batch,

@@ -71,6 +71,12 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
                                           float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream,
                                           GemmScratch scratch = GemmScratch());
 
+// Opt-in (process-wide; default off, or KJARNI_HIP_F32_ON_BF16=1): the large-batch projections compute their f32 products on the
+// bf16 matrix cores -- every operand split exactly into three bf16 pieces, six of the nine cross products (gemm.hip, "fp32
+// products on the bf16 matrix cores").  f32 in, f32 out, f32-level error; 2-3x the f32 MFMA rate.
+void set_f32_on_bf16(bool on);
+bool get_f32_on_bf16();
+
 // (the kernel A/B switches of the tuning build live in tuning.h)
 
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.

@@ -83,6 +83,16 @@ def _tuning(name: str):
     return fn
 
 
+def set_f32_on_bf16(on: bool) -> bool:
+    """Process-wide opt-in (kjarni_hip_set_f32_on_bf16): the large-batch projections compute their f32 products on the bf16
+    matrix cores from three exact bf16 pieces per operand.  Returns the previous setting."""
+    return bool(lib().kjarni_hip_set_f32_on_bf16(1 if on else 0))
+
+
+def get_f32_on_bf16() -> bool:
+    return bool(lib().kjarni_hip_get_f32_on_bf16())
+
+
 def has_tuning() -> bool:
     return hasattr(lib(), "kjarni_hip_set_gemm_variant")
 
