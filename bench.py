@@ -33,6 +33,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 (H2D of ids/mask + D2H of the embeddings inside the timed region) and with
                 ragged lengths U{16..128}.
   value_by_call_size  (N = 1, embed) one host-pointer call at a time of 1 / 32 / 256 sentences.
+  value_f32_on_bf16   (N = 1, embed) the headline workload in the opt-in mode kjarni_hip_set_f32_on_bf16 (default off;
+                never part of `value`), with the largest difference of its embeddings from the default path's.
 """
 import argparse
 import json
@@ -486,10 +488,29 @@ def main():
             dtc = (time.perf_counter() - t1) / reps
             by_call[str(b)] = {"ms_per_call": round(dtc * 1e3, 4), "sentences_per_s": round(b / dtc, 1)}
         extras["value_by_call_size"] = by_call
+        # Opt-in mode (kjarni_hip_set_f32_on_bf16, default OFF and never part of `value`): the same workload with the
+        # large-batch projections' f32 products computed on the bf16 matrix cores from three exact bf16 pieces per operand
+        # (six cross products, f32 accumulation: DESIGN.md section 3); its output against the default path's, all rows.
+        from kjarni_amd import ops as _ops
+        ref_emb = result_holder["emb"]
+        before = _ops.set_f32_on_bf16(True)
+        try:
+            enc.embed_dev(ids.data_ptr(), mask.data_ptr(), 2048, S, out.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                enc.embed_dev(ids.data_ptr(), mask.data_ptr(), n_local, S, out.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            extras["value_f32_on_bf16"] = round(2 * n_local / (time.perf_counter() - t1), 1)
+            extras["f32_on_bf16_max_abs_diff_vs_default"] = float((out - ref_emb).abs().max().item())
+        finally:
+            _ops.set_f32_on_bf16(before)
         extras["extras_note"] = ("value_host_ptrs: ids/mask handed over as host buffers, embeddings returned to the "
                                  "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128, run over the kept tokens only "
                                  "(packed rows); value_ragged_padded_layout: the same batch with every [PAD] row computed; 2 steps each; "
-                                 "value_by_call_size: one host-pointer call at a time of 1 / 32 / 256 sentences x 128 tokens")
+                                 "value_by_call_size: one host-pointer call at a time of 1 / 32 / 256 sentences x 128 tokens; "
+                                 "value_f32_on_bf16: the headline workload in the opt-in mode kjarni_hip_set_f32_on_bf16 (f32 products "
+                                 "from three exact bf16 pieces per operand on the bf16 matrix cores; off by default, not part of `value`)")
 
     if rank == 0:
         total = n_total * args.steps

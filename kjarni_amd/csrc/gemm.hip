@@ -878,10 +878,14 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int SP_BK = 16;                              // K per step: one 32 x 32 x 16 MFMA block
-constexpr int SP_ST = 24;                              // bf16 per LDS row: 16 of K + 8 of padding (48-byte rows: conflict-free b128 reads)
+// LDS rows are 16 bf16 = 32 bytes with NO padding; the two 16-byte halves of a row swap places in rows 8..15 of every 16
+// (half ^ ((row >> 3) & 1)).  A fragment read (16 lanes x 16 bytes: rows r .. r + 15, one logical half) then covers all 64
+// banks once, and so does a staging store (32 lanes x 8 bytes: 8 whole rows) -- with padded rows one of the two always
+// collides (48-byte rows: a third of the LDS cycles were bank conflicts).
+constexpr int SP_ST = 16;                              // bf16 per LDS row
 constexpr int SP_PLANE = 128 * SP_ST;                  // bf16 per piece plane of a 128-row tile
 constexpr int SP_STAGE = 2 * 3 * SP_PLANE;             // A and W, three planes each (bf16 elements)
-constexpr int SP_LDS_BYTES = 2 * SP_STAGE * 2;         // two stages: 73 728 bytes -- two workgroups per CU
+constexpr int SP_LDS_BYTES = 2 * SP_STAGE * 2;         // two stages: 49 152 bytes
 
 __device__ __forceinline__ uint32_t sp_pack(float a, float b)
 {
@@ -938,8 +942,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
     }
     constexpr int SETS = 4;    // register sets of raw rows: requests run SETS - 1 steps ahead of the split (memory latency >> one 768-cycle step)
     f32x4 ga[SETS][2], gb[SETS][2];  // [register set][piece]
-    const int st_off = ld_row * SP_ST + ld_c4 * 4;  // (bf16 elements)
-    const int fa = (wr * 64 + l31) * SP_ST + half * 8, fb = 3 * SP_PLANE + (wc * 64 + l31) * SP_ST + half * 8;
+    const int st_off = ld_row * SP_ST + (((ld_c4 >> 1) ^ ((ld_row >> 3) & 1)) * 2 + (ld_c4 & 1)) * 4;  // (bf16 elements; halves swapped in rows 8..15)
+    const int sw_half = half ^ ((l31 >> 3) & 1);
+    const int fa = (wr * 64 + l31) * SP_ST + sw_half * 8, fb = 3 * SP_PLANE + (wc * 64 + l31) * SP_ST + sw_half * 8;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
     // stores (64 four-byte stores per lane straight from the accumulators made the store issue, not the MFMAs, the tile's time).
     __syncthreads();
     float* sw = reinterpret_cast<float*>(sp_smem) + wid * (32 * EPI_STRIDE);
-    static_assert(4 * 32 * EPI_STRIDE * 4 <= SP_LDS_BYTES, "four wave-private epilogue regions must fit the operand planes");
+    static_assert(4 * 32 * EPI_STRIDE * 4 <= SP_LDS_BYTES, "four wave-private epilogue regions must fit the operand planes");  // 34 816 <= 49 152
     const int e_row = lane >> 4, e_c4 = lane & 15;
     const int n = n0 + wc * 64 + e_c4 * 4;
     const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1509,9 +1514,10 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         }
     }
     if (!R || !gamma || !beta) return hipErrorInvalidValue;
-    // f32-on-bf16 mode, large calls: the split kernel with the residual epilogue + the LayerNorm kernel (the fused LayerNorm tile
-    // has no split form yet)
-    if (f32_on_bf16() && M > kMidMaxRows && N % BN == 0 && K % 64 == 0 && ldy == N && lda % 4 == 0 && al16(A) && al16(W) &&
+    // f32-on-bf16 mode, large calls with a long K (FC2): the split kernel with the residual epilogue + the LayerNorm kernel (the
+    // fused LayerNorm tile has no split form yet; at K = 384 -- out-proj -- the fused f32 tile is the faster of the two: 0.62
+    // against 0.60 + 0.17 ms)
+    if (f32_on_bf16() && M > kMidMaxRows && N % BN == 0 && K % 64 == 0 && K >= 1024 && gemm_residual_layernorm_supported(N, K) && ldy == N && lda % 4 == 0 && al16(A) && al16(W) &&
         (int64_t)BM * lda * 4 < ((int64_t)1 << 31) && (int64_t)BN * K * 4 < ((int64_t)1 << 31)) {
         const hipError_t e = launch_split<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
         if (e != hipSuccess) return e;
