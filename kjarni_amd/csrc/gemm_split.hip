@@ -1,0 +1,298 @@
+// f32 projections on the bf16 matrix cores (opt-in mode; its own translation unit because it is compiled with
+// -fno-slp-vectorize: the SLP vectoriser packs the split's f32 subtractions into v_pk_add_f32, which costs ~26 issue cycles
+// beside MFMAs against 4 + 4 for two plain subtractions -- MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever beside MFMAs").
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+
+#include "device_utils.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace kjarni {
+
+namespace {
+
+constexpr int BM = 128, BN = 128;  // block tile (as gemm.hip's large-batch tiles)
+constexpr int EPI_STRIDE = 68;     // floats per staged output row (64 + 4), as gemm.hip
+
+// ---- fp32 products on the bf16 matrix cores (opt-in: kjarni_hip_set_f32_on_bf16 / KJARNI_HIP_F32_ON_BF16=1) -----------------
+// gfx950's bf16 MFMA rate is 16x its f32 MFMA rate (2.5 PFLOP/s against 157 TFLOP/s), and an f32 number is EXACTLY the sum of
+// three bf16 numbers (8 + 8 + 8 significand bits; bf16 has f32's exponent range): x = x1 + x2 + x3 with x1 = bf16(x),
+// x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), every subtraction exact in f32.  A product a b is then the nine cross products
+// a_i b_j, each exact in the MFMA's f32 accumulation; the three with i + j >= 5 are below 2^-24 of the product -- f32's own
+// rounding -- and are dropped: SIX bf16 MFMAs (32 x 32 x 16, 32 cycles each) do the work of eight f32 ones (32 x 32 x 2, 64 cycles
+// each), 2.67x the f32 matrix peak at the accuracy of f32 arithmetic (the dropped terms and the f32 accumulation are the only
+// roundings: |error| <= ~3 x 2^-24 per product, against 2^-24 for a chain of f32 FMAs; measured against the oracle in
+// tests/test_gpu_split.py).  The operands stay f32 in memory: a tile's rows are split on their way into LDS (4.5 vector
+// instructions per element, which issue in the gaps of the bf16 MFMAs -- unlike beside the f32 MFMAs), three bf16 planes per
+// operand, 80-byte rows (conflict-free 16-byte fragment reads).  Not the default: the reference computes in f32, and whether an
+// f32 result assembled from bf16 pieces counts as "the reference's precision" is the integrator's call; non-finite inputs
+// (inf - inf in the split) come out as NaN where the f32 path keeps an infinity.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int SP_BK = 16;                              // K per step: one 32 x 32 x 16 MFMA block
+// LDS rows are 16 bf16 = 32 bytes with NO padding; the two 16-byte halves of a row swap places in rows 8..15 of every 16
+// (half ^ ((row >> 3) & 1)).  A fragment read (16 lanes x 16 bytes: rows r .. r + 15, one logical half) then covers all 64
+// banks once, and so does a staging store (32 lanes x 8 bytes: 8 whole rows) -- with padded rows one of the two always
+// collides (48-byte rows: a third of the LDS cycles were bank conflicts).
+constexpr int SP_ST = 16;                              // bf16 per LDS row
+constexpr int SP_PLANE = 128 * SP_ST;                  // bf16 per piece plane of a 128-row tile
+constexpr int SP_STAGE = 2 * 3 * SP_PLANE;             // A and W, three planes each (bf16 elements)
+constexpr int SP_LDS_BYTES = 2 * SP_STAGE * 2;         // two stages: 49 152 bytes
+
+__device__ __forceinline__ uint32_t sp_pack(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v{a, b}, bf16x2));  // v_cvt_pk_bf16_f32, round to nearest even
+}
+__device__ __forceinline__ void sp_split(const f32x4 x, u32x2& p1, u32x2& p2, u32x2& p3)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        const uint32_t a = sp_pack(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, a << 16), r1 = x1 - __builtin_bit_cast(float, a & 0xffff0000u);
+        const uint32_t b = sp_pack(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, b << 16), s1 = r1 - __builtin_bit_cast(float, b & 0xffff0000u);
+        p1[i] = a;
+        p2[i] = b;
+        p3[i] = sp_pack(s0, s1);
+    }
+}
+
+// One K-step = 16 of K: 24 MFMAs per wave (2 x 2 tiles x 6 products).  Software pipeline inside the wave: while step k is
+// multiplied from LDS stage k & 1, the raw f32 rows of step k + 1 (in registers since the previous step) are split and stored to
+// the other stage, and the rows of step k + 2 are requested into the registers step k's rows left -- the split's vector
+// instructions issue in the gaps of the bf16 MFMAs (an MFMA holds the vector issue port 8 of its 32 cycles).  One barrier per step.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
+                                                            int64_t ldy, int64_t M, int N, int K, int n_tiles, int64_t total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t sp_smem[];  // [2 stages][A | W][3][128][SP_ST]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    // XCD-aware tile order, as gemm_nt_f32_mfma (one workgroup per tile)
+    const unsigned nwg = (unsigned)total_tiles, q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned wg = blockIdx.x, xcd = wg & 7u, slot = wg >> 3;
+    const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const unsigned m_tile = bid / (unsigned)n_tiles;
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = (int)(bid - m_tile * (unsigned)n_tiles) * BN;
+
+    // staging: 128 rows x 16 floats per operand = 512 sixteen-byte pieces, two per thread; buffer descriptors (rows past M: zeros)
+    const int ld_row = tid >> 2, ld_c4 = tid & 3;
+    const int64_t rows_a = (M - m0 < BM) ? (M - m0) : BM;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + m0 * lda), 0,
+                                                                           (int)(((rows_a - 1) * lda + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)n0 * K), 0,
+                                                                           (int)((int64_t)BN * K * 4), 0x00020000);
+    uint32_t offA[2], offW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = ld_row + 64 * i;
+        offA[i] = (uint32_t)((r * lda + ld_c4 * 4) * 4);
+        offW[i] = (uint32_t)((r * K + ld_c4 * 4) * 4);
+    }
+    constexpr int SETS = 4;    // register sets of raw rows: requests run SETS - 1 steps ahead of the split (memory latency >> one 768-cycle step)
+    f32x4 ga[SETS][2], gb[SETS][2];  // [register set][piece]
+    const int st_off = ld_row * SP_ST + (((ld_c4 >> 1) ^ ((ld_row >> 3) & 1)) * 2 + (ld_c4 & 1)) * 4;  // (bf16 elements; halves swapped in rows 8..15)
+    const int sw_half = half ^ ((l31 >> 3) & 1);
+    const int fa = (wr * 64 + l31) * SP_ST + sw_half * 8, fb = 3 * SP_PLANE + (wc * 64 + l31) * SP_ST + sw_half * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto load_set = [&](auto set, int k0) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ga[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[i], k0 * 4, 0));
+            gb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, offW[i], k0 * 4, 0));
+        }
+    };
+    auto split_store = [&](auto set, int stage) {
+        constexpr int S = decltype(set)::value;
+        uint16_t* base = sp_smem + stage * SP_STAGE + st_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 p1, p2, p3;
+            sp_split(ga[S][i], p1, p2, p3);
+            *reinterpret_cast<u32x2*>(base + 64 * i * SP_ST) = p1;
+            *reinterpret_cast<u32x2*>(base + SP_PLANE + 64 * i * SP_ST) = p2;
+            *reinterpret_cast<u32x2*>(base + 2 * SP_PLANE + 64 * i * SP_ST) = p3;
+            sp_split(gb[S][i], p1, p2, p3);
+            *reinterpret_cast<u32x2*>(base + 3 * SP_PLANE + 64 * i * SP_ST) = p1;
+            *reinterpret_cast<u32x2*>(base + 4 * SP_PLANE + 64 * i * SP_ST) = p2;
+            *reinterpret_cast<u32x2*>(base + 5 * SP_PLANE + 64 * i * SP_ST) = p3;
+        }
+    };
+    const int nk = K / SP_BK;
+    // step kt: MFMAs from stage kt & 1; set (kt + 1) % SETS (raw rows of step kt + 1) -> split -> stage (kt + 1) & 1;
+    // set kt % SETS (split during the previous step) <- the rows of step kt + SETS
+    auto step = [&](auto cur_set, int kt) {
+        constexpr int C = decltype(cur_set)::value;
+        using Next = std::integral_constant<int, (C + 1) % SETS>;
+        const uint16_t* st = sp_smem + (kt & 1) * SP_STAGE;
+        bf16x8 a[2][3], b[2][3];
+        // (in the order the products below need them: the first four MFMAs wait for four reads, not twelve)
+        constexpr int RA[3] = {2, 1, 0}, RB[3] = {0, 1, 2};
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t][RA[o]] = *reinterpret_cast<const bf16x8*>(st + RA[o] * SP_PLANE + fa + t * 32 * SP_ST);
+                b[t][RB[o]] = *reinterpret_cast<const bf16x8*>(st + RB[o] * SP_PLANE + fb + t * 32 * SP_ST);
+            }
+        // (unconditional: the last steps request and split rows nobody multiplies -- past K a row's bytes are the next row's or,
+        // past the descriptor, zeros -- so that the step stays one straight-line block the MFMAs can be interleaved with)
+        load_set(cur_set, (kt + SETS) * SP_BK);
+        split_store(Next{}, (kt + 1) & 1);
+        // the six products with i + j <= 4, the smallest first
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        // spread the split (vector ALU), its LDS stores and the requests over the MFMAs: ~3 vector instructions per MFMA gap
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+            if (g % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            if (g < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+        }
+        __syncthreads();
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+    load_set(S0{}, 0);
+    load_set(S1{}, SP_BK);
+    load_set(S2{}, 2 * SP_BK);
+    load_set(S3{}, 3 * SP_BK);
+    split_store(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 4) {   // (K % 64 == 0)
+        step(S0{}, kt);
+        step(S1{}, kt + 1);
+        step(S2{}, kt + 2);
+        step(S3{}, kt + 3);
+    }
+
+    // Epilogue through LDS, as gemm_nt_f32_mfma's: the accumulators of a 32-row tile go to a wave-private [32][68] region (the
+    // operand planes are free after the barrier), then 16 lanes own a row: 16-byte row-contiguous loads of the residual and
+    // stores (64 four-byte stores per lane straight from the accumulators made the store issue, not the MFMAs, the tile's time).
+    __syncthreads();
+    float* sw = reinterpret_cast<float*>(sp_smem) + wid * (32 * EPI_STRIDE);
+    static_assert(4 * 32 * EPI_STRIDE * 4 <= SP_LDS_BYTES, "four wave-private epilogue regions must fit the operand planes");  // 34 816 <= 49 152
+    const int e_row = lane >> 4, e_c4 = lane & 15;
+    const int n = n0 + wc * 64 + e_c4 * 4;
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sw[acc_row(r, half) * EPI_STRIDE + j * 32 + l31] = acc[i][j][r];
+        const int64_t m_base = m0 + wr * 64 + i * 32 + e_row;
+        f32x4 res[8];
+        if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_MUL_SILU) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int64_t m = m_base + it * 4;
+                m = m < M ? m : M - 1;
+                res[it] = *reinterpret_cast<const f32x4*>(R + m * ldr + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t m = m_base + it * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
+            v += bv;
+            if (EPI == EPI_BIAS_RESIDUAL) v += res[it];
+            if (EPI == EPI_BIAS_MUL_SILU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= silu_ref(res[it][c]);
+            }
+            if (EPI == EPI_BIAS_GELU) {
+                const f32x2 lo = gelu_erf_fast2(f32x2{v[0], v[1]}), hi = gelu_erf_fast2(f32x2{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
+            }
+            if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
+        }
+    }
+}
+
+std::atomic<int> g_f32_on_bf16{-1};  // -1: not decided yet (KJARNI_HIP_F32_ON_BF16 is read at the first launch)
+inline bool f32_on_bf16()
+{
+    int v = g_f32_on_bf16.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = std::getenv("KJARNI_HIP_F32_ON_BF16");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_f32_on_bf16.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
+template <int EPI>
+hipError_t launch_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                        int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
+{
+    static bool attr_set[64] = {};  // > 64 KiB of dynamic LDS needs the opt-in once per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_set[dev & 63]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_split<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    const int n_tiles = N / BN;
+    const int64_t total = ((M + BM - 1) / BM) * n_tiles;
+    if (total > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_nt_f32_split<EPI>), dim3((unsigned)total), dim3(256), SP_LDS_BYTES, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N,
+                       K, n_tiles, total);
+    return hipGetLastError();
+}
+
+
+}  // namespace
+
+void set_f32_on_bf16(bool on) { g_f32_on_bf16.store(on ? 1 : 0, std::memory_order_relaxed); }
+bool get_f32_on_bf16() { return f32_on_bf16(); }
+
+hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                             int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream)
+{
+    if (M <= 0) return hipSuccess;
+    if (N % BN != 0 || K % 64 != 0) return hipErrorInvalidValue;
+    switch (epi) {
+    case EPI_BIAS: return launch_split<EPI_BIAS>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_GELU: return launch_split<EPI_BIAS_GELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_GELU_NEW: return launch_split<EPI_BIAS_GELU_NEW>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_RELU: return launch_split<EPI_BIAS_RELU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_TANH: return launch_split<EPI_BIAS_TANH>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_RESIDUAL: return launch_split<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_MUL_SILU: return launch_split<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace kjarni

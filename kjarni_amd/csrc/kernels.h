@@ -76,6 +76,9 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
 // products on the bf16 matrix cores").  f32 in, f32 out, f32-level error; 2-3x the f32 MFMA rate.
 void set_f32_on_bf16(bool on);
 bool get_f32_on_bf16();
+// (gemm_split.hip; N % 128 == 0, K % 64 == 0; the residual / gate operand R as launch_gemm)
+hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                             int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream);
 
 // (the kernel A/B switches of the tuning build live in tuning.h)
 
