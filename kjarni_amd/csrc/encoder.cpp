@@ -657,11 +657,11 @@ void EncoderModel::forward_chunk(Workspace& ws, const uint32_t* ids, const uint3
     const double f_fc1 = 2.0 * Td * Hd * Id, b_fc1 = 4.0 * (Td * Hd + Hd * Id + Td * Id);
     const double f_fc2 = 2.0 * Td * Hd * Id, b_fc2 = 4.0 * (Td * Id + Hd * Id + 2 * Td * Hd);
     const double b_ln = 8.0 * Td * Hd;
-    // Up to gemm_few_rows_max() tokens the projections take the few-rows kernel (K split over the waves of a workgroup,
+    // Up to gemm_few_rows_max(H) tokens the projections take the few-rows kernel (K split over the waves of a workgroup,
     // gemm.hip) and LayerNorm stays its own small launch (after FC2: the reduce of its K slices); beyond that the residual
     // projections carry it in their epilogue.
     const GemmScratch sc{ws.split, ws.split_floats};
-    const int64_t few = gemm_few_rows_max();
+    const int64_t few = gemm_few_rows_max(H);
     const bool fused_ln = T > few && (fuse_layernorm() || (gemm_mid_layernorm_supported(T, H, H) && gemm_mid_layernorm_supported(T, H, I)));
 
     hipEvent_t pe = prof_start(KK_EMBED_LN, stream, 0.0, 4.0 * (2 * Td + 2 * Td * Hd));

@@ -1074,13 +1074,22 @@ __global__ __launch_bounds__(256) void mid_reduce_ln_kernel(const float* __restr
 }
 
 constexpr int64_t kFewRowsMax = 256, kMidMaxRows = 8192;
-inline int64_t few_rows_max() { return tune::few_rows_max_override() > 0 ? tune::few_rows_max_override() : kFewRowsMax; }
+// ... for models up to 512 wide; wider ones have more column tiles per row group and reach two workgroups per CU sooner: 128 rows
+// for <= 1 024 (a 768-wide model: 128 rows 0.529 against 0.626 ms on the 64 x 64 tiles, 192 rows even, 256 rows 0.681 against
+// 0.639; tools/few_rows_sweep_768.sh), 64 beyond.  The width is min(N, K): the same for all four projections of a layer (QKV,
+// out-proj and FC1 have K = hidden, FC2 has N = hidden), so a call takes one route throughout.
+inline int64_t few_rows_max(int N, int K)
+{
+    if (tune::few_rows_max_override() > 0) return tune::few_rows_max_override();
+    const int width = N < K ? N : K;
+    return width <= 512 ? kFewRowsMax : (width <= 1024 ? 128 : 64);
+}
 constexpr int kMidResident = 256 * 4;  // workgroups of gemm_nt_f32_mid the chip holds at once (36 KiB of LDS each)
 
 inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
                          const float* bias, const float* R, int64_t min_rows = -1)
 {
-    if (min_rows < 0) min_rows = few_rows_max() + 1;
+    if (min_rows < 0) min_rows = few_rows_max(N, K) + 1;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return M >= min_rows && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
            al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && !tune::no_mid_route();
@@ -1132,7 +1141,7 @@ inline bool aligned6(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t 
     (void)Y;
     (void)bias;
     (void)R;
-    return M <= few_rows_max() && N % 32 == 0 && K % 128 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+    return M <= few_rows_max(N, K) && N % 32 == 0 && K % 128 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
            (int64_t)32 * K * 4 < ((int64_t)1 << 31);
 }
@@ -1178,9 +1187,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
 // first row -- unsliced, the few-rows kernel has N / 32 = 12 workgroups there, and a workgroup's MFMAs run on one CU however
 // its K is dealt over the waves (13 us for one sentence, + 5 us of LayerNorm launch; four slices of the same kernel on
 // 48 CUs + the LayerNorm reduce: 10.5 us) -- otherwise from kFewRowsMax + 1.
-inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 : few_rows_max() + 1; }
+inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 : few_rows_max(N, K) + 1; }
 
-int64_t gemm_few_rows_max() { return few_rows_max(); }
+int64_t gemm_few_rows_max(int hidden) { return few_rows_max(hidden, hidden); }
 
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
 {
@@ -1214,7 +1223,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
             // up to 64 rows: the slices' partial tiles from the few-rows kernel (K over the sixteen waves of a workgroup: a
             // 3-step chain per wave instead of the tile kernel's 12-step one -- FC2 + LayerNorm of one sentence 15.5 -> 10.5 us)
             const int k_len = K / ksplit;
-            if (M <= few_rows_max() && ksplit > 1 && N % 32 == 0 && k_len % 128 == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
+            if (M <= few_rows_max(N, K) && ksplit > 1 && N % 32 == 0 && k_len % 128 == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
                 (int64_t)32 * K * 4 < ((int64_t)1 << 31) && !tune::no_few_rows_route() && !tune::no_few_rows_k_slices()) {
                 constexpr int LDS = 16 * 32 * 32 * 4;
                 const int z1 = ((int)M + 31) / 32;
@@ -1252,7 +1261,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
     }
     // a handful of rows and a short K: the few-rows projection + a LayerNorm launch (the 64-row tiles would be one workgroup
     // walking all of K alone: 38 us for out-proj at 28 rows against 11)
-    const bool few_rows_pair = M <= few_rows_max() && ldy == N && aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route();
+    const bool few_rows_pair = M <= few_rows_max(N, K) && ldy == N && aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route();
     if (few_rows_pair || !gemm_residual_layernorm_supported(N, K) || lda % 4 || ldr % 4 || ldy % 4 ||
         (int64_t)64 * lda * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31 ||
         !al16(A) || !al16(W) || !al16(bias) || !al16(R) || !al16(gamma) || !al16(beta) || !al16(Y)) {

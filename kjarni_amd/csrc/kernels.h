@@ -63,8 +63,8 @@ bool gemm_residual_layernorm_supported(int N, int K);
 // With a scratch slab of gemm_scratch_floats(rows, N) floats, calls of 257 .. 8192 rows (and up to 256 with a long K) also take any N <= 1024:
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K);
 // Calls of up to this many rows take the few-rows kernel (K over the waves of a workgroup; LayerNorm a launch of its own
-// unless the K-sliced route above applies).
-int64_t gemm_few_rows_max();
+// unless the K-sliced route above applies): 256 for models up to 512 wide, 128 up to 1 024, 64 beyond.
+int64_t gemm_few_rows_max(int hidden);
 size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n);
 hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
                                           const float* R, int64_t ldr, const float* gamma, const float* beta, float eps,

@@ -21,7 +21,10 @@ if os.environ.get("ATTN_VARIANT"):
     ops.set_attention_variant(int(os.environ["ATTN_VARIANT"]))
 with tempfile.TemporaryDirectory() as tmp:
     d = os.path.join(tmp, "m")
-    synth.minilm_embedder(d, seed=0)
+    if os.environ.get("MODEL") == "base":   # BERT-base shape (768 x 12 heads of 64, inner 3072), 6 layers
+        synth.minilm_embedder(d, seed=0, hidden_size=768, num_attention_heads=12, intermediate_size=3072)
+    else:
+        synth.minilm_embedder(d, seed=0)
     enc = kjarni_amd.HipEncoder(d, 0)
     ids, mask = synth.synthetic_ids(b, seq, seed=1)
     enc.embed(ids, mask)
