@@ -82,7 +82,7 @@ KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
 /* Opt-in, process-wide, default OFF (or environment KJARNI_HIP_F32_ON_BF16=1, read once at the first projection): the
- * large-batch projections (calls of more than 8 192 token rows) compute their f32 products on the bf16 matrix cores.  Every
+ * large-batch projections (calls of 6 144 token rows and more) compute their f32 products on the bf16 matrix cores.  Every
  * f32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits) on its way into LDS and six of the nine
  * cross products are accumulated in f32 -- the three dropped ones are below 2^-24 of a product, f32's own rounding --
  * so inputs, outputs and the error level are those of f32 arithmetic (measured against float64: the same 2-4e-6 as the f32

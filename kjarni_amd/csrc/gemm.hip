@@ -1078,6 +1078,10 @@ constexpr int64_t kFewRowsMax = 256, kMidMaxRows = 8192;
 // for <= 1 024 (a 768-wide model: 128 rows 0.529 against 0.626 ms on the 64 x 64 tiles, 192 rows even, 256 rows 0.681 against
 // 0.639; tools/few_rows_sweep_768.sh), 64 beyond.  The width is min(N, K): the same for all four projections of a layer (QKV,
 // out-proj and FC1 have K = hidden, FC2 has N = hidden), so a call takes one route throughout.
+// (8 192 rows: 1.94 -> 1.58 ms per call in the mode; 4 096 rows: 1.14 against 1.11 on the 64 x 64 f32 tiles; 2 048: 0.92 against
+// 0.69 -- tools/split_min_rows_sweep.sh)
+inline int64_t split_min_rows() { return tune::split_min_rows_override() > 0 ? tune::split_min_rows_override() : 6144; }
+
 inline int64_t few_rows_max(int N, int K)
 {
     if (tune::few_rows_max_override() > 0) return tune::few_rows_max_override();
@@ -1165,6 +1169,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
     const bool tiles_fill_chip = aligned && ((M + BM - 1) / BM) * (int64_t)(N / BN) >= 768;
     if (aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route() && !mid && !tiles_fill_chip)
         return launch_skinny<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream);
+    // f32-on-bf16 mode: from split_min_rows() the split kernel's 128 x 128 tiles also replace the 64 x 64-tile route
+    if (mid && aligned && get_f32_on_bf16() && K % 64 == 0 && M >= split_min_rows())
+        return launch_gemm_split(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, (GemmEpilogue)EPI, stream);
     // a few hundred to a few thousand rows (and a caller that lends a scratch slab): quarter-size tiles, K slices
     if (mid)
         return launch_mid<EPI>(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, stream, scratch);
@@ -1214,6 +1221,15 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
 {
     if (M <= 0) return hipSuccess;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // f32-on-bf16 mode, large calls with a long K (FC2): the split kernel with the residual epilogue + the LayerNorm kernel (the
+    // fused LayerNorm tile has no split form yet; at K = 384 -- out-proj -- the fused f32 tile is the faster of the two: 0.62
+    // against 0.60 + 0.17 ms)
+    if (R && gamma && beta && get_f32_on_bf16() && M >= split_min_rows() && N % BN == 0 && K % 64 == 0 && K >= 1024 && gemm_residual_layernorm_supported(N, K) && ldy == N && lda % 4 == 0 && al16(A) && al16(W) &&
+        (int64_t)BM * lda * 4 < ((int64_t)1 << 31) && (int64_t)BN * K * 4 < ((int64_t)1 << 31)) {
+        const hipError_t e = launch_gemm_split(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, EPI_BIAS_RESIDUAL, stream);
+        if (e != hipSuccess) return e;
+        return launch_layernorm(Y, gamma, beta, eps, M, N, Y, stream);
+    }
     if (scratch.p && R && gamma && beta && N <= 1024 && al16(gamma) && al16(beta) &&
         mid_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R, mid_ln_min_rows(N, K))) {
         const int ksplit = mid_ksplit(N, K);
@@ -1250,15 +1266,6 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         }
     }
     if (!R || !gamma || !beta) return hipErrorInvalidValue;
-    // f32-on-bf16 mode, large calls with a long K (FC2): the split kernel with the residual epilogue + the LayerNorm kernel (the
-    // fused LayerNorm tile has no split form yet; at K = 384 -- out-proj -- the fused f32 tile is the faster of the two: 0.62
-    // against 0.60 + 0.17 ms)
-    if (get_f32_on_bf16() && M > kMidMaxRows && N % BN == 0 && K % 64 == 0 && K >= 1024 && gemm_residual_layernorm_supported(N, K) && ldy == N && lda % 4 == 0 && al16(A) && al16(W) &&
-        (int64_t)BM * lda * 4 < ((int64_t)1 << 31) && (int64_t)BN * K * 4 < ((int64_t)1 << 31)) {
-        const hipError_t e = launch_gemm_split(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, EPI_BIAS_RESIDUAL, stream);
-        if (e != hipSuccess) return e;
-        return launch_layernorm(Y, gamma, beta, eps, M, N, Y, stream);
-    }
     // a handful of rows and a short K: the few-rows projection + a LayerNorm launch (the 64-row tiles would be one workgroup
     // walking all of K alone: 38 us for out-proj at 28 rows against 11)
     const bool few_rows_pair = M <= few_rows_max(N, K) && ldy == N && aligned6(M, N, K, lda, ldy, ldr, A, W, Y, bias, R) && !tune::no_few_rows_route();

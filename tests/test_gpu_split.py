@@ -21,7 +21,9 @@ def split_mode():
 
 
 @pytest.mark.parametrize("m,k,n", [(8193, 384, 1152), (8300, 1536, 384), (16384, 384, 1536), (9000, 768, 768), (8200, 3072, 768),
-                                   (8193, 64, 128)])
+                                   (8193, 64, 128),
+                                   # 6 144 .. 8 192 rows: in the mode the split kernel also replaces the 64 x 64-tile route
+                                   (6144, 384, 1152), (7001, 1536, 384)])
 def test_projections_all_epilogues(split_mode, m, k, n):
     """Every epilogue of the split kernel against the oracle at 1e-5 (rows past the last full 128-row tile included), on sampled
     rows; and against float64: the error stays at the f32 kernels' level."""
@@ -63,7 +65,11 @@ def test_split_is_exact_on_bf16_representable_operands(split_mode):
 def test_residual_layernorm_route(split_mode):
     from kjarni_amd import ops
     rng = np.random.default_rng(11)
-    m, k, n = 8400, 1536, 384
+    for m, k, n in ((8400, 1536, 384), (6500, 1536, 384)):
+        _residual_layernorm_case(ops, rng, m, k, n)
+
+
+def _residual_layernorm_case(ops, rng, m, k, n):
     x = rng.standard_normal((m, k)).astype(np.float32)
     w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
     b = rng.standard_normal(n).astype(np.float32)
