@@ -97,8 +97,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
         offA[i] = (uint32_t)((r * lda + ld_c4 * 4) * 4);
         offW[i] = (uint32_t)((r * K + ld_c4 * 4) * 4);
     }
-    constexpr int SETS = 4;    // register sets of raw rows: requests run SETS - 1 steps ahead of the split (memory latency >> one 768-cycle step)
-    f32x4 ga[SETS][2], gb[SETS][2];  // [register set][piece]
+    // Raw rows are requested a GROUP (two K-steps = 32 floats = one 128-byte line per row) at a time, the two 64-byte halves of
+    // every line by two back-to-back instructions; two register sets of a group each.  (Measured the same as one half-line per
+    // row and step with the requests three steps ahead, 1.53 ms for the QKV launch either way -- like every other change to the
+    // staging: under this load the chip is at its power limit (1.5 GHz), and only moving fewer bytes per product buys time.)
+    f32x4 ga[2][2][2], gb[2][2][2];  // [group set][row pass][half line]
     const int st_off = ld_row * SP_ST + (((ld_c4 >> 1) ^ ((ld_row >> 3) & 1)) * 2 + (ld_c4 & 1)) * 4;  // (bf16 elements; halves swapped in rows 8..15)
     const int sw_half = half ^ ((l31 >> 3) & 1);
     const int fa = (wr * 64 + l31) * SP_ST + sw_half * 8, fb = 3 * SP_PLANE + (wc * 64 + l31) * SP_ST + sw_half * 8;
@@ -111,36 +114,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    auto load_set = [&](auto set, int k0) {
+    auto load_group = [&](auto set, int k0) {   // k0 = the group's first k (a multiple of 32)
         constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ga[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[i], k0 * 4, 0));
-            gb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, offW[i], k0 * 4, 0));
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ga[S][i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[i], (k0 + 16 * h) * 4, 0));
+                gb[S][i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, offW[i], (k0 + 16 * h) * 4, 0));
+            }
     };
-    auto split_store = [&](auto set, int stage) {
-        constexpr int S = decltype(set)::value;
+    auto split_store = [&](auto set, auto hline, int stage) {
+        constexpr int S = decltype(set)::value, HL = decltype(hline)::value;
         uint16_t* base = sp_smem + stage * SP_STAGE + st_off;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             u32x2 p1, p2, p3;
-            sp_split(ga[S][i], p1, p2, p3);
+            sp_split(ga[S][i][HL], p1, p2, p3);
             *reinterpret_cast<u32x2*>(base + 64 * i * SP_ST) = p1;
             *reinterpret_cast<u32x2*>(base + SP_PLANE + 64 * i * SP_ST) = p2;
             *reinterpret_cast<u32x2*>(base + 2 * SP_PLANE + 64 * i * SP_ST) = p3;
-            sp_split(gb[S][i], p1, p2, p3);
+            sp_split(gb[S][i][HL], p1, p2, p3);
             *reinterpret_cast<u32x2*>(base + 3 * SP_PLANE + 64 * i * SP_ST) = p1;
             *reinterpret_cast<u32x2*>(base + 4 * SP_PLANE + 64 * i * SP_ST) = p2;
             *reinterpret_cast<u32x2*>(base + 5 * SP_PLANE + 64 * i * SP_ST) = p3;
         }
     };
     const int nk = K / SP_BK;
-    // step kt: MFMAs from stage kt & 1; set (kt + 1) % SETS (raw rows of step kt + 1) -> split -> stage (kt + 1) & 1;
-    // set kt % SETS (split during the previous step) <- the rows of step kt + SETS
-    auto step = [&](auto cur_set, int kt) {
-        constexpr int C = decltype(cur_set)::value;
-        using Next = std::integral_constant<int, (C + 1) % SETS>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // step kt: MFMAs from stage kt & 1, while the rows of step kt + 1 -- half (kt + 1) & 1 of group (kt + 1) / 2 -- are split into
+    // stage (kt + 1) & 1; on odd steps the set whose second half was split during the previous step receives group kt / 2 + 2.
+    auto step = [&](auto split_set, auto split_half, auto load, auto load_set, int kt) {
         const uint16_t* st = sp_smem + (kt & 1) * SP_STAGE;
         bf16x8 a[2][3], b[2][3];
         // (in the order the products below need them: the first four MFMAs wait for four reads, not twelve)
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
             }
         // (unconditional: the last steps request and split rows nobody multiplies -- past K a row's bytes are the next row's or,
         // past the descriptor, zeros -- so that the step stays one straight-line block the MFMAs can be interleaved with)
-        load_set(cur_set, (kt + SETS) * SP_BK);
-        split_store(Next{}, (kt + 1) & 1);
+        if (decltype(load)::value) load_group(load_set, (kt / 2 + 2) * 32);
+        split_store(split_set, split_half, (kt + 1) & 1);
         // the six products with i + j <= 4, the smallest first
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -171,25 +176,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
             if (g % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-            if (g < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+            if (g < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
         }
         __syncthreads();
     };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    using S3 = std::integral_constant<int, 3>;
-    load_set(S0{}, 0);
-    load_set(S1{}, SP_BK);
-    load_set(S2{}, 2 * SP_BK);
-    load_set(S3{}, 3 * SP_BK);
-    split_store(S0{}, 0);
+    load_group(I0{}, 0);
+    load_group(I1{}, 32);
+    split_store(I0{}, I0{}, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 4) {   // (K % 64 == 0)
-        step(S0{}, kt);
-        step(S1{}, kt + 1);
-        step(S2{}, kt + 2);
-        step(S3{}, kt + 3);
+        step(I0{}, I1{}, I0{}, I0{}, kt);       // split group 2j half 1;   no request
+        step(I1{}, I0{}, I1{}, I0{}, kt + 1);   // split group 2j+1 half 0; set 0 <- group 2j+2
+        step(I1{}, I1{}, I0{}, I0{}, kt + 2);   // split group 2j+1 half 1
+        step(I0{}, I0{}, I1{}, I1{}, kt + 3);   // split group 2j+2 half 0; set 1 <- group 2j+3
     }
 
     // Epilogue through LDS, as gemm_nt_f32_mfma's: the accumulators of a 32-row tile go to a wave-private [32][68] region (the
