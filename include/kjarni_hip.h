@@ -202,6 +202,12 @@ typedef enum KjarniHipEpilogue {
 KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* x, const float* w, const float* bias,
                                      const float* residual, int64_t m, int32_t k, int32_t n,
                                      KjarniHipEpilogue epilogue, float* y, int32_t iters, float* ms_out);
+/* The same with bf16 weights (w: n x k bf16 values, row-major): the decoder's prompt projections on the bf16 matrix cores --
+ * every activation split exactly into three bf16 pieces, the weights taken as they are, f32 accumulation: the products of an
+ * f32 GEMM on the widened weights.  n % 128 == 0, k % 64 == 0; epilogues BIAS, BIAS_RESIDUAL, BIAS_MUL_SILU. */
+KjarniErrorCode kjarni_hip_op_linear_bf16_weights(int32_t device, const float* x, const uint16_t* w_bf16, const float* bias,
+                                                  const float* residual, int64_t m, int32_t k, int32_t n,
+                                                  KjarniHipEpilogue epilogue, float* y, int32_t iters, float* ms_out);
 /* qkv: [batch*seq, 3*heads*head_dim] (Q | K | V); mask: u32 [batch, seq] or NULL; ctx: [batch*seq, heads*head_dim]. */
 KjarniErrorCode kjarni_hip_op_attention(int32_t device, const float* qkv, const uint32_t* mask, int64_t batch,
                                         int32_t seq, int32_t heads, int32_t head_dim, float mask_value,

@@ -435,6 +435,8 @@ SIGNATURES = {
                                                  _f32p]),
     "kjarni_hip_op_linear": (c_int32, [c_int32, _f32p, _f32p, _f32p, _f32p, c_int64, c_int32, c_int32, c_int32,
                                        _f32p, c_int32, _f32p]),
+    "kjarni_hip_op_linear_bf16_weights": (c_int32, [c_int32, _f32p, c_void_p, _f32p, _f32p, c_int64, c_int32, c_int32, c_int32,
+                                                    _f32p, c_int32, _f32p]),
     "kjarni_hip_op_attention": (c_int32, [c_int32, _f32p, _u32p, c_int64, c_int32, c_int32, c_int32, c_float,
                                           _f32p, c_int32, _f32p]),
     "kjarni_hip_op_layer_norm": (c_int32, [c_int32, _f32p, _f32p, _f32p, c_float, c_int64, c_int32, _f32p,

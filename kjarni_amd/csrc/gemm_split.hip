@@ -34,6 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SP_BK = 16;                              // K per step: one 32 x 32 x 16 MFMA block
 // LDS rows are 16 bf16 = 32 bytes with NO padding; the two 16-byte halves of a row swap places in rows 8..15 of every 16
 // (half ^ ((row >> 3) & 1)).  A fragment read (16 lanes x 16 bytes: rows r .. r + 15, one logical half) then covers all 64
@@ -43,6 +44,7 @@ constexpr int SP_ST = 16;                              // bf16 per LDS row
 constexpr int SP_PLANE = 128 * SP_ST;                  // bf16 per piece plane of a 128-row tile
 constexpr int SP_STAGE = 2 * 3 * SP_PLANE;             // A and W, three planes each (bf16 elements)
 constexpr int SP_LDS_BYTES = 2 * SP_STAGE * 2;         // two stages: 49 152 bytes
+static_assert(4 * 32 * EPI_STRIDE * 4 <= SP_LDS_BYTES, "four wave-private epilogue regions must fit the operand planes");
 
 __device__ __forceinline__ uint32_t sp_pack(float a, float b)
 {
@@ -60,6 +62,57 @@ __device__ __forceinline__ void sp_split(const f32x4 x, u32x2& p1, u32x2& p2, u3
         p1[i] = a;
         p2[i] = b;
         p3[i] = sp_pack(s0, s1);
+    }
+}
+
+// Epilogue through LDS, as gemm_nt_f32_mfma's: the accumulators of a 32-row tile go to a wave-private [32][68] region (the
+// operand planes are free after the barrier), then 16 lanes own a row: 16-byte row-contiguous loads of the residual and
+// stores (64 four-byte stores per lane straight from the accumulators made the store issue, not the MFMAs, the tile's time).
+template <int EPI>
+__device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][2], float* lds, const float* __restrict__ bias, const float* R, int64_t ldr,
+                                            float* Y, int64_t ldy, int64_t M, int64_t m0, int n0, int wid, int wr, int wc, int lane, int l31,
+                                            int half)
+{
+    __syncthreads();
+    float* sw = lds + wid * (32 * EPI_STRIDE);
+    const int e_row = lane >> 4, e_c4 = lane & 15;
+    const int n = n0 + wc * 64 + e_c4 * 4;
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sw[acc_row(r, half) * EPI_STRIDE + j * 32 + l31] = acc[i][j][r];
+        const int64_t m_base = m0 + wr * 64 + i * 32 + e_row;
+        f32x4 res[8];
+        if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_MUL_SILU) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int64_t m = m_base + it * 4;
+                m = m < M ? m : M - 1;
+                res[it] = *reinterpret_cast<const f32x4*>(R + m * ldr + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t m = m_base + it * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
+            v += bv;
+            if (EPI == EPI_BIAS_RESIDUAL) v += res[it];
+            if (EPI == EPI_BIAS_MUL_SILU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= silu_ref(res[it][c]);
+            }
+            if (EPI == EPI_BIAS_GELU) {
+                const f32x2 lo = gelu_erf_fast2(f32x2{v[0], v[1]}), hi = gelu_erf_fast2(f32x2{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
+            }
+            if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
+        }
     }
 }
 
@@ -191,51 +244,151 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
         step(I0{}, I0{}, I1{}, I1{}, kt + 3);   // split group 2j+2 half 0; set 1 <- group 2j+3
     }
 
-    // Epilogue through LDS, as gemm_nt_f32_mfma's: the accumulators of a 32-row tile go to a wave-private [32][68] region (the
-    // operand planes are free after the barrier), then 16 lanes own a row: 16-byte row-contiguous loads of the residual and
-    // stores (64 four-byte stores per lane straight from the accumulators made the store issue, not the MFMAs, the tile's time).
-    __syncthreads();
-    float* sw = reinterpret_cast<float*>(sp_smem) + wid * (32 * EPI_STRIDE);
-    static_assert(4 * 32 * EPI_STRIDE * 4 <= SP_LDS_BYTES, "four wave-private epilogue regions must fit the operand planes");  // 34 816 <= 49 152
-    const int e_row = lane >> 4, e_c4 = lane & 15;
-    const int n = n0 + wc * 64 + e_c4 * 4;
-    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sp_epilogue<EPI>(acc, reinterpret_cast<float*>(sp_smem), bias, R, ldr, Y, ldy, M, m0, n0, wid, wr, wc, lane, l31, half);
+}
+
+// ---- f32 activations x bf16 weights (the decoder's prompt projections; always on for bf16 checkpoints) ---------------------------
+// The weights ARE bf16, so only the activations need pieces: a w = a1 w + a2 w + a3 w, every term exact in the MFMA's f32
+// accumulation and none dropped -- the same products as widening w to f32 and multiplying in f32, in another order of summation.
+// Three bf16 MFMAs (32 cycles) per 32 x 32 x 16 block instead of eight f32 ones (64 cycles), and no f32 copy of the weights.
+// K-step = 32: A as three planes + W as one, 64-byte rows whose four 16-byte chunks are XOR-swizzled with (row >> 2) & 3
+// (fragment reads of 16 rows x one chunk, and staging stores of 4 rows x 64 bytes, both cover all 64 banks once); two LDS stages
+// of 32 KiB, two workgroups per CU; pipeline as gemm_nt_f32_split.
+constexpr int BW_ST = 32;                       // bf16 per LDS row
+constexpr int BW_PLANE = 128 * BW_ST;           // bf16 per plane of a 128-row tile
+constexpr int BW_STAGE = 4 * BW_PLANE;          // A1 | A2 | A3 | W
+constexpr int BW_LDS_BYTES = 2 * BW_STAGE * 2;  // 65 536
+static_assert(4 * 32 * EPI_STRIDE * 4 <= BW_LDS_BYTES, "four wave-private epilogue regions must fit the operand planes");
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_bf16w(const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ W,
+                                                            const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
+                                                            int64_t ldy, int64_t M, int N, int K, int n_tiles, int64_t total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t sp_smem[];  // [2 stages][A1 | A2 | A3 | W][128][BW_ST]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    const unsigned nwg = (unsigned)total_tiles, q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned wg = blockIdx.x, xcd = wg & 7u, slot = wg >> 3;
+    const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const unsigned m_tile = bid / (unsigned)n_tiles;
+    const int64_t m0 = (int64_t)m_tile * BM;
+    const int n0 = (int)(bid - m_tile * (unsigned)n_tiles) * BN;
+
+    // staging per step: A 128 rows x 32 floats = 1 024 sixteen-byte pieces (four per thread: row = tid / 8 + 32 i, floats 4 (tid % 8) ..);
+    // W 128 rows x 32 bf16 = 512 pieces (two per thread: row = tid / 4 + 64 i, bf16 8 (tid % 4) ..)
+    const int a_row = tid >> 3, a_c4 = tid & 7, w_row = tid >> 2, w_c = tid & 3;
+    const int64_t rows_a = (M - m0 < BM) ? (M - m0) : BM;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + m0 * lda), 0,
+                                                                           (int)(((rows_a - 1) * lda + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(W + (int64_t)n0 * K), 0,
+                                                                           (int)((int64_t)BN * K * 2), 0x00020000);
+    uint32_t offA[4], offW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offA[i] = (uint32_t)((((int64_t)a_row + 32 * i) * lda + a_c4 * 4) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offW[i] = (uint32_t)((((int64_t)w_row + 64 * i) * K + w_c * 8) * 2);
+    f32x4 ga[2][4];
+    u32x4 gw[2][2];
+    // LDS offsets (bf16 elements); chunk c of a row sits at chunk c ^ ((row >> 2) & 3)
+    int stA[4], stW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = a_row + 32 * i;
+        stA[i] = row * BW_ST + (((a_c4 >> 1) ^ ((row >> 2) & 3)) * 2 + (a_c4 & 1)) * 4;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        const int row = w_row + 64 * i;
+        stW[i] = 3 * BW_PLANE + row * BW_ST + (w_c ^ ((row >> 2) & 3)) * 8;
+    }
+    const int fsw = (l31 >> 2) & 3;
+    const int fa = (wr * 64 + l31) * BW_ST, fb = 3 * BW_PLANE + (wc * 64 + l31) * BW_ST;  // (+ 32 rows for the second tile: same swizzle)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sw[acc_row(r, half) * EPI_STRIDE + j * 32 + l31] = acc[i][j][r];
-        const int64_t m_base = m0 + wr * 64 + i * 32 + e_row;
-        f32x4 res[8];
-        if (EPI == EPI_BIAS_RESIDUAL || EPI == EPI_BIAS_MUL_SILU) {
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto load_set = [&](auto set, int k0) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                int64_t m = m_base + it * 4;
-                m = m < M ? m : M - 1;
-                res[it] = *reinterpret_cast<const f32x4*>(R + m * ldr + n);
-            }
+        for (int i = 0; i < 4; ++i) ga[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, offA[i], k0 * 4, 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gw[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, offW[i], k0 * 2, 0));
+    };
+    auto split_store = [&](auto set, int stage) {
+        constexpr int S = decltype(set)::value;
+        uint16_t* base = sp_smem + stage * BW_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 p1, p2, p3;
+            sp_split(ga[S][i], p1, p2, p3);
+            *reinterpret_cast<u32x2*>(base + stA[i]) = p1;
+            *reinterpret_cast<u32x2*>(base + BW_PLANE + stA[i]) = p2;
+            *reinterpret_cast<u32x2*>(base + 2 * BW_PLANE + stA[i]) = p3;
         }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int64_t m = m_base + it * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
-            v += bv;
-            if (EPI == EPI_BIAS_RESIDUAL) v += res[it];
-            if (EPI == EPI_BIAS_MUL_SILU) {
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(base + stW[i]) = gw[S][i];
+    };
+    const int nk = K / 32;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // step kt: MFMAs from stage kt & 1; set (kt + 1) & 1 -> split -> stage (kt + 1) & 1; set kt & 1 <- the rows of step kt + 2
+    auto step = [&](auto cur_set, auto next_set, int kt) {
+        const uint16_t* st = sp_smem + (kt & 1) * BW_STAGE;
+        load_set(cur_set, (kt + 2) * 32);          // (unconditional, as gemm_nt_f32_split: the step stays one straight-line block)
+        split_store(next_set, (kt + 1) & 1);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] *= silu_ref(res[it][c]);
-            }
-            if (EPI == EPI_BIAS_GELU) {
-                const f32x2 lo = gelu_erf_fast2(f32x2{v[0], v[1]}), hi = gelu_erf_fast2(f32x2{v[2], v[3]});
-                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
-            } else {
+        for (int kb = 0; kb < 2; ++kb) {
+            const int ch = ((kb * 2 + half) ^ fsw) * 8;
+            bf16x8 a[2][3], b[2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
+            for (int t = 0; t < 2; ++t) {
+                b[t] = *reinterpret_cast<const bf16x8*>(st + fb + t * 32 * BW_ST + ch);
+#pragma unroll
+                for (int p = 2; p >= 0; --p) a[t][p] = *reinterpret_cast<const bf16x8*>(st + p * BW_PLANE + fa + t * 32 * BW_ST + ch);
             }
-            if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
+#pragma unroll
+            for (int p = 2; p >= 0; --p)   // the smallest piece first
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][p], b[j], acc[i][j], 0, 0, 0);
         }
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+            if (g % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+            if (g < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+        }
+        __syncthreads();
+    };
+    load_set(S0{}, 0);
+    load_set(S1{}, 32);
+    split_store(S0{}, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {   // (K % 64 == 0)
+        step(S0{}, S1{}, kt);
+        step(S1{}, S0{}, kt + 1);
     }
+    sp_epilogue<EPI>(acc, reinterpret_cast<float*>(sp_smem), bias, R, ldr, Y, ldy, M, m0, n0, wid, wr, wc, lane, l31, half);
+}
+
+template <int EPI>
+hipError_t launch_bf16w(const float* A, int64_t lda, const uint16_t* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                        int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
+{
+    const int n_tiles = N / BN;
+    const int64_t total = ((M + BM - 1) / BM) * n_tiles;
+    if (total > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_nt_f32_bf16w<EPI>), dim3((unsigned)total), dim3(256), BW_LDS_BYTES, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N,
+                       K, n_tiles, total);
+    return hipGetLastError();
 }
 
 std::atomic<int> g_f32_on_bf16{-1};  // -1: not decided yet (KJARNI_HIP_F32_ON_BF16 is read at the first launch)
@@ -292,6 +445,23 @@ hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const 
     case EPI_BIAS_MUL_SILU: return launch_split<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_bf16_weights(const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R, int64_t ldr,
+                                    float* Y, int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream)
+{
+    if (M <= 0) return hipSuccess;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (N % BN != 0 || K % 64 != 0 || lda % 4 || ldy % 4 || (R && ldr % 4) || !al16(A) || !al16(W_bf16) || !al16(Y) || !al16(bias) || !al16(R) ||
+        (int64_t)BM * lda * 4 >= ((int64_t)1 << 31) || (int64_t)BN * K * 2 >= ((int64_t)1 << 31))
+        return hipErrorInvalidValue;
+    const uint16_t* W = static_cast<const uint16_t*>(W_bf16);
+    switch (epi) {
+    case EPI_BIAS: return launch_bf16w<EPI_BIAS>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_RESIDUAL: return launch_bf16w<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    case EPI_BIAS_MUL_SILU: return launch_bf16w<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace kjarni

@@ -407,6 +407,34 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* 
     });
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear_bf16_weights(int32_t device, const float* x, const uint16_t* w_bf16,
+                                                                const float* bias, const float* residual, int64_t m, int32_t k,
+                                                                int32_t n, KjarniHipEpilogue epilogue, float* y, int32_t iters,
+                                                                float* ms_out)
+{
+    if (!x || !w_bf16 || !y) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (m < 0 || k <= 0 || n <= 0 || n % 128 != 0 || k % 64 != 0) throw InvalidConfig("invalid GEMM dimensions (n % 128, k % 64)");
+        if ((epilogue == KJARNI_HIP_EPI_BIAS_RESIDUAL || epilogue == KJARNI_HIP_EPI_BIAS_MUL_SILU) && !residual)
+            throw InvalidConfig("residual epilogue without residual");
+        use_device(device);
+        if (m == 0) return;
+        const size_t xb = (size_t)m * k * 4, wb = (size_t)n * k * 2, yb = (size_t)m * n * 4;
+        DeviceBuf xd(xb), wd(wb), bd((size_t)n * 4), rd(residual ? yb : 4), yd(yb);
+        hip_check(hipMemcpy(xd.p, x, xb, hipMemcpyHostToDevice), "H2D x");
+        hip_check(hipMemcpy(wd.p, w_bf16, wb, hipMemcpyHostToDevice), "H2D w");
+        if (bias) hip_check(hipMemcpy(bd.p, bias, (size_t)n * 4, hipMemcpyHostToDevice), "H2D bias");
+        if (residual) hip_check(hipMemcpy(rd.p, residual, yb, hipMemcpyHostToDevice), "H2D residual");
+        time_launches(iters, ms_out, [&] {
+            hip_check(launch_gemm_bf16_weights((const float*)xd.p, k, wd.p, bias ? (const float*)bd.p : nullptr,
+                                               residual ? (const float*)rd.p : nullptr, n, (float*)yd.p, n, m, n, k,
+                                               (GemmEpilogue)epilogue, nullptr),
+                      "gemm (bf16 weights)");
+        });
+        hip_check(hipMemcpy(y, yd.p, yb, hipMemcpyDeviceToHost), "D2H y");
+    });
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_attention(int32_t device, const float* qkv, const uint32_t* mask,
                                                       int64_t batch, int32_t seq, int32_t heads, int32_t head_dim,
                                                       float mask_value, float* ctx, int32_t iters, float* ms_out)

@@ -80,6 +80,12 @@ bool get_f32_on_bf16();
 hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
                              int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream);
 
+// f32 activations x bf16 weights [N, K] on the bf16 matrix cores: every activation split exactly into three bf16 pieces, the
+// weights taken as they are -- the same products as an f32 GEMM on widened weights (gemm_split.hip).  N % 128 == 0, K % 64 == 0,
+// 16-byte aligned rows; epilogues EPI_BIAS, EPI_BIAS_RESIDUAL (R may alias Y), EPI_BIAS_MUL_SILU (R = the gate, may alias Y).
+hipError_t launch_gemm_bf16_weights(const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R, int64_t ldr,
+                                    float* Y, int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream);
+
 // (the kernel A/B switches of the tuning build live in tuning.h)
 
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.

@@ -351,9 +351,14 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
         auto proj = [&](const float* Ain, int lda, const void* W, const float* bias, const float* R, float* Y, int ldy, int N, int K,
                         float* gate, const char* what) {
 #ifdef KJARNI_TUNING
-            static const int min_tiles = [] { const char* v = std::getenv("KJARNI_HIP_LLM_MIN_TILES"); return v ? std::atoi(v) : 208; }();
+            static const int min_tiles_env = [] { const char* v = std::getenv("KJARNI_HIP_LLM_MIN_TILES"); return v ? std::atoi(v) : 0; }();
+            const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (bf16_ ? 96 : 208);
 #else
-            constexpr int min_tiles = 208;  // measured on the 1B shape: 192 tiles (1 536 rows x 2 048 columns) are faster on the 64 x 64 kernel, 224 on the tiles
+            // measured on the 1B shape, f32 weights: 192 tiles (1 536 rows x 2 048 columns) are faster on the 64 x 64 kernel, 224 on the
+            // tiles; bf16 weights (the bf16-matrix-core tiles, half the time per tile): 96 tiles (768 rows x 2 048 columns) are
+            // faster on the tiles, 64 (512 rows) on the 64 x 64 kernel -- prompts of 768 / 1 024 / 1 536 tokens 11.3 / 14.5 / 22.0 ->
+            // 10.2 / 11.6 / 15.5 ms
+            const int min_tiles = bf16_ ? 96 : 208;
 #endif
             const bool tiles = tile_shapes && m >= kTileRows && (int64_t)((m + 127) / 128) * (N / 128) >= min_tiles;
             if (!tiles) {
@@ -361,6 +366,20 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
                 return;
             }
             ++tile_gemm_calls_;
+            // bf16 weights: the bf16 matrix cores take them as they are, the f32 activations as three exact bf16 pieces (the same
+            // products as the f32 GEMM on a widened copy: gemm_split.hip) -- 2 048-token prompt 33.8 -> 18.1 ms, no 100 MB copy
+#ifdef KJARNI_TUNING
+            static const bool widen = [] { const char* v = std::getenv("KJARNI_HIP_LLM_WIDEN"); return v && v[0] == '1'; }();
+#else
+            constexpr bool widen = false;
+#endif
+            if (bf16_ && !widen && K % 64 == 0) {
+                if (gate)
+                    hip_check(launch_gemm_bf16_weights(Ain, lda, W, bias, gate, ldy, gate, ldy, m, N, K, EPI_BIAS_MUL_SILU, s), what);
+                else
+                    hip_check(launch_gemm_bf16_weights(Ain, lda, W, bias, R, ldy, Y, ldy, m, N, K, R ? EPI_BIAS_RESIDUAL : EPI_BIAS, s), what);
+                return;
+            }
             const float* W32 = static_cast<const float*>(W);
             if (bf16_) {
                 hip_check(launch_widen_bf16(W, pw32_, (size_t)N * K, s), "widen");

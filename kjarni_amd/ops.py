@@ -34,6 +34,30 @@ def linear(x, w, bias=None, residual=None, epilogue: int = EPI_BIAS, iters: int 
     return y, (float(ms.value) if iters > 0 else None)
 
 
+def to_bf16(w: np.ndarray) -> np.ndarray:
+    """f32 -> bf16 bit patterns (uint16), round to nearest even (finite inputs)."""
+    u = np.ascontiguousarray(w, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(w16: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(w16, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def linear_bf16_weights(x, w_bf16, bias=None, residual=None, epilogue: int = EPI_BIAS, iters: int = 0, device: int = 0
+                        ) -> Tuple[np.ndarray, Optional[float]]:
+    """y = epilogue(x . w^T + bias (+ residual)) with w given as bf16 bit patterns [n, k] (kjarni_hip_op_linear_bf16_weights)."""
+    x, bias, residual = _c(x), _c(bias), _c(residual)
+    w16 = np.ascontiguousarray(w_bf16, np.uint16)
+    m, k = x.shape
+    n = w16.shape[0]
+    y = np.empty((m, n), np.float32)
+    ms = C.c_float(0)
+    check_error(lib().kjarni_hip_op_linear_bf16_weights(device, _f(x), w16.ctypes.data_as(C.c_void_p), _f(bias), _f(residual), m, k, n,
+                                                        epilogue, _f(y), iters, C.byref(ms)))
+    return y, (float(ms.value) if iters > 0 else None)
+
+
 def attention(qkv, mask, heads: int, mask_value: float = -1e9, iters: int = 0, device: int = 0
               ) -> Tuple[np.ndarray, Optional[float]]:
     qkv = _c(qkv)

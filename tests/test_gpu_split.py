@@ -101,3 +101,32 @@ def test_forward_equals_default_path_and_oracle(tmp_path):
     sel = [0, 1, 50, 99]
     assert float(np.abs(got[sel] - orc.embed_batch(ids[sel], mask[sel])).max()) < 1e-4
     enc.close()
+
+
+@pytest.mark.parametrize("m,k,n", [(2048, 2048, 2048), (513, 2048, 512), (700, 8192, 2048), (128, 64, 128), (1000, 4096, 1024)])
+def test_bf16_weight_projections(m, k, n):
+    """The decoder's prompt projections: f32 activations (three exact bf16 pieces) x bf16 weights (as they are) on the bf16 matrix
+    cores, against float64 on the same bf16 weights at the f32 GEMM's error level, with every epilogue the decoder uses; and bit
+    for bit where pieces, products and partial sums are exactly representable."""
+    from kjarni_amd import ops
+    rng = np.random.default_rng(m + k)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w16 = ops.to_bf16((rng.standard_normal((n, k)) * 0.03).astype(np.float32))
+    w = ops.bf16_to_f32(w16)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32)
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(max(0, m - 140), m), rng.choice(m, 60, replace=False)]))
+    lin = x[rows].astype(np.float64) @ w.astype(np.float64).T + b
+    tol = 3e-6 * max(1.0, float(np.abs(lin).max())) * max(1.0, np.sqrt(k / 384.0))
+    got, _ = ops.linear_bf16_weights(x, w16, b, None, ops.EPI_BIAS)
+    assert float(np.abs(got[rows] - lin).max()) < tol
+    got, _ = ops.linear_bf16_weights(x, w16, b, r, ops.EPI_BIAS_RESIDUAL)
+    assert float(np.abs(got[rows] - (lin + r[rows])).max()) < tol
+    got, _ = ops.linear_bf16_weights(x, w16, None, r, ops.EPI_BIAS_MUL_SILU)
+    g = r[rows].astype(np.float64)
+    silu = np.where(g <= -20.0, 0.0, np.where(g >= 20.0, g, g / (1.0 + np.exp(-g))))
+    assert float(np.abs(got[rows] - silu * (lin - b)).max()) < tol * max(1.0, float(np.abs(silu).max()))
+    xi = rng.integers(-7, 8, (m, k)).astype(np.float32) * np.float32(2.0 ** -3) + rng.integers(-3, 4, (m, k)).astype(np.float32) * np.float32(2.0 ** -11)
+    wi = ops.to_bf16(rng.integers(-5, 6, (n, k)).astype(np.float32) * np.float32(0.25))
+    got, _ = ops.linear_bf16_weights(xi, wi, None, None, ops.EPI_BIAS)
+    assert np.array_equal(got, (xi.astype(np.float64) @ ops.bf16_to_f32(wi).astype(np.float64).T).astype(np.float32))
