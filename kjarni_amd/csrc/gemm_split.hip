@@ -391,6 +391,108 @@ hipError_t launch_bf16w(const float* A, int64_t lda, const uint16_t* W, const fl
     return hipGetLastError();
 }
 
+// The same for the decoder's SHORT prompt blocks (llm_kernels.hip's prefill_gemm_kernel: 64 x 64 tiles, optional K slices whose
+// partial tiles prefill_splitk_reduce_kernel adds): with bf16 weights, six bf16 MFMAs per wave and K-step of 32 instead of sixteen
+// f32 ones.  Same tile order, slices and partial layout as that kernel, so its launcher and reduce kernel serve both.
+constexpr int PGW_BM = 64, PGW_BN = 64, PGW_BK = 32;
+constexpr int PGW_PLANE = 64 * 32;  // bf16 per plane (64 rows x 64 bytes, chunks swizzled as above)
+
+template <bool RESIDUAL>
+__global__ __launch_bounds__(256) void prefill_gemm_bf16w_kernel(const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ W,
+                                                                 const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
+                                                                 int64_t ldy, int M, int N, int K, int m_tiles, int ksplit,
+                                                                 float* __restrict__ P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t sp[2][4 * PGW_PLANE];  // [stage][A1 | A2 | A3 | W]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int ks = (int)(bid0 % (unsigned)ksplit);
+    const unsigned bid = bid0 / (unsigned)ksplit;
+    const int m0 = (int)(bid % (unsigned)m_tiles) * PGW_BM;
+    const int n0 = (int)(bid / (unsigned)m_tiles) * PGW_BN;
+    const int k_len = K / ksplit, k_begin = ks * k_len;
+
+    const int a_row = tid >> 3, a_c4 = tid & 7, b_row = tid >> 2, b_c = tid & 3;
+    const float* a_ptr[2];
+    int stA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = a_row + 32 * i;
+        a_ptr[i] = A + (int64_t)min(m0 + row, M - 1) * lda + a_c4 * 4 + k_begin;
+        stA[i] = row * 32 + (((a_c4 >> 1) ^ ((row >> 2) & 3)) * 2 + (a_c4 & 1)) * 4;
+    }
+    const uint16_t* b_ptr = W + (int64_t)min(n0 + b_row, N - 1) * K + b_c * 8 + k_begin;
+    const int stW = 3 * PGW_PLANE + b_row * 32 + (b_c ^ ((b_row >> 2) & 3)) * 8;
+    f32x4 ga[2];
+    u32x4 gw;
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ga[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
+        gw = *reinterpret_cast<const u32x4*>(b_ptr + k0);
+    };
+    auto store = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 p1, p2, p3;
+            sp_split(ga[i], p1, p2, p3);
+            *reinterpret_cast<u32x2*>(&sp[stage][stA[i]]) = p1;
+            *reinterpret_cast<u32x2*>(&sp[stage][PGW_PLANE + stA[i]]) = p2;
+            *reinterpret_cast<u32x2*>(&sp[stage][2 * PGW_PLANE + stA[i]]) = p3;
+        }
+        *reinterpret_cast<u32x4*>(&sp[stage][stW]) = gw;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nk = k_len / PGW_BK;
+    const int fsw = (l31 >> 2) & 3;
+    const int fa = (wr * 32 + l31) * 32, fb = 3 * PGW_PLANE + (wc * 32 + l31) * 32;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load((kt + 1) * PGW_BK);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int ch = ((kb * 2 + half) ^ fsw) * 8;
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(&sp[cur][fb + ch]);
+#pragma unroll
+            for (int p = 2; p >= 0; --p) {   // the smallest piece first
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sp[cur][p * PGW_PLANE + fa + ch]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store(cur ^ 1);
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col < N) {
+        if (ksplit > 1) {
+            float* out = P + (int64_t)ks * M * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 32 + acc_row(r, half);
+                if (row < M) out[(int64_t)row * N + col] = acc[r];
+            }
+            return;
+        }
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + acc_row(r, half);
+            if (row < M) {
+                float v = acc[r] + bv;
+                if (RESIDUAL) v += R[(int64_t)row * ldr + col];
+                Y[(int64_t)row * ldy + col] = v;
+            }
+        }
+    }
+}
+
 std::atomic<int> g_f32_on_bf16{-1};  // -1: not decided yet (KJARNI_HIP_F32_ON_BF16 is read at the first launch)
 inline bool f32_on_bf16()
 {
@@ -445,6 +547,20 @@ hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const 
     case EPI_BIAS_MUL_SILU: return launch_split<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_prefill_tiles_bf16w(unsigned grid, const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R,
+                                      int64_t ldr, float* Y, int64_t ldy, int M, int N, int K, int m_tiles, int ksplit, float* partials,
+                                      hipStream_t stream)
+{
+    const uint16_t* W = static_cast<const uint16_t*>(W_bf16);
+    if (R)
+        hipLaunchKernelGGL((prefill_gemm_bf16w_kernel<true>), dim3(grid), dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles,
+                           ksplit, partials);
+    else
+        hipLaunchKernelGGL((prefill_gemm_bf16w_kernel<false>), dim3(grid), dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles,
+                           ksplit, partials);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_bf16_weights(const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R, int64_t ldr,

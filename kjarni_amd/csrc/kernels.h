@@ -86,6 +86,12 @@ hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const 
 hipError_t launch_gemm_bf16_weights(const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R, int64_t ldr,
                                     float* Y, int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream);
 
+// The 64 x 64-tile form for the decoder's short prompt blocks: the grid, tile order, K slices and partial layout of
+// llm_kernels.hip's prefill_gemm_kernel (whose launcher calls this for bf16 weights); K / ksplit a multiple of 32, K % 8 == 0.
+hipError_t launch_prefill_tiles_bf16w(unsigned grid, const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R,
+                                      int64_t ldr, float* Y, int64_t ldy, int M, int N, int K, int m_tiles, int ksplit, float* partials,
+                                      hipStream_t stream);
+
 // (the kernel A/B switches of the tuning build live in tuning.h)
 
 // R6/R7/R8: fused QK^T -> scale -> mask -> softmax -> PV for all heads.

@@ -352,13 +352,12 @@ void LlmModel::prefill_rows(const uint32_t* ids_host, int n)
                         float* gate, const char* what) {
 #ifdef KJARNI_TUNING
             static const int min_tiles_env = [] { const char* v = std::getenv("KJARNI_HIP_LLM_MIN_TILES"); return v ? std::atoi(v) : 0; }();
-            const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (bf16_ ? 96 : 208);
+            const int min_tiles = min_tiles_env > 0 ? min_tiles_env : 208;
 #else
-            // measured on the 1B shape, f32 weights: 192 tiles (1 536 rows x 2 048 columns) are faster on the 64 x 64 kernel, 224 on the
-            // tiles; bf16 weights (the bf16-matrix-core tiles, half the time per tile): 96 tiles (768 rows x 2 048 columns) are
-            // faster on the tiles, 64 (512 rows) on the 64 x 64 kernel -- prompts of 768 / 1 024 / 1 536 tokens 11.3 / 14.5 / 22.0 ->
-            // 10.2 / 11.6 / 15.5 ms
-            const int min_tiles = bf16_ ? 96 : 208;
+            // measured on the 1B shape: 192 tiles (1 536 rows x 2 048 columns) are faster on the 64 x 64 kernel, 224 on the tiles -- with
+            // f32 weights (both kernels on the f32 matrix cores) and again with bf16 weights (both on the bf16 matrix cores: 768 /
+            // 1 024 tokens 8.1 / 9.8 ms at 208 against 9.9 / 11.2 at 96 and 8.8 / 11.2 with no tiles at all)
+            constexpr int min_tiles = 208;
 #endif
             const bool tiles = tile_shapes && m >= kTileRows && (int64_t)((m + 127) / 128) * (N / 128) >= min_tiles;
             if (!tiles) {

@@ -13,6 +13,7 @@
 
 #include "device_utils.h"
 #include "llm_kernels.h"
+#include "kernels.h"
 
 namespace kjarni {
 
@@ -1334,6 +1335,18 @@ size_t prefill_gemm_scratch_floats(int max_rows, int max_n)
     return (size_t)1024 * PG_BM * PG_BN;
 }
 
+namespace {
+inline bool prefill_f32_mfma_for_bf16()
+{
+#ifdef KJARNI_TUNING
+    static const bool v = [] { const char* e = std::getenv("KJARNI_HIP_LLM_WIDEN"); return e && e[0] == '1'; }();
+    return v;
+#else
+    return false;
+#endif
+}
+}  // namespace
+
 hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int bf16, const float* bias, const float* R, int64_t ldr, float* Y,
                                int64_t ldy, int M, int N, int K, hipStream_t stream, float* split_scratch, float* silu_gate)
 {
@@ -1349,7 +1362,12 @@ hipError_t launch_prefill_gemm(const float* A, int64_t lda, const void* W, int b
 #define KJ_PG(WT, RES)                                                                                                              \
     hipLaunchKernelGGL((prefill_gemm_kernel<WT, RES>), grid, dim3(256), 0, stream, A, lda, static_cast<const WT*>(W), bias, R, ldr, Y, ldy, \
                        M, N, K, m_tiles, ksplit, split_scratch)
-    if (bf16) {
+    if (bf16 && !prefill_f32_mfma_for_bf16()) {
+        // bf16 weights: on the bf16 matrix cores, the activations as three exact bf16 pieces (gemm_split.hip)
+        const hipError_t e = launch_prefill_tiles_bf16w((unsigned)(m_tiles * n_tiles * ksplit), A, lda, W, bias, R, ldr, Y, ldy, M, N, K, m_tiles,
+                                                        ksplit, split_scratch, stream);
+        if (e != hipSuccess) return e;
+    } else if (bf16) {
         if (R) KJ_PG(uint16_t, true);
         else KJ_PG(uint16_t, false);
     } else {

@@ -238,8 +238,8 @@ def test_decode_over_several_key_ranges(tmp_path):
 @pytest.mark.parametrize("store_bf16", [True, False], ids=["bf16-weights", "f32-weights"])
 def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
     """A projection of a prompt block runs a 128 x 128-tile GEMM when its tiles number at least 208 (f32 weights: the encoder's
-    f32 MFMA tiles) or 96 (bf16 weights: the bf16-matrix-core tiles on three exact pieces of every activation, gemm_split.hip),
-    else the 64 x 64 prompt kernel.  Hidden 1 792 = 14 x 128 with a 1 792-wide FFN: a 2 048-row
+    f32 MFMA tiles; bf16 weights: the bf16-matrix-core tiles on three exact pieces of every activation, gemm_split.hip), else
+    the 64 x 64 prompt kernel (f32 weights on the f32 matrix cores, bf16 weights on the bf16 ones).  Hidden 1 792 = 14 x 128 with a 1 792-wide FFN: a 2 048-row
     block has 16 x 14 = 224 tiles for q, o (in-place residual), gate, up * silu(gate) and down (in-place residual) -- five tiled
     projections per layer -- while k / v (256 wide: 32 tiles) and the 1 900-row prompt (15 x 14 = 210 ... also tiled) and the
     252-row tail (not tiled) take their own routes.  The route is asserted through the library's counter."""
@@ -249,7 +249,7 @@ def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
     orc, gpu, cfg = _pair(tmp_path, base, seed=13, bf16_values=True, store_bf16=store_bf16, std=0.02)
     rng = np.random.default_rng(6)
     assert gpu.tile_gemm_calls() == 0
-    for n_prompt, tiled_blocks in ((1500, 1 if store_bf16 else 0), (2300, 1)):
+    for n_prompt, tiled_blocks in ((1500, 0), (2300, 1)):
         cache = orc.new_cache()
         gpu.reset()
         before = gpu.tile_gemm_calls()
@@ -262,7 +262,7 @@ def test_long_prompt_blocks_take_the_tile_gemm(tmp_path, store_bf16):
             scale = max(1.0, float(np.abs(ref_h).max()))
             assert np.abs(h[-k:] - ref_h[-k:]).max() < TOL * scale, (n, np.abs(h[-k:] - ref_h[-k:]).max())
             assert np.abs(logits - ref_l).max() < TOL * max(1.0, float(np.abs(ref_l).max())), (n, np.abs(logits - ref_l).max())
-        # 1 500 rows: 12 x 14 = 168 tiles per projection, below the f32 threshold and above the bf16 one; 2 300 rows = a 2 048-row block (224 tiles: q, o,
+        # 1 500 rows: 12 x 14 = 168 tiles per projection, below the threshold; 2 300 rows = a 2 048-row block (224 tiles: q, o,
         # gate, up, down tiled in each of the 2 layers) + a 252-row block (below the 512-row floor)
         assert gpu.tile_gemm_calls() - before == tiled_blocks * 5 * cfg["num_hidden_layers"], (n_prompt, gpu.tile_gemm_calls() - before)
 
