@@ -383,6 +383,7 @@ template <int EPI>
 hipError_t launch_bf16w(const float* A, int64_t lda, const uint16_t* W, const float* bias, const float* R, int64_t ldr, float* Y,
                         int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
 {
+    static_assert(BW_LDS_BYTES <= 64 * 1024, "more dynamic LDS than a launch gets without the opt-in attribute");
     const int n_tiles = N / BN;
     const int64_t total = ((M + BM - 1) / BM) * n_tiles;
     if (total > 0x7fffffff) return hipErrorInvalidValue;
@@ -509,15 +510,7 @@ template <int EPI>
 hipError_t launch_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
                         int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
 {
-    static bool attr_set[64] = {};  // > 64 KiB of dynamic LDS needs the opt-in once per device
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (!attr_set[dev & 63]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_split<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set[dev & 63] = true;
-    }
+    static_assert(SP_LDS_BYTES <= 64 * 1024, "more dynamic LDS than a launch gets without the opt-in attribute");
     const int n_tiles = N / BN;
     const int64_t total = ((M + BM - 1) / BM) * n_tiles;
     if (total > 0x7fffffff) return hipErrorInvalidValue;
