@@ -82,11 +82,13 @@ KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
 /* Opt-in, process-wide, default OFF (or environment KJARNI_HIP_F32_ON_BF16=1, read once at the first projection): the
- * large-batch projections (calls of 6 144 token rows and more) compute their f32 products on the bf16 matrix cores.  Every
+ * projections of calls above the few-rows range (more than 256 token rows; 128 for models wider than 512) compute their f32
+ * products on the bf16 matrix cores.  Every
  * f32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits) on its way into LDS and six of the nine
  * cross products are accumulated in f32 -- the three dropped ones are below 2^-24 of a product, f32's own rounding --
  * so inputs, outputs and the error level are those of f32 arithmetic (measured against float64: the same 2-4e-6 as the f32
- * MFMA kernels, tests/test_gpu_split.py), at 1.1-1.25x their speed.  Differences: sums run in another
+ * MFMA kernels, tests/test_gpu_split.py), at 1.1-1.3x their speed (the reference's default batch of 32 sentences x 128
+ * tokens: 1.12 -> 0.94 ms per call).  Differences: sums run in another
  * order (results equal to the default path to rounding, not bit for bit), and a non-finite INPUT element turns its products
  * into NaN (inf - inf in the split) where the default path keeps an infinity.  The reference computes in f32
  * (kjarni-transformers/src/linear_layer/linear_layer.rs:160-282); whether f32 results assembled from bf16 pieces meet a

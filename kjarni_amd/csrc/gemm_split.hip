@@ -494,6 +494,116 @@ __global__ __launch_bounds__(256) void prefill_gemm_bf16w_kernel(const float* __
     }
 }
 
+// The opt-in mode's form of gemm.hip's 64 x 64-tile route (calls of 257 .. 6 143 rows): both operands f32, three planes each, six
+// products -- twelve bf16 MFMAs per wave and K-step of 32 instead of sixteen f32 ones at twice the cycles.  One workgroup per
+// (tile, K slice), gemm_nt_f32_mid's tile order and partial-slab layout (its reduce kernels serve both).
+template <int EPI, bool PARTIAL>
+__global__ __launch_bounds__(256) void gemm_nt_f32_mid_split(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
+                                                             int64_t ldy, int M, int N, int K, int n_tiles, int ksplit, float* __restrict__ P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t sp[2][6 * PGW_PLANE];  // [stage][A1 | A2 | A3 | W1 | W2 | W3]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned bid0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const unsigned bid = bid0 / (unsigned)ksplit;
+    const int ks = (int)(bid0 - bid * (unsigned)ksplit);
+    const unsigned mt = bid / (unsigned)n_tiles;
+    const int m0 = (int)mt * 64, n0 = (int)(bid - mt * (unsigned)n_tiles) * 64;
+    const int k_len = K / ksplit, k_begin = ks * k_len;
+
+    const int s_row = tid >> 3, s_c4 = tid & 7;
+    const float *a_ptr[2], *b_ptr[2];
+    int st[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = s_row + 32 * i;
+        a_ptr[i] = A + (int64_t)min(m0 + row, M - 1) * lda + s_c4 * 4 + k_begin;
+        b_ptr[i] = W + (int64_t)min(n0 + row, N - 1) * K + s_c4 * 4 + k_begin;
+        st[i] = row * 32 + (((s_c4 >> 1) ^ ((row >> 2) & 3)) * 2 + (s_c4 & 1)) * 4;
+    }
+    f32x4 ga[2], gb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ga[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + k0);
+            gb[i] = *reinterpret_cast<const f32x4*>(b_ptr[i] + k0);
+        }
+    };
+    auto store = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x2 p1, p2, p3;
+            sp_split(ga[i], p1, p2, p3);
+            *reinterpret_cast<u32x2*>(&sp[stage][st[i]]) = p1;
+            *reinterpret_cast<u32x2*>(&sp[stage][PGW_PLANE + st[i]]) = p2;
+            *reinterpret_cast<u32x2*>(&sp[stage][2 * PGW_PLANE + st[i]]) = p3;
+            sp_split(gb[i], p1, p2, p3);
+            *reinterpret_cast<u32x2*>(&sp[stage][3 * PGW_PLANE + st[i]]) = p1;
+            *reinterpret_cast<u32x2*>(&sp[stage][4 * PGW_PLANE + st[i]]) = p2;
+            *reinterpret_cast<u32x2*>(&sp[stage][5 * PGW_PLANE + st[i]]) = p3;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nk = k_len / 32;
+    const int fsw = (l31 >> 2) & 3;
+    const int fa = (wr * 32 + l31) * 32, fb = 3 * PGW_PLANE + (wc * 32 + l31) * 32;
+    float bv = 0.0f;
+    if (!PARTIAL && bias != nullptr) {
+        const int bcol = n0 + wc * 32 + l31;
+        bv = bias[bcol < N ? bcol : N - 1];
+    }
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load((kt + 1) * 32);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int ch = ((kb * 2 + half) ^ fsw) * 8;
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(&sp[cur][p * PGW_PLANE + fa + ch]);
+                b[p] = *reinterpret_cast<const bf16x8*>(&sp[cur][p * PGW_PLANE + fb + ch]);
+            }
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // i + j <= 4, the smallest first
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b[PB[q]], acc, 0, 0, 0);
+        }
+        if (kt + 1 < nk) store(cur ^ 1);
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col < N) {
+        if (PARTIAL) {
+            float* out = P + (int64_t)ks * M * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 32 + acc_row(r, half);
+                if (row < M) out[(int64_t)row * N + col] = acc[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 32 + acc_row(r, half);
+                if (row < M) {
+                    float v = acc[r] + bv;
+                    if (EPI == EPI_BIAS_RESIDUAL) v += R[(int64_t)row * ldr + col];
+                    else if (EPI == EPI_BIAS_MUL_SILU) v *= silu_ref(R[(int64_t)row * ldr + col]);
+                    else v = epilogue<EPI>(v);
+                    Y[(int64_t)row * ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
 std::atomic<int> g_f32_on_bf16{-1};  // -1: not decided yet (KJARNI_HIP_F32_ON_BF16 is read at the first launch)
 inline bool f32_on_bf16()
 {
@@ -539,6 +649,36 @@ hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const 
     case EPI_BIAS_RESIDUAL: return launch_split<EPI_BIAS_RESIDUAL>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     case EPI_BIAS_MUL_SILU: return launch_split<EPI_BIAS_MUL_SILU>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
     }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_mid_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                                 int64_t ldy, int M, int N, int K, int ksplit, float* partials, GemmEpilogue epi, hipStream_t stream)
+{
+    if (M <= 0) return hipSuccess;
+    if (K % (32 * ksplit) != 0 || lda % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return hipErrorInvalidValue;
+    const int m_tiles = (M + 63) / 64, n_tiles = (N + 63) / 64;
+    const dim3 grid((unsigned)(m_tiles * n_tiles * ksplit));
+#define KJ_MS(EPI_)                                                                                                                   \
+    hipLaunchKernelGGL((gemm_nt_f32_mid_split<EPI_, false>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, n_tiles, 1, \
+                       nullptr);                                                                                                      \
+    return hipGetLastError()
+    if (partials) {
+        hipLaunchKernelGGL((gemm_nt_f32_mid_split<EPI_BIAS, true>), grid, dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N, K, n_tiles,
+                           ksplit, partials);
+        return hipGetLastError();
+    }
+    if (ksplit != 1) return hipErrorInvalidValue;
+    switch (epi) {
+    case EPI_BIAS: KJ_MS(EPI_BIAS);
+    case EPI_BIAS_GELU: KJ_MS(EPI_BIAS_GELU);
+    case EPI_BIAS_GELU_NEW: KJ_MS(EPI_BIAS_GELU_NEW);
+    case EPI_BIAS_RELU: KJ_MS(EPI_BIAS_RELU);
+    case EPI_BIAS_TANH: KJ_MS(EPI_BIAS_TANH);
+    case EPI_BIAS_RESIDUAL: KJ_MS(EPI_BIAS_RESIDUAL);
+    case EPI_BIAS_MUL_SILU: KJ_MS(EPI_BIAS_MUL_SILU);
+    }
+#undef KJ_MS
     return hipErrorInvalidValue;
 }
 

@@ -86,6 +86,11 @@ hipError_t launch_gemm_split(const float* A, int64_t lda, const float* W, const 
 hipError_t launch_gemm_bf16_weights(const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R, int64_t ldr,
                                     float* Y, int64_t ldy, int64_t M, int N, int K, GemmEpilogue epi, hipStream_t stream);
 
+// The opt-in mode's 64 x 64-tile projections (gemm.hip's mid-size route calls this when the mode is on): partials != null -> the
+// K slices' partial tiles [ksplit][M][N] for mid_reduce_*; else ksplit == 1 and the epilogue is applied.  K / ksplit % 32 == 0.
+hipError_t launch_gemm_mid_split(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                                 int64_t ldy, int M, int N, int K, int ksplit, float* partials, GemmEpilogue epi, hipStream_t stream);
+
 // The 64 x 64-tile form for the decoder's short prompt blocks: the grid, tile order, K slices and partial layout of
 // llm_kernels.hip's prefill_gemm_kernel (whose launcher calls this for bf16 weights); K / ksplit a multiple of 32, K % 8 == 0.
 hipError_t launch_prefill_tiles_bf16w(unsigned grid, const float* A, int64_t lda, const void* W_bf16, const float* bias, const float* R,

@@ -15,6 +15,7 @@
 //   15  residual projection + LayerNorm of up to 64 rows with a long K: the 64 x 64-tile K slices instead of the few-rows kernel's
 //   31..34  persistent grid of the 64 x 64-tile kernel: 768 / 512 / 256 / 1 280 workgroups instead of 1 024
 //   21..26  knock-out diagnostics of the 64 x 64-tile kernel (unsliced launches): its DIAG template parameter 1..6
+//   17  f32-on-bf16 mode: the 64 x 64-tile route stays on the f32 matrix cores
 // 100000 + r  f32-on-bf16 mode: the split kernel takes calls from r rows (instead of 2 048) in place of the 64 x 64-tile route
 // 1000 + r  the few-rows kernel takes calls of up to r rows (sweeps of the few-rows / 64 x 64-tile crossover)
 // attention variant (kjarni_hip_set_attention_variant):
@@ -56,6 +57,7 @@ inline bool no_persistent_tile_loop() { return gemm() == 10; }
 inline bool persistent_layernorm_tiles() { return gemm() == 11; }
 inline bool no_few_rows_k_slices() { return gemm() == 15; }
 inline int mid_grid_override() { return gemm() >= 31 && gemm() <= 34 ? (gemm() == 31 ? 768 : gemm() == 32 ? 512 : gemm() == 33 ? 256 : 1280) : 0; }
+inline bool mid_split_off() { return gemm() == 17; }
 inline int mid_knockout() { return gemm() >= 21 && gemm() <= 26 ? gemm() - 20 : 0; }
 inline int split_min_rows_override() { return gemm() >= 100000 ? gemm() - 100000 : 0; }  // (measurements: 100000 + rows)
 inline int few_rows_max_override() { return gemm() >= 1000 && gemm() < 100000 ? gemm() - 1000 : 0; }  // (measurements: 1000 + rows)

@@ -23,7 +23,10 @@ def split_mode():
 @pytest.mark.parametrize("m,k,n", [(8193, 384, 1152), (8300, 1536, 384), (16384, 384, 1536), (9000, 768, 768), (8200, 3072, 768),
                                    (8193, 64, 128),
                                    # 6 144 .. 8 192 rows: in the mode the split kernel also replaces the 64 x 64-tile route
-                                   (6144, 384, 1152), (7001, 1536, 384)])
+                                   (6144, 384, 1152), (7001, 1536, 384),
+                                   # 257 .. 6 143 rows: the 64 x 64 tiles themselves on the bf16 matrix cores (with K slices for the
+                                   # narrow outputs: 1 536 -> 384)
+                                   (300, 384, 1152), (768, 384, 1152), (4096, 384, 1536), (1000, 1536, 384), (3000, 768, 768), (5000, 3072, 768)])
 def test_projections_all_epilogues(split_mode, m, k, n):
     """Every epilogue of the split kernel against the oracle at 1e-5 (rows past the last full 128-row tile included), on sampled
     rows; and against float64: the error stays at the f32 kernels' level."""
@@ -65,7 +68,7 @@ def test_split_is_exact_on_bf16_representable_operands(split_mode):
 def test_residual_layernorm_route(split_mode):
     from kjarni_amd import ops
     rng = np.random.default_rng(11)
-    for m, k, n in ((8400, 1536, 384), (6500, 1536, 384)):
+    for m, k, n in ((8400, 1536, 384), (6500, 1536, 384), (4100, 1536, 384), (900, 384, 384)):
         _residual_layernorm_case(ops, rng, m, k, n)
 
 
