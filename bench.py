@@ -503,6 +503,11 @@ def main():
             torch.cuda.synchronize()
             extras["value_f32_on_bf16"] = round(2 * n_local / (time.perf_counter() - t1), 1)
             extras["f32_on_bf16_max_abs_diff_vs_default"] = float((out - ref_emb).abs().max().item())
+            enc.embed(ids_np[:32], mask_np[:32])   # the reference's default call size in the mode (host pointers, as value_by_call_size)
+            t1 = time.perf_counter()
+            for _ in range(64):
+                enc.embed(ids_np[:32], mask_np[:32])
+            extras["f32_on_bf16_ms_per_call_of_32"] = round((time.perf_counter() - t1) / 64 * 1e3, 4)
         finally:
             _ops.set_f32_on_bf16(before)
         extras["extras_note"] = ("value_host_ptrs: ids/mask handed over as host buffers, embeddings returned to the "
