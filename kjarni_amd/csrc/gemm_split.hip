@@ -1,6 +1,8 @@
-// f32 projections on the bf16 matrix cores (opt-in mode; its own translation unit because it is compiled with
-// -fno-slp-vectorize: the SLP vectoriser packs the split's f32 subtractions into v_pk_add_f32, which costs ~26 issue cycles
-// beside MFMAs against 4 + 4 for two plain subtractions -- MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever beside MFMAs").
+// f32 projections on the bf16 matrix cores: the opt-in mode of the encoder (both operands f32: six products per f32 product) and
+// the decoder's prompt projections over bf16 weights (always on: three products, nothing dropped).  Its own translation unit
+// because it is compiled with -fno-slp-vectorize: the SLP vectoriser packs the split's f32 subtractions into v_pk_add_f32, which
+// costs ~26 issue cycles beside MFMAs against 4 + 4 for two plain subtractions (MI355X_MICROARCH.md, "packed f32 VALU ... an
+// anti-lever beside MFMAs").
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdlib>
@@ -27,7 +29,7 @@ constexpr int EPI_STRIDE = 68;     // floats per staged output row (64 + 4), as 
 // roundings: |error| <= ~3 x 2^-24 per product, against 2^-24 for a chain of f32 FMAs; measured against the oracle in
 // tests/test_gpu_split.py).  The operands stay f32 in memory: a tile's rows are split on their way into LDS (4.5 vector
 // instructions per element, which issue in the gaps of the bf16 MFMAs -- unlike beside the f32 MFMAs), three bf16 planes per
-// operand, 80-byte rows (conflict-free 16-byte fragment reads).  Not the default: the reference computes in f32, and whether an
+// operand (layout below).  Not the default: the reference computes in f32, and whether an
 // f32 result assembled from bf16 pieces counts as "the reference's precision" is the integrator's call; non-finite inputs
 // (inf - inf in the split) come out as NaN where the f32 path keeps an infinity.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
