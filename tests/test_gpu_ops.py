@@ -74,7 +74,8 @@ def test_residual_projection_with_fused_layernorm(m, k, n, eps):
         assert float(np.abs(got - ref).max()) < 1e-5 * max(1.0, float(np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (768, 3072), (1024, 32)])
+@pytest.mark.parametrize("k,n", [(384, 384), (1536, 384), (768, 3072), (1024, 32),
+                                 (384, 4096)])   # 128 column tiles: from 5 row groups on, two row groups per workgroup
 def test_few_rows_results_do_not_depend_on_the_batch(k, n):
     """Up to 256 rows (128 for models wider than 512: the bound follows min(N, K)) the projections run the split-K kernel, one
     workgroup per 32 columns and group of 32 rows; a row's result must be bit-identical whatever other rows share the call
