@@ -104,6 +104,19 @@ def host_description():
     return info
 
 
+def cpus_granted():
+    """CPUs this process may use: the affinity mask, cut to the cgroup's CPU quota when there is one."""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            usable = min(usable, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, usable)
+
+
 def cpu_baseline(cfg, tensors, budget_s=60.0, cap_sentences=4096):
     """The reference's CPU path as oracle/kjarni_cpu_baseline.c ports it (fused QKV, 64-row / 4x3 AVX2 GEMM
     blocks, per-(b,h) attention GEMMs, persistent buffers), one thread per physical core (the reference pins its
@@ -244,6 +257,11 @@ def main():
     import torch  # imported before libkjarni_ffi.so so both share torch's HIP runtime
     import torch.distributed as dist
 
+    # Host threads: torch's intra-op pool defaults to every logical CPU of the box (256 on the GPU host) while the job's cgroup
+    # may grant far fewer (16 there), and N ranks share that grant: each rank takes its share for the host-side sort / copies.
+    host_cpus = cpus_granted()
+    torch.set_num_threads(max(1, host_cpus // max(1, world)))
+
     from kjarni_amd import distributed as D
     from tests import synth
 
@@ -300,9 +318,9 @@ def main():
     if rerank:
         n_total = args.pairs
         start, n_local = D.shard_rows(n_total, world, rank)
-        ids_np, mask_np, types_np = synth.synthetic_pairs(n_total, S, seed=1)  # the same 100 000 pairs on every rank
-        ids, mask, types = (to_dev(a[start:start + n_local]) for a in (ids_np, mask_np, types_np))
-        del ids_np, mask_np, types_np
+        # this rank's rows of the one fixed pair set (the same 100 000 pairs at every world size; no rank builds the others' rows)
+        ids_np, mask_np, types_np = synth.synthetic_pairs_rows(start, n_local, S, seed=1)
+        ids, mask, types = (to_dev(a) for a in (ids_np, mask_np, types_np))
     else:
         n_local = args.sentences
         n_total = world * n_local
@@ -313,7 +331,9 @@ def main():
     def step():
         if rerank:
             scores = D.sharded_rerank_scores(enc, ids, mask, types, n_total=n_total)
-            result_holder["order"] = D.rerank_order_arrays(scores)  # D2H + stable descending sort on the host
+            # D2H + stable descending sort on the host, by the rank that hands the ranking to the caller (rank 0); the gathered
+            # scores are on every rank
+            result_holder["order"] = D.rerank_order_arrays(scores) if rank == 0 else None
             result_holder["scores"] = scores
         else:
             result_holder["emb"] = D.sharded_embed(enc, ids, mask, n_total=n_total)
@@ -356,8 +376,9 @@ def main():
     if rerank:
         sc, order = result_holder["scores"], result_holder["order"]
         assert sc.shape == (n_total,) and bool(torch.isfinite(sc).all()), "rerank scores are not finite"
-        assert order[0].shape == (n_total,) and bool((order[1][:-1] >= order[1][1:]).all()), "order is not descending"
-        assert bool(torch.equal(torch.sort(order[0]).values, torch.arange(n_total))), "order is not a permutation"
+        if rank == 0:
+            assert order[0].shape == (n_total,) and bool((order[1][:-1] >= order[1][1:]).all()), "order is not descending"
+            assert bool(torch.equal(torch.sort(order[0]).values, torch.arange(n_total))), "order is not a permutation"
     else:
         emb = result_holder["emb"]
         assert emb.shape == (n_total, H)
@@ -401,14 +422,14 @@ def main():
             ce.set_chunk_tokens(args.chunk_tokens)
         p_total = args.pairs
         p_start, p_local = D.shard_rows(p_total, world, rank)
-        pi, pm, pt = synth.synthetic_pairs(p_total, S, seed=1)
-        pi_d, pm_d, pt_d = (to_dev(a[p_start:p_start + p_local]) for a in (pi, pm, pt))
+        pi, pm, pt = synth.synthetic_pairs_rows(p_start, p_local, S, seed=1)  # this rank's rows only
+        pi_d, pm_d, pt_d = (to_dev(a) for a in (pi, pm, pt))
         r_steps = args.rerank_steps or max(1, min(args.steps, 5))
         held = {}
 
         def rerank_step():
             held["scores"] = D.sharded_rerank_scores(ce, pi_d, pm_d, pt_d, n_total=p_total)
-            held["order"] = D.rerank_order_arrays(held["scores"])
+            held["order"] = D.rerank_order_arrays(held["scores"]) if rank == 0 else None  # (rank 0 hands the ranking to the caller)
 
         for _ in range(1 if args.warmup else 0):
             rerank_step()
@@ -424,19 +445,19 @@ def main():
             r_elapsed = float(t.item())
         sc, order = held["scores"], held["order"]
         assert sc.shape == (p_total,) and bool(torch.isfinite(sc).all()), "rerank scores are not finite"
-        assert bool((order[1][:-1] >= order[1][1:]).all()), "rerank order is not descending"
+        assert rank != 0 or bool((order[1][:-1] >= order[1][1:]).all()), "rerank order is not descending"
         rerank_leg = {"pairs_per_s": round(p_total * r_steps / r_elapsed, 1), "ms_per_step": round(r_elapsed / r_steps * 1e3, 3),
                       "n_gpus": world, "scaling": "strong", "steps": r_steps, "pairs_per_step": p_total,
                       "pairs_per_gpu": p_local, "unit": "pairs/s",
                       "workload": f"minilm-l6-v2-cross-encoder Reranker over {p_total} synthetic query-doc pairs x {S} tokens in "
-                                  f"total, row blocks over {world} GPU(s), all-gather of the scores + the host's stable "
-                                  "descending sort inside the timed region (BASELINE.json configs[2])"}
+                                  f"total, row blocks over {world} GPU(s), all-gather of the scores + rank 0's stable "
+                                  "descending sort on the host inside the timed region (BASELINE.json configs[2])"}
         if rank == 0 and not dry and not args.no_parity_check:
             from oracle import oracle as O
             prng = np.random.default_rng(321)
             sel = np.unique(np.concatenate([np.array([0, p_local - 1]), prng.choice(p_local, min(32, p_local), replace=False)]))[:32]
             ref = O.OracleModel(ce_tensors, ce_cfg, blocked_gemm=True).rerank_scores(
-                *(np.ascontiguousarray(a[p_start + sel]) for a in (pi, pm, pt)))
+                *(np.ascontiguousarray(a[sel]) for a in (pi, pm, pt)))
             got = sc[torch.from_numpy(p_start + sel).to(sc.device)].cpu().numpy()
             rerank_leg["max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
             rerank_leg["rows_checked_vs_oracle"] = int(len(sel))
@@ -460,6 +481,8 @@ def main():
         rid_d, rmask_d = to_dev(rid), to_dev(rmask)
         out = torch.empty((n_local, H), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream().cuda_stream
+        # (packed rows on DEVICE pointers are opt-in, kjarni_hip_encoder_set_packing(enc, 2): the call then synchronises its stream once)
+        enc.set_packing(2)
         enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), 1024, S, out.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -468,14 +491,14 @@ def main():
         torch.cuda.synchronize()
         extras["value_ragged"] = round(2 * n_local / (time.perf_counter() - t1), 1)
         extras["ragged_kept_token_fraction"] = round(float(rmask.sum()) / rmask.size, 4)
-        enc.set_packing(False)   # the same ragged batch on the padded layout (every [PAD] row computed, as the reference does)
+        enc.set_packing(0)   # the same ragged batch on the padded layout (every [PAD] row computed, as the reference does)
         enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), 1024, S, out.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         enc.embed_dev(rid_d.data_ptr(), rmask_d.data_ptr(), n_local, S, out.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         extras["value_ragged_padded_layout"] = round(n_local / (time.perf_counter() - t1), 1)
-        enc.set_packing(True)
+        enc.set_packing(1)
         # the sizes callers make: one call at a time of 1 / 32 / 256 sentences through host pointers (the reference's default
         # batch is 32, crates/kjarni-ffi/src/embedder.rs); 1 and 32 take the few-rows / mid-size GEMM routes
         by_call = {}
@@ -591,6 +614,7 @@ def main():
             result["rerank"] = rerank_leg
         if comm_info:
             result["collective"] = comm_info
+        result["host_threads_per_rank"] = torch.get_num_threads()  # (the rank's share of the CPUs the cgroup grants)
         result.update(extras)
         if world == 1 and not rerank and not dry and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, tensors)

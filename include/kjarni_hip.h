@@ -74,11 +74,16 @@ int32_t kjarni_hip_encoder_device(const KjarniHipEncoder* enc);
 KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64_t tokens);
 /* Ragged batches: embed / logits run the layers over the kept tokens only (mask != 0) when a call has padding, every
  * sentence keeps its token 0 and the mask holds only 0 / 1 -- a padded token is observable through neither output
- * (pooling skips it, pooling/mod.rs:11-33; as a key its score is overwritten, utils/masks.rs:4-36).  On by default;
- * 0 makes every call take the padded layout (what hidden_states always does).  Results agree to rounding (<= 1e-6).
- * With packing on, a device-pointer embed / logits call of more than one sentence synchronises `stream` once before the
- * layers are enqueued (4 bytes per sentence come back to place the chunks), so it cannot be captured into a HIP graph;
- * turn packing off for that. */
+ * (pooling skips it, pooling/mod.rs:11-33; as a key its score is overwritten, utils/masks.rs:4-36).  Results agree with the
+ * padded layout to rounding (<= 1e-6).  `on`:
+ *   0  never: every call takes the padded layout (what hidden_states always does);
+ *   1  (default) the host-pointer entry points (..._host, and everything built on them: the string-level handles, groups),
+ *      whose mask is already on the host -- the device-pointer entry points stay "enqueued on `stream`, never synchronised",
+ *      graph-capturable, on the padded layout;
+ *   2  the device-pointer embed / logits too: a call of more than one sentence then reads 4 bytes per sentence back and
+ *      SYNCHRONISES `stream` once before the layers are enqueued (it blocks the calling thread behind whatever the stream
+ *      holds; on a capturing stream the call falls back to the padded layout).  Opt in when ragged device-resident batches
+ *      matter more than asynchrony (1.76 x on lengths U{16..128}). */
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
 /* Opt-in, process-wide, default OFF (or environment KJARNI_HIP_F32_ON_BF16=1, read once at the first projection): the

@@ -873,7 +873,8 @@ hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batc
                             int head_dim, float mask_value, float* ctx, hipStream_t stream, const int32_t* cu)
 {
     if (batch <= 0 || seq <= 0) return hipSuccess;
-    const bool aligned = ((heads * head_dim) % 4 == 0) && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
+    const bool aligned = ((heads * head_dim) % 4 == 0) && ((reinterpret_cast<uintptr_t>(qkv) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(ctx) & 15) == 0);  // (16-byte loads of qkv, 16-byte stores of ctx)
     if (head_dim == 32 && aligned) return launch_d<32>(qkv, mask, batch, seq, heads, mask_value, ctx, stream, cu);
     if (head_dim == 64 && aligned) return launch_d<64>(qkv, mask, batch, seq, heads, mask_value, ctx, stream, cu);
     const float scale = 1.0f / sqrtf((float)head_dim);

@@ -726,7 +726,9 @@ hipError_t launch_cosine_scores(const float* queries, int nq, const float* corpu
                            ((reinterpret_cast<uintptr_t>(queries) & 15) == 0) &&
                            ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
     // Crossover: a streaming pass serves 4 queries, the matrix-core scan 64 at about the cost of two passes.
-    if (nq >= 20 && aligned16 && dim % MQ_BK == 0 && (int64_t)MQ_D * dim * 4 < ((int64_t)1 << 31) && (mode == 0 || mode == 1) &&
+    // (dim >= 2 K-steps: with a single K-step per tile the double-buffered row norms of tile T + 2 would be stored while slower
+    // waves still read tile T's in their epilogue)
+    if (nq >= 20 && aligned16 && dim % MQ_BK == 0 && dim >= 2 * MQ_BK && (int64_t)MQ_D * dim * 4 < ((int64_t)1 << 31) && (mode == 0 || mode == 1) &&
         !tune::scan_streaming_only())
         return scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream);
     return scan_passes(queries, nq, corpus, n_docs, dim, mode, scores, n_docs, stream);

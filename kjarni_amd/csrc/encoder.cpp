@@ -55,6 +55,7 @@ EncoderModel::~EncoderModel()
                         (void*)w->tok_src, (void*)w->cu, (void*)w->lens})
             if (p) (void)hipFree(p);
         if (w->pin) (void)hipHostFree(w->pin);
+        if (w->lens_host) (void)hipHostFree(w->lens_host);
         if (w->done) (void)hipEventDestroy(w->done);
         if (w->stream) (void)hipStreamDestroy(w->stream);
     }
@@ -757,9 +758,12 @@ void EncoderModel::plan_packing(Workspace& ws, const uint32_t* mask_dev, const u
                                 hipStream_t stream, PackPlan& plan)
 {
     plan.packed = false;
-    if (!packing_ || !mask_dev || batch <= 0 || seq <= 1) return;
-    std::vector<uint32_t> lens((size_t)batch);
+    const int mode = packing_;
+    if (mode == 0 || !mask_dev || batch <= 0 || seq <= 1) return;
+    std::vector<uint32_t> lens_vec;
+    const uint32_t* lens = nullptr;
     if (mask_host) {
+        lens_vec.resize((size_t)batch);
         for (int64_t b = 0; b < batch; ++b) {
             const uint32_t* row = mask_host + b * seq;
             uint32_t n = 0, over = 0;
@@ -767,31 +771,46 @@ void EncoderModel::plan_packing(Workspace& ws, const uint32_t* mask_dev, const u
                 n += row[s] != 0u;
                 over |= row[s];
             }
-            lens[(size_t)b] = n | ((over > 1u || row[0] == 0u) ? 0x80000000u : 0u);
+            lens_vec[(size_t)b] = n | ((over > 1u || row[0] == 0u) ? 0x80000000u : 0u);
         }
+        lens = lens_vec.data();
     } else {
-        // the mask lives on the device: one small kernel + a read-back of 4 bytes per sentence.  A single sentence is
-        // not worth the round trip (a lone sentence is normally as long as its padded length).
-        if (batch == 1) return;
-        if ((size_t)batch > ws.lens_cap) {
+        // The mask lives on the device (packing mode 2 only: the call then blocks on `stream`): one small kernel + a read-back
+        // of 4 bytes per sentence into pinned memory.  A single sentence is not worth the round trip (a lone sentence is
+        // normally as long as its padded length); a capturing stream cannot be synchronised, so it takes the padded layout.
+        if (mode < 2 || batch == 1) return;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        if (cap != hipStreamCaptureStatusNone) return;
+        // (pinned buffer: lens [batch] on the way down, then cu [batch + chunks] on the way up -- 2 * batch + 64 words cover both)
+        const size_t want = 2 * (size_t)batch + 64;
+        if (want > ws.lens_cap) {
             if (ws.done_pending) {
                 hip_check(hipEventSynchronize(ws.done), "hipEventSynchronize(lens)");
                 ws.done_pending = false;
             }
             ws.lens_cap = 0;
             if (ws.lens) (void)hipFree(ws.lens);
+            if (ws.lens_host) (void)hipHostFree(ws.lens_host);
             ws.lens = nullptr;
+            ws.lens_host = nullptr;
             hip_check(hipMalloc((void**)&ws.lens, (size_t)batch * sizeof(uint32_t)), "hipMalloc(lens)");
-            ws.lens_cap = (size_t)batch;
+            hip_check(hipHostMalloc((void**)&ws.lens_host, want * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc(lens)");
+            ws.lens_cap = want;
         }
         hip_check(launch_mask_lengths(mask_dev, batch, seq, ws.lens, stream), "mask_lengths");
-        hip_check(hipMemcpyAsync(lens.data(), ws.lens, (size_t)batch * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "D2H lens");
+        hip_check(hipMemcpyAsync(ws.lens_host, ws.lens, (size_t)batch * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "D2H lens");
         hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(lens)");
+        lens_vec.assign(ws.lens_host, ws.lens_host + batch);  // (the pinned buffer is reused for cu below)
+        lens = lens_vec.data();
     }
     int64_t total = 0;
-    for (uint32_t l : lens) {
-        if (l & 0x80000000u) return;
-        total += l;
+    for (int64_t b = 0; b < batch; ++b) {
+        if (lens[b] & 0x80000000u) return;
+        total += lens[b];
     }
     if (total == batch * seq) return;  // nothing is padded
 
@@ -826,9 +845,16 @@ void EncoderModel::plan_packing(Workspace& ws, const uint32_t* mask_dev, const u
         hip_check(hipMalloc((void**)&ws.cu, plan.cu.size() * sizeof(int32_t)), "hipMalloc(cu)");
         ws.cu_ints = plan.cu.size();
     }
-    hip_check(hipMemcpyAsync(ws.cu, plan.cu.data(), plan.cu.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream), "H2D cu");
-    // (device-pointer entry points return without synchronising: the copy must have read plan.cu before it goes away)
-    if (!mask_host) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(cu)");
+    if (!mask_host && plan.cu.size() <= ws.lens_cap) {
+        // device-pointer call: the prefix sums go up from the workspace's pinned buffer, which outlives the call (the workspace is
+        // not leased again before this stream has passed its `done` event) -- no second synchronisation
+        std::memcpy(ws.lens_host, plan.cu.data(), plan.cu.size() * sizeof(int32_t));
+        hip_check(hipMemcpyAsync(ws.cu, ws.lens_host, plan.cu.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream), "H2D cu");
+    } else {
+        hip_check(hipMemcpyAsync(ws.cu, plan.cu.data(), plan.cu.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream), "H2D cu");
+        // (device-pointer entry points return without synchronising: the copy must have read plan.cu before it goes away)
+        if (!mask_host) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(cu)");
+    }
     plan.packed = true;
 }
 

@@ -99,7 +99,8 @@ struct Workspace {
     int32_t* tok_src = nullptr;
     int32_t* cu = nullptr;
     size_t cu_ints = 0;
-    uint32_t* lens = nullptr;
+    uint32_t* lens = nullptr;       // device: kept tokens per sentence (packing mode 2)
+    uint32_t* lens_host = nullptr;  // pinned: its read-back, then the chunks' prefix sums on their way up
     size_t lens_cap = 0;
     void* stage = nullptr;  // ids / mask / types in, outputs back, for the host-pointer entry points
     size_t stage_bytes = 0;
@@ -149,12 +150,15 @@ public:
     size_t weight_bytes() const { return weight_bytes_; }
     void set_chunk_tokens(int64_t t) { if (t > 0) chunk_tokens_ = t; }
     int64_t chunk_tokens() const { return chunk_tokens_; }
-    // Ragged batches run over the kept tokens only (embed / logits; default on).  Off: every call takes the padded layout.
-    void set_packing(bool on) { packing_ = on; }
-    bool packing() const { return packing_; }
+    // Ragged batches run over the kept tokens only (embed / logits).  0: never (every call takes the padded layout);
+    // 1 (default): the host-pointer entry points, whose mask is already on the host; 2: the device-pointer entry points too --
+    // those then read 4 bytes per sentence back and SYNCHRONISE `stream` once per call before the layers are enqueued (not
+    // graph-capturable, blocks the calling thread behind whatever the stream holds), which is why it is not the default.
+    void set_packing(int mode) { packing_ = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+    int packing() const { return packing_; }
 
-    // All pointers are DEVICE pointers on this model's device; work is enqueued
-    // on `stream` and not synchronised.  ids/mask/type_ids: u32 [batch, seq].
+    // All pointers are DEVICE pointers on this model's device; work is enqueued on `stream` and not synchronised
+    // (exception: packing mode 2, above).  ids/mask/type_ids: u32 [batch, seq].
     // R1: get_hidden_states_batch_from_ids (cpu/encoder/traits.rs:66-139).
     void hidden_states(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids,
                        int64_t batch, int seq, float mask_value, float* out, hipStream_t stream);
@@ -247,7 +251,7 @@ private:
     int device_ = 0;
     size_t weight_bytes_ = 0;
     std::atomic<int64_t> chunk_tokens_{262144};
-    std::atomic<bool> packing_{true};
+    std::atomic<int> packing_{1};
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,

@@ -1099,6 +1099,23 @@ inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int6
            al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && !tune::no_mid_route();
 }
 
+// gemm_flex.hip takes the mid-size calls (EPI_GELU_LIBM, a tuning-build epilogue, stays on the 64 x 64 tiles)
+inline bool flex_route_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
+                          const float* bias, const float* R)
+{
+    return !tune::no_flex_route() && gemm_flex_shape_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R);
+}
+
+// Physical K slices of a call whose result is DEFINED as the in-order sum of `logical` slices: all of them as separate workgroups
+// (slabs + a reduce launch) or none (the workgroup adds its slices itself), whichever the cost estimate says is faster; the
+// slabs cost their bytes twice (written, then read by the reduce kernel).
+inline int flex_physical_split(int M, int N, int K, int logical)
+{
+    if (logical <= 1) return 1;
+    const double slab_cycles = 2.0 * (logical - 1) * (double)M * N * 4.0 / 2000.0 + 4000.0;
+    return gemm_flex_cost(M, N, K, logical) + slab_cycles < gemm_flex_cost(M, N, K, 1) ? logical : 1;
+}
+
 template <int EPI>
 hipError_t launch_mid(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
                       int64_t ldy, int M, int N, int K, hipStream_t stream, const GemmScratch& scratch)
@@ -1117,6 +1134,18 @@ hipError_t launch_mid(const float* A, int64_t lda, const float* W, const float* 
         const int64_t quads = (int64_t)M * (N / 4);
         hipLaunchKernelGGL(mid_reduce_kernel<EPI>, dim3((unsigned)std::min<int64_t>(2048, (quads + 255) / 256)), dim3(256), 0, stream, scratch.p,
                            ksplit, bias, R, ldr, Y, ldy, M, N);
+        return hipGetLastError();
+    }
+    // one workgroup per CU on a tile chosen for this call (gemm_flex.hip); K slices only while the call is too small to fill the
+    // chip without them -- a workgroup that owns all the slices adds them in the reduce kernel's order, so the result is the same
+    if (EPI != EPI_GELU_LIBM && flex_route_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R)) {
+        const int phys = flex_physical_split(M, N, K, ksplit);
+        if (phys == 1) return launch_gemm_flex(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, (GemmEpilogue)EPI, 1, ksplit, nullptr, stream);
+        const hipError_t e = launch_gemm_flex(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, (GemmEpilogue)EPI, phys, ksplit, scratch.p, stream);
+        if (e != hipSuccess) return e;
+        const int64_t quads = (int64_t)M * (N / 4);
+        hipLaunchKernelGGL(mid_reduce_kernel<EPI>, dim3((unsigned)std::min<int64_t>(2048, (quads + 255) / 256)), dim3(256), 0, stream, scratch.p,
+                           phys, bias, R, ldr, Y, ldy, M, N);
         return hipGetLastError();
     }
     const dim3 grid((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : (tune::mid_grid_override() > 0 ? tune::mid_grid_override() : kMidResident)));
@@ -1236,7 +1265,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
     // f32-on-bf16 mode, large calls with a long K (FC2): the split kernel with the residual epilogue + the LayerNorm kernel (the
     // fused LayerNorm tile has no split form yet; at K = 384 -- out-proj -- the fused f32 tile is the faster of the two: 0.62
     // against 0.60 + 0.17 ms)
-    if (R && gamma && beta && get_f32_on_bf16() && M >= split_min_rows() && N % BN == 0 && K % 64 == 0 && K >= 1024 && gemm_residual_layernorm_supported(N, K) && ldy == N && lda % 4 == 0 && al16(A) && al16(W) &&
+    if (R && gamma && beta && get_f32_on_bf16() && M >= split_min_rows() && N % BN == 0 && K % 64 == 0 && K >= 1024 && gemm_residual_layernorm_supported(N, K) && ldy == N && lda % 4 == 0 && ldr % 4 == 0 && al16(A) && al16(W) && al16(R) && al16(Y) && al16(bias) &&
         (int64_t)BM * lda * 4 < ((int64_t)1 << 31) && (int64_t)BN * K * 4 < ((int64_t)1 << 31)) {
         const hipError_t e = launch_gemm_split(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, EPI_BIAS_RESIDUAL, stream);
         if (e != hipSuccess) return e;
@@ -1248,9 +1277,10 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
         if ((size_t)ksplit * M * N <= scratch.floats) {
             const int m_tiles = ((int)M + MID_BM - 1) / MID_BM, n_tiles = (N + MID_BN - 1) / MID_BN;
             const int total = m_tiles * n_tiles * ksplit;
-            // up to 64 rows: the slices' partial tiles from the few-rows kernel (K over the sixteen waves of a workgroup: a
+            // up to few_rows_max() rows (256 for models up to 512 wide): the slices' partial tiles from the few-rows kernel (K over the sixteen waves of a workgroup: a
             // 3-step chain per wave instead of the tile kernel's 12-step one -- FC2 + LayerNorm of one sentence 15.5 -> 10.5 us)
             const int k_len = K / ksplit;
+            int slabs = ksplit;  // slabs the reduce kernel adds
             if (M <= few_rows_max(N, K) && ksplit > 1 && N % 32 == 0 && k_len % 128 == 0 && (int64_t)64 * lda * 4 < ((int64_t)1 << 31) &&
                 (int64_t)32 * K * 4 < ((int64_t)1 << 31) && !tune::no_few_rows_route() && !tune::no_few_rows_k_slices()) {
                 constexpr int LDS = 16 * 32 * 32 * 4;
@@ -1265,12 +1295,17 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
             } else if (get_f32_on_bf16() && !tune::mid_split_off()) {
                 const hipError_t e = launch_gemm_mid_split(A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, ksplit, scratch.p, EPI_BIAS, stream);
                 if (e != hipSuccess) return e;
+            } else if (flex_route_ok(M, N, K, lda, ldy, ldr, A, W, Y, bias, R)) {
+                // (gemm_flex.hip: slabs of the physical slices; a workgroup that owns all the slices has added them in slice order)
+                slabs = flex_physical_split((int)M, N, K, ksplit);
+                const hipError_t e = launch_gemm_flex(A, lda, W, nullptr, nullptr, 0, Y, ldy, (int)M, N, K, EPI_BIAS, slabs, ksplit, scratch.p, stream);
+                if (e != hipSuccess) return e;
             } else
             hipLaunchKernelGGL((gemm_nt_f32_mid<EPI_BIAS, true>), dim3((unsigned)std::min(total, tune::mid_one_workgroup_per_tile() ? total : kMidResident)),
                                dim3(256), 0, stream, A, lda, W, bias, R, ldr, Y, ldy, (int)M, N, K, m_tiles, ksplit, scratch.p, n_tiles, total);
             const dim3 rgrid((unsigned)((M + 3) / 4));
 #define KJ_MID_LN(NCH)                                                                                                              \
-    hipLaunchKernelGGL(mid_reduce_ln_kernel<NCH>, rgrid, dim3(256), 0, stream, scratch.p, ksplit, bias, R, ldr, gamma, beta, eps, Y, \
+    hipLaunchKernelGGL(mid_reduce_ln_kernel<NCH>, rgrid, dim3(256), 0, stream, scratch.p, slabs, bias, R, ldr, gamma, beta, eps, Y, \
                        ldy, (int)M, N)
             if (N <= 256) KJ_MID_LN(1);
             else if (N <= 512) KJ_MID_LN(2);

@@ -116,7 +116,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncod
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on)
 {
     if (!enc) return KJARNI_ERROR_NULL_POINTER;
-    enc->model->set_packing(on != 0);
+    enc->model->set_packing((int)on);
     return KJARNI_OK;
 }
 

@@ -71,6 +71,16 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
                                           float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream,
                                           GemmScratch scratch = GemmScratch());
 
+// The mid-size projections' kernel (gemm_flex.hip; gemm.hip's route for calls of a few hundred to a few thousand rows calls it):
+// one workgroup per CU, tile shape chosen per call.  ksplit = physical K slices (1 or logical_slices), logical_slices = slices in
+// the result's summation order; partials != null: raw sums to slabs [ksplit][M][N] for the reduce kernels, else Y with the epilogue.
+bool gemm_flex_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
+                        const float* bias, const float* R);
+double gemm_flex_cost(int M, int N, int K, int ksplit);
+hipError_t launch_gemm_flex(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
+                            int64_t ldy, int M, int N, int K, GemmEpilogue epi, int ksplit, int logical_slices, float* partials,
+                            hipStream_t stream);
+
 // Opt-in (process-wide; default off, or KJARNI_HIP_F32_ON_BF16=1): the large-batch projections compute their f32 products on the
 // bf16 matrix cores -- every operand split exactly into three bf16 pieces, six of the nine cross products (gemm.hip, "fp32
 // products on the bf16 matrix cores").  f32 in, f32 out, f32-level error; 2-3x the f32 MFMA rate.

@@ -63,9 +63,10 @@ class HipEncoder:
     def set_chunk_tokens(self, tokens: int):
         check_error(lib().kjarni_hip_encoder_set_chunk_tokens(self._h, int(tokens)))
 
-    def set_packing(self, on: bool):
-        """Ragged batches over the kept tokens only (default on); off = the padded layout for every call."""
-        check_error(lib().kjarni_hip_encoder_set_packing(self._h, 1 if on else 0))
+    def set_packing(self, mode):
+        """Ragged batches over the kept tokens only: 0 / False never, 1 / True (default) the host-array entry points, 2 also
+        the device-pointer ones (embed_dev / logits_dev then synchronise their stream once per call: kjarni_hip.h)."""
+        check_error(lib().kjarni_hip_encoder_set_packing(self._h, int(mode)))
 
     KINDS = ("embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm", "gemm_fc1", "gemm_fc2",
              "pool", "head", "rope")

@@ -277,6 +277,26 @@ def synthetic_pairs(n: int, seq: int, vocab: int = 30522, seed: int = 1, qlen: i
     return ids, mask, types
 
 
+def synthetic_pairs_rows(start: int, count: int, seq: int, vocab: int = 30522, seed: int = 1, qlen: int = 16, block: int = 1024):
+    """Rows start .. start + count of ONE fixed synthetic pair set (the layout of synthetic_pairs), generated in blocks of
+    `block` rows seeded by (seed, block index): every rank of a sharded run builds only its own rows, and the rows are the same
+    at every world size (strong scaling over the same 100 000 pairs)."""
+    ids = np.empty((count, seq), np.uint32)
+    b0, b1 = start // block, (start + count + block - 1) // block if count else start // block
+    for b in range(b0, b1):
+        rows = np.random.default_rng([seed, b]).integers(1000, vocab, size=(block, seq), dtype=np.int64).astype(np.uint32)
+        lo, hi = max(start, b * block), min(start + count, (b + 1) * block)
+        ids[lo - start:hi - start] = rows[lo - b * block:hi - b * block]
+    ids[:, 0] = 101
+    q_end = min(1 + qlen, seq - 2)
+    ids[:, q_end] = 102
+    ids[:, seq - 1] = 102
+    types = np.zeros((count, seq), np.uint32)
+    types[:, q_end + 1:] = 1
+    mask = np.ones((count, seq), np.uint32)
+    return ids, mask, types
+
+
 GOLDEN_TOKENIZER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_small.json")
 
 

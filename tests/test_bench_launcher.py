@@ -60,3 +60,15 @@ def test_single_rank_has_no_collective_and_can_skip_the_rerank_leg():
     assert r["n_gpus"] == 1 and "collective" not in r and "rerank" not in r
     r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--sentences", "10", "--pairs", "77"])
     assert r["rerank"]["pairs_per_step"] == 77 and r["rerank"]["n_gpus"] == 1
+
+
+def test_eight_ranks_as_the_driver_launches_them():
+    """The driver's 8-GPU form (--gpus 8, one rank per GPU) on the CPU stub: the communicator spans 8 ranks, the embed leg is
+    weak (rows per step = 8 x sentences), the rerank leg strong over 100 003 pairs (uneven blocks: 3 ranks hold one pair more),
+    every rank builds only its own rows, and the host-thread pool of a rank is its share of the granted CPUs."""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "1", "--dry-run-cpu", "--sentences", "33", "--pairs", "100003"])
+    assert r["n_gpus"] == 8 and r["config"]["rows_per_step"] == 8 * 33 and r["scaling"] == "weak"
+    assert r["collective"]["ranks"] == 8 and r["collective"]["allreduce_of_ones"] == 8
+    leg = r["rerank"]
+    assert leg["n_gpus"] == 8 and leg["scaling"] == "strong" and leg["pairs_per_step"] == 100003 and leg["pairs_per_gpu"] == 12501
+    assert 1 <= r["host_threads_per_rank"] <= max(1, (os.cpu_count() or 8) // 8)

@@ -151,3 +151,19 @@ def test_world_size_2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_world_size_3_uneven_rows_gloo():
+    """An N that no world size divides (100 003 rows over 3 ranks: 33 335 + 33 334 + 33 334): blocks padded to the common size for the
+    ONE collective and compacted after it, through the product entry points (full batch on every rank and shard only)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, [2, 100003], q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True), (2, True)]

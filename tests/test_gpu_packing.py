@@ -145,7 +145,8 @@ def test_packed_chunks_cover_the_call(minilm):
 
 
 def test_device_pointer_calls_pack_too(minilm):
-    """kjarni_hip_encoder_embed on device pointers: the lengths come from a device-side scan of the mask."""
+    """kjarni_hip_encoder_embed on device pointers, packing mode 2 (opt-in: the call synchronises its stream): the lengths
+    come from a device-side scan of the mask.  In the default mode the same call takes the padded layout."""
     import torch
     enc, orc = minilm
     ids, mask = synth.synthetic_ids(150, 128, seed=31, ragged=True)
@@ -156,8 +157,18 @@ def test_device_pointer_calls_pack_too(minilm):
     stream = torch.cuda.current_stream().cuda_stream
     enc.embed_dev(ti.data_ptr(), tm.data_ptr(), 150, 128, out.data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    got = out.cpu().numpy()
+    padded = out.cpu().numpy()
+    assert float(np.abs(padded - orc.embed_batch(ids, mask)).max()) < TOL
+    enc.set_packing(2)
+    try:
+        out.zero_()
+        enc.embed_dev(ti.data_ptr(), tm.data_ptr(), 150, 128, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+    finally:
+        enc.set_packing(1)
     assert float(np.abs(got - orc.embed_batch(ids, mask)).max()) < TOL
+    assert float(np.abs(got - padded).max()) < 1e-6
     assert float(np.abs(got - enc.embed(ids, mask)).max()) < 1e-6   # host-pointer call, same packed layout
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Crossover of the few-rows kernel (row groups over the grid) against the 64 x 64-tile route: whole forwards at several call
 # sizes with the bound moved (tuning build, GEMM_VARIANT = 1000 + rows).
+set -u
 export KJARNI_FFI_LIB=kjarni_amd/lib/libkjarni_ffi_tuning.so
 for shape in "1 128" "2 128" "4 128" "8 128" "16 128" "32 128"; do
   set -- $shape

@@ -11,5 +11,7 @@ run b GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_L
 run f FETCH_SIZE
 run w WRITE_SIZE
 run d GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCP_PENDING_STALL_CYCLES_sum
-python tools/pmc_summary.py gpurun_out/pmcs | grep -A28 "cosine_scan_mfma" | tee gpurun_out/pmcs/summary.txt
-find gpurun_out/pmcs -name "*.csv" -delete
+# (the raw CSVs go only once the summary exists: a failed summary keeps the run)
+if python tools/pmc_summary.py gpurun_out/pmcs > gpurun_out/pmcs/summary_all.txt && grep -A28 "cosine_scan_mfma" gpurun_out/pmcs/summary_all.txt | tee gpurun_out/pmcs/summary.txt | grep -q .; then
+  find gpurun_out/pmcs -name "*.csv" -delete
+fi

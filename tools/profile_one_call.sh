@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 per-kernel table of one 28-token sentence through the encoder (tools/mid_probe.py 1 28)
+set -u
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_x
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_x -- python tools/mid_probe.py 1 28 500 > gpurun_out/prof_x.log 2>&1

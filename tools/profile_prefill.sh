@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 per-kernel table of a 2 048-token prompt (tools/prefill_probe.py)
+set -u
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_pf
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pf -- python tools/prefill_probe.py 2048 5 > gpurun_out/prof_pf.log 2>&1
