@@ -1113,7 +1113,7 @@ inline int flex_physical_split(int M, int N, int K, int logical)
 {
     if (logical <= 1) return 1;
     const double slab_cycles = 2.0 * (logical - 1) * (double)M * N * 4.0 / 2000.0 + 4000.0;
-    return gemm_flex_cost(M, N, K, logical) + slab_cycles < gemm_flex_cost(M, N, K, 1) ? logical : 1;
+    return gemm_flex_cost(M, N, K, logical, logical) + slab_cycles < gemm_flex_cost(M, N, K, 1, logical) ? logical : 1;
 }
 
 template <int EPI>

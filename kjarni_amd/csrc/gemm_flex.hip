@@ -60,8 +60,13 @@ struct Flex {
     static constexpr int MFMAS = 4 * RA * CB;  // per phase
 };
 
-// One workgroup per CU: every launch asks for more than half of the CU's 160 KiB.
-constexpr int kFlexLdsBytes = 104 * 1024;
+// Registers: the smaller tiles are compiled for two waves per SIMD (<= 256 registers), so that two workgroups share a CU where
+// their LDS fits and one's epilogue runs under the other's K-loop; the larger ones take the whole file (one wave per SIMD).
+constexpr int flex_waves_per_simd(int ra, int cb, bool vslices)
+{
+    return vslices ? (ra * cb <= 8 ? 2 : 1) : ((ra == 1 && cb <= 9) || (ra == 2 && cb <= 6) ? 2 : 1);
+}
+constexpr int kFlexLdsBytes = 104 * 1024;  // (tuning build: the claim that forces one workgroup per CU)
 
 template <int RA, int CB>
 struct FlexFrag {
@@ -70,7 +75,7 @@ struct FlexFrag {
 
 // DIAG (tuning build, tools/flex_probe.py): knock-outs that show where a tile's time goes -- tuning.h
 template <int RA, int CB, bool VSLICES, int DIAG = 0>
-__global__ __launch_bounds__(256, 1) void gemm_nt_f32_flex(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+__global__ __launch_bounds__(256, flex_waves_per_simd(RA, CB, VSLICES)) void gemm_nt_f32_flex(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                           int64_t ldw, const float* __restrict__ bias, const float* R, int64_t ldr,
                                                           float* Y, int64_t ldy, int M, int N, int k_len, int ksplit, int vslices,
                                                           int epi, int partial, int n_tiles, int total)
@@ -116,7 +121,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_f32_flex(const float* __restri
     for (int i = 0; i < T::NB; ++i) offW[i] = (uint32_t)(((int64_t)(r0 + 32 * i) * ldw + c8 * 4) * 4);
     f32x4 ga[T::NA], gb[T::NB];
     auto ld16 = [](__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, int k0) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, k0 * 4, 0));
+        // (DIAG 6 / 7 / 8: the cache-policy bits of the staging loads -- sc1 = 16, sc0 = 1, nt = 2)
+        constexpr int AUX = DIAG == 6 ? 16 : DIAG == 7 ? 1 : DIAG == 8 ? 2 : 0;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, k0 * 4, AUX));
     };
     // (a row's 16-byte chunk c sits at chunk c ^ ((row >> 1) & 7); rows 32 apart share the term)
     const int st_off = r0 * FROW + ((c8 ^ ((r0 >> 1) & 7)) << 2);
@@ -314,40 +321,6 @@ struct FlexChoice {
     double cost = 0.0;
 };
 
-// Estimated time of a call in MFMA-cycle units: rounds x (tile's matrix time + its fixed cost), matrix time not below what
-// staging its operands through L2 allows.  The constants are measured (tools/flex_probe.py).
-inline double flex_cost(int M, int N, int k_len, int ksplit, int ra, int cb)
-{
-    const int bm = 64 * ra, bn = 16 * cb;
-    const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ksplit;
-    const int64_t rounds = (tiles + 255) / 256;
-    const double mfma = (double)bm * bn * k_len / 128.0 * 1.07;
-    const double stage = (double)(bm + ((bn + 31) / 32) * 32) * k_len * 4.0 / 14.0;
-    return (double)rounds * (std::max(mfma, stage) + 6000.0 + 0.012 * bm * bn);
-}
-
-constexpr int kFlexCb[] = {3, 4, 6, 8, 9, 12};
-
-inline FlexChoice flex_choose(int M, int N, int k_len, int ksplit)
-{
-    FlexChoice best;
-#ifdef KJARNI_TUNING
-    if (tune::flex_config_override() > 0) {
-        best.ra = tune::flex_config_override() / 100;
-        best.cb = tune::flex_config_override() % 100;
-        best.cost = flex_cost(M, N, k_len, ksplit, best.ra, best.cb);
-        return best;
-    }
-#endif
-    for (int ra = 1; ra <= 2; ++ra)
-        for (int cb : kFlexCb) {
-            if (16 * cb > N && cb != kFlexCb[0]) continue;
-            const double c = flex_cost(M, N, k_len, ksplit, ra, cb);
-            if (best.ra == 0 || c < best.cost) best = FlexChoice{ra, cb, c};
-        }
-    return best;
-}
-
 template <int RA, int CB, bool VS, int DIAG = 0>
 hipError_t flex_launch_one(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* R, int64_t ldr,
                            float* Y, int64_t ldy, int M, int N, int k_len, int ksplit, int vslices, int epi, int partial,
@@ -368,9 +341,86 @@ hipError_t flex_launch_one(const float* A, int64_t lda, const float* W, int64_t 
     const int n_tiles = (N + T::BN - 1) / T::BN;
     const int64_t total = (int64_t)((M + T::BM - 1) / T::BM) * n_tiles * ksplit;
     if (total > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_nt_f32_flex<RA, CB, VS, DIAG>), dim3((unsigned)total), dim3(256), kFlexLdsBytes, stream, A, lda, W, ldw, bias, R, ldr,
+    // (the LDS a tile needs, so that the smaller tiles share a CU; the tuning build can claim more than half a CU instead)
+    const int lds = tune::flex_one_workgroup_per_cu() ? kFlexLdsBytes : T::LDS_FLOATS * 4;
+    hipLaunchKernelGGL((gemm_nt_f32_flex<RA, CB, VS, DIAG>), dim3((unsigned)total), dim3(256), lds, stream, A, lda, W, ldw, bias, R, ldr,
                        Y, ldy, M, N, k_len, ksplit, vslices, epi, partial, n_tiles, (int)total);
     return hipGetLastError();
+}
+
+constexpr int kFlexCb[] = {3, 4, 6, 8, 9, 12};
+constexpr int kFlexConfigs = 12;
+
+// Workgroups of a tile kernel one CU holds at once (registers, LDS): asked of the runtime once per process and kernel.
+template <int RA, int CB, bool VS>
+int flex_residency_of()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm_nt_f32_flex<RA, CB, VS, 0>), 256,
+                                                     Flex<RA, CB>::LDS_FLOATS * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    return n < 1 ? 1 : (n > 4 ? 4 : n);
+}
+
+struct FlexResidency {
+    int wg[2][kFlexConfigs];  // [vslices][config]
+    FlexResidency()
+    {
+#define KJ_RES(I_, RA_, CB_)                               \
+    wg[0][I_] = flex_residency_of<RA_, CB_, false>();      \
+    wg[1][I_] = flex_residency_of<RA_, CB_, true>();
+        KJ_RES(0, 1, 3) KJ_RES(1, 1, 4) KJ_RES(2, 1, 6) KJ_RES(3, 1, 8) KJ_RES(4, 1, 9) KJ_RES(5, 1, 12)
+        KJ_RES(6, 2, 3) KJ_RES(7, 2, 4) KJ_RES(8, 2, 6) KJ_RES(9, 2, 8) KJ_RES(10, 2, 9) KJ_RES(11, 2, 12)
+#undef KJ_RES
+    }
+};
+
+inline int flex_residency(int ra, int cb, bool vs)
+{
+    static const FlexResidency table;  // (one device kind per process: every GPU of a node is the same part)
+    int ci = 0;
+    while (ci < 6 && kFlexCb[ci] != cb) ++ci;
+    return table.wg[vs ? 1 : 0][(ra - 1) * 6 + (ci < 6 ? ci : 0)];
+}
+
+// Estimated time of a call in shader cycles (fitted to tools/flex_probe.py on the MiniLM shapes, 1 024 .. 8 192 rows): the
+// busiest CU's tiles at the K-loop's measured efficiency (1.2 x the MFMA issue time; 1.3 x for the one-wave-per-SIMD tiles) --
+// not below what staging the operands through L2 allows --, a fixed cost per round of resident workgroups (launch ramp,
+// prologue, the epilogue's own instructions) and the last round's output draining at ~3 TB/s with nothing to hide behind.
+inline double flex_cost(int M, int N, int k_len, int ksplit, int ra, int cb, bool vs)
+{
+    const int bm = 64 * ra, bn = 16 * cb;
+    const int64_t tiles = (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ksplit;
+    const int wg = tune::flex_one_workgroup_per_cu() ? 1 : flex_residency(ra, cb, vs);
+    const int64_t per_cu = (tiles + 255) / 256, rounds = (tiles + 256 * wg - 1) / (256 * wg);
+    const double mfma = (double)bm * bn * k_len / 128.0 * (flex_waves_per_simd(ra, cb, vs) == 1 ? 1.3 : 1.2);
+    const double stage = (double)(bm + ((bn + 31) / 32) * 32) * k_len * 4.0 / 14.0;
+    const int64_t last = tiles - (rounds - 1) * 256 * wg;
+    const double tail = (double)std::min<int64_t>(last, 256 * wg) * bm * bn * 4.0 / 1300.0;
+    return (double)per_cu * std::max(mfma, stage) + (double)rounds * 7000.0 + tail;
+}
+
+inline FlexChoice flex_choose(int M, int N, int k_len, int ksplit, bool vs)
+{
+    FlexChoice best;
+#ifdef KJARNI_TUNING
+    if (tune::flex_config_override() > 0) {
+        best.ra = tune::flex_config_override() / 100;
+        best.cb = tune::flex_config_override() % 100;
+        best.cost = flex_cost(M, N, k_len, ksplit, best.ra, best.cb, vs);
+        return best;
+    }
+#endif
+    for (int ra = 1; ra <= 2; ++ra)
+        for (int cb : kFlexCb) {
+            if (16 * cb > N && cb != kFlexCb[0]) continue;
+            if (vs && ra == 2 && cb == 12) continue;  // (two register sets of 96 accumulators: spills)
+            const double c = flex_cost(M, N, k_len, ksplit, ra, cb, vs);
+            if (best.ra == 0 || c < best.cost) best = FlexChoice{ra, cb, c};
+        }
+    return best;
 }
 
 }  // namespace
@@ -384,7 +434,10 @@ bool gemm_flex_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64
            (int64_t)224 * K * 4 < ((int64_t)1 << 31);
 }
 
-double gemm_flex_cost(int M, int N, int K, int ksplit) { return flex_choose(M, N, K / ksplit, ksplit).cost; }
+double gemm_flex_cost(int M, int N, int K, int ksplit, int logical_slices)
+{
+    return flex_choose(M, N, K / ksplit, ksplit, logical_slices / ksplit > 1).cost;
+}
 
 // ksplit: physical K slices (1, or the logical count); logical_slices: how many slices the result's summation order has
 // (1 or 4: mid_ksplit(N, K)).  partial: raw sums to slabs P[ksplit][M][N] (no bias / epilogue) for mid_reduce_*.
@@ -395,15 +448,15 @@ hipError_t launch_gemm_flex(const float* A, int64_t lda, const float* W, const f
     if (M <= 0) return hipSuccess;
     const int k_len = K / ksplit;
     const int vslices = logical_slices / ksplit;  // slices a workgroup adds up itself
-    const FlexChoice ch = flex_choose(M, N, k_len, ksplit);
+    const FlexChoice ch = flex_choose(M, N, k_len, ksplit, vslices > 1);
     const int partial = partials != nullptr;
     float* out = partial ? partials : Y;
 #ifdef KJARNI_TUNING
 #define KJ_FLEX_DIAG(RA_, CB_, D_)                                                                                                     \
     if (ch.ra == RA_ && ch.cb == CB_ && tune::flex_knockout() == D_ && vslices <= 1)                                                    \
         return flex_launch_one<RA_, CB_, false, D_>(A, lda, W, K, bias, R, ldr, out, ldy, M, N, k_len, ksplit, 1, (int)epi, partial, stream);
-    KJ_FLEX_DIAG(2, 9, 1) KJ_FLEX_DIAG(2, 9, 2) KJ_FLEX_DIAG(2, 9, 3) KJ_FLEX_DIAG(2, 9, 4) KJ_FLEX_DIAG(2, 9, 5)
-    KJ_FLEX_DIAG(2, 12, 1) KJ_FLEX_DIAG(2, 12, 2) KJ_FLEX_DIAG(2, 12, 3) KJ_FLEX_DIAG(2, 12, 4) KJ_FLEX_DIAG(2, 12, 5)
+    KJ_FLEX_DIAG(2, 9, 1) KJ_FLEX_DIAG(2, 9, 2) KJ_FLEX_DIAG(2, 9, 3) KJ_FLEX_DIAG(2, 9, 4) KJ_FLEX_DIAG(2, 9, 5) KJ_FLEX_DIAG(2, 9, 6) KJ_FLEX_DIAG(2, 9, 7) KJ_FLEX_DIAG(2, 9, 8)
+    KJ_FLEX_DIAG(2, 12, 1) KJ_FLEX_DIAG(2, 12, 2) KJ_FLEX_DIAG(2, 12, 3) KJ_FLEX_DIAG(2, 12, 4) KJ_FLEX_DIAG(2, 12, 5) KJ_FLEX_DIAG(2, 12, 6) KJ_FLEX_DIAG(2, 12, 7) KJ_FLEX_DIAG(2, 12, 8)
 #undef KJ_FLEX_DIAG
 #endif
 #define KJ_FLEX(RA_, CB_)                                                                                                             \

@@ -76,7 +76,7 @@ hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const flo
 // the result's summation order; partials != null: raw sums to slabs [ksplit][M][N] for the reduce kernels, else Y with the epilogue.
 bool gemm_flex_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64_t ldr, const float* A, const float* W, const float* Y,
                         const float* bias, const float* R);
-double gemm_flex_cost(int M, int N, int K, int ksplit);
+double gemm_flex_cost(int M, int N, int K, int ksplit, int logical_slices);  // estimated shader cycles of the call
 hipError_t launch_gemm_flex(const float* A, int64_t lda, const float* W, const float* bias, const float* R, int64_t ldr, float* Y,
                             int64_t ldy, int M, int N, int K, GemmEpilogue epi, int ksplit, int logical_slices, float* partials,
                             hipStream_t stream);

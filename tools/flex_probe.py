@@ -76,6 +76,12 @@ for M in rows:
                     line += f"(ERR {err_c:.1e})"
                 if best is None or ms_c < best[0]:
                     best = (ms_c, ra, cb)
-            line += f" | best {64 * best[1]}x{16 * best[2]} {best[0] * 1e3:.2f} us"
+            line += f" | best {64 * best[1]}x{16 * best[2]} {best[0] * 1e3:.2f} us | one workgroup per CU:"
+            for ra, cb in CONFIGS:
+                if 16 * cb > N:
+                    continue
+                ops.set_gemm_variant(3000 + 100 * ra + cb)
+                _, ms_c, err_c = run(name, K, N, epi, ln, M, False)
+                line += f" {64 * ra}x{16 * cb}:{ms_c * 1e3:.1f}"
             ops.set_gemm_variant(0)
         print(line, flush=True)
