@@ -277,6 +277,17 @@ KjarniErrorCode kjarni_hip_cosine_topk(int32_t device, const float* scores_dev, 
                                        int64_t n_docs, int32_t k, void* workspace_dev,
                                        int64_t* idx_out_dev, float* score_out_dev, void* stream);
 
+/* Scan + selection in one call on device pointers, enqueued on `stream`: per-query top-k with no caller-visible score
+ * array.  One query over dim 128 / 256 / 384 / 512 / 768 / 1024 with k <= 256 runs ONE fused pass (every wave keeps its
+ * best keys in registers; the scores never exist in memory) and one small merge launch; anything else runs the two calls
+ * above inside the workspace.  Same order and the same scores, bit for bit, as kjarni_hip_cosine_scores +
+ * kjarni_hip_cosine_topk.  workspace_dev: kjarni_hip_cosine_search_workspace_bytes(n_queries, n_docs, dim, k) bytes. */
+size_t kjarni_hip_cosine_search_workspace_bytes(int32_t n_queries, int64_t n_docs, int32_t dim, int32_t k);
+KjarniErrorCode kjarni_hip_cosine_search(int32_t device, const float* queries_dev, int32_t n_queries,
+                                         const float* corpus_dev, int64_t n_docs, int32_t dim,
+                                         KjarniHipCosineMode mode, int32_t k, void* workspace_dev,
+                                         int64_t* idx_out_dev, float* score_out_dev, void* stream);
+
 /* Whole search with host buffers (scan + top-k + copies + synchronise):
  * idx_out int64 [n_queries, k], score_out f32 [n_queries, k]; *n_hits_out =
  * min(k, n_docs) (0 for a Segment-mode query whose norm is < 1e-9 is reported
@@ -285,6 +296,12 @@ KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, const float* queri
                                               const float* corpus, int64_t n_docs, int32_t dim,
                                               KjarniHipCosineMode mode, int32_t k, int64_t* idx_out,
                                               float* score_out, int64_t* n_hits_out);
+
+/* Where the calling thread's last kjarni_searcher_search* / kjarni_hip_index_search call spent its time, in microseconds:
+ * out[0] re-opening the index, out[1] the scan over the index's device image (lookup, copies, two launches, wait), out[2] of it
+ * between the query's H2D copy and the hits' arrival, out[3] the whole call; the rest is host work (BM25, rank fusion, reading
+ * the hits' documents and metadata, for a Searcher the query's tokenisation and embedding).  Up to n <= 4 values. */
+void kjarni_hip_search_breakdown(double* out, size_t n);
 
 /* ---- tokenizer -----------------------------------------------------------------
  * The reference tokenises on the host with the HF `tokenizers` crate configured at

@@ -467,6 +467,10 @@ SIGNATURES = {
     "kjarni_hip_cosine_topk_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32]),
     "kjarni_hip_cosine_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
+    "kjarni_hip_search_breakdown": (None, [POINTER(C.c_double), c_size_t]),
+    "kjarni_hip_cosine_search_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32, c_int32]),
+    "kjarni_hip_cosine_search": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "kjarni_hip_cosine_search_host": (c_int32, [c_int32, _f32p, c_int32, _f32p, c_int64, c_int32, c_int32,
                                                 c_int32, _i64p, _f32p, _i64p]),
     "kjarni_tokenizer_load": (c_int32, [c_char_p, c_size_t, POINTER(c_void_p)]),

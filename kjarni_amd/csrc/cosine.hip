@@ -289,14 +289,245 @@ __device__ __forceinline__ void bitonic_merge_desc(uint64_t* keys, int n, int ti
     __syncthreads();
 }
 
-// One block reduces candidates [blk*seg, +seg), seg = TK_TILE*tiles_per_block, of query blockIdx.y to its
-// best KPAD keys (descending).  Level 0 reads float scores (index = position), later levels read
-// keys.  Keys >= `upper` are ignored (multi-pass k > 1024).
+// ---------------------------------------------------------------------------------------------------------------------
+// One query, scan and selection in ONE pass: the scores never exist in memory.
+//
+// VectorStore::search / Segment::search_vectors score every document and then sort (kjarni-search/src/vector.rs:150-166,
+// kjarni-rag/src/segment.rs:307-337); the two-launch form above writes 4 bytes per document and reads them back -- for one
+// query over 10^5 documents the selection launches cost twice the scan.  Here every wave of the streaming kernel keeps the best
+// 64 S keys it has seen IN REGISTERS: lane l, slot s holds the (64 s + l)-th best key of the wave, sorted descending, and the
+// smallest kept key is a wave-uniform threshold.  A group's R scores are turned into keys (orderable score << 32 | ~index: score
+// descending, ties by ascending index -- the reference's stable sort) and only a key above the threshold is inserted: a ballot
+// finds its place, the tail shifts down by one lane.  Insertions are rare once the threshold has risen (about K ln(n / K) of
+// a wave's n rows), and the loop has no barrier, so the stream runs at the rate of the score-only kernel.  At the end the four
+// waves of a workgroup merge through LDS (one bitonic sort of 4 x 64 S keys) and the workgroup writes its best KOUT keys; a
+// last small launch (topk_reduce_kernel on keys) merges the workgroups' lists and decodes.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int S>
+struct WaveTopK {
+    uint64_t k[S];
+    uint64_t thr;  // wave-uniform: the smallest kept key (slot S - 1 of lane 63); 0 while the list is not full
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) k[s] = 0ull;
+        thr = 0ull;
+    }
+    // c: wave-uniform, c > thr
+    __device__ __forceinline__ void insert(uint64_t c, int lane)
+    {
+        int pos = 0;  // keys above c (all keys are distinct: the index is part of the key)
+#pragma unroll
+        for (int s = 0; s < S; ++s) pos += __popcll(__ballot(k[s] > c));
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            uint64_t up = __shfl_up(k[s], 1, kWave);
+            if (s > 0) {
+                const uint64_t carry = readlane64(k[s - 1], 63);
+                up = lane == 0 ? carry : up;
+            }
+            const int idx = s * 64 + lane;
+            k[s] = idx > pos ? up : (idx == pos ? c : k[s]);
+        }
+        thr = readlane64(k[S - 1], 63);
+    }
+};
+
+template <int NV4, int R, int S>
+__global__ __launch_bounds__(256) void cosine_search_stream_kernel(const float* __restrict__ query, const float* __restrict__ corpus,
+                                                                   int64_t n_groups, int64_t n_docs, int mode, int kout,
+                                                                   uint64_t* __restrict__ cand)
+{
+    static_assert((R * NV4) % 64 == 0, "a group must be a whole number of wave-wide loads");
+    constexpr int T = R * NV4 / 64;
+    constexpr int DIM = NV4 * 4;
+    constexpr int KW = 64 * S;
+    __shared__ uint64_t keys[4 * KW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    f32x4 q[T];
+    float qn2;
+    {
+        const f32x4* qv = reinterpret_cast<const f32x4*>(query);
+        float s = 0.0f;
+        for (int c4 = lane; c4 < NV4; c4 += 64) {
+            const f32x4 v = qv[c4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s = fmaf(v[c], v[c], s);
+        }
+        qn2 = wave_sum(s);
+#pragma unroll
+        for (int t = 0; t < T; ++t) q[t] = qv[(t * 64 + lane) % NV4];
+    }
+    WaveTopK<S> tk;
+    tk.init();
+    auto offer = [&](uint64_t key) {  // key: this lane's candidate (0: none)
+        uint64_t m = __ballot(key > tk.thr);
+        while (m) {
+            const int l = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint64_t c = readlane64(key, l);
+            if (c > tk.thr) tk.insert(c, lane);  // (the threshold may have risen since the ballot)
+        }
+    };
+
+    // A wave's next group is requested before its current one is reduced and offered (the loads of group g + n_waves are in
+    // flight under the shuffles and the insertions of group g; past the last group the request repeats it: no branch around
+    // a memory operation in the loop).
+    f32x4 xn[T];
+    {
+        const int64_t g0 = wave < n_groups ? wave : (n_groups > 0 ? n_groups - 1 : 0);
+        const f32x4* base = reinterpret_cast<const f32x4*>(corpus + g0 * (int64_t)(R * DIM));
+#pragma unroll
+        for (int t = 0; t < T; ++t) xn[t] = n_groups > 0 ? __builtin_nontemporal_load(base + t * 64 + lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t g = wave; g < n_groups; g += n_waves) {
+        f32x4 x[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[t] = xn[t];
+        {
+            const int64_t gn = g + n_waves < n_groups ? g + n_waves : g;
+            const f32x4* base = reinterpret_cast<const f32x4*>(corpus + gn * (int64_t)(R * DIM));
+#pragma unroll
+            for (int t = 0; t < T; ++t) xn[t] = __builtin_nontemporal_load(base + t * 64 + lane);
+        }
+        float dn[R], dt[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) dn[r] = dt[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float s2 = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s2 = fmaf(x[t][c], x[t][c], s2);
+                sq = fmaf(q[t][c], x[t][c], sq);
+            }
+            const int r_lo = (t * 64) / NV4, r_hi = (t * 64 + 63) / NV4;  // constants after unrolling
+            if (r_lo == r_hi) {
+                dn[r_lo] += s2;
+                dt[r_lo] += sq;
+            } else {
+                const int my = (t * 64 + lane) / NV4;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r >= r_lo && r <= r_hi) {
+                        const bool in = my == r;
+                        dn[r] += in ? s2 : 0.0f;
+                        dt[r] += in ? sq : 0.0f;
+                    }
+                }
+            }
+        }
+        // (the arithmetic of cosine_scores_stream_kernel<NV4, R, 1>, operation for operation: the same scores to the bit)
+        float mine = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float d2 = wave_sum(dn[r]);
+            const float dj = wave_sum(dt[r]);
+            const float sc = cosine_finish(dj, qn2, d2, mode);
+            mine = (lane == r) ? sc : mine;
+        }
+        offer(lane < R ? make_key(mine, (uint32_t)(g * R + lane)) : 0ull);
+    }
+    // the (< R) rows past the last whole group: one wave of the launch, a row at a time
+    if (wave == 0) {
+        for (int64_t d = n_groups * R; d < n_docs; ++d) {
+            const f32x4* row = reinterpret_cast<const f32x4*>(corpus + d * DIM);
+            const f32x4* qv = reinterpret_cast<const f32x4*>(query);
+            float s2 = 0.0f, sq = 0.0f;
+            for (int c4 = lane; c4 < NV4; c4 += 64) {
+                const f32x4 xv = row[c4], qq = qv[c4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s2 = fmaf(xv[c], xv[c], s2);
+                    sq = fmaf(qq[c], xv[c], sq);
+                }
+            }
+            const float sc = cosine_finish(wave_sum(sq), qn2, wave_sum(s2), mode);
+            offer(lane == 0 ? make_key(sc, (uint32_t)d) : 0ull);
+        }
+    }
+    // workgroup merge: 4 x KW keys, sorted descending; the best kout leave
+#pragma unroll
+    for (int s = 0; s < S; ++s) keys[wid * KW + s * 64 + lane] = tk.k[s];
+    bitonic_sort_desc(keys, 4 * KW, tid);
+    for (int i = tid; i < kout; i += 256) cand[(int64_t)blockIdx.x * kout + i] = keys[i];
+}
+
+// One block (256 threads) folds candidates [seg0, seg0 + TK_TILE * tiles) of one query into its best KPAD keys, left sorted
+// descending in best[].  Level 0 reads float scores (index = position), later levels read keys.  Keys >= `upper` are ignored
+// (multi-pass k > 1024).
 //
 // Only candidates above the block's current KPAD-th best can matter, and on anything but adversarial
 // input that threshold rises quickly: candidates that pass it are compacted into a pending buffer
 // (wave-aggregated LDS append) and the bitonic sort + merge runs only when that buffer might overflow
 // and once at the end -- typically twice per block instead of once per 2048 candidates.
+template <int KPAD>
+__device__ __forceinline__ void topk_block_reduce(const float* __restrict__ scores, const uint64_t* __restrict__ in_keys, int64_t n,
+                                                  int64_t seg0, int tiles, uint64_t upper, uint64_t* pend, uint64_t* best, int* pend_count)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < KPAD; i += 256) best[i] = 0ull;
+    if (tid == 0) *pend_count = 0;
+    __syncthreads();
+
+    // sort the pending keys, fold them into best[], reset the buffer
+    auto flush = [&]() {
+        const int cnt = *pend_count;  // uniform: read after a barrier
+        int p2 = KPAD;
+        while (p2 < cnt) p2 <<= 1;
+        __syncthreads();  // everyone has read pend_count
+        for (int i = cnt + tid; i < p2; i += 256) pend[i] = 0ull;
+        if (tid == 0) *pend_count = 0;
+        bitonic_sort_desc(pend, p2, tid);
+        // best (desc) and the reversed head of pend (asc) form a bitonic sequence whose element-wise
+        // max holds the top KPAD of the union.
+        for (int i = tid; i < KPAD; i += 256) {
+            const uint64_t a = best[i], b2 = pend[KPAD - 1 - i];
+            best[i] = a > b2 ? a : b2;
+        }
+        bitonic_merge_desc(best, KPAD, tid);
+    };
+
+    for (int tl = 0; tl < tiles; ++tl) {
+        const int64_t t0 = seg0 + (int64_t)tl * TK_TILE;
+        if (t0 >= n) break;
+        if (*pend_count + TK_TILE > TK_PEND) flush();  // uniform branch (barrier at the end of the last tile)
+        const uint64_t thr = best[KPAD - 1];
+        for (int i = tid; i < TK_TILE; i += 256) {
+            const int64_t p = t0 + i;
+            uint64_t key = 0ull;
+            if (p < n) {
+                key = scores ? make_key(scores[p], (uint32_t)p) : in_keys[p];
+                if (key >= upper) key = 0ull;
+            }
+            const bool take = key > thr;
+            const uint64_t m = __ballot(take);
+            if (m) {
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(pend_count, __popcll(m));
+                base = __shfl(base, leader, kWave);
+                if (take) pend[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
+        }
+        __syncthreads();
+    }
+    if (*pend_count > 0) flush();
+    __syncthreads();
+}
+
+// One block reduces candidates [blk*seg, +seg), seg = TK_TILE*tiles_per_block, of query blockIdx.y to its
+// best KPAD keys (descending).
 template <int KPAD>
 __global__ __launch_bounds__(256) void topk_reduce_kernel(const float* __restrict__ scores,
                                                           const uint64_t* __restrict__ in_keys,
@@ -308,61 +539,81 @@ __global__ __launch_bounds__(256) void topk_reduce_kernel(const float* __restric
     __shared__ uint64_t pend[TK_PEND];
     __shared__ uint64_t best[KPAD];
     __shared__ int pend_count;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int qi = blockIdx.y;
     const uint64_t upper = upper_ptr ? upper_ptr[qi] : ~0ull;
-    const int64_t seg0 = (int64_t)blockIdx.x * TK_TILE * tiles_per_block;
-    for (int i = tid; i < KPAD; i += 256) best[i] = 0ull;
-    if (tid == 0) pend_count = 0;
-    __syncthreads();
+    topk_block_reduce<KPAD>(scores ? scores + (int64_t)qi * in_stride : nullptr, in_keys ? in_keys + (int64_t)qi * in_stride : nullptr, n,
+                            (int64_t)blockIdx.x * TK_TILE * tiles_per_block, tiles_per_block, upper, pend, best, &pend_count);
+    for (int i = tid; i < KPAD; i += 256)
+        out_keys[(int64_t)qi * out_stride + (int64_t)blockIdx.x * KPAD + i] = best[i];
+}
 
-    // sort the pending keys, fold them into best[], reset the buffer
-    auto flush = [&]() {
-        const int cnt = pend_count;  // uniform: read after a barrier
-        int p2 = KPAD;
-        while (p2 < cnt) p2 <<= 1;
-        __syncthreads();  // everyone has read pend_count
-        for (int i = cnt + tid; i < p2; i += 256) pend[i] = 0ull;
-        if (tid == 0) pend_count = 0;
-        bitonic_sort_desc(pend, p2, tid);
-        // best (desc) and the reversed head of pend (asc) form a bitonic sequence whose element-wise
-        // max holds the top KPAD of the union.
-        for (int i = tid; i < KPAD; i += 256) {
-            const uint64_t a = best[i], b2 = pend[KPAD - 1 - i];
-            best[i] = a > b2 ? a : b2;
-        }
-        bitonic_merge_desc(best, KPAD, tid);
-    };
-
-    for (int tl = 0; tl < tiles_per_block; ++tl) {
-        const int64_t t0 = seg0 + (int64_t)tl * TK_TILE;
-        if (t0 >= n) break;
-        if (pend_count + TK_TILE > TK_PEND) flush();  // uniform branch (barrier at the end of the last tile)
-        const uint64_t thr = best[KPAD - 1];
-        for (int i = tid; i < TK_TILE; i += 256) {
-            const int64_t p = t0 + i;
-            uint64_t key = 0ull;
-            if (p < n) {
-                key = scores ? make_key(scores[(int64_t)qi * in_stride + p], (uint32_t)p)
-                             : in_keys[(int64_t)qi * in_stride + p];
-                if (key >= upper) key = 0ull;
-            }
-            const bool take = key > thr;
-            const uint64_t m = __ballot(take);
-            if (m) {
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&pend_count, __popcll(m));
-                base = __shfl(base, leader, kWave);
-                if (take) pend[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+// The last step of the fused one-query search: `lists` (<= 2 048) sorted lists of KPAD keys each (the scan's workgroups) -> the
+// best k_take, decoded.  Any threshold T with at least k keys at or above it will do: the answer is the best k of the keys >= T.
+// T = the k-th largest of a SAMPLE of up to 256 list heads (every ceil(lists / 256)-th list; a head is its list's largest key,
+// so k sampled heads >= T are k keys >= T): one 256-key sort.  A list whose head is below T holds nothing of interest; the
+// others are read from the top down while their keys stay >= T -- on anything but adversarial placements a few dozen keys in
+// all -- sorted, decoded.  A few microseconds where the generic threshold-and-flush reduction over lists x KPAD keys took 120.
+// Should the gathered set not fit the buffer (4 096 keys), the block runs the generic reduction over everything.
+template <int KPAD>
+__global__ __launch_bounds__(256) void topk_lists_final_kernel(const uint64_t* __restrict__ keys, int lists, int k_take,
+                                                               int64_t* __restrict__ out_idx, float* __restrict__ out_score)
+{
+    __shared__ uint64_t buf[TK_PEND];
+    __shared__ uint64_t best[KPAD];
+    __shared__ int count;
+    const int tid = threadIdx.x;
+    constexpr int PER = 8;  // lists per thread (2 048 / 256)
+    uint64_t head[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int l = tid + 256 * j;
+        head[j] = l < lists ? keys[(int64_t)l * KPAD] : 0ull;
+    }
+    const int stride = (lists + 255) / 256, m = (lists + stride - 1) / stride;  // the sample: lists 0, stride, 2 stride, ...
+    buf[tid] = tid < m ? keys[(int64_t)tid * stride * KPAD] : 0ull;
+    if (tid == 0) count = 0;
+    bitonic_sort_desc(buf, 256, tid);
+    const uint64_t thr = k_take - 1 < m ? buf[k_take - 1] : 0ull;
+    __syncthreads();  // everyone has read thr before the buffer is reused
+    bool generic = lists > 256 * PER;
+    if (!generic) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (head[j] == 0ull || head[j] < thr) continue;
+            const uint64_t* lk = keys + (int64_t)(tid + 256 * j) * KPAD;
+            for (int i = 0; i < KPAD; ++i) {
+                const uint64_t key = i == 0 ? head[j] : lk[i];
+                if (key == 0ull || key < thr) break;  // (sorted descending)
+                const int at = atomicAdd(&count, 1);
+                if (at < TK_PEND) buf[at] = key;
             }
         }
         __syncthreads();
+        generic = count > TK_PEND;
     }
-    if (pend_count > 0) flush();
+    if (!generic) {  // (uniform)
+        const int cnt = count;
+        int c2 = 1;
+        while (c2 < cnt) c2 <<= 1;
+        __syncthreads();
+        for (int i = cnt + tid; i < c2; i += 256) buf[i] = 0ull;
+        bitonic_sort_desc(buf, c2, tid);
+        for (int i = tid; i < k_take; i += 256) {
+            const uint64_t key = i < cnt ? buf[i] : 0ull;
+            out_idx[i] = key == 0ull ? -1 : (int64_t)(uint32_t)(~(uint32_t)(key & 0xFFFFFFFFull));
+            out_score[i] = key == 0ull ? -INFINITY : from_orderable((uint32_t)(key >> 32));
+        }
+        return;
+    }
     __syncthreads();
-    for (int i = tid; i < KPAD; i += 256)
-        out_keys[(int64_t)qi * out_stride + (int64_t)blockIdx.x * KPAD + i] = best[i];
+    const int64_t n = (int64_t)lists * KPAD;
+    topk_block_reduce<KPAD>(nullptr, keys, n, 0, (int)((n + TK_TILE - 1) / TK_TILE), ~0ull, buf, best, &count);
+    for (int i = tid; i < k_take; i += 256) {
+        const uint64_t key = i < KPAD ? best[i] : 0ull;
+        out_idx[i] = key == 0ull ? -1 : (int64_t)(uint32_t)(~(uint32_t)(key & 0xFFFFFFFFull));
+        out_score[i] = key == 0ull ? -INFINITY : from_orderable((uint32_t)(key >> 32));
+    }
 }
 
 __global__ void topk_decode_kernel(const uint64_t* __restrict__ keys, int64_t key_stride, int k_take,
@@ -813,6 +1064,97 @@ hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k
                            out_idx, out_score, (int64_t)k, (int64_t)done, upper);
     }
     return hipGetLastError();
+}
+
+namespace {
+
+// Workgroups of the fused one-query pass: every wave gets at least ~4 groups (a wave walks its groups one after the other, a
+// group ahead in flight: with 16 groups per wave a 10^5-row corpus was a 40 us latency chain), at most the 2 048 the streaming
+// kernels use.
+inline int64_t search_blocks(int64_t n_groups)
+{
+    const int64_t b = n_groups / (4 * 4);
+    return b < 1 ? 1 : (b > 2048 ? 2048 : b);
+}
+
+template <int NV4, int R>
+void launch_search_stream(int kw, const float* query, const float* corpus, int64_t n_groups, int64_t n_docs, int mode, int kout,
+                          uint64_t* cand, unsigned blocks, hipStream_t stream)
+{
+#define KJ_SRCH(S_)                                                                                                                 \
+    hipLaunchKernelGGL((cosine_search_stream_kernel<NV4, R, S_>), dim3(blocks), dim3(256), 0, stream, query, corpus, n_groups, n_docs, \
+                       mode, kout, cand)
+    if (kw <= 64) KJ_SRCH(1);
+    else if (kw <= 128) KJ_SRCH(2);
+    else KJ_SRCH(4);
+#undef KJ_SRCH
+}
+
+// The one-query fused pass: widths the streaming kernel is specialised for, k <= 256, 16-byte aligned rows.
+inline bool search_fused_ok(int nq, int dim, int mode, int k, const float* queries, const float* corpus, int64_t n_docs)
+{
+    const int R = stream_rows(dim, false);
+    return nq == 1 && k <= 256 && R > 0 && n_docs >= R && (mode == 0 || mode == 1) && (reinterpret_cast<uintptr_t>(corpus) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(queries) & 15) == 0 && !tune::scan_two_launches();
+}
+
+// The last step over the scan's `lists` sorted lists of kpad keys: one block, outputs decoded.
+void final_lists(int kpad, const uint64_t* keys, int lists, int k, int64_t* out_idx, float* out_score, hipStream_t stream)
+{
+#define KJ_FIN(KP_) hipLaunchKernelGGL(topk_lists_final_kernel<KP_>, dim3(1), dim3(256), 0, stream, keys, lists, k, out_idx, out_score)
+    switch (kpad) {
+    case 16: KJ_FIN(16); break;
+    case 32: KJ_FIN(32); break;
+    case 64: KJ_FIN(64); break;
+    case 128: KJ_FIN(128); break;
+    default: KJ_FIN(256); break;
+    }
+#undef KJ_FIN
+}
+
+}  // namespace
+
+// Workspace of launch_cosine_search: the workgroups' candidate lists (+ one intermediate level) for the fused one-query pass,
+// otherwise the scores [nq, n_docs] and the selection's buffers.
+size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k)
+{
+    (void)dim;
+    const size_t fused = (size_t)(2048 * 256 + 2 * 2048) * sizeof(uint64_t);
+    const size_t two = (size_t)nq * (size_t)n_docs * sizeof(float) + 256 + cosine_topk_workspace_bytes(nq, n_docs, k);
+    return fused > two ? fused : two;
+}
+
+// Per-query top-k of cosine(query, corpus row): out_idx / out_score [nq, k], score descending, ties by ascending row index
+// (VectorStore::search, kjarni-search/src/vector.rs:150-166; Segment::search_vectors, kjarni-rag/src/segment.rs:307-337);
+// slots past the corpus hold -1 / -inf.  One query takes the fused pass (no score array); otherwise scores + selection.
+hipError_t launch_cosine_search(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode, int k,
+                                void* workspace, int64_t* out_idx, float* out_score, hipStream_t stream)
+{
+    if (nq <= 0 || k <= 0) return hipSuccess;
+    if (n_docs <= 0 || n_docs >= (int64_t)0xFFFFFFFF) return hipErrorInvalidValue;
+    if (search_fused_ok(nq, dim, mode, k, queries, corpus, n_docs)) {
+        const int R = stream_rows(dim, false);
+        const int64_t groups = n_docs / R;
+        const unsigned blocks = (unsigned)search_blocks(groups);
+        const int kout = kpad_for(k), kw = kout < 64 ? 64 : kout;
+        uint64_t* cand = reinterpret_cast<uint64_t*>(workspace);
+        switch (dim) {
+        case 384: launch_search_stream<96, 4>(kw, queries, corpus, groups, n_docs, mode, kout, cand, blocks, stream); break;
+        case 768: launch_search_stream<192, 2>(kw, queries, corpus, groups, n_docs, mode, kout, cand, blocks, stream); break;
+        case 1024: launch_search_stream<256, 2>(kw, queries, corpus, groups, n_docs, mode, kout, cand, blocks, stream); break;
+        case 512: launch_search_stream<128, 4>(kw, queries, corpus, groups, n_docs, mode, kout, cand, blocks, stream); break;
+        case 256: launch_search_stream<64, 8>(kw, queries, corpus, groups, n_docs, mode, kout, cand, blocks, stream); break;
+        case 128: launch_search_stream<32, 16>(kw, queries, corpus, groups, n_docs, mode, kout, cand, blocks, stream); break;
+        default: return hipErrorInvalidValue;
+        }
+        final_lists(kout, cand, (int)blocks, k, out_idx, out_score, stream);
+        return hipGetLastError();
+    }
+    float* scores = reinterpret_cast<float*>(workspace);
+    const size_t s_bytes = ((size_t)nq * (size_t)n_docs * sizeof(float) + 255) & ~(size_t)255;
+    const hipError_t e = launch_cosine_scores(queries, nq, corpus, n_docs, dim, mode, scores, stream);
+    if (e != hipSuccess) return e;
+    return launch_cosine_topk(scores, nq, n_docs, k, static_cast<uint8_t*>(workspace) + s_bytes, out_idx, out_score, stream);
 }
 
 }  // namespace kjarni

@@ -8,6 +8,8 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -25,15 +27,15 @@ using namespace kjarni;
 
 namespace {
 
-// Device copy of one segment's vectors.bin, revalidated on every scan by the file's identity
-// (size, mtime, ctime, inode -- a segment re-created under the same name is a different file).
-struct DeviceSegment {
-    float* vectors = nullptr;
-    size_t bytes = 0;
-    int64_t mtime_ns = 0, ctime_ns = 0;
-    uint64_t inode = 0;
-    uint64_t last_used = 0;  // scan counter: least-recently-used copies go first when the budget is exceeded
+// Where a query's time went (thread-local, the calling thread's last retrieval): kjarni_hip_search_breakdown().
+struct SearchBreakdown {
+    double open_us = 0, scan_us = 0, device_us = 0, hits_us = 0, total_us = 0;
 };
+thread_local SearchBreakdown t_breakdown;
+inline double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 void fill_results(const std::vector<SearchHit>& hits, KjarniSearchResults* out)
 {
@@ -69,8 +71,20 @@ class SegmentScanner;
 std::mutex g_scanners_mu;
 std::vector<SegmentScanner*> g_scanners;  // live scanners, so that kjarni_index_delete can drop their device copies
 
-// Segment::search_vectors (kjarni-rag/src/segment.rs:307-337) on the GPU, with the device copies of
-// the segments it has seen.
+// Segment::search_vectors (kjarni-rag/src/segment.rs:307-337) for all the segments of an index at once.
+//
+// The reference scans segment after segment and merges (index_reader.rs:207-228: every segment's top `limit`, then one sort
+// by score).  Segments are immutable once written, so the scanner keeps ONE device image per index: the segments' vectors.bin
+// concatenated in segment order, [sum of doc_count, dim].  A query is then one fused scan + selection over that image
+// (launch_cosine_search: a single pass, the scores never exist in memory) on a stream of the scanner's own -- two launches and
+// two small copies per query, whatever the number of segments.  The global top `limit` with ties by ascending row equals the
+// reference's merge of per-segment lists (a stable sort of segment-ordered, index-ordered lists), and a row maps back to
+// (segment, local id) through the image's prefix offsets.
+//
+// An image is keyed by the uids of the parsed Segment objects it was built from (index.h: a changed file makes a new Segment,
+// hence a new uid), so a query validates it by comparing a few integers -- no stat() here; the reader's own revalidation decides
+// which Segment objects a query sees.  Queries on one scanner run concurrently: each leases a context (stream, workspace,
+// pinned staging) for its launches; images are reference-counted, so an eviction never frees what a running scan reads.
 class SegmentScanner {
 public:
     explicit SegmentScanner(int device) : device_(device)
@@ -79,8 +93,9 @@ public:
             std::lock_guard<std::mutex> lock(g_scanners_mu);
             g_scanners.push_back(this);
         }
-        // The copies may take half of the device's memory; past that, copies no scan has touched longest are dropped
+        // The images may take half of the device's memory; past that, images no scan has touched longest are dropped
         // (a long-lived searcher that walks many indexes must not grow until hipMalloc fails).
+        DeviceGuard guard;
         size_t free_b = 0, total_b = 0;
         if (hipSetDevice(device_) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
             budget_bytes_ = total_b / 2;
@@ -88,7 +103,13 @@ public:
             (void)hipGetLastError();
     }
     void set_budget(size_t bytes) { budget_bytes_ = bytes; }
-    size_t cached_bytes() const { return cached_bytes_; }
+    size_t cached_bytes() const
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        size_t b = 0;
+        for (const auto& im : images_) b += im->bytes;
+        return b;
+    }
     SegmentScanner(const SegmentScanner&) = delete;
     SegmentScanner& operator=(const SegmentScanner&) = delete;
     ~SegmentScanner()
@@ -97,13 +118,21 @@ public:
             std::lock_guard<std::mutex> lock(g_scanners_mu);
             g_scanners.erase(std::remove(g_scanners.begin(), g_scanners.end(), this), g_scanners.end());
         }
+        DeviceGuard guard;
         (void)hipSetDevice(device_);
-        for (auto& kv : cache_)
-            if (kv.second.vectors) (void)hipFree(kv.second.vectors);
-        if (work_) (void)hipFree(work_);
+        images_.clear();
+        for (auto& c : contexts_) {
+            if (c->stream) {
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipStreamDestroy(c->stream);
+            }
+            if (c->work) (void)hipFree(c->work);
+            if (c->io) (void)hipFree(c->io);
+            if (c->pin) (void)hipHostFree(c->pin);
+        }
     }
 
-    // One query against every segment: the kernels of all segments are enqueued back to back and the host waits once.
+    // One query against every segment: ONE fused scan over the index's device image.
     std::vector<SegmentHits> scan(const std::vector<const Segment*>& segs, const float* query, size_t query_dim, size_t limit)
     {
         std::vector<SegmentHits> out(segs.size());
@@ -112,136 +141,205 @@ public:
         for (size_t i = 0; i < query_dim; ++i) qn += query[i] * query[i];
         if (std::sqrt(qn) < 1e-9f) return out;                          // segment.rs:315-317
 
-        std::lock_guard<std::mutex> lock(mu_);
-        hip_check(hipSetDevice(device_), "hipSetDevice");
-        const uint64_t tick = ++tick_;
-        auto pad = [](size_t b) { return 256 * ((b + 255) / 256); };
-        struct Plan {
-            size_t seg, n;
-            int k;
-            DeviceSegment* ds;
-            size_t s_off, w_off, r_off;  // scores, top-k workspace, slot in the result arrays
-        };
-        std::vector<Plan> plans;
-        size_t cursor = pad(query_dim * 4), slots = 0;
+        // the segments a query of this width can match, in index order
+        std::vector<size_t> use;
+        std::vector<uint64_t> uids;
         for (size_t si = 0; si < segs.size(); ++si) {
             const Segment& seg = *segs[si];
             const size_t n = seg.doc_count(), dim = seg.dimension();
             if (n == 0 || dim != query_dim) continue;                        // query.len() != dimension -> empty
             if (seg.vectors_bytes() < n * dim * sizeof(float)) continue;     // get_embedding() would return None
-            struct stat st;
-            const std::string vpath = seg.dir() + "/vectors.bin";
-            if (::stat(vpath.c_str(), &st) != 0) continue;
-            const int64_t mt = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
-            const int64_t ct = (int64_t)st.st_ctim.tv_sec * 1000000000ll + st.st_ctim.tv_nsec;
-            DeviceSegment& ds = cache_[vpath];
-            const size_t bytes = n * dim * sizeof(float);
-            if (!ds.vectors || ds.bytes != bytes || ds.mtime_ns != mt || ds.ctime_ns != ct || ds.inode != (uint64_t)st.st_ino) {
-                drop(ds);
-                make_room(bytes, tick);
-                hip_check(hipMalloc((void**)&ds.vectors, bytes), "hipMalloc(segment vectors)");
-                ds.bytes = bytes;
-                cached_bytes_ += bytes;
-                hip_check(hipMemcpy(ds.vectors, seg.vectors(), bytes, hipMemcpyHostToDevice), "H2D segment vectors");
-                ds.mtime_ns = mt;
-                ds.ctime_ns = ct;
-                ds.inode = (uint64_t)st.st_ino;
+            use.push_back(si);
+            uids.push_back(seg.uid());
+        }
+        if (use.empty()) return out;
+
+        DeviceGuard guard;  // (the caller's current device comes back)
+        hip_check(hipSetDevice(device_), "hipSetDevice");
+        const std::shared_ptr<Image> image = image_for(segs, use, uids, query_dim);
+        const size_t total = image->offsets.back();
+        if (total >= (size_t)0xFFFFFFFFu) throw std::runtime_error("index too large for one scan (2^32 rows)");
+        const int k = (int)std::min(limit, total);
+
+        ContextLease lease(*this);
+        Context& c = lease.ctx();
+        const size_t need = cosine_search_workspace_bytes(1, (int64_t)total, (int)query_dim, k);
+        if (need > c.work_bytes) {
+            if (c.work) {
+                hip_check(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+                (void)hipFree(c.work);
+                c.work = nullptr;
+                c.work_bytes = 0;
             }
-            ds.last_used = tick;
-            Plan p;
-            p.seg = si;
-            p.n = n;
-            p.k = (int)std::min(limit, n);
-            p.ds = &ds;
-            p.s_off = cursor;
-            cursor += pad(n * 4);
-            p.w_off = cursor;
-            cursor += pad(cosine_topk_workspace_bytes(1, (int64_t)n, p.k));
-            p.r_off = slots;
-            slots += (size_t)p.k;
-            plans.push_back(p);
+            hip_check(hipMalloc((void**)&c.work, need), "hipMalloc(scan workspace)");
+            c.work_bytes = need;
         }
-        if (plans.empty()) return out;
-        const size_t i_off = cursor, o_off = i_off + pad(slots * 8), total = o_off + pad(slots * 4);
-        if (total > work_bytes_) {
-            if (work_) {
-                hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
-                (void)hipFree(work_);
-                work_ = nullptr;
-                work_bytes_ = 0;
+        // staging: [query | idx[k] | score[k]] in one pinned buffer and one device buffer
+        auto pad = [](size_t b) { return 256 * ((b + 255) / 256); };
+        const size_t q_bytes = pad(query_dim * 4), i_off = q_bytes, s_off = i_off + pad((size_t)k * 8), io_bytes = s_off + pad((size_t)k * 4);
+        if (io_bytes > c.io_bytes) {
+            if (c.io) {
+                hip_check(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+                (void)hipFree(c.io);
+                (void)hipHostFree(c.pin);
+                c.io = nullptr;
+                c.pin = nullptr;
+                c.io_bytes = 0;
             }
-            hip_check(hipMalloc((void**)&work_, total), "hipMalloc(scan workspace)");
-            work_bytes_ = total;
+            hip_check(hipMalloc((void**)&c.io, io_bytes), "hipMalloc(scan staging)");
+            hip_check(hipHostMalloc((void**)&c.pin, io_bytes, hipHostMallocDefault), "hipHostMalloc(scan staging)");
+            c.io_bytes = io_bytes;
         }
-        float* q_d = reinterpret_cast<float*>(work_);
-        int64_t* i_d = reinterpret_cast<int64_t*>(work_ + i_off);
-        float* o_d = reinterpret_cast<float*>(work_ + o_off);
-        hip_check(hipMemcpyAsync(q_d, query, query_dim * 4, hipMemcpyHostToDevice, nullptr), "H2D query");
-        for (const Plan& p : plans) {
-            float* s_d = reinterpret_cast<float*>(work_ + p.s_off);
-            hip_check(launch_cosine_scores(q_d, 1, p.ds->vectors, (int64_t)p.n, (int)query_dim, /*segment mode*/ 1, s_d, nullptr),
-                      "cosine_scores");
-            hip_check(launch_cosine_topk(s_d, 1, (int64_t)p.n, p.k, work_ + p.w_off, i_d + p.r_off, o_d + p.r_off, nullptr),
-                      "cosine_topk");
+        const double t0 = now_us();
+        std::memcpy(c.pin, query, query_dim * 4);
+        hip_check(hipMemcpyAsync(c.io, c.pin, query_dim * 4, hipMemcpyHostToDevice, c.stream), "H2D query");
+        hip_check(launch_cosine_search(reinterpret_cast<const float*>(c.io), 1, image->vectors, (int64_t)total, (int)query_dim,
+                                       /*segment mode*/ 1, k, c.work, reinterpret_cast<int64_t*>(c.io + i_off),
+                                       reinterpret_cast<float*>(c.io + s_off), c.stream),
+                  "cosine_search");
+        hip_check(hipMemcpyAsync(c.pin + i_off, c.io + i_off, (s_off - i_off) + (size_t)k * 4, hipMemcpyDeviceToHost, c.stream), "D2H hits");
+        hip_check(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
+        t_breakdown.device_us += now_us() - t0;
+        const int64_t* idx = reinterpret_cast<const int64_t*>(c.pin + i_off);
+        const float* sc = reinterpret_cast<const float*>(c.pin + s_off);
+        for (int i = 0; i < k; ++i) {
+            if (idx[i] < 0) continue;
+            const size_t row = (size_t)idx[i];
+            const size_t u = (size_t)(std::upper_bound(image->offsets.begin(), image->offsets.end(), row) - image->offsets.begin()) - 1;
+            out[use[u]].emplace_back(row - image->offsets[u], sc[i]);
         }
-        std::vector<int64_t> idx(slots);
-        std::vector<float> sc(slots);
-        hip_check(hipMemcpyAsync(idx.data(), i_d, slots * 8, hipMemcpyDeviceToHost, nullptr), "D2H idx");
-        hip_check(hipMemcpyAsync(sc.data(), o_d, slots * 4, hipMemcpyDeviceToHost, nullptr), "D2H scores");
-        hip_check(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
-        for (const Plan& p : plans)
-            for (int i = 0; i < p.k; ++i)
-                if (idx[p.r_off + (size_t)i] >= 0) out[p.seg].emplace_back((size_t)idx[p.r_off + (size_t)i], sc[p.r_off + (size_t)i]);
         return out;
     }
 
-    // Drops the copies of every segment under `root` (the index there is being deleted or rebuilt).
+    // Drops the images that hold a segment under `root` (the index there is being deleted or rebuilt).
     void forget_under(const std::string& root)
     {
-        std::lock_guard<std::mutex> lock(mu_);
-        (void)hipSetDevice(device_);
         const std::string prefix = root.empty() || root.back() == '/' ? root : root + "/";
-        for (auto it = cache_.begin(); it != cache_.end();)
-            if (it->first.compare(0, prefix.size(), prefix) == 0) {
-                drop(it->second);
-                it = cache_.erase(it);
-            } else {
-                ++it;
-            }
-    }
-
-private:
-    void drop(DeviceSegment& ds)
-    {
-        if (!ds.vectors) return;
-        (void)hipDeviceSynchronize();  // earlier scans may still be reading it
-        (void)hipFree(ds.vectors);
-        ds.vectors = nullptr;
-        cached_bytes_ -= ds.bytes;
-        ds.bytes = 0;
-    }
-    // Evicts least-recently-used copies that the current scan (tick) has not touched until `incoming` more bytes fit.
-    void make_room(size_t incoming, uint64_t tick)
-    {
-        while (budget_bytes_ && cached_bytes_ + incoming > budget_bytes_) {
-            auto victim = cache_.end();
-            for (auto it = cache_.begin(); it != cache_.end(); ++it)
-                if (it->second.vectors && it->second.last_used != tick &&
-                    (victim == cache_.end() || it->second.last_used < victim->second.last_used))
-                    victim = it;
-            if (victim == cache_.end()) return;  // everything resident belongs to this scan
-            drop(victim->second);
-            cache_.erase(victim);
+        std::lock_guard<std::mutex> lock(mu_);
+        DeviceGuard guard;
+        (void)hipSetDevice(device_);
+        for (auto it = images_.begin(); it != images_.end();) {
+            bool hit = false;
+            for (const std::string& d : (*it)->dirs) hit = hit || d.compare(0, prefix.size(), prefix) == 0;
+            it = hit ? images_.erase(it) : std::next(it);  // (freed when the last running scan lets go of it)
         }
     }
 
+private:
+    struct Image {
+        std::vector<uint64_t> uids;    // Segment::uid() of the segments, in order
+        std::vector<std::string> dirs;
+        std::vector<size_t> offsets;   // first row of segment i; back() = rows in all
+        float* vectors = nullptr;
+        size_t bytes = 0, dim = 0;
+        uint64_t last_used = 0;
+        ~Image()
+        {
+            if (vectors) (void)hipFree(vectors);  // (runs on a thread whose current device is the scanner's)
+        }
+    };
+    struct Context {
+        hipStream_t stream = nullptr;
+        uint8_t *work = nullptr, *io = nullptr, *pin = nullptr;
+        size_t work_bytes = 0, io_bytes = 0;
+        bool busy = false;
+    };
+    static constexpr int kMaxContexts = 8;
+    class ContextLease {
+    public:
+        explicit ContextLease(SegmentScanner& s) : s_(s), c_(nullptr)
+        {
+            std::unique_lock<std::mutex> lock(s.mu_);
+            for (;;) {
+                for (auto& c : s.contexts_)
+                    if (!c->busy) c_ = c.get();
+                if (!c_ && (int)s.contexts_.size() < kMaxContexts) {
+                    s.contexts_.push_back(std::make_unique<Context>());
+                    c_ = s.contexts_.back().get();
+                }
+                if (c_) break;
+                s.ctx_cv_.wait(lock);
+            }
+            c_->busy = true;
+            lock.unlock();
+            if (!c_->stream && hipStreamCreateWithFlags(&c_->stream, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                release();
+                throw std::runtime_error("hipStreamCreate failed");
+            }
+        }
+        ~ContextLease() { release(); }
+        Context& ctx() { return *c_; }
+
+    private:
+        void release()
+        {
+            if (!c_) return;
+            std::lock_guard<std::mutex> lock(s_.mu_);
+            c_->busy = false;
+            c_ = nullptr;
+            s_.ctx_cv_.notify_one();
+        }
+        SegmentScanner& s_;
+        Context* c_;
+    };
+
+    // The image of this segment list: the resident one, or a new upload (other queries wait for it under the lock: the
+    // first query against an index pays the copy once).
+    std::shared_ptr<Image> image_for(const std::vector<const Segment*>& segs, const std::vector<size_t>& use,
+                                     const std::vector<uint64_t>& uids, size_t dim)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        const uint64_t tick = ++tick_;
+        for (auto& im : images_)
+            if (im->dim == dim && im->uids == uids) {
+                im->last_used = tick;
+                return im;
+            }
+        auto im = std::make_shared<Image>();
+        im->uids = uids;
+        im->dim = dim;
+        im->offsets.push_back(0);
+        for (size_t u : use) {
+            im->dirs.push_back(segs[u]->dir());
+            im->offsets.push_back(im->offsets.back() + segs[u]->doc_count());
+        }
+        im->bytes = im->offsets.back() * dim * sizeof(float);
+        // a superseded image of the same index (a segment was added: the old list is a prefix or shares directories) goes first,
+        // then least-recently-used ones until the new image fits the budget
+        for (auto it = images_.begin(); it != images_.end();) {
+            bool same_index = false;
+            for (const std::string& d : (*it)->dirs) same_index = same_index || d == im->dirs.front();
+            it = same_index ? images_.erase(it) : std::next(it);
+        }
+        while (budget_bytes_ && !images_.empty()) {
+            size_t held = 0;
+            for (const auto& x : images_) held += x->bytes;
+            if (held + im->bytes <= budget_bytes_) break;
+            auto victim = images_.begin();
+            for (auto it = images_.begin(); it != images_.end(); ++it)
+                if ((*it)->last_used < (*victim)->last_used) victim = it;
+            images_.erase(victim);
+        }
+        hip_check(hipMalloc((void**)&im->vectors, im->bytes ? im->bytes : 4), "hipMalloc(index image)");
+        for (size_t i = 0; i < use.size(); ++i) {
+            const Segment& seg = *segs[use[i]];
+            hip_check(hipMemcpy(im->vectors + im->offsets[i] * dim, seg.vectors(), seg.doc_count() * dim * sizeof(float),
+                                hipMemcpyHostToDevice),
+                      "H2D segment vectors");
+        }
+        im->last_used = tick;
+        images_.push_back(im);
+        return im;
+    }
+
     int device_;
-    std::mutex mu_;
-    std::map<std::string, DeviceSegment> cache_;
-    size_t cached_bytes_ = 0, budget_bytes_ = 0;
+    mutable std::mutex mu_;
+    std::condition_variable ctx_cv_;
+    std::vector<std::shared_ptr<Image>> images_;
+    std::vector<std::unique_ptr<Context>> contexts_;
+    size_t budget_bytes_ = 0;
     uint64_t tick_ = 0;
-    uint8_t* work_ = nullptr;
-    size_t work_bytes_ = 0;
 };
 
 struct ResolvedOptions {
@@ -400,7 +498,10 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
         const ResolvedOptions o = resolve_options(options, s->default_mode, s->default_top_k, s->reranker != nullptr);
 
         // Searcher::search_with_options (crates/kjarni/src/searcher/model.rs:96-187)
+        t_breakdown = SearchBreakdown();
+        const double t_begin = now_us();
         std::unique_ptr<IndexReader> reader = open_index(index_path);
+        t_breakdown.open_us = now_us() - t_begin;
         const size_t model_dim = (size_t)s->embedder->config().hidden;
         if (reader->dimension() != model_dim)
             throw InvalidConfig("Index dimension (" + std::to_string(reader->dimension()) +
@@ -408,7 +509,10 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
         const bool rerank = o.use_reranker && s->reranker;
         const size_t fetch_k = rerank ? o.top_k * 5 : o.top_k;
         const SegmentScanFn scan = [&](const std::vector<const Segment*>& segs, const float* q, size_t limit) {
-            return s->scanner->scan(segs, q, model_dim, limit);
+            const double t0 = now_us();
+            std::vector<SegmentHits> hits = s->scanner->scan(segs, q, model_dim, limit);
+            t_breakdown.scan_us += now_us() - t0;
+            return hits;
         };
         std::vector<float> q;
         if (o.mode != KJARNI_SEARCH_KEYWORD)  // embedder.embed(query): mean pool, normalised (embedder/model.rs:118-140)
@@ -434,6 +538,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_searcher_search_with_options(KjarniSearcher
         }
         apply_threshold_and_limit(results, o);
         fill_results(results, out);
+        t_breakdown.total_us = now_us() - t_begin;
         return KJARNI_OK;
     } catch (const InvalidConfig& e) {
         set_last_error(e.what());
@@ -554,7 +659,10 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, co
         const ResolvedOptions o = resolve_options(options, KJARNI_SEARCH_HYBRID, 10, false);
         if (o.mode != KJARNI_SEARCH_SEMANTIC && !text_query) return KJARNI_ERROR_NULL_POINTER;
         if (o.mode != KJARNI_SEARCH_KEYWORD && !query_emb) return KJARNI_ERROR_NULL_POINTER;
+        t_breakdown = SearchBreakdown();
+        const double t_begin = now_us();
         std::unique_ptr<IndexReader> reader = open_index(index_path);
+        t_breakdown.open_us = now_us() - t_begin;
         if (o.mode != KJARNI_SEARCH_KEYWORD && reader->dimension() != dim)
             throw InvalidConfig("Index dimension (" + std::to_string(reader->dimension()) +
                                 ") doesn't match query dimension (" + std::to_string(dim) + ")");
@@ -569,12 +677,16 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, co
                     scanner = std::make_unique<SegmentScanner>(0);
                 }
             }
-            return scanner->scan(segs, q, dim, limit);
+            const double t0 = now_us();
+            std::vector<SegmentHits> hits = scanner->scan(segs, q, dim, limit);
+            t_breakdown.scan_us += now_us() - t0;
+            return hits;
         };
         std::vector<SearchHit> results =
             retrieve(*reader, o.mode, text_query ? text_query : "", query_emb, o.top_k, o.filter, scan);
         apply_threshold_and_limit(results, o);
         fill_results(results, out);
+        t_breakdown.total_us = now_us() - t_begin;
         return KJARNI_OK;
     } catch (const GpuUnavailable& e) {
         set_last_error(e.what());
@@ -589,4 +701,14 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, co
         set_last_error("unknown error");
         return KJARNI_ERROR_INFERENCE_FAILED;
     }
+}
+
+// Where the calling thread's last kjarni_searcher_search* / kjarni_hip_index_search call spent its time, microseconds:
+// out[0] re-opening the index (revalidation of the parsed segments), out[1] the scan callback (image lookup, copies, launches,
+// wait), out[2] of it between the query's H2D copy and the hits' arrival, out[3] the whole call -- the rest is host work: BM25,
+// rank fusion, reading the hits' documents and metadata back, (for a Searcher) tokenising and embedding the query.
+KJARNI_EXPORT void kjarni_hip_search_breakdown(double* out, size_t n)
+{
+    const double v[4] = {t_breakdown.open_us, t_breakdown.scan_us, t_breakdown.device_us, t_breakdown.total_us};
+    for (size_t i = 0; i < n && i < 4; ++i) out[i] = v[i];
 }

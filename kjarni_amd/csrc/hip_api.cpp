@@ -566,6 +566,27 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_topk(int32_t device, const float
     });
 }
 
+KJARNI_EXPORT size_t kjarni_hip_cosine_search_workspace_bytes(int32_t n_queries, int64_t n_docs, int32_t dim, int32_t k)
+{
+    if (n_queries <= 0 || n_docs <= 0 || k <= 0 || dim <= 0) return 256;
+    return cosine_search_workspace_bytes(n_queries, n_docs, dim, k);
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_search(int32_t device, const float* queries_dev, int32_t n_queries,
+                                                       const float* corpus_dev, int64_t n_docs, int32_t dim,
+                                                       KjarniHipCosineMode mode, int32_t k, void* workspace_dev,
+                                                       int64_t* idx_out_dev, float* score_out_dev, void* stream)
+{
+    if (!queries_dev || !corpus_dev || !workspace_dev || !idx_out_dev || !score_out_dev) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (dim <= 0 || n_queries < 0 || n_docs < 0 || k < 0) throw InvalidConfig("invalid search dimensions");
+        use_device(device);
+        hip_check(launch_cosine_search(queries_dev, n_queries, corpus_dev, n_docs, dim, (int)mode, k, workspace_dev, idx_out_dev,
+                                       score_out_dev, (hipStream_t)stream),
+                  "cosine_search");
+    });
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, const float* queries,
                                                             int32_t n_queries, const float* corpus,
                                                             int64_t n_docs, int32_t dim, KjarniHipCosineMode mode,
@@ -579,17 +600,14 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, cons
         if (n_queries == 0 || n_docs == 0 || k == 0) return;
         use_device(device);
         const size_t qb = (size_t)n_queries * dim * 4, cb = (size_t)n_docs * dim * 4;
-        DeviceBuf q_d(qb), c_d(cb), s_d((size_t)n_queries * n_docs * 4);
-        DeviceBuf ws(cosine_topk_workspace_bytes(n_queries, n_docs, k));
+        DeviceBuf q_d(qb), c_d(cb);
+        DeviceBuf ws(cosine_search_workspace_bytes(n_queries, n_docs, dim, k));
         DeviceBuf i_d((size_t)n_queries * k * 8), o_d((size_t)n_queries * k * 4);
         hip_check(hipMemcpy(q_d.p, queries, qb, hipMemcpyHostToDevice), "H2D queries");
         hip_check(hipMemcpy(c_d.p, corpus, cb, hipMemcpyHostToDevice), "H2D corpus");
-        hip_check(launch_cosine_scores((const float*)q_d.p, n_queries, (const float*)c_d.p, n_docs, dim, (int)mode,
-                                       (float*)s_d.p, nullptr),
-                  "cosine_scores");
-        hip_check(launch_cosine_topk((const float*)s_d.p, n_queries, n_docs, k, ws.p, (int64_t*)i_d.p,
-                                     (float*)o_d.p, nullptr),
-                  "cosine_topk");
+        hip_check(launch_cosine_search((const float*)q_d.p, n_queries, (const float*)c_d.p, n_docs, dim, (int)mode, k, ws.p,
+                                       (int64_t*)i_d.p, (float*)o_d.p, nullptr),
+                  "cosine_search");
         hip_check(hipMemcpy(idx_out, i_d.p, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost), "D2H idx");
         hip_check(hipMemcpy(score_out, o_d.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost), "D2H scores");
         if (mode == KJARNI_HIP_COSINE_SEGMENT) {

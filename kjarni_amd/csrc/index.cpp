@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -491,6 +492,8 @@ std::unique_ptr<Segment> Segment::open(const std::string& dir)
 {
     std::unique_ptr<Segment> s(new Segment());
     s->dir_ = dir;
+    static std::atomic<uint64_t> next_uid{1};
+    s->uid_ = next_uid.fetch_add(1, std::memory_order_relaxed);
     const Json meta = Json::parse(slurp(dir + "/segment.json"));
     s->doc_count_ = (size_t)meta.get_int("doc_count", 0);
     s->dimension_ = (size_t)meta.get_int("dimension", 0);
@@ -528,20 +531,23 @@ std::unique_ptr<Segment> Segment::open(const std::string& dir)
 }
 
 namespace {
-// (size, mtime, ctime, inode) of each file a parsed Segment depends on; a rewritten or replaced file changes one.
+// (size, mtime, ctime, inode) of what a parsed Segment is revalidated by.
 struct SegmentStamp {
     uint64_t v[24] = {};
     bool operator==(const SegmentStamp& o) const { return std::memcmp(v, o.v, sizeof v) == 0; }
 };
+// What a query re-checks of a parsed segment: the segment DIRECTORY (a file created, removed or renamed in it changes its
+// mtime; a directory removed and re-created is another inode), segment.json and vectors.bin.  Segments are immutable once
+// written -- the reference's writer and this one create a segment directory and never touch it again
+// (kjarni-rag/src/segment.rs:90-170) -- so this is enough to see an index deleted, rebuilt or extended; an in-place edit of
+// docs.bin / bm25.bin behind the library's back is not a case either implementation supports.  Three stat calls per segment
+// and query instead of seven system calls.
 bool stamp_of(const std::string& dir, SegmentStamp& out)
 {
-    static const char* const kFiles[6] = {"segment.json", "vectors.bin", "docs.idx", "bm25.bin", "docs.bin", "metadata.jsonl"};
-    for (int i = 0; i < 6; ++i) {
+    static const char* const kFiles[3] = {"", "/segment.json", "/vectors.bin"};
+    for (int i = 0; i < 3; ++i) {
         struct stat st;
-        if (::stat((dir + "/" + kFiles[i]).c_str(), &st) != 0) {
-            if (i < 4) return false;  // Segment::open would throw
-            continue;
-        }
+        if (::stat((dir + kFiles[i]).c_str(), &st) != 0) return false;  // Segment::open would throw
         out.v[4 * i] = (uint64_t)st.st_size;
         out.v[4 * i + 1] = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
         out.v[4 * i + 2] = (uint64_t)st.st_ctim.tv_sec * 1000000000ull + (uint64_t)st.st_ctim.tv_nsec;
@@ -586,6 +592,8 @@ void Segment::forget_under(const std::string& root)
 Segment::~Segment()
 {
     if (map_) munmap(map_, map_len_);
+    if (docs_map_) munmap(const_cast<char*>(docs_map_), (size_t)docs_size_);
+    if (meta_map_) munmap(const_cast<char*>(meta_map_), (size_t)meta_size_);
 }
 
 namespace {
@@ -618,41 +626,64 @@ uint64_t fd_size(int fd)
 }
 }  // namespace
 
+// docs.bin / metadata.jsonl of a parsed segment are mapped on first use and stay mapped while the Segment lives (segments are
+// immutable; a changed file makes a new Segment): a hit's text and metadata are then copies out of the page cache with no
+// system call -- ten hits were sixty open / pread / close calls per query.  No descriptor is held (an index may have thousands
+// of segments).  A file that cannot be mapped (empty, or mmap fails) is read with pread as before.
+namespace {
+const char* map_whole(const std::string& path, uint64_t& size_out)
+{
+    const ScopedFd f(path);
+    if (f.fd < 0) throw std::runtime_error("cannot open " + path);
+    size_out = fd_size(f.fd);
+    if (size_out == 0) return nullptr;
+    void* m = mmap(nullptr, (size_t)size_out, PROT_READ, MAP_PRIVATE, f.fd, 0);
+    return m == MAP_FAILED ? nullptr : static_cast<const char*>(m);
+}
+void read_range(const char* map, const std::string& path, char* dst, size_t n, uint64_t off)
+{
+    if (n == 0) return;
+    if (map) {
+        std::memcpy(dst, map + off, n);
+        return;
+    }
+    const ScopedFd f(path);
+    if (f.fd < 0) throw std::runtime_error("cannot open " + path);
+    pread_all(f.fd, dst, n, off, path);
+}
+}  // namespace
+
 std::string Segment::get_document(size_t doc_id) const
 {
     if (doc_id >= doc_count_ || doc_id >= doc_offsets_.size()) throw std::runtime_error("Document ID out of range");
     const std::string path = dir_ + "/docs.bin";
-    const ScopedFd f(path);
-    if (f.fd < 0) throw std::runtime_error("cannot open " + path);
-    const int fd = f.fd;
-    std::call_once(docs_once_, [&] { docs_size_ = fd_size(fd); });
+    std::call_once(docs_once_, [&] { docs_map_ = map_whole(path, docs_size_); });
     const uint64_t start = doc_offsets_[doc_id];
     // the next document's offset, or the file's end; -1 for the newline
     const uint64_t next = doc_id + 1 < doc_offsets_.size() ? doc_offsets_[doc_id + 1] : docs_size_;
     if (next == 0 || next - 1 < start || next - 1 > docs_size_) throw std::runtime_error("corrupt document offsets");
     const uint64_t end = next - 1;
     std::string buf((size_t)(end - start), '\0');
-    if (!buf.empty()) pread_all(fd, &buf[0], buf.size(), start, dir_ + "/docs.bin");
+    read_range(docs_map_, path, buf.empty() ? nullptr : &buf[0], buf.size(), start);
     if (!unicode::is_valid_utf8(buf.data(), buf.size())) throw std::runtime_error("Invalid UTF-8 in document");
     return buf;
 }
 
 Metadata Segment::get_metadata(size_t doc_id) const
 {
-    const ScopedFd f(dir_ + "/metadata.jsonl");
-    if (f.fd < 0) throw std::runtime_error("cannot open metadata.jsonl");
-    const int fd = f.fd;
+    const std::string path = dir_ + "/metadata.jsonl";
     std::call_once(meta_once_, [&] {  // one pass for the line starts; later lookups read one line
-        meta_size_ = fd_size(fd);
-        std::vector<char> chunk(1 << 16);
+        meta_map_ = map_whole(path, meta_size_);
+        std::vector<char> chunk(meta_map_ ? 0 : (1 << 16));
         uint64_t off = 0;
         bool at_line_start = true;
         while (off < meta_size_) {
-            const size_t want = (size_t)std::min<uint64_t>(chunk.size(), meta_size_ - off);
-            pread_all(fd, chunk.data(), want, off, "metadata.jsonl");
+            const size_t want = (size_t)std::min<uint64_t>(1 << 16, meta_size_ - off);
+            const char* p = meta_map_ ? meta_map_ + off : chunk.data();
+            if (!meta_map_) read_range(nullptr, path, chunk.data(), want, off);
             for (size_t i = 0; i < want; ++i) {
                 if (at_line_start) meta_offsets_.push_back(off + i);
-                at_line_start = chunk[i] == '\n';
+                at_line_start = p[i] == '\n';
             }
             off += want;
         }
@@ -661,7 +692,7 @@ Metadata Segment::get_metadata(size_t doc_id) const
     const uint64_t start = meta_offsets_[doc_id];
     uint64_t end = doc_id + 1 < meta_offsets_.size() ? meta_offsets_[doc_id + 1] : meta_size_;
     std::string line((size_t)(end - start), '\0');
-    if (!line.empty()) pread_all(fd, &line[0], line.size(), start, "metadata.jsonl");
+    read_range(meta_map_, path, line.empty() ? nullptr : &line[0], line.size(), start);
     while (!line.empty() && line.back() == '\n') line.pop_back();
     const Json j = Json::parse(line);
     if (!j.is_object()) throw std::runtime_error("Invalid JSON: metadata is not an object");
@@ -687,7 +718,8 @@ std::unique_ptr<IndexReader> IndexReader::open(const std::string& root)
             while (dirent* e = readdir(d)) {
                 const std::string n = e->d_name;
                 if (n == "." || n == "..") continue;
-                if (is_dir(segdir + "/" + n)) names.push_back(n);
+                // (d_type where the file system reports it: no stat per entry)
+                if (e->d_type == DT_DIR || ((e->d_type == DT_UNKNOWN || e->d_type == DT_LNK) && is_dir(segdir + "/" + n))) names.push_back(n);
             }
             closedir(d);
         }

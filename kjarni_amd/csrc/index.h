@@ -88,6 +88,8 @@ public:
     const float* vectors() const { return vectors_; }  // mmap of vectors.bin
     size_t vectors_bytes() const { return map_len_; }
     const std::string& dir() const { return dir_; }
+    // Unique per parsed Segment object in this process (never reused): the key of device-side copies of its vectors.
+    uint64_t uid() const { return uid_; }
     std::string get_document(size_t doc_id) const;     // segment.rs:264-289
     Metadata get_metadata(size_t doc_id) const;        // segment.rs:292-304
     std::vector<std::pair<size_t, float>> search_keywords(const std::string& q, size_t limit) const
@@ -98,17 +100,19 @@ public:
 
 private:
     std::string dir_;
+    uint64_t uid_ = 0;
     size_t doc_count_ = 0, dimension_ = 0;
     const float* vectors_ = nullptr;
     void* map_ = nullptr;
     size_t map_len_ = 0;
     std::vector<uint64_t> doc_offsets_;
     Bm25Index bm25_;
-    // Hits are read with open + pread + close (no descriptor is held: an index may have thousands of segments).  The
-    // file sizes and the byte offset of every metadata.jsonl line are taken once per parsed segment (a changed file makes a
-    // new Segment, see open_shared).
+    // Hits are read out of mappings of docs.bin / metadata.jsonl made on first use (no descriptor is held: an index may have
+    // thousands of segments).  The file sizes and the byte offset of every metadata.jsonl line are taken once per parsed segment
+    // (a changed segment makes a new Segment, see open_shared).
     mutable std::once_flag docs_once_, meta_once_;
     mutable uint64_t docs_size_ = 0, meta_size_ = 0;
+    mutable const char *docs_map_ = nullptr, *meta_map_ = nullptr;  // mapped on first use (null: read with pread)
     mutable std::vector<uint64_t> meta_offsets_;
 };
 

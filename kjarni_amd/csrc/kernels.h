@@ -147,4 +147,12 @@ size_t cosine_topk_workspace_bytes(int nq, int64_t n_docs, int k);
 hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k, void* workspace,
                               int64_t* out_idx, float* out_score, hipStream_t stream);
 
+// R14, scan + selection in one call: per-query top-k without a caller-visible score array.  One query over a width the
+// streaming kernel is specialised for (128 .. 1024) and k <= 256 runs ONE fused pass -- every wave keeps its best keys in
+// registers, the scores never exist in memory -- plus one small merge launch; everything else runs launch_cosine_scores +
+// launch_cosine_topk inside the workspace.  out_idx / out_score: [nq, k].
+size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k);
+hipError_t launch_cosine_search(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode, int k,
+                                void* workspace, int64_t* out_idx, float* out_score, hipStream_t stream);
+
 }  // namespace kjarni

@@ -32,6 +32,7 @@
 //   22  small calls (<= 256 items) on the item-per-workgroup kernels instead of the split one (a key tile per wave)
 // cosine variant (kjarni_hip_set_cosine_variant):
 //    1  streaming passes only (no GEMM route for many queries)
+//    2  one query: scores + selection as separate launches instead of the fused pass
 #pragma once
 
 #ifdef KJARNI_TUNING
@@ -79,6 +80,7 @@ inline bool no_short_attention() { return attention() == 21; }
 inline bool no_split_attention() { return attention() == 22 || attention() == 21; }
 
 inline bool scan_streaming_only() { return cosine() == 1; }
+inline bool scan_two_launches() { return cosine() == 2; }
 
 }  // namespace tune
 }  // namespace kjarni

@@ -112,6 +112,14 @@ def rrf_fuse(keyword_ids, semantic_ids, limit: int):
     return [(int(ids[i]), float(sc[i])) for i in range(n.value)]
 
 
+def search_breakdown() -> Dict[str, float]:
+    """Where this thread's last search call spent its time, in microseconds (kjarni_hip_search_breakdown): re-opening the
+    index, the scan over the device image, of it the device round trip, the whole call."""
+    v = (C.c_double * 4)()
+    lib().kjarni_hip_search_breakdown(v, 4)
+    return {"open_us": v[0], "scan_us": v[1], "device_us": v[2], "total_us": v[3], "host_rest_us": v[3] - v[0] - v[1]}
+
+
 def index_search(index_path: str, text_query: Optional[str] = None, query_emb=None, mode: Optional[str] = None,
                  top_k: Optional[int] = None, threshold: Optional[float] = None, source_pattern: Optional[str] = None,
                  filter_key: Optional[str] = None, filter_value: Optional[str] = None) -> List[Dict]:

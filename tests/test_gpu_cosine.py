@@ -152,3 +152,53 @@ def test_topk_adversarial_orders(n, nq, k):
             assert (idx[j][:kk][nan_free] == order[:kk][nan_free]).all()
             np.testing.assert_array_equal(out[j][:kk][nan_free], s[order[:kk]][nan_free])
             assert (idx[j][kk:] == -1).all()
+
+
+@pytest.mark.parametrize("n,dim,k", [(1, 384, 1), (3, 384, 10), (4, 384, 4), (5, 384, 16), (999, 384, 17), (40_003, 384, 10),
+                                     (40_003, 384, 64), (40_002, 384, 65), (40_001, 384, 128), (40_000, 384, 256), (300_001, 384, 100),
+                                     (9_001, 128, 10), (9_001, 256, 33), (9_001, 512, 10), (9_001, 768, 129), (9_001, 1024, 10)])
+def test_one_call_search_equals_scores_plus_topk(n, dim, k):
+    """kjarni_hip_cosine_search (one query: a single fused pass, every wave keeping its best keys in registers) against
+    kjarni_hip_cosine_scores + kjarni_hip_cosine_topk: the same indices and the same scores bit for bit -- on rows with exact
+    duplicates (ties resolve to the lowest index), on a corpus whose scores ASCEND with the row index (every row beats the running
+    threshold: the worst case for the insertions), with a zero row, a tail of rows past the last whole group, and in both modes."""
+    import torch
+    from kjarni_amd import _ffi
+    L = _ffi.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(n * 7 + dim + k)
+    q = rng.standard_normal(dim).astype(np.float32)
+    base = rng.standard_normal((n, dim)).astype(np.float32)
+    ramp = np.linspace(0.0, 3.0, n, dtype=np.float32)[:, None]
+    corpora = [base.copy(), (base + ramp * q).astype(np.float32)]           # random; ascending cosine with the row index
+    dup = base.copy()
+    dup[n // 2:] = dup[: n - n // 2]                                          # the second half repeats the first: exact ties
+    corpora.append(dup)
+    for ci, corpus in enumerate(corpora):
+        if n > 2:
+            corpus[n // 3] = 0.0
+        c_d = torch.from_numpy(corpus).to(dev)
+        q_d = torch.from_numpy(q).to(dev)
+        for mode in (0, 1):
+            scores = torch.empty((1, n), dtype=torch.float32, device=dev)
+            ws = torch.empty(L.kjarni_hip_cosine_topk_workspace_bytes(1, n, k), dtype=torch.uint8, device=dev)
+            idx2 = torch.empty((1, k), dtype=torch.int64, device=dev)
+            sc2 = torch.empty((1, k), dtype=torch.float32, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            _ffi.check_error(L.kjarni_hip_cosine_scores(0, q_d.data_ptr(), 1, c_d.data_ptr(), n, dim, mode, scores.data_ptr(), st))
+            _ffi.check_error(L.kjarni_hip_cosine_topk(0, scores.data_ptr(), 1, n, k, ws.data_ptr(), idx2.data_ptr(), sc2.data_ptr(), st))
+            ws1 = torch.empty(L.kjarni_hip_cosine_search_workspace_bytes(1, n, dim, k), dtype=torch.uint8, device=dev)
+            idx1 = torch.full((1, k), -7, dtype=torch.int64, device=dev)
+            sc1 = torch.full((1, k), 7.0, dtype=torch.float32, device=dev)
+            _ffi.check_error(L.kjarni_hip_cosine_search(0, q_d.data_ptr(), 1, c_d.data_ptr(), n, dim, mode, k, ws1.data_ptr(),
+                                                        idx1.data_ptr(), sc1.data_ptr(), st))
+            torch.cuda.synchronize()
+            a, b = idx1.cpu().numpy()[0], idx2.cpu().numpy()[0]
+            assert (a == b).all(), (ci, mode, a[:12], b[:12])
+            sa, sb = sc1.cpu().numpy()[0], sc2.cpu().numpy()[0]
+            assert (sa.view(np.uint32) == sb.view(np.uint32)).all(), (ci, mode)
+            kk = min(k, n)
+            assert (a[kk:] == -1).all() and (a[:kk] >= 0).all()
+            # and against the oracle: order by (score descending, index ascending)
+            ridx, rsc = O.search(q, corpus, k, mode=mode)
+            assert np.abs(sa[:kk] - rsc).max() < 1e-4

@@ -217,6 +217,16 @@ def main():
                 t_scan = timed(scan, sync, steps, 2)
                 t_topk = timed(topk, sync, steps, 2)
                 t_all = timed(lambda: (scan(), topk()), sync, steps, 2)
+                two_idx, two_sc = idx.clone(), sc.clone()
+                # the one-call form (kjarni_hip_cosine_search): for one query a single fused pass, no score array
+                ws2 = torch.empty(L.kjarni_hip_cosine_search_workspace_bytes(nq, n, dim, k), dtype=torch.uint8, device=dev)
+
+                def search():
+                    _ffi.check_error(L.kjarni_hip_cosine_search(0, q.data_ptr(), nq, corpus.data_ptr(), n, dim, 1, k, ws2.data_ptr(),
+                                                                idx.data_ptr(), sc.data_ptr(), stream()))
+                t_search = timed(search, sync, steps, 2)
+                fused_equal = bool(torch.equal(idx, two_idx)) and bool(torch.equal(sc, two_sc))
+                del ws2
                 ref_idx = torch.topk(q @ corpus.T if n <= 1_000_000 else scores, k, dim=1).indices
                 same = bool(torch.equal(torch.sort(ref_idx, dim=1).values, torch.sort(idx, dim=1).values))
                 alg = n * dim * 4
@@ -237,7 +247,9 @@ def main():
                       "unit": "doc-queries/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"corpus [{n}, 384] unit-norm Gaussian rows resident in HBM, {nq} quer{'y' if nq == 1 else 'ies'}, k=10"},
                       "topk_set_equals_torch_topk": same, "ms_scan": round(t_scan * 1e3, 4), "ms_topk": round(t_topk * 1e3, 4),
-                      "ms_total": round(t_all * 1e3, 4), "roofline": roof})
+                      "ms_total": round(t_all * 1e3, 4), "ms_search_one_call": round(t_search * 1e3, 4),
+                      "search_gbs": round(alg * ((nq + 3) // 4 if nq < 20 else (nq + 63) // 64) / t_search / 1e9, 1),
+                      "one_call_equals_two_calls_bit_for_bit": fused_equal, "roofline": roof})
                 del scores, ws, idx, sc, q
             del corpus
             torch.cuda.empty_cache()
@@ -372,11 +384,18 @@ def main():
                           ("hybrid", lambda q: index_search(ipath, "glacier fjord basalt", q, mode="hybrid", top_k=10)),
                           ("semantic_filtered", lambda q: index_search(ipath, None, q, mode="semantic", top_k=10, source_pattern="f1*.txt"))):
             fn(queries[1])
+            from kjarni_amd.searcher import search_breakdown
             t0 = time.perf_counter()
+            acc = {}
             for q in queries[:32]:
                 r = fn(q)
+                for k_, v_ in search_breakdown().items():
+                    acc[k_] = acc.get(k_, 0.0) + v_ / 32
             dt = (time.perf_counter() - t0) / 32
-            runs[label] = {"ms_per_query": round(dt * 1e3, 3), "queries_per_s": round(1.0 / dt, 1), "results": len(r)}
+            # per query, microseconds: re-opening the index | the scan over the device image (of it the device round trip) | the
+            # rest on the host (BM25, fusion, reading the hits' documents and metadata back)
+            runs[label] = {"ms_per_query": round(dt * 1e3, 3), "queries_per_s": round(1.0 / dt, 1), "results": len(r),
+                           "breakdown_us": {k_: round(v_, 1) for k_, v_ in acc.items()}}
         # the whole Searcher: query string -> tokenise -> embed on the GPU -> retrieval (-> cross-encoder over 5x candidates)
         ce_dir = os.path.join(tmp, "cache", "cross-encoder_ms-marco-MiniLM-L-6-v2")
         synth.minilm_cross_encoder(ce_dir, seed=1)
