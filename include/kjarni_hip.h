@@ -86,6 +86,16 @@ KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64
  *      matter more than asynchrony (1.76 x on lengths U{16..128}). */
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
+/* Concurrent small calls on one handle.  The reference serialises nothing on a handle (kjarni-ffi/src/lib.rs:25-32): N
+ * threads may each embed or classify one sentence at once.  A single-sentence forward is ~45 dependent launches on a fraction
+ * of the chip, so by default the HOST-pointer entry points (and everything built on them: the string-level handles, groups)
+ * COMBINE small calls (<= 8 rows, <= 1 024 tokens) that arrive while another small call of the same kind is on the device: a
+ * call that finds the handle idle runs at once exactly as before; calls that queue up behind it ride along with the next
+ * leader as ONE packed batch (one forward per round instead of one per thread).  A combined call's result equals the solo
+ * call's to rounding (<= 1e-6: the rows take the packed layout and another tile route), not bit for bit.  0 turns it off
+ * (every call runs alone; environment KJARNI_HIP_COMBINE=0 does the same for every handle of the process). */
+KjarniErrorCode kjarni_hip_encoder_set_combining(KjarniHipEncoder* enc, int32_t on);
+
 /* Opt-in, process-wide, default OFF (or environment KJARNI_HIP_F32_ON_BF16=1, read once at the first projection): the
  * projections of calls above the few-rows range (more than 256 token rows; 128 for models wider than 512) compute their f32
  * products on the bf16 matrix cores.  Every

@@ -210,6 +210,7 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
 
     std::unique_ptr<EncoderModel> m(new EncoderModel());
     m->device_ = device;
+    if (const char* e = std::getenv("KJARNI_HIP_COMBINE")) m->combining_ = !(e[0] == '0' && e[1] == '\0');
     EncoderConfig& c = m->cfg_;
     c.config_json = read_file(dir + "/config.json");
     Json cfg = Json::parse(c.config_json);
@@ -1043,8 +1044,8 @@ void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask,
              });
 }
 
-void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
-                              int seq, PoolMode pool, bool normalize, float mask_value, float* out)
+void EncoderModel::embed_host_now(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                                  int seq, PoolMode pool, bool normalize, float mask_value, float* out)
 {
     run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.hidden, out, true,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
@@ -1054,8 +1055,8 @@ void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const u
              });
 }
 
-void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
-                               int seq, float mask_value, float* out)
+void EncoderModel::logits_host_now(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                                   int seq, float mask_value, float* out)
 {
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
     run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.num_labels, out, true,
@@ -1064,6 +1065,137 @@ void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const 
                  plan_packing(ws, k, mask, batch, seq, st, plan);
                  logits_on(ws, i, k, t, batch, seq, mask_value, o, st, plan);
              });
+}
+
+// ---- call combining -------------------------------------------------------------------------------------
+// A small call (a sentence to embed or classify, a handful) is ~45 dependent launches of ~5 us on a fraction of the chip, and
+// the reference lets any number of threads call one handle at once (kjarni-ffi/src/lib.rs:25-32).  Threads that do so share
+// the launches: a call queues itself; if no leader is at work it becomes one and runs -- alone when nothing else is queued,
+// which is the uncontended case and costs one uncontended lock more than before; calls that arrive while a leader's batch is
+// on the device wait, and the next leader (the first of them to wake) takes every compatible queued call along as ONE batch of
+// packed rows (sentences of different lengths padded to the longest: the packed layout drops the padding again).  Up to
+// two batches are in flight at once (one stages and tokenises while the other computes).
+namespace {
+constexpr int64_t kCombineMaxCallRows = 8, kCombineMaxCallTokens = 1024;  // what counts as a small call
+constexpr int64_t kCombineMaxBatchRows = 256, kCombineMaxBatchTokens = 16384;
+constexpr int kCombineLeadersDefault = 2;
+// (measurements: KJARNI_HIP_COMBINE_LEADERS = batches in flight at once)
+int combine_leaders()
+{
+    static const int n = [] {
+        const char* e = std::getenv("KJARNI_HIP_COMBINE_LEADERS");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1 && v <= 4 ? v : kCombineLeadersDefault;
+    }();
+    return n;
+}
+}  // namespace
+
+void EncoderModel::run_combined(const std::vector<CombineReq*>& reqs)
+{
+    const CombineReq& f = *reqs.front();
+    if (reqs.size() == 1) {
+        if (f.kind == 0) embed_host_now(f.ids, f.mask, f.type_ids, f.batch, f.seq, (PoolMode)f.pool, f.normalize, f.mask_value, f.out);
+        else logits_host_now(f.ids, f.mask, f.type_ids, f.batch, f.seq, f.mask_value, f.out);
+        return;
+    }
+    int64_t rows = 0;
+    int seq = 0;
+    for (const CombineReq* r : reqs) {
+        rows += r->batch;
+        seq = std::max(seq, r->seq);
+    }
+    const size_t n = (size_t)rows * (size_t)seq;
+    std::vector<uint32_t> ids(n, 0u), mask(n, 0u), types(f.type_ids ? n : 0, 0u);
+    int64_t at = 0;
+    for (const CombineReq* r : reqs)
+        for (int64_t b = 0; b < r->batch; ++b, ++at) {
+            std::memcpy(&ids[(size_t)at * seq], r->ids + b * r->seq, (size_t)r->seq * 4);
+            std::memcpy(&mask[(size_t)at * seq], r->mask + b * r->seq, (size_t)r->seq * 4);
+            if (f.type_ids) std::memcpy(&types[(size_t)at * seq], r->type_ids + b * r->seq, (size_t)r->seq * 4);
+        }
+    std::vector<float> out((size_t)rows * f.out_per_row);
+    if (f.kind == 0)
+        embed_host_now(ids.data(), mask.data(), f.type_ids ? types.data() : nullptr, rows, seq, (PoolMode)f.pool, f.normalize, f.mask_value,
+                       out.data());
+    else
+        logits_host_now(ids.data(), mask.data(), f.type_ids ? types.data() : nullptr, rows, seq, f.mask_value, out.data());
+    at = 0;
+    for (const CombineReq* r : reqs) {
+        std::memcpy(r->out, &out[(size_t)at * f.out_per_row], (size_t)r->batch * f.out_per_row * sizeof(float));
+        at += r->batch;
+    }
+}
+
+void EncoderModel::submit_small(CombineReq& req)
+{
+    std::unique_lock<std::mutex> lock(combine_mu_);
+    combine_queue_.push_back(&req);
+    while (!req.done) {
+        if (combine_leaders_ >= combine_leaders() || combine_queue_.empty()) {
+            combine_cv_.wait(lock);
+            continue;
+        }
+        // lead: the oldest queued call and every compatible one behind it, within the batch bounds
+        ++combine_leaders_;
+        std::vector<CombineReq*> take;
+        int64_t rows = 0, tokens = 0;
+        for (auto it = combine_queue_.begin(); it != combine_queue_.end();) {
+            CombineReq* r = *it;
+            const int seq = take.empty() ? r->seq : std::max(r->seq, take.front()->seq);
+            if ((take.empty() || (r->compatible(*take.front()) && rows + r->batch <= kCombineMaxBatchRows &&
+                                  (rows + r->batch) * seq <= kCombineMaxBatchTokens))) {
+                take.push_back(r);
+                rows += r->batch;
+                tokens = rows * seq;
+                it = combine_queue_.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        (void)tokens;
+        lock.unlock();
+        std::exception_ptr err;
+        try {
+            run_combined(take);
+        } catch (...) {
+            err = std::current_exception();
+        }
+        lock.lock();
+        for (CombineReq* r : take) {
+            r->error = err;
+            r->done = true;
+        }
+        --combine_leaders_;
+        combine_cv_.notify_all();
+    }
+    lock.unlock();
+    if (req.error) std::rethrow_exception(req.error);
+}
+
+void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                              int seq, PoolMode pool, bool normalize, float mask_value, float* out)
+{
+    if (batch <= 0 || seq <= 0) return;
+    if (combining_ && batch <= kCombineMaxCallRows && batch * seq <= kCombineMaxCallTokens) {
+        CombineReq r{0, ids, mask, type_ids, batch, seq, (int)pool, normalize, mask_value, out, (size_t)cfg_.hidden, false, nullptr};
+        submit_small(r);
+        return;
+    }
+    embed_host_now(ids, mask, type_ids, batch, seq, pool, normalize, mask_value, out);
+}
+
+void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
+                               int seq, float mask_value, float* out)
+{
+    if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
+    if (batch <= 0 || seq <= 0) return;
+    if (combining_ && batch <= kCombineMaxCallRows && batch * seq <= kCombineMaxCallTokens) {
+        CombineReq r{1, ids, mask, type_ids, batch, seq, 0, false, mask_value, out, (size_t)cfg_.num_labels, false, nullptr};
+        submit_small(r);
+        return;
+    }
+    logits_host_now(ids, mask, type_ids, batch, seq, mask_value, out);
 }
 
 }  // namespace kjarni

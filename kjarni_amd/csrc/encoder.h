@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <exception>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
@@ -192,6 +193,15 @@ public:
     // two streams never see each other's activations.  The profiler is a single-caller tool.
     static constexpr int kMaxWorkspaces = 4;
 
+    // Small host-pointer calls that arrive while another small call of the same kind is on the device are COMBINED: a call
+    // becomes the leader when none is running (an uncontended call runs at once, exactly as before), and a leader takes every
+    // compatible call that queued up meanwhile along as ONE packed batch -- N threads that each embed or classify one sentence
+    // then cost one forward pass per round, not N x ~45 launches (the reference serialises nothing on a handle,
+    // kjarni-ffi/src/lib.rs:25-32; on a 256-CU part a single-sentence forward occupies a fraction of the chip).  Results equal
+    // the solo call's to rounding (the rows take the packed layout and another tile route).  On by default.
+    void set_combining(bool on) { combining_ = on; }
+    bool combining() const { return combining_; }
+
 private:
     EncoderModel() = default;
     float* upload(const std::vector<float>& host);
@@ -252,6 +262,37 @@ private:
     size_t weight_bytes_ = 0;
     std::atomic<int64_t> chunk_tokens_{262144};
     std::atomic<int> packing_{1};
+    std::atomic<bool> combining_{true};
+
+    // ---- combining of concurrent small host-pointer calls (encoder.cpp, "call combining") ----
+    struct CombineReq {
+        int kind;  // 0 embed, 1 logits
+        const uint32_t *ids, *mask, *type_ids;
+        int64_t batch;
+        int seq;
+        int pool;
+        bool normalize;
+        float mask_value;
+        float* out;
+        size_t out_per_row;
+        bool done = false;
+        std::exception_ptr error;
+        bool compatible(const CombineReq& o) const
+        {
+            return kind == o.kind && pool == o.pool && normalize == o.normalize && mask_value == o.mask_value &&
+                   (type_ids != nullptr) == (o.type_ids != nullptr);
+        }
+    };
+    void submit_small(CombineReq& req);
+    void run_combined(const std::vector<CombineReq*>& reqs);
+    void embed_host_now(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq, PoolMode pool,
+                        bool normalize, float mask_value, float* out);
+    void logits_host_now(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq, float mask_value,
+                         float* out);
+    std::mutex combine_mu_;
+    std::condition_variable combine_cv_;
+    std::vector<CombineReq*> combine_queue_;
+    int combine_leaders_ = 0;
     std::vector<void*> allocs_;
 
     float *word_ = nullptr, *pos_ = nullptr, *type_ = nullptr, *emb_ln_g_ = nullptr,

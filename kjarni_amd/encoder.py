@@ -68,6 +68,11 @@ class HipEncoder:
         the device-pointer ones (embed_dev / logits_dev then synchronise their stream once per call: kjarni_hip.h)."""
         check_error(lib().kjarni_hip_encoder_set_packing(self._h, int(mode)))
 
+    def set_combining(self, on: bool):
+        """Small host-array calls that arrive while another is on the device ride along with the next one as one packed batch
+        (default on; kjarni_hip.h: kjarni_hip_encoder_set_combining)."""
+        check_error(lib().kjarni_hip_encoder_set_combining(self._h, 1 if on else 0))
+
     KINDS = ("embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm", "gemm_fc1", "gemm_fc2",
              "pool", "head", "rope")
 

@@ -120,9 +120,11 @@ def test_bad_device_list_is_invalid_config(tmp_path):
 
 
 def test_two_threads_on_one_handle_are_oracle_equal(tmp_path):
-    """The reference serialises nothing on a handle (kjarni-ffi/src/lib.rs:25-32).  Two host threads hammer ONE
-    token-level handle and ONE string-level handle with different inputs; every result must equal the oracle /
-    the single-threaded result (a shared workspace would mix the two threads' activations)."""
+    """The reference serialises nothing on a handle (kjarni-ffi/src/lib.rs:25-32).  Sixteen host threads hammer ONE
+    token-level handle and ONE string-level handle with different inputs -- batches and single sentences, so that small calls
+    are combined into shared forwards (kjarni_hip.h: kjarni_hip_encoder_set_combining) while larger ones run on workspaces of
+    their own.  Every result must equal the oracle at 1e-4 and the single-threaded result at 1e-6 (a shared workspace would
+    mix the threads' activations; a combined call takes the packed layout, hence rounding and not bit equality)."""
     import kjarni_amd
     from oracle import oracle as O
     d = str(tmp_path / "e")
@@ -130,10 +132,15 @@ def test_two_threads_on_one_handle_are_oracle_equal(tmp_path):
     synth.add_tokenizer(d)
     enc = kjarni_amd.HipEncoder(d)
     oracle = O.OracleModel(t, cfg)
+    n_threads = 16
+    # threads 0-3: ragged batches of 5 .. 14 sentences (5 and 8 rows are small calls, the others are not); 4-15: one sentence
     inputs = [synth.synthetic_ids(5 + 3 * i, 32 + 16 * i, seed=10 + i, ragged=True) for i in range(4)]
+    inputs += [synth.synthetic_ids(1, 12 + 3 * i, seed=40 + i) for i in range(n_threads - 4)]
     refs = [oracle.embed_batch(i, m) for i, m in inputs]
+    solo = [enc.embed(i, m) for i, m in inputs]
     emb = kjarni_amd.Embedder(model_path=d)
     texts = [[f"sentence number {j} of thread {i} " * (1 + j % 3) for j in range(6 + i)] for i in range(4)]
+    texts += [[f"a lone sentence from thread {i} " * (1 + i % 4)] for i in range(4, n_threads)]
     text_refs = [emb.encode_batch(tx) for tx in texts]
     errors = []
 
@@ -142,15 +149,44 @@ def test_two_threads_on_one_handle_are_oracle_equal(tmp_path):
             for _ in range(25):
                 got = enc.embed(*inputs[i])
                 if float(np.abs(got - refs[i]).max()) >= 1e-4:
-                    errors.append(f"token-level thread {i}: {float(np.abs(got - refs[i]).max())}")
+                    errors.append(f"token-level thread {i} vs oracle: {float(np.abs(got - refs[i]).max())}")
                     return
-                if not np.array_equal(emb.encode_batch(texts[i]), text_refs[i]):
+                if float(np.abs(got - solo[i]).max()) > 1e-6:
+                    errors.append(f"token-level thread {i} vs solo: {float(np.abs(got - solo[i]).max())}")
+                    return
+                got = emb.encode_batch(texts[i])
+                if got.shape != text_refs[i].shape or float(np.abs(got - text_refs[i]).max()) > 1e-6:
                     errors.append(f"string-level thread {i}")
                     return
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
 
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+
+
+def test_without_combining_threads_get_the_solo_bits(tmp_path):
+    """kjarni_hip_encoder_set_combining(0): every call runs alone, so concurrent callers get exactly the single-threaded bits."""
+    import kjarni_amd
+    d = str(tmp_path / "e")
+    synth.minilm_embedder(d, seed=0, num_hidden_layers=2)
+    enc = kjarni_amd.HipEncoder(d)
+    enc.set_combining(False)
+    inputs = [synth.synthetic_ids(1 + i % 3, 16 + 5 * i, seed=70 + i, ragged=True) for i in range(8)]
+    solo = [enc.embed(i, m) for i, m in inputs]
+    errors = []
+
+    def work(i):
+        for _ in range(30):
+            if not np.array_equal(enc.embed(*inputs[i]), solo[i]):
+                errors.append(i)
+                return
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
     for th in threads:
         th.start()
     for th in threads:

@@ -336,7 +336,11 @@ def main():
               "kjarni_embedder_encode (minilm-l6-v2 shape)": lat(lambda: emb.encode(sentence)),
               "kjarni_classifier_classify (distilbert-sst2 shape, 6 x 768)": lat(lambda: clf.classify(sentence)),
               "kjarni_embedder_encode, 4 threads on one handle": concurrent(lambda: emb.encode(sentence)),
-              "kjarni_classifier_classify, 4 threads on one handle": concurrent(lambda: clf.classify(sentence))})
+              "kjarni_embedder_encode, 16 threads on one handle": concurrent(lambda: emb.encode(sentence), threads=16),
+              "kjarni_classifier_classify, 4 threads on one handle": concurrent(lambda: clf.classify(sentence)),
+              "kjarni_classifier_classify, 16 threads on one handle": concurrent(lambda: clf.classify(sentence), threads=16),
+              "note": "small calls that arrive while another is on the device are combined into one packed forward "
+                      "(kjarni_hip_encoder_set_combining, default on)"})
         del emb, clf
 
     if "indexer" in which:
