@@ -104,8 +104,9 @@ KjarniErrorCode kjarni_hip_encoder_set_combining(KjarniHipEncoder* enc, int32_t 
  * so inputs, outputs and the error level are those of f32 arithmetic (measured against float64: the same 2-4e-6 as the f32
  * MFMA kernels, tests/test_gpu_split.py), at 1.1-1.3x their speed (the reference's default batch of 32 sentences x 128
  * tokens: 1.12 -> 0.94 ms per call).  Differences: sums run in another
- * order (results equal to the default path to rounding, not bit for bit), and a non-finite INPUT element turns its products
- * into NaN (inf - inf in the split) where the default path keeps an infinity.  The reference computes in f32
+ * order (results equal to the default path to rounding, not bit for bit), and NON-FINITE inputs: an element that is +-inf or NaN
+ * turns every product it takes part in into NaN (the split computes x - bf16(x), and inf - inf is NaN) where the default
+ * path keeps an infinity an infinity (inf * finite = inf); finite inputs whose products overflow behave the same in both.  The reference computes in f32
  * (kjarni-transformers/src/linear_layer/linear_layer.rs:160-282); whether f32 results assembled from bf16 pieces meet a
  * deployment's precision policy is the integrator's decision, hence off by default.  Returns the previous setting. */
 int32_t kjarni_hip_set_f32_on_bf16(int32_t on);

@@ -68,9 +68,20 @@ def cross6(tmp_path_factory):
     enc.close()
 
 
+@pytest.fixture(params=["f32", "f32_on_bf16"])
+def products(request):
+    """(a) and (c) run twice: on the f32 matrix cores (the default, what `value` is measured on) and with the opt-in mode that
+    computes the same f32 products from exact bf16 pieces on the bf16 matrix cores (kjarni_hip_set_f32_on_bf16) -- the same
+    1e-4 / 1e-5 bars in both."""
+    from kjarni_amd import ops
+    before = ops.set_f32_on_bf16(request.param == "f32_on_bf16")
+    yield request.param
+    ops.set_f32_on_bf16(before)
+
+
 # ------------------------------------------------------------------------------------------------ (a)
 @pytest.mark.parametrize("B,S,ragged", [(2100, 128, True), (300, 100, True), (2048, 128, False)])
-def test_whole_chunk_and_tail_embed_every_row(minilm2, B, S, ragged):
+def test_whole_chunk_and_tail_embed_every_row(minilm2, products, B, S, ragged):
     """2 100 x 128 = one full 2 048-sentence chunk (18 432 QKV tiles, 24 576 attention items) + a 52-sentence tail on the
     mid-size route; 300 x 100 = 30 000 tokens in one chunk with a sequence length that is not a tile multiple."""
     enc, orc = minilm2
@@ -82,7 +93,7 @@ def test_whole_chunk_and_tail_embed_every_row(minilm2, B, S, ragged):
     assert float(err.max()) < TOL, (int(err.argmax()), float(err.max()))
 
 
-def test_whole_chunk_and_tail_rerank_logits_every_row(cross2):
+def test_whole_chunk_and_tail_rerank_logits_every_row(cross2, products):
     enc, orc = cross2
     ids, mask, types = synth.synthetic_pairs(2060, 128, seed=9)
     rng = np.random.default_rng(9)
@@ -181,7 +192,7 @@ def test_attention_on_the_item_loop(B, S, d):
 
 
 # ------------------------------------------------------------------------------------------------ (c)
-def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6):
+def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6, products):
     """BASELINE.json configs[1] once: 65 536 x 128 through one call (32 chunks).  64 sampled rows (chunk edges included)
     against the oracle; those and 192 more re-encoded in 64-sentence calls (mid-size route) agree to 1e-5; another
     chunk size gives the same vectors."""
@@ -211,7 +222,7 @@ def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6):
     assert float(np.abs(other - full).max()) < 1e-5
 
 
-def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6):
+def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6, products):
     """BASELINE.json configs[2] on one GPU: 100 000 pairs x 128."""
     enc, orc = cross6
     N, S = 100000, 128
