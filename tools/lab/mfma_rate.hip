@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NACC>
-__global__ __launch_bounds__(256, 1) void k16(float* out, unsigned long long* cyc, int iters, float a0, float b0)
+__global__ __launch_bounds__(256, 2) void k16(float* out, unsigned long long* cyc, int iters, float a0, float b0)
 {
     f32x4 acc[NACC];
 #pragma unroll
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 1) void k16(float* out, unsigned long long* cy
 }
 
 template <int NACC>
-__global__ __launch_bounds__(256, 1) void k32(float* out, unsigned long long* cyc, int iters, float a0, float b0)
+__global__ __launch_bounds__(256, 2) void k32(float* out, unsigned long long* cyc, int iters, float a0, float b0)
 {
     f32x16 acc[NACC];
 #pragma unroll
@@ -91,7 +91,7 @@ int main()
     hipMalloc(&out, 1024);
     hipMalloc(&cyc, 4096 * 8);
     const int iters = 24;
-    for (int grid : {256, 64}) {
+    for (int grid : {256, 512, 1024}) {  // 1, 2, 4 waves per SIMD (256-thread workgroups, as many per CU as fit)
         std::printf("grid %d\n", grid);
         run("16x16x4, 24 accumulators", [&] { hipLaunchKernelGGL(k16<24>, dim3(grid), dim3(256), 0, 0, out, cyc, iters, 1.f, 2.f); }, 96, 2.0 * 16 * 16 * 4, iters, grid, cyc);
         run("16x16x4, 18 accumulators", [&] { hipLaunchKernelGGL(k16<18>, dim3(grid), dim3(256), 0, 0, out, cyc, iters, 1.f, 2.f); }, 72, 2.0 * 16 * 16 * 4, iters, grid, cyc);
