@@ -96,6 +96,13 @@ KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on
  * (every call runs alone; environment KJARNI_HIP_COMBINE=0 does the same for every handle of the process). */
 KjarniErrorCode kjarni_hip_encoder_set_combining(KjarniHipEncoder* enc, int32_t on);
 
+/* Mid-size host-pointer calls (2 304 .. 8 192 kept tokens: the reference's default batch of 32 sentences) run as two halves
+ * on two workspaces / streams, the second enqueued by a helper thread of the handle: one half's launch gaps, prologues and
+ * output bursts fall under the other's matrix work (32 x 128 tokens: 1.02 -> 0.94 ms).  Sentences are independent and both
+ * halves take the same projection route, so results are bit-identical to the unsplit call.  On by default; 0 (or environment
+ * KJARNI_HIP_TWO_LANES=0) runs every call as one launch sequence. */
+KjarniErrorCode kjarni_hip_encoder_set_two_lanes(KjarniHipEncoder* enc, int32_t on);
+
 /* Opt-in, process-wide, default OFF (or environment KJARNI_HIP_F32_ON_BF16=1, read once at the first projection): the
  * projections of calls above the few-rows range (more than 256 token rows; 128 for models wider than 512) compute their f32
  * products on the bf16 matrix cores.  Every

@@ -420,6 +420,7 @@ SIGNATURES = {
     "kjarni_hip_encoder_set_chunk_tokens": (c_int32, [c_void_p, c_int64]),
     "kjarni_hip_encoder_set_packing": (c_int32, [c_void_p, c_int32]),
     "kjarni_hip_encoder_set_combining": (c_int32, [c_void_p, c_int32]),
+    "kjarni_hip_encoder_set_two_lanes": (c_int32, [c_void_p, c_int32]),
     "kjarni_hip_set_f32_on_bf16": (c_int32, [c_int32]),
     "kjarni_hip_get_f32_on_bf16": (c_int32, []),
     "kjarni_hip_encoder_hidden_states": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,

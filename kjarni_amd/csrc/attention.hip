@@ -869,6 +869,10 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
 
 }  // namespace
 
+// Calls of up to this many (sentence, head) items take the small-call kernel (another summation order than the item-per-workgroup
+// kernels): callers that cut a batch in two keep both halves above it so that the cut does not change a bit of the result.
+int attention_small_call_items() { return kSplitMaxItems; }
+
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads,
                             int head_dim, float mask_value, float* ctx, hipStream_t stream, const int32_t* cu)
 {

@@ -211,6 +211,7 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
     std::unique_ptr<EncoderModel> m(new EncoderModel());
     m->device_ = device;
     if (const char* e = std::getenv("KJARNI_HIP_COMBINE")) m->combining_ = !(e[0] == '0' && e[1] == '\0');
+    if (const char* e = std::getenv("KJARNI_HIP_TWO_LANES")) m->two_lanes_ = !(e[0] == '0' && e[1] == '\0');
     EncoderConfig& c = m->cfg_;
     c.config_json = read_file(dir + "/config.json");
     Json cfg = Json::parse(c.config_json);
@@ -1044,9 +1045,126 @@ void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask,
              });
 }
 
+// ---- two lanes -------------------------------------------------------------------------------------------
+// A call of a few thousand tokens (the reference's default batch of 32) is ~43 kernels of 15-50 us, each of which pays a
+// launch gap, a prologue and an output burst that nothing overlaps: the chip idles a third of the time.
+// Sentences are independent, so such a call runs as two halves (cut where the kept tokens halve) on two workspaces and two
+// streams, the second half enqueued by a persistent helper thread: the halves drift apart by a fraction of a kernel and each
+// one's idle phases fall under the other's matrix work.  Measured (tools/overlap_probe.py): 24 / 32 / 64 sentences x 128
+// tokens 0.93 / 1.02 / 1.84 -> 0.83 / 0.94 / 1.75 ms; below ~2 300 tokens and above ~8 192 one launch sequence is faster
+// (16 x 128: 0.64 against 0.66; 128 x 128: 3.10 against 3.23), so only that range splits.  Both halves stay in the mid-size
+// projection route, where a row's result does not depend on the rows beside it: the split is invisible in the results.
+// The helper serves one call at a time; a call that finds it busy runs unsplit.
+namespace {
+constexpr int64_t kTwoLaneMinTokens = 2304, kTwoLaneMaxTokens = 8192;
+}
+
+EncoderModel::Lane::~Lane()
+{
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    if (thread_.joinable()) thread_.join();
+}
+
+void EncoderModel::Lane::loop()
+{
+    std::unique_lock<std::mutex> lock(mu_);
+    for (;;) {
+        cv_.wait(lock, [&] { return has_task_ || stop_; });
+        if (stop_) return;
+        std::function<void()> t = std::move(task_);
+        lock.unlock();
+        std::exception_ptr err;
+        try {
+            t();
+        } catch (...) {
+            err = std::current_exception();
+        }
+        lock.lock();
+        error_ = err;
+        has_task_ = false;
+        cv_.notify_all();
+    }
+}
+
+bool EncoderModel::Lane::try_begin(std::function<void()> task)
+{
+    std::lock_guard<std::mutex> lock(mu_);
+    if (busy_ || stop_) return false;
+    if (!thread_.joinable()) thread_ = std::thread([this] { loop(); });
+    busy_ = true;
+    has_task_ = true;
+    error_ = nullptr;
+    task_ = std::move(task);
+    cv_.notify_all();
+    return true;
+}
+
+void EncoderModel::Lane::wait()
+{
+    std::unique_lock<std::mutex> lock(mu_);
+    cv_.wait(lock, [&] { return !has_task_; });
+    const std::exception_ptr err = error_;
+    error_ = nullptr;
+    busy_ = false;
+    lock.unlock();
+    if (err) std::rethrow_exception(err);
+}
+
+// half(b0, nb): runs sentences [b0, b0 + nb) of the call.  Returns false when the call does not split (the caller runs it whole).
+template <class F>
+bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F&& half)
+{
+    if (!two_lanes_ || batch < 4 || batch * seq < kTwoLaneMinTokens) return false;
+    // kept tokens (what the packed layout computes on) and where they halve
+    std::vector<int64_t> upto((size_t)batch + 1, 0);
+    for (int64_t b = 0; b < batch; ++b) {
+        int64_t n = 0;
+        const uint32_t* row = mask + b * seq;
+        for (int s = 0; s < seq; ++s) n += row[s] != 0u;
+        upto[(size_t)b + 1] = upto[(size_t)b] + (packing_ >= 1 ? n : seq);
+    }
+    const int64_t total = upto[(size_t)batch];
+    if (total < kTwoLaneMinTokens || total > kTwoLaneMaxTokens) return false;
+    int64_t cut = 1;
+    while (cut < batch - 1 && upto[(size_t)cut] * 2 < total) ++cut;
+    // both halves on the kernels the whole call would take (the small-call attention kernel sums in another order)
+    if (seq <= 128 && std::min(cut, batch - cut) * cfg_.heads <= attention_small_call_items()) return false;
+    std::exception_ptr second;
+    if (!lane_.try_begin([&, cut] { half(cut, batch - cut); })) return false;
+    std::exception_ptr first;
+    try {
+        half(0, cut);
+    } catch (...) {
+        first = std::current_exception();
+    }
+    try {
+        lane_.wait();
+    } catch (...) {
+        second = std::current_exception();
+    }
+    if (first) std::rethrow_exception(first);
+    if (second) std::rethrow_exception(second);
+    return true;
+}
+
 void EncoderModel::embed_host_now(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch,
                                   int seq, PoolMode pool, bool normalize, float mask_value, float* out)
 {
+    const int H = cfg_.hidden;
+    auto one = [&](int64_t b0, int64_t nb) {
+        const uint32_t *i0 = ids + b0 * seq, *m0 = mask + b0 * seq, *t0 = type_ids ? type_ids + b0 * seq : nullptr;
+        run_host(i0, m0, t0, nb, seq, (size_t)nb * H, out + b0 * H, true,
+                 [&, m0, nb](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
+                     PackPlan plan;  // (lives until run_host has synchronised the stream)
+                     plan_packing(ws, k, m0, nb, seq, st, plan);
+                     embed_on(ws, i, k, t, nb, seq, pool, normalize, mask_value, o, st, plan);
+                 });
+    };
+    if (run_two_lanes(mask, batch, seq, one)) return;
     run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.hidden, out, true,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
                  PackPlan plan;  // (lives until run_host has synchronised the stream)
@@ -1059,6 +1177,17 @@ void EncoderModel::logits_host_now(const uint32_t* ids, const uint32_t* mask, co
                                    int seq, float mask_value, float* out)
 {
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
+    const int NL = cfg_.num_labels;
+    auto one = [&](int64_t b0, int64_t nb) {
+        const uint32_t *i0 = ids + b0 * seq, *m0 = mask + b0 * seq, *t0 = type_ids ? type_ids + b0 * seq : nullptr;
+        run_host(i0, m0, t0, nb, seq, (size_t)nb * NL, out + b0 * NL, true,
+                 [&, m0, nb](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
+                     PackPlan plan;
+                     plan_packing(ws, k, m0, nb, seq, st, plan);
+                     logits_on(ws, i, k, t, nb, seq, mask_value, o, st, plan);
+                 });
+    };
+    if (run_two_lanes(mask, batch, seq, one)) return;
     run_host(ids, mask, type_ids, batch, seq, (size_t)batch * cfg_.num_labels, out, true,
              [&](Workspace& ws, uint32_t* i, uint32_t* k, uint32_t* t, float* o, hipStream_t st) {
                  PackPlan plan;

@@ -8,6 +8,8 @@
 
 #include <atomic>
 #include <exception>
+#include <functional>
+#include <thread>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
@@ -201,6 +203,9 @@ public:
     // the solo call's to rounding (the rows take the packed layout and another tile route).  On by default.
     void set_combining(bool on) { combining_ = on; }
     bool combining() const { return combining_; }
+    // Mid-size host-pointer calls (2 304 .. 8 192 kept tokens) run as two halves on two workspaces / streams, the second on a
+    // helper thread: one half's launch gaps, prologues and output bursts fall under the other's matrix work (encoder.cpp).
+    void set_two_lanes(bool on) { two_lanes_ = on; }
 
 private:
     EncoderModel() = default;
@@ -289,6 +294,26 @@ private:
                         bool normalize, float mask_value, float* out);
     void logits_host_now(const uint32_t* ids, const uint32_t* mask, const uint32_t* type_ids, int64_t batch, int seq, float mask_value,
                          float* out);
+    // ---- two lanes for mid-size host-pointer calls (encoder.cpp, "two lanes") ----
+    // A persistent helper thread that runs the second half of a call on a workspace (and stream) of its own.
+    class Lane {
+    public:
+        ~Lane();
+        bool try_begin(std::function<void()> task);  // false: the lane is busy with another call (the caller runs alone)
+        void wait();                                  // joins the task, rethrows what it threw
+    private:
+        void loop();
+        std::thread thread_;
+        std::mutex mu_;
+        std::condition_variable cv_;
+        std::function<void()> task_;
+        std::exception_ptr error_;
+        bool busy_ = false, has_task_ = false, stop_ = false;
+    };
+    Lane lane_;
+    std::atomic<bool> two_lanes_{true};
+    template <class F>
+    bool run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F&& half);
     std::mutex combine_mu_;
     std::condition_variable combine_cv_;
     std::vector<CombineReq*> combine_queue_;

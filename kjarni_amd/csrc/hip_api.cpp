@@ -127,6 +127,13 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_combining(KjarniHipEncoder*
     return KJARNI_OK;
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_set_two_lanes(KjarniHipEncoder* enc, int32_t on)
+{
+    if (!enc) return KJARNI_ERROR_NULL_POINTER;
+    enc->model->set_two_lanes(on != 0);
+    return KJARNI_OK;
+}
+
 KJARNI_EXPORT int32_t kjarni_hip_set_f32_on_bf16(int32_t on)
 {
     const int32_t before = kjarni::get_f32_on_bf16() ? 1 : 0;

@@ -117,6 +117,8 @@ hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batc
                             int heads, int head_dim, float mask_value, float* ctx,
                             hipStream_t stream, const int32_t* cu = nullptr);
 
+int attention_small_call_items();  // calls of up to this many (sentence, head) items take the small-call attention kernel
+
 // RoPE on the Q and K thirds of qkv [tokens, 3*hidden] in place, position = token index within its sentence
 // (RoPE::apply_3d with offset 0, cpu/rope/mod.rs:118-170, 210-245; encoder_self_attention.rs:81-85).
 // cos / sin are the reference's caches [>= seq, head_dim].

@@ -73,6 +73,10 @@ class HipEncoder:
         (default on; kjarni_hip.h: kjarni_hip_encoder_set_combining)."""
         check_error(lib().kjarni_hip_encoder_set_combining(self._h, 1 if on else 0))
 
+    def set_two_lanes(self, on: bool):
+        """Mid-size host-array calls as two halves on two streams (default on; kjarni_hip.h: kjarni_hip_encoder_set_two_lanes)."""
+        check_error(lib().kjarni_hip_encoder_set_two_lanes(self._h, 1 if on else 0))
+
     KINDS = ("embed_layernorm", "gemm_qkv", "attention", "gemm_out_proj", "layernorm", "gemm_fc1", "gemm_fc2",
              "pool", "head", "rope")
 

@@ -164,3 +164,28 @@ def test_rerank_logits_equal_the_hf_fixtures(cross, fixtures, B, S):
     tag = f"pairs_{B}x{S}"
     got = enc.logits(fixtures[tag + "_ids"], fixtures[tag + "_mask"], fixtures[tag + "_types"])
     assert float(np.abs(got - fixtures[tag + "_logits"]).max()) < TOL
+
+
+def test_two_lanes_are_invisible_in_the_results(tmp_path):
+    """Calls of 2 304 .. 8 192 kept tokens run as two halves on two streams (kjarni_hip_encoder_set_two_lanes): bit-identical to
+    the same call as one launch sequence -- full, ragged (the cut follows the kept tokens) and pair batches -- and oracle-equal."""
+    import kjarni_amd
+    from oracle import oracle as O
+    d, c = str(tmp_path / "e"), str(tmp_path / "c")
+    cfg, t = synth.minilm_embedder(d, seed=3, num_hidden_layers=2)
+    ccfg, ct = synth.minilm_cross_encoder(c, seed=4, num_hidden_layers=2)
+    enc, ce = kjarni_amd.HipEncoder(d), kjarni_amd.HipEncoder(c)
+    for B, S, ragged in ((32, 128, False), (24, 128, True), (64, 128, True), (40, 100, False), (19, 128, False)):
+        ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=ragged)
+        two = enc.embed(ids, mask)
+        enc.set_two_lanes(False)
+        one = enc.embed(ids, mask)
+        enc.set_two_lanes(True)
+        assert np.array_equal(two, one), (B, S, ragged)
+        assert float(np.abs(two - O.OracleModel(t, cfg).embed_batch(ids, mask)).max()) < 1e-4
+    ids, mask, types = synth.synthetic_pairs(48, 96, seed=5)
+    two = ce.logits(ids, mask, types)
+    ce.set_two_lanes(False)
+    one = ce.logits(ids, mask, types)
+    assert np.array_equal(two, one)
+    assert float(np.abs(two[:, 0] - O.OracleModel(ct, ccfg).rerank_scores(ids, mask, types)).max()) < 1e-4
