@@ -534,11 +534,13 @@ __global__ __launch_bounds__(256) void topk_reduce_kernel(const float* __restric
                                                           int64_t n, int64_t in_stride,
                                                           const uint64_t* __restrict__ upper_ptr,
                                                           uint64_t* __restrict__ out_keys,
-                                                          int64_t out_stride, int tiles_per_block)
+                                                          int64_t out_stride, int tiles_per_block,
+                                                          const unsigned* __restrict__ run_flag = nullptr)
 {
     __shared__ uint64_t pend[TK_PEND];
     __shared__ uint64_t best[KPAD];
     __shared__ int pend_count;
+    if (run_flag != nullptr && *run_flag == 0u) return;  // (uniform: a fallback launch that is not needed)
     const int tid = threadIdx.x;
     const int qi = blockIdx.y;
     const uint64_t upper = upper_ptr ? upper_ptr[qi] : ~0ull;
@@ -616,11 +618,34 @@ __global__ __launch_bounds__(256) void topk_lists_final_kernel(const uint64_t* _
     }
 }
 
+// The selection behind the fused many-query scan: one block per query folds that query's candidate list into its best
+// k_take, decoded.  Returns at once when a list overflowed (the two-call form runs instead).
+template <int KPAD>
+__global__ __launch_bounds__(256) void topk_candidates_kernel(const uint64_t* __restrict__ cand_key, const unsigned* __restrict__ cand_count,
+                                                              unsigned cap, int k_take, int64_t* __restrict__ out_idx,
+                                                              float* __restrict__ out_score)
+{
+    __shared__ uint64_t pend[TK_PEND];
+    __shared__ uint64_t best[KPAD];
+    __shared__ int pend_count;
+    if (cand_count[0] != 0u) return;
+    const int tid = threadIdx.x, qi = blockIdx.x;
+    const int64_t n = cand_count[1 + qi] < cap ? cand_count[1 + qi] : cap;
+    topk_block_reduce<KPAD>(nullptr, cand_key + (size_t)qi * cap, n, 0, (int)((n + TK_TILE - 1) / TK_TILE), ~0ull, pend, best, &pend_count);
+    for (int i = tid; i < k_take; i += 256) {
+        const uint64_t key = i < KPAD ? best[i] : 0ull;
+        const int64_t o = (int64_t)qi * k_take + i;
+        out_idx[o] = key == 0ull ? -1 : (int64_t)(uint32_t)(~(uint32_t)(key & 0xFFFFFFFFull));
+        out_score[o] = key == 0ull ? -INFINITY : from_orderable((uint32_t)(key >> 32));
+    }
+}
+
 __global__ void topk_decode_kernel(const uint64_t* __restrict__ keys, int64_t key_stride, int k_take,
                                    int64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                    int64_t out_stride, int64_t out_offset,
-                                   uint64_t* __restrict__ last_key)
+                                   uint64_t* __restrict__ last_key, const unsigned* __restrict__ run_flag = nullptr)
 {
+    if (run_flag != nullptr && *run_flag == 0u) return;
     const int qi = blockIdx.x;
     for (int i = threadIdx.x; i < k_take; i += blockDim.x) {
         const uint64_t key = keys[(int64_t)qi * key_stride + i];
@@ -661,25 +686,25 @@ int64_t blocks_for(int64_t n, int nq)
 template <int KPAD>
 void launch_reduce(const float* scores, const uint64_t* in_keys, int64_t n, int64_t in_stride,
                    const uint64_t* upper, uint64_t* out_keys, int64_t out_stride, int nq,
-                   hipStream_t stream)
+                   hipStream_t stream, const unsigned* run_flag)
 {
     dim3 grid((unsigned)blocks_for(n, nq), (unsigned)nq);
     hipLaunchKernelGGL(topk_reduce_kernel<KPAD>, grid, dim3(256), 0, stream, scores, in_keys, n,
-                       in_stride, upper, out_keys, out_stride, tiles_per_block_for(n, nq));
+                       in_stride, upper, out_keys, out_stride, tiles_per_block_for(n, nq), run_flag);
 }
 
 void dispatch_reduce(int kpad, const float* scores, const uint64_t* in_keys, int64_t n,
                      int64_t in_stride, const uint64_t* upper, uint64_t* out_keys, int64_t out_stride,
-                     int nq, hipStream_t stream)
+                     int nq, hipStream_t stream, const unsigned* run_flag = nullptr)
 {
     switch (kpad) {
-    case 16: launch_reduce<16>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
-    case 32: launch_reduce<32>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
-    case 64: launch_reduce<64>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
-    case 128: launch_reduce<128>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
-    case 256: launch_reduce<256>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
-    case 512: launch_reduce<512>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
-    default: launch_reduce<1024>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream); break;
+    case 16: launch_reduce<16>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
+    case 32: launch_reduce<32>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
+    case 64: launch_reduce<64>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
+    case 128: launch_reduce<128>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
+    case 256: launch_reduce<256>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
+    case 512: launch_reduce<512>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
+    default: launch_reduce<1024>(scores, in_keys, n, in_stride, upper, out_keys, out_stride, nq, stream, run_flag); break;
     }
 }
 
@@ -753,19 +778,41 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MQ_Q = 64, MQ_D = 256, MQ_BK = 16, MQ_STRIDE = MQ_BK + 4;
 constexpr int MQ_STAGE_FLOATS = (MQ_Q + MQ_D) * MQ_STRIDE;
-constexpr int MQ_LDS_BYTES = (2 * MQ_STAGE_FLOATS + 2 * MQ_D + MQ_Q) * 4;
+constexpr int MQ_LDS_BYTES = (2 * MQ_STAGE_FLOATS + 2 * MQ_D + 2 * MQ_Q) * 4;
 
-template <int MODE>
+// Selection inside the scan (FUSED).  VectorStore::search keeps the best k of every query (vector.rs:150-166); written out,
+// 64 queries x 10^7 documents are 2.56 GB of scores that the selection reads back (2.1 of 7.5 ms).  With a per-query lower
+// bound of the k-th best score -- the k-th best of a strided SAMPLE of the corpus' tiles, scanned first with this same kernel
+// -- only scores at or above the bound can be in the answer, and the epilogue appends those (query, key) pairs to a candidate
+// list instead of storing anything: about k x (tiles / sampled tiles) candidates per query.  The list is bounded; if an
+// adversarial order overflows it the overflow word is raised and the launches of the two-call form, queued behind with that
+// word as their run flag, do the work instead (they return at once otherwise).
+struct ScanFuse {
+    const float* thr_score;   // [nq, thr_k]: the sample's best thr_k scores per query (descending); bound = the last one
+    const int64_t* thr_idx;   // [nq, thr_k]: -1 where the sample had fewer documents (bound = -inf)
+    int thr_k;
+    uint64_t* cand_key;       // [nq, cap]: a list per query (index within the whole call)
+    unsigned* cand_count;     // [0]: overflow word, [1 + q]: candidates appended to query q's list
+    unsigned cap;             // entries per query
+    int q_base;               // this launch's first query
+};
+
+// tile_stride > 1 (the sample pass, not FUSED): tiles 0, tile_stride, 2 tile_stride, ... are scanned and their scores written
+// compactly ([nq, n_tiles * 256]).  run_flag != null: the launch runs only if *run_flag != 0.
+template <int MODE, bool FUSED>
 __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* __restrict__ queries, int nq,
                                                                   const float* __restrict__ corpus, int64_t n_docs, int dim,
                                                                   const float* __restrict__ qn2, float* __restrict__ scores,
-                                                                  int64_t stride, int64_t n_tiles)
+                                                                  int64_t stride, int64_t n_tiles, int tile_stride,
+                                                                  const unsigned* __restrict__ run_flag, ScanFuse fuse)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sQ = smem;                                   // [2][64][20]   (stage s at + s * MQ_STAGE_FLOATS)
     float* sD = smem + MQ_Q * MQ_STRIDE;                // [2][256][20]
     float* sDn = smem + 2 * MQ_STAGE_FLOATS;            // [2][256]: ||doc||^2 of a tile, by tile parity
     float* sQn = sDn + 2 * MQ_D;                        // [64]: sqrt(||q||^2)
+    float* sThr = sQn + MQ_Q;                           // [64]: FUSED: the query's score bound
+    if (run_flag != nullptr && *run_flag == 0u) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -797,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     int s_tile = (int)blockIdx.x;  // tile of the step to be requested next
     int s_k = 0, s_par = 0;        // its K-step; parity of the tile whose rows sit in the registers
     auto tile_rsrc = [&](int tile) {
-        const int64_t d0 = (int64_t)tile * MQ_D;
+        const int64_t d0 = (int64_t)tile * tile_stride * MQ_D;
         const int64_t rows = n_docs - d0 < MQ_D ? n_docs - d0 : MQ_D;   // documents past n_docs: zeros
         return rsrc(corpus + d0 * dim, rows * dim * 4);
     };
@@ -840,7 +887,15 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
         }
     };
 
-    if (tid < MQ_Q) sQn[tid] = tid < nq ? sqrtf(qn2[tid]) : 0.0f;
+    if (tid < MQ_Q) {
+        sQn[tid] = tid < nq ? sqrtf(qn2[tid]) : 0.0f;
+        if (FUSED) {
+            float t = -INFINITY;
+            if (tid < nq && fuse.thr_idx[(int64_t)(fuse.q_base + tid) * fuse.thr_k + fuse.thr_k - 1] >= 0)
+                t = fuse.thr_score[(int64_t)(fuse.q_base + tid) * fuse.thr_k + fuse.thr_k - 1];
+            sThr[tid] = t;
+        }
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -909,13 +964,16 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
             // quotient (r = 1 / den to 1 ulp, v = dot r, v += (dot - den v) r): the IEEE division sequence without its
             // range scaling, which den = ||q|| ||doc|| never needs; 6 vector instructions per score instead of 15 -- the
             // f32 MFMAs do not hide vector work.
-            const int64_t d_base = (int64_t)c_tile * MQ_D + wid * 64 + l31;
-            const bool whole = nq == MQ_Q && (int64_t)(c_tile + 1) * MQ_D <= n_docs;  // no row or column of the tile is cut
+            const int64_t d_base = (int64_t)c_tile * MQ_D + wid * 64 + l31;          // where the score goes (compact in a sample pass)
+            const int64_t a_base = (int64_t)c_tile * tile_stride * MQ_D + wid * 64 + l31;  // the document's index
+            const bool whole = nq == MQ_Q && ((int64_t)c_tile * tile_stride + 1) * MQ_D <= n_docs;  // no row or column of the tile is cut
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int64_t d = d_base + j * 32;
+                const int64_t d = d_base + j * 32, ad = a_base + j * 32;
                 const float dn = sqrtf(sDn[c_par * MQ_D + wid * 64 + j * 32 + l31]);
                 float* out = scores + d;
+                bool hit[FUSED ? 32 : 1];
+                float val[FUSED ? 32 : 1];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -928,9 +986,40 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                         float v = dot * rc;
                         v = fmaf(fmaf(-den, v, dot), rc, v);
                         if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
-                        if (whole || (q < nq && d < n_docs)) out[(int64_t)q * stride] = v;
+                        if (FUSED) {
+                            // (not below the bound: ties and NaN scores go to the exact comparison of the selection)
+                            hit[i * 16 + r] = (whole || (q < nq && ad < n_docs)) && !(v < sThr[q]);
+                            val[i * 16 + r] = v;
+                        } else if (whole || (q < nq && ad < n_docs)) {
+                            out[(int64_t)q * stride] = v;
+                        }
                         acc[i][j][r] = 0.0f;
                     }
+                if (FUSED) {
+                    // one vote per 32 x 64 block of scores; the appends (rare once the bounds are in place) run per score: the two
+                    // half-waves of a register belong to two queries, each half appends to its query's list with one atomic
+                    bool any = false;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) any = any || hit[e];
+                    if (__ballot(any) != 0ull) {
+#pragma unroll
+                        for (int e = 0; e < 32; ++e) {
+                            const uint64_t m = __ballot(hit[e]);
+                            if (m == 0ull) continue;
+                            const int q = (e >> 4) * 32 + acc_row(e & 15, half);
+                            const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+                            const int leader = (half << 5) + (mh ? __ffs((int)mh) - 1 : 0);
+                            unsigned base = 0;
+                            if (mh != 0u && lane == leader) base = atomicAdd(fuse.cand_count + 1 + fuse.q_base + q, (unsigned)__popc(mh));
+                            base = (unsigned)__shfl((int)base, leader, kWave);
+                            if (hit[e]) {
+                                const unsigned at = base + (unsigned)__popc(mh & ((1u << l31) - 1u));
+                                if (at < fuse.cap) fuse.cand_key[(size_t)(fuse.q_base + q) * fuse.cap + at] = make_key(val[e], (uint32_t)ad);
+                                else fuse.cand_count[0] = 1u;  // overflow: the two-call form behind this launch takes over
+                            }
+                        }
+                    }
+                }
             }
             c_k = 0;
             c_par ^= 1;
@@ -944,23 +1033,37 @@ hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_
                        float* scores, int64_t score_stride, hipStream_t stream);
 
 // Many queries: blocks of 64 through the fused matrix-core scan (one corpus read per block).
+//   tile_stride > 1: the sample pass (scores of every tile_stride-th tile, compact, row length `score_stride`)
+//   fuse != null:    selection inside the scan (no scores): candidates into fuse's list
+//   run_flag:        the launches run only if *run_flag != 0
 hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
-                     float* scores, hipStream_t stream)
+                     float* scores, hipStream_t stream, int tile_stride = 1, int64_t score_stride = -1, const ScanFuse* fuse = nullptr,
+                     const unsigned* run_flag = nullptr)
 {
     float* qn2 = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&qn2), (size_t)(nq + 8) * sizeof(float), stream);
     if (e != hipSuccess) return e;
     e = scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);  // squared norms of the queries (query operand unused)
-    const int64_t n_tiles = (n_docs + MQ_D - 1) / MQ_D;
+    const int64_t all_tiles = (n_docs + MQ_D - 1) / MQ_D;
+    const int64_t n_tiles = (all_tiles + tile_stride - 1) / tile_stride;
+    if (score_stride < 0) score_stride = n_docs;
     const unsigned grid = (unsigned)std::min<int64_t>(n_tiles, 256 * 2);  // the workgroups the chip holds at once (two per CU)
     for (int q0 = 0; q0 < nq && e == hipSuccess; q0 += MQ_Q) {
         const int m = nq - q0 < MQ_Q ? nq - q0 : MQ_Q;
-        if (mode == 0)
-            hipLaunchKernelGGL(cosine_scan_mfma_kernel<0>, dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, m,
-                               corpus, n_docs, dim, qn2 + q0, scores + (int64_t)q0 * n_docs, n_docs, n_tiles);
-        else
-            hipLaunchKernelGGL(cosine_scan_mfma_kernel<1>, dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, m,
-                               corpus, n_docs, dim, qn2 + q0, scores + (int64_t)q0 * n_docs, n_docs, n_tiles);
+        ScanFuse f = fuse ? *fuse : ScanFuse{};
+        f.q_base = q0;
+        float* sc = scores ? scores + (int64_t)q0 * score_stride : nullptr;
+#define KJ_SCAN(MODE_, FUSED_)                                                                                                      \
+    hipLaunchKernelGGL((cosine_scan_mfma_kernel<MODE_, FUSED_>), dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, \
+                       m, corpus, n_docs, dim, qn2 + q0, sc, score_stride, n_tiles, tile_stride, run_flag, f)
+        if (fuse) {
+            if (mode == 0) KJ_SCAN(0, true);
+            else KJ_SCAN(1, true);
+        } else {
+            if (mode == 0) KJ_SCAN(0, false);
+            else KJ_SCAN(1, false);
+        }
+#undef KJ_SCAN
         e = hipGetLastError();
     }
     const hipError_t fe = hipFreeAsync(qn2, stream);
@@ -1035,8 +1138,21 @@ size_t cosine_topk_workspace_bytes(int nq, int64_t n_docs, int k)
     return (size_t)(2 * per_q * nq + nq) * sizeof(uint64_t) + 256;
 }
 
+namespace {
+hipError_t cosine_topk_impl(const float* scores, int nq, int64_t n_docs, int k, void* workspace, int64_t* out_idx, float* out_score,
+                            hipStream_t stream, const unsigned* run_flag);
+}
+
 hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k, void* workspace,
                               int64_t* out_idx, float* out_score, hipStream_t stream)
+{
+    return cosine_topk_impl(scores, nq, n_docs, k, workspace, out_idx, out_score, stream, nullptr);
+}
+
+namespace {
+// run_flag != null: every launch returns at once unless *run_flag != 0 (the fallback behind a fused scan)
+hipError_t cosine_topk_impl(const float* scores, int nq, int64_t n_docs, int k, void* workspace, int64_t* out_idx, float* out_score,
+                            hipStream_t stream, const unsigned* run_flag)
 {
     if (nq <= 0 || k <= 0) return hipSuccess;
     if (n_docs <= 0 || n_docs >= (int64_t)0xFFFFFFFF) return hipErrorInvalidValue;
@@ -1050,21 +1166,22 @@ hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k
     for (int done = 0; done < k; done += 1024) {
         const int take = (k - done < 1024) ? (k - done) : 1024;
         dispatch_reduce(kpad, scores, nullptr, n_docs, n_docs, done ? upper : nullptr, buf_a, per_q, nq,
-                        stream);
+                        stream, run_flag);
         int64_t n = blocks_for(n_docs, nq) * kpad;
         uint64_t *src = buf_a, *dst = buf_b;
         while (n > kpad) {
-            dispatch_reduce(kpad, nullptr, src, n, per_q, nullptr, dst, per_q, nq, stream);
+            dispatch_reduce(kpad, nullptr, src, n, per_q, nullptr, dst, per_q, nq, stream, run_flag);
             n = blocks_for(n, nq) * kpad;
             uint64_t* t = src;
             src = dst;
             dst = t;
         }
         hipLaunchKernelGGL(topk_decode_kernel, dim3((unsigned)nq), dim3(256), 0, stream, src, per_q, take,
-                           out_idx, out_score, (int64_t)k, (int64_t)done, upper);
+                           out_idx, out_score, (int64_t)k, (int64_t)done, upper, run_flag);
     }
     return hipGetLastError();
 }
+}  // namespace
 
 namespace {
 
@@ -1116,11 +1233,19 @@ void final_lists(int kpad, const uint64_t* keys, int lists, int k, int64_t* out_
 
 // Workspace of launch_cosine_search: the workgroups' candidate lists (+ one intermediate level) for the fused one-query pass,
 // otherwise the scores [nq, n_docs] and the selection's buffers.
+namespace {
+constexpr size_t kManyCandCap = (size_t)4 << 20;       // candidate keys of the fused many-query scan over all its queries (32 MB)
+constexpr int64_t kManyFusedMinDocs = 400000;           // below: the two-call form (its selection is a small share there)
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
 size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k)
 {
     (void)dim;
     const size_t fused = (size_t)(2048 * 256 + 2 * 2048) * sizeof(uint64_t);
-    const size_t two = (size_t)nq * (size_t)n_docs * sizeof(float) + 256 + cosine_topk_workspace_bytes(nq, n_docs, k);
+    size_t two = pad256((size_t)nq * (size_t)n_docs * sizeof(float)) + pad256(cosine_topk_workspace_bytes(nq, n_docs, k));
+    // the fused many-query scan: candidate list, counters, the sample's best k per query
+    two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4);
     return fused > two ? fused : two;
 }
 
@@ -1151,10 +1276,62 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         return hipGetLastError();
     }
     float* scores = reinterpret_cast<float*>(workspace);
-    const size_t s_bytes = ((size_t)nq * (size_t)n_docs * sizeof(float) + 255) & ~(size_t)255;
+    const size_t s_bytes = pad256((size_t)nq * (size_t)n_docs * sizeof(float));
+    uint8_t* topk_ws = static_cast<uint8_t*>(workspace) + s_bytes;
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) && ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
+    if (nq >= 20 && nq <= 1024 && n_docs >= kManyFusedMinDocs && k <= 1024 && aligned16 && dim % MQ_BK == 0 && dim >= 2 * MQ_BK &&
+        (int64_t)MQ_D * dim * 4 < ((int64_t)1 << 31) && (mode == 0 || mode == 1) && !tune::scan_streaming_only() &&
+        !tune::scan_two_launches()) {
+        // Many queries, selection inside the scan (ScanFuse): sample pass -> per-query bounds -> fused scan -> per-query selection
+        // of the candidates; the two-call form is queued behind with the overflow word as its run flag.
+        uint8_t* p = topk_ws + pad256(cosine_topk_workspace_bytes(nq, n_docs, k));
+        uint64_t* cand_key = reinterpret_cast<uint64_t*>(p);
+        p += pad256(kManyCandCap * 8);
+        unsigned* counters = reinterpret_cast<unsigned*>(p);  // [0] overflow, [1 + q] list lengths
+        const size_t counter_bytes = pad256((size_t)(nq + 1) * 4);
+        p += counter_bytes;
+        int64_t* thr_idx = reinterpret_cast<int64_t*>(p);
+        p += pad256((size_t)nq * k * 8);
+        float* thr_score = reinterpret_cast<float*>(p);
+        const unsigned cap_q = (unsigned)(kManyCandCap / (size_t)nq);
+        hipError_t e = hipMemsetAsync(counters, 0, counter_bytes, stream);
+        if (e != hipSuccess) return e;
+        const int64_t all_tiles = (n_docs + MQ_D - 1) / MQ_D;
+        const int ts = (int)std::max<int64_t>(1, all_tiles / 256);           // ~256-511 sampled tiles, spread over the corpus
+        const int64_t ns = (all_tiles + ts - 1) / ts;
+        const int64_t last_rows = std::min<int64_t>(MQ_D, n_docs - (ns - 1) * ts * (int64_t)MQ_D);
+        const int64_t n_sample = (ns - 1) * MQ_D + last_rows;
+        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, n_sample);
+        if (e != hipSuccess) return e;
+        e = cosine_topk_impl(scores, nq, n_sample, k, topk_ws, thr_idx, thr_score, stream, nullptr);
+        if (e != hipSuccess) return e;
+        ScanFuse f{thr_score, thr_idx, k, cand_key, counters, cap_q, 0};
+        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, nullptr, stream, 1, -1, &f);
+        if (e != hipSuccess) return e;
+        const int kpad = kpad_for(k);
+#define KJ_CAND(KP_)                                                                                                          \
+    hipLaunchKernelGGL(topk_candidates_kernel<KP_>, dim3((unsigned)nq), dim3(256), 0, stream, cand_key, counters, cap_q, k, out_idx, \
+                       out_score)
+        switch (kpad) {
+        case 16: KJ_CAND(16); break;
+        case 32: KJ_CAND(32); break;
+        case 64: KJ_CAND(64); break;
+        case 128: KJ_CAND(128); break;
+        case 256: KJ_CAND(256); break;
+        case 512: KJ_CAND(512); break;
+        default: KJ_CAND(1024); break;
+        }
+#undef KJ_CAND
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // the two-call form, run only if the candidate list overflowed
+        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, 1, -1, nullptr, counters);
+        if (e != hipSuccess) return e;
+        return cosine_topk_impl(scores, nq, n_docs, k, topk_ws, out_idx, out_score, stream, counters);
+    }
     const hipError_t e = launch_cosine_scores(queries, nq, corpus, n_docs, dim, mode, scores, stream);
     if (e != hipSuccess) return e;
-    return launch_cosine_topk(scores, nq, n_docs, k, static_cast<uint8_t*>(workspace) + s_bytes, out_idx, out_score, stream);
+    return launch_cosine_topk(scores, nq, n_docs, k, topk_ws, out_idx, out_score, stream);
 }
 
 }  // namespace kjarni

@@ -202,3 +202,51 @@ def test_one_call_search_equals_scores_plus_topk(n, dim, k):
             # and against the oracle: order by (score descending, index ascending)
             ridx, rsc = O.search(q, corpus, k, mode=mode)
             assert np.abs(sa[:kk] - rsc).max() < 1e-4
+
+
+@pytest.mark.parametrize("case", ["random", "ascending", "overflow"])
+def test_many_queries_one_call_selects_inside_the_scan(case):
+    """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries selects inside the matrix-core scan: a strided
+    sample of the corpus gives every query a lower bound of its k-th best score, the full scan appends only scores at or above
+    it to a candidate list, a per-query selection finishes -- no [queries, documents] score array.  Same indices and score bits
+    as kjarni_hip_cosine_scores + kjarni_hip_cosine_topk: on random rows; on rows whose scores ascend with the index (the sample
+    under-estimates every bound); and when the candidate list overflows (identical queries, every sampled tile anti-correlated,
+    every other row correlated: 28 M candidates against a 4 M list), where the queued two-call form takes over."""
+    import torch
+    from kjarni_amd import _ffi
+    L = _ffi.lib()
+    dev = torch.device("cuda", 0)
+    n, dim, nq, k = 450_123, 384, 70, 12
+    g = torch.Generator(device=dev).manual_seed(11)
+    corpus = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
+    q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
+    if case == "ascending":
+        corpus += torch.linspace(0.0, 2.0, n, device=dev)[:, None] * q[3][None, :]
+    if case == "overflow":
+        q[:] = q[0]
+        tiles = (n + 255) // 256
+        ts = max(1, tiles // 256)
+        row_tile = torch.arange(n, device=dev) // 256
+        sampled = (row_tile % ts) == 0
+        corpus[sampled] = -q[0] + 0.01 * corpus[sampled]
+        corpus[~sampled] = q[0] + 0.05 * corpus[~sampled]
+    corpus[1000] = 0.0
+    for mode in (0, 1):
+        st = torch.cuda.current_stream().cuda_stream
+        scores = torch.empty((nq, n), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.kjarni_hip_cosine_topk_workspace_bytes(nq, n, k), dtype=torch.uint8, device=dev)
+        idx2 = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        sc2 = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        _ffi.check_error(L.kjarni_hip_cosine_scores(0, q.data_ptr(), nq, corpus.data_ptr(), n, dim, mode, scores.data_ptr(), st))
+        _ffi.check_error(L.kjarni_hip_cosine_topk(0, scores.data_ptr(), nq, n, k, ws.data_ptr(), idx2.data_ptr(), sc2.data_ptr(), st))
+        del scores, ws
+        ws1 = torch.empty(L.kjarni_hip_cosine_search_workspace_bytes(nq, n, dim, k), dtype=torch.uint8, device=dev)
+        idx1 = torch.full((nq, k), -7, dtype=torch.int64, device=dev)
+        sc1 = torch.full((nq, k), 7.0, dtype=torch.float32, device=dev)
+        _ffi.check_error(L.kjarni_hip_cosine_search(0, q.data_ptr(), nq, corpus.data_ptr(), n, dim, mode, k, ws1.data_ptr(),
+                                                    idx1.data_ptr(), sc1.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert bool(torch.equal(idx1, idx2)), (case, mode)
+        assert bool(torch.equal(sc1.view(torch.int32), sc2.view(torch.int32))), (case, mode)
+        assert bool((sc1[:, :-1] >= sc1[:, 1:]).all())
+        del ws1
