@@ -1095,7 +1095,7 @@ inline bool mid_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int6
 {
     if (min_rows < 0) min_rows = few_rows_max(N, K) + 1;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return M >= min_rows && M <= kMidMaxRows && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
+    return M >= min_rows && (M <= kMidMaxRows || (tune::flex_any_rows() && M <= 65536 * 8)) && N % 4 == 0 && K % MID_BK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) &&
            al16(A) && al16(W) && al16(Y) && al16(bias) && al16(R) && !tune::no_mid_route();
 }
 

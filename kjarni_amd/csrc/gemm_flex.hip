@@ -429,7 +429,7 @@ bool gemm_flex_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldy, int64
                         const float* bias, const float* R)
 {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return M >= 1 && M <= 65536 && N % 4 == 0 && N >= 16 && K % FBK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) && al16(A) &&
+    return M >= 1 && M <= 65536 * 8 && N % 4 == 0 && N >= 16 && K % FBK == 0 && lda % 4 == 0 && ldy % 4 == 0 && (!R || ldr % 4 == 0) && al16(A) &&
            al16(W) && al16(Y) && al16(bias) && al16(R) && (int64_t)128 * lda * 4 < ((int64_t)1 << 31) &&
            (int64_t)224 * K * 4 < ((int64_t)1 << 31);
 }

@@ -21,6 +21,7 @@
 //    8  mid-size calls on the 64 x 64 tiles of gemm.hip instead of gemm_flex.hip's per-call tile
 // 2000 + 100 RA + CB  gemm_flex.hip: this tile (64 RA rows x 16 CB columns) instead of the launcher's choice
 // 3000 + 100 RA + CB  the same tile with an LDS claim of more than half a CU (one workgroup per CU, never two)
+// 5000 + 100 RA + CB  that tile for calls of any size (the per-call tile kernel against the large-batch tiles at 10^5 rows)
 // 10000 d + 2000 + 100 RA + CB  the same with knock-out d (tiles 128 x 144 and 128 x 192 only): 1 no output stores, 2 no global loads in
 //      the K-loop, 3 nothing but the MFMAs in the K-loop, 4 no barrier in the K-loop, 5 no staging (loads + LDS writes) in the K-loop,
 //      6 / 7 / 8 staging loads with the sc1 / sc0 / nt cache-policy bit
@@ -68,8 +69,9 @@ inline bool mid_split_off() { return gemm() == 17; }
 inline int mid_knockout() { return gemm() >= 21 && gemm() <= 26 ? gemm() - 20 : 0; }
 inline int split_min_rows_override() { return gemm() >= 100000 ? gemm() - 100000 : 0; }  // (measurements: 100000 + rows)
 inline int few_rows_max_override() { return gemm() >= 1000 && gemm() < 2000 ? gemm() - 1000 : 0; }  // (measurements: 1000 + rows)
-inline int flex_config_override() { return gemm() < 100000 && gemm() % 10000 >= 2000 && gemm() % 10000 < 4000 ? gemm() % 1000 : 0; }  // (2000 + 100 RA + CB: gemm_flex.hip's tile)
+inline int flex_config_override() { return gemm() < 100000 && gemm() % 10000 >= 2000 && gemm() % 10000 < 6000 && gemm() % 10000 / 1000 != 4 ? gemm() % 1000 : 0; }  // (2000 + 100 RA + CB: gemm_flex.hip's tile)
 inline bool flex_one_workgroup_per_cu() { return gemm() < 100000 && gemm() % 10000 >= 3000 && gemm() % 10000 < 4000; }  // (3000 + 100 RA + CB: claim more than half of the LDS)
+inline bool flex_any_rows() { return gemm() < 100000 && gemm() % 10000 >= 5000 && gemm() % 10000 < 6000; }  // (5000 + 100 RA + CB: that tile at ANY row count)
 inline int flex_knockout() { return gemm() >= 12000 && gemm() < 100000 && flex_config_override() ? gemm() / 10000 : 0; }
 inline bool no_flex_route() { return gemm() == 8; }
 

@@ -12,5 +12,7 @@ run c GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_VMEM SQ_INSTS_SALU SQ_WAVES 
 if [ "${1:-}" = full ]; then
 run d GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
 fi
-python tools/pmc_summary.py gpurun_out/pmcm | grep -A30 "gemm_nt_f32_mid<0, false>" | tee gpurun_out/pmcm/summary.txt
-find gpurun_out/pmcm -name "*.csv" -delete
+# (round 4: the mid-size projections are gemm_nt_f32_flex<RA, CB, VSLICES>; the raw CSVs go only once the summary exists)
+if python tools/pmc_summary.py gpurun_out/pmcm > gpurun_out/pmcm/summary_all.txt && grep -A32 -E "gemm_nt_f32_flex|gemm_nt_f32_mid<" gpurun_out/pmcm/summary_all.txt | tee gpurun_out/pmcm/summary.txt | grep -q .; then
+  find gpurun_out/pmcm -name "*.csv" -delete
+fi
