@@ -127,6 +127,14 @@ int32_t kjarni_hip_get_f32_on_bf16(void);
  * ENQUEUE on `stream` (NULL = the legacy default stream); host-pointer forms run on a stream of their own and
  * return when the result is in the caller's buffer.  The profiler (profile_begin / _end) is single-caller.
  *
+ * What a sentence's result depends on.  Sentences never influence each other's VALUES beyond rounding, and within one kernel
+ * route a row's result is bit-identical whatever shares its call (tests/test_gpu_large_batch.py, test_gpu_encoder.py).  The
+ * route, however, follows the call's size -- projections: up to 256 rows / 257 .. 8 192 / more; attention: up to 128
+ * (sentence, head) items / more; pooling: calls below 2 048 sentences / more; packed or padded layout -- and every route sums
+ * in its own order, so the same sentence in calls of different sizes (or combined with other callers' sentences, below)
+ * agrees to rounding (measured <= 1e-6 on unit-norm embeddings), not bit for bit.  The reference makes the same kind of
+ * choice by size (linear_layer.rs:164-173: row-vector kernel below 1 000 rows, 4 x 3 block kernel above).
+ *
  * hidden_out_dev: f32 [batch, seq, hidden].  type_ids_dev may be NULL (token
  * type row 0 is added to every token, cpu/embeddings/mod.rs:216-223). */
 KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
