@@ -49,6 +49,14 @@
 #include "kernels.h"
 #include "tuning.h"
 
+// Output-tile stores of the large kernels.  (Lab build -DKJARNI_LAB_NT_OUT: streaming stores, to see whether the output burst
+// evicts the A panels / weights from the XCD's L2.)
+#ifdef KJARNI_LAB_NT_OUT
+#define KJ_STORE_OUT(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define KJ_STORE_OUT(ptr, v) (*(ptr) = (v))
+#endif
+
 namespace kjarni {
 
 namespace {
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
             }
-            if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
+            if (m < M) KJ_STORE_OUT(reinterpret_cast<f32x4*>(Y + m * ldy + n), v);
         }
     }
     if (!kSplitRounds) __syncthreads();  // (the one-round staging overlaps the first operand stage of a next tile)
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_mfma_ln(
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (x[q][e] - mean) * inv_std * g[e] + b[e];
-                *reinterpret_cast<f32x4*>(Y + m * ldy + c) = o;
+                KJ_STORE_OUT(reinterpret_cast<f32x4*>(Y + m * ldy + c), o);
             }
         }
     }

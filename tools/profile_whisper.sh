@@ -1,3 +1,5 @@
+#!/bin/bash
+set -u
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_w -- python tools/bench_more.py whisper > gpurun_out/whisper_prof.json 2>gpurun_out/prof_w.err
