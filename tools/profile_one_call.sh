@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 per-kernel table of one 28-token sentence through the encoder (tools/mid_probe.py 1 28)
+# rocprofv3 per-kernel table of one sentence of $1 tokens (default 28) through the encoder (tools/mid_probe.py 1 TOKENS)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_x
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_x -- python tools/mid_probe.py 1 28 500 > gpurun_out/prof_x.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_x -- python tools/mid_probe.py 1 ${1:-28} 500 > gpurun_out/prof_x.log 2>&1
 grep "^batch" gpurun_out/prof_x.log
 f=$(find gpurun_out/prof_x -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
