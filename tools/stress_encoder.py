@@ -1,5 +1,7 @@
 """Concurrency soak of one encoder handle: N host threads issue calls of mixed sizes (all three projection routes, workspaces
-growing and being reused) for a while; every result must equal the single-threaded result bit for bit:
+growing and being reused, two lanes, call combining) for a while.  Every result must equal the single-threaded result bit for
+bit -- except small calls (<= 8 rows, <= 1 024 tokens) while combining is on (the default): those share a forward with whatever
+else is queued and are held to 1e-6 (KJARNI_HIP_COMBINE=0: bit for bit again):
 python tools/stress_encoder.py [threads] [seconds]."""
 import os
 import sys
@@ -25,6 +27,9 @@ def main():
         shapes = [(1, 12), (2, 30), (5, 64), (16, 40), (32, 128), (70, 128), (100, 90), (300, 128), (3, 500)]
         inputs = [synth.synthetic_ids(b, s, seed=50 + i, ragged=True) for i, (b, s) in enumerate(shapes)]
         refs = [enc.embed(i, m) for i, m in inputs]
+        combining = os.environ.get("KJARNI_HIP_COMBINE", "1") != "0"
+        small = [combining and b <= 8 and b * s <= 1024 for b, s in shapes]
+        worst = [0.0]
         errors, calls = [], [0] * n_threads
         stop = time.time() + seconds
 
@@ -34,7 +39,12 @@ def main():
                 while time.time() < stop and not errors:
                     j = int(rng.integers(0, len(inputs)))
                     got = enc.embed(*inputs[j])
-                    if not np.array_equal(got, refs[j]):
+                    if small[j]:
+                        d = float(np.abs(got - refs[j]).max())
+                        worst[0] = max(worst[0], d)
+                        if not d <= 1e-6:
+                            errors.append(f"thread {t}: small call {shapes[j]} differs by {d:.3e} (> 1e-6)")
+                    elif not np.array_equal(got, refs[j]):
                         errors.append(f"thread {t}: shape {shapes[j]} differs by {float(np.abs(got - refs[j]).max()):.3e}")
                     calls[t] += 1
             except Exception as e:  # noqa: BLE001
@@ -45,7 +55,7 @@ def main():
             x.start()
         for x in th:
             x.join()
-        print(f"{sum(calls)} calls from {n_threads} threads in {seconds:.0f} s: {'OK, all bit-identical' if not errors else errors[:3]}")
+        print(f"{sum(calls)} calls from {n_threads} threads in {seconds:.0f} s: {('OK, large calls bit-identical' + (f', combined small calls within {worst[0]:.1e}' if combining else ', small calls too')) if not errors else errors[:3]}")
         sys.exit(1 if errors else 0)
 
 
