@@ -11,6 +11,7 @@
 //    9  128 x 128 tiles without an epilogue (micro-benchmark upper bound)
 //   10  plain-epilogue 128 x 128 tiles without the persistent tile loop
 //   11  fused LayerNorm tiles as a persistent launch (two workgroups per CU)
+//   12  128 x 128 tiles: plain output stores whatever the output's size (no streaming stores for outputs >= 256 MB)
 //   14  fused LayerNorm tiles read bias / gamma / beta from global memory in the epilogue (rounds 1-2) instead of from LDS
 //   15  residual projection + LayerNorm of up to 64 rows with a long K: the 64 x 64-tile K slices instead of the few-rows kernel's
 //   31..34  persistent grid of the 64 x 64-tile kernel: 768 / 512 / 256 / 1 280 workgroups instead of 1 024
@@ -74,6 +75,7 @@ inline bool flex_one_workgroup_per_cu() { return gemm() < 100000 && gemm() % 100
 inline bool flex_any_rows() { return gemm() < 100000 && gemm() % 10000 >= 5000 && gemm() % 10000 < 6000; }  // (5000 + 100 RA + CB: that tile at ANY row count)
 inline int flex_knockout() { return gemm() >= 12000 && gemm() < 100000 && flex_config_override() ? gemm() / 10000 : 0; }
 inline bool no_flex_route() { return gemm() == 8; }
+inline bool no_streaming_output_stores() { return gemm() == 12; }
 
 inline bool no_pipelined_attention() { return attention() == 1; }
 inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }
