@@ -70,7 +70,7 @@ __device__ __forceinline__ void sp_split(const f32x4 x, u32x2& p1, u32x2& p2, u3
 // Epilogue through LDS, as gemm_nt_f32_mfma's: the accumulators of a 32-row tile go to a wave-private [32][68] region (the
 // operand planes are free after the barrier), then 16 lanes own a row: 16-byte row-contiguous loads of the residual and
 // stores (64 four-byte stores per lane straight from the accumulators made the store issue, not the MFMAs, the tile's time).
-template <int EPI>
+template <int EPI, bool STREAM_OUT = false>
 __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][2], float* lds, const float* __restrict__ bias, const float* R, int64_t ldr,
                                             float* Y, int64_t ldy, int64_t M, int64_t m0, int n0, int wid, int wr, int wc, int lane, int l31,
                                             int half)
@@ -113,7 +113,12 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][2], float* lds, con
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
             }
-            if (m < M) *reinterpret_cast<f32x4*>(Y + m * ldy + n) = v;
+            if (m < M) {
+                // (STREAM_OUT: outputs of 256 MB and more, as gemm_nt_f32_mfma -- plain stores evict the operand panels from the L2)
+                f32x4* dst = reinterpret_cast<f32x4*>(Y + m * ldy + n);
+                if (STREAM_OUT) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
+            }
         }
     }
 }
@@ -122,7 +127,7 @@ __device__ __forceinline__ void sp_epilogue(f32x16 (&acc)[2][2], float* lds, con
 // multiplied from LDS stage k & 1, the raw f32 rows of step k + 1 (in registers since the previous step) are split and stored to
 // the other stage, and the rows of step k + 2 are requested into the registers step k's rows left -- the split's vector
 // instructions issue in the gaps of the bf16 MFMAs (an MFMA holds the vector issue port 8 of its 32 cycles).  One barrier per step.
-template <int EPI>
+template <int EPI, bool STREAM_OUT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                             const float* __restrict__ bias, const float* R, int64_t ldr, float* Y,
                                                             int64_t ldy, int64_t M, int N, int K, int n_tiles, int64_t total_tiles)
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_split(const float* __restr
         step(I0{}, I0{}, I1{}, I1{}, kt + 3);   // split group 2j+2 half 0; set 1 <- group 2j+3
     }
 
-    sp_epilogue<EPI>(acc, reinterpret_cast<float*>(sp_smem), bias, R, ldr, Y, ldy, M, m0, n0, wid, wr, wc, lane, l31, half);
+    sp_epilogue<EPI, STREAM_OUT>(acc, reinterpret_cast<float*>(sp_smem), bias, R, ldr, Y, ldy, M, m0, n0, wid, wr, wc, lane, l31, half);
 }
 
 // ---- f32 activations x bf16 weights (the decoder's prompt projections; always on for bf16 checkpoints) ---------------------------
@@ -626,8 +631,12 @@ hipError_t launch_split(const float* A, int64_t lda, const float* W, const float
     const int n_tiles = N / BN;
     const int64_t total = ((M + BM - 1) / BM) * n_tiles;
     if (total > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_nt_f32_split<EPI>), dim3((unsigned)total), dim3(256), SP_LDS_BYTES, stream, A, lda, W, bias, R, ldr, Y, ldy, M, N,
-                       K, n_tiles, total);
+    if ((int64_t)M * N * 4 >= ((int64_t)256 << 20) && R != Y)  // (not in place: those rows are the next projection's residual)
+        hipLaunchKernelGGL((gemm_nt_f32_split<EPI, true>), dim3((unsigned)total), dim3(256), SP_LDS_BYTES, stream, A, lda, W, bias, R, ldr, Y, ldy,
+                           M, N, K, n_tiles, total);
+    else
+        hipLaunchKernelGGL((gemm_nt_f32_split<EPI, false>), dim3((unsigned)total), dim3(256), SP_LDS_BYTES, stream, A, lda, W, bias, R, ldr, Y, ldy,
+                           M, N, K, n_tiles, total);
     return hipGetLastError();
 }
 
