@@ -309,7 +309,15 @@ __global__ __launch_bounds__(256, flex_waves_per_simd(RA, CB, VSLICES)) void gem
                     for (int c = 0; c < 4; ++c) v[c] = tanhf(v[c]);
                 }
             }
-            if (m < M && n < N && (DIAG != 1 || v[0] == 123456.789f)) *reinterpret_cast<f32x4*>(Yb + (int64_t)m * ldo + n) = v;
+            if (m < M && n < N && (DIAG != 1 || v[0] == 123456.789f)) {
+                // Plain stores ON PURPOSE: the tile stays in this XCD's L2, and the XCD-aware tile order gives the same rows to the
+                // same XCD in the consuming launch (FC1 -> FC2, QKV -> attention).  Streaming stores make THIS kernel faster (the
+                // write-back burst at its end goes: FC1 + GELU at 4 096 rows 51.1 -> 45.0 us alone, DIAG 9) and the call slower
+                // (16 x 128 tokens 0.646 -> 0.675 ms): the consumers then read from memory.
+                f32x4* dst = reinterpret_cast<f32x4*>(Yb + (int64_t)m * ldo + n);
+                if (DIAG == 9) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
+            }
         }
     }
     __syncthreads();  // (the epilogue regions overlap the operand stages of a next tile)
@@ -455,8 +463,8 @@ hipError_t launch_gemm_flex(const float* A, int64_t lda, const float* W, const f
 #define KJ_FLEX_DIAG(RA_, CB_, D_)                                                                                                     \
     if (ch.ra == RA_ && ch.cb == CB_ && tune::flex_knockout() == D_ && vslices <= 1)                                                    \
         return flex_launch_one<RA_, CB_, false, D_>(A, lda, W, K, bias, R, ldr, out, ldy, M, N, k_len, ksplit, 1, (int)epi, partial, stream);
-    KJ_FLEX_DIAG(2, 9, 1) KJ_FLEX_DIAG(2, 9, 2) KJ_FLEX_DIAG(2, 9, 3) KJ_FLEX_DIAG(2, 9, 4) KJ_FLEX_DIAG(2, 9, 5) KJ_FLEX_DIAG(2, 9, 6) KJ_FLEX_DIAG(2, 9, 7) KJ_FLEX_DIAG(2, 9, 8)
-    KJ_FLEX_DIAG(2, 12, 1) KJ_FLEX_DIAG(2, 12, 2) KJ_FLEX_DIAG(2, 12, 3) KJ_FLEX_DIAG(2, 12, 4) KJ_FLEX_DIAG(2, 12, 5) KJ_FLEX_DIAG(2, 12, 6) KJ_FLEX_DIAG(2, 12, 7) KJ_FLEX_DIAG(2, 12, 8)
+    KJ_FLEX_DIAG(2, 9, 1) KJ_FLEX_DIAG(2, 9, 2) KJ_FLEX_DIAG(2, 9, 3) KJ_FLEX_DIAG(2, 9, 4) KJ_FLEX_DIAG(2, 9, 5) KJ_FLEX_DIAG(2, 9, 6) KJ_FLEX_DIAG(2, 9, 7) KJ_FLEX_DIAG(2, 9, 8) KJ_FLEX_DIAG(2, 9, 9)
+    KJ_FLEX_DIAG(2, 12, 1) KJ_FLEX_DIAG(2, 12, 2) KJ_FLEX_DIAG(2, 12, 3) KJ_FLEX_DIAG(2, 12, 4) KJ_FLEX_DIAG(2, 12, 5) KJ_FLEX_DIAG(2, 12, 6) KJ_FLEX_DIAG(2, 12, 7) KJ_FLEX_DIAG(2, 12, 8) KJ_FLEX_DIAG(2, 12, 9)
 #undef KJ_FLEX_DIAG
 #endif
 #define KJ_FLEX(RA_, CB_)                                                                                                             \

@@ -25,7 +25,7 @@
 // 5000 + 100 RA + CB  that tile for calls of any size (the per-call tile kernel against the large-batch tiles at 10^5 rows)
 // 10000 d + 2000 + 100 RA + CB  the same with knock-out d (tiles 128 x 144 and 128 x 192 only): 1 no output stores, 2 no global loads in
 //      the K-loop, 3 nothing but the MFMAs in the K-loop, 4 no barrier in the K-loop, 5 no staging (loads + LDS writes) in the K-loop,
-//      6 / 7 / 8 staging loads with the sc1 / sc0 / nt cache-policy bit
+//      6 / 7 / 8 staging loads with the sc1 / sc0 / nt cache-policy bit, 9 streaming (nt) output stores
 // attention variant (kjarni_hip_set_attention_variant):
 //    1  never the persistent pipelined kernel (seq <= 128)
 //   11..16  knock-out diagnostics of the pipelined kernel (its DIAG template parameter 1..6)
