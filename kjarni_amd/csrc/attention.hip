@@ -343,7 +343,10 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
     };
     // (sentence, head) of an item advance with the grid stride without divisions
     const int step_b = (int)(gridDim.x / (unsigned)heads), step_h = (int)(gridDim.x % (unsigned)heads);
-    int cur_b = (int)(blockIdx.x / (unsigned)heads), cur_h = (int)(blockIdx.x % (unsigned)heads);
+    // A workgroup per item (calls of up to a few hundred sentences): every XCD takes one contiguous run of items -- of sentences,
+    // the rows the QKV projection's tiles left in this XCD's L2 and the rows the output projection's tiles will read here.
+    const unsigned first = gridDim.x == n_items ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    int cur_b = (int)(first / (unsigned)heads), cur_h = (int)(first % (unsigned)heads);
     auto advance = [&](int& bb, int& hh) {
         bb += step_b;
         hh += step_h;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         for (int kk = 0; kk < D / 8; ++kk) qf[kk] = ld16(rq, off_q, kk * 32);
     };
 
-    int64_t item = blockIdx.x;
+    int64_t item = first;
     if (item < n_items) {
         prefetch_kv(cur_b, cur_h, true);
         request_mask(cur_b);
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
 
     for (; item < n_items; item += gridDim.x) {
         // registers -> LDS (K row-major, V transposed)
-        if (DIAG != 2 || item == (int64_t)blockIdx.x)
+        if (DIAG != 2 || item == (int64_t)first)
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
             const int f = tid + it * 256;

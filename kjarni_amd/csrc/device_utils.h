@@ -24,6 +24,15 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (a private L2 each).  The unit workgroup `wg` of a launch of `total`
+// workgroups should take so that every XCD owns ONE contiguous run of units (bijective for any total): the projections' tile
+// order does this, and a row-wise kernel that follows it finds the rows its XCD's L2 already holds.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned wg, unsigned total)
+{
+    const unsigned q8 = total >> 3, r8 = total & 7u, xcd = wg & 7u, slot = wg >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+}
+
 // activations.rs:56-59
 __device__ __forceinline__ float gelu_erf(float x)
 {

@@ -1068,7 +1068,9 @@ __global__ __launch_bounds__(256) void mid_reduce_ln_kernel(const float* __restr
                                                             int M, int N)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (four rows per workgroup, the XCDs' runs of rows as the projections' tiles deal them: the slabs and the residual this
+    // workgroup reads were written, and the rows it writes will be read, by tiles of its own XCD)
+    const int64_t row = (int64_t)xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int64_t slab = (int64_t)M * N;
     f32x4 v[NCH];

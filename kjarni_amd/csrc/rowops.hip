@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(
     const int32_t* __restrict__ tok_src, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t t = (int64_t)xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);  // (the XCDs' runs of rows as the projections deal them)
     if (t >= tokens) return;
     const int nv4 = hidden >> 2;
     // packed rows (ragged batches): output row t is the token at index tok_src[t] of the padded [batch, seq] arrays
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t t = (int64_t)xcd_contiguous(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);  // (the XCDs' runs of rows as the projections deal them)
     if (t >= rows) return;
     const int nv4 = hidden >> 2;
     const float* irow = in + t * hidden;
