@@ -78,13 +78,15 @@ template <int RA, int CB, bool VSLICES, int DIAG = 0>
 __global__ __launch_bounds__(256, flex_waves_per_simd(RA, CB, VSLICES)) void gemm_nt_f32_flex(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                           int64_t ldw, const float* __restrict__ bias, const float* R, int64_t ldr,
                                                           float* Y, int64_t ldy, int M, int N, int k_len, int ksplit, int vslices,
-                                                          int epi, int partial, int n_tiles, int total)
+                                                          int epi, int out_mode, int n_tiles, int total)
 // R and Y are not __restrict__: the residual epilogue runs in place (every element is read by the lane that stores it).
 {
     using T = Flex<RA, CB>;
     constexpr int BM = T::BM, BN = T::BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sBias = smem + T::MAIN_FLOATS;
+    const int partial = out_mode & 1;          // raw sums to slabs
+    const bool write_through = out_mode & 2;   // output stores with the sc1 policy (below)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -310,19 +312,35 @@ __global__ __launch_bounds__(256, flex_waves_per_simd(RA, CB, VSLICES)) void gem
                 }
             }
             if (m < M && n < N && (DIAG != 1 || v[0] == 123456.789f)) {
-                // Plain stores ON PURPOSE: the tile stays in this XCD's L2, and the XCD-aware tile order gives the same rows to the
-                // same XCD in the consuming launch (FC1 -> FC2, QKV -> attention).  Streaming stores make THIS kernel faster (the
-                // write-back burst at its end goes: FC1 + GELU at 4 096 rows 51.1 -> 45.0 us alone, DIAG 9) and the call slower
-                // (16 x 128 tokens 0.646 -> 0.675 ms): the consumers then read from memory.
+                // Where the tile goes.  Plain stores park it dirty in this XCD's L2 and the kernel ENDS with the write-back of all of
+                // it at once, nothing left to overlap (FC1 + GELU at 4 096 rows: 5 of its 50 us, tools/flex_knockout.py).  Streaming
+                // (nt) stores remove that and lose the call: the XCD-aware tile order gives the same rows to the same XCD in the
+                // consuming launch, which then reads from memory (16 x 128 tokens 0.646 -> 0.675 ms).  Write-through stores (sc1) do
+                // both -- the line goes to memory at once AND stays in L2: 8 / 16 / 32 x 128 tokens 0.458 / 0.627 / 0.90 -> 0.440 /
+                // 0.602 / 0.889 ms.  Calls of more than kWriteThroughMaxRows rows keep plain stores (64 x 128: no difference;
+                // their halves run on two streams, and the other half's work covers the burst).
                 f32x4* dst = reinterpret_cast<f32x4*>(Yb + (int64_t)m * ldo + n);
                 if (DIAG == 9) __builtin_nontemporal_store(v, dst);
-                else *dst = v;
+                else if (DIAG >= 10 && DIAG <= 12) {
+                    // (measurement: write-through stores -- cache-policy bits sc1 = 16 / sc0 = 1 / both; the tile's rows through a descriptor)
+                    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Yb + (int64_t)m0 * ldo, 0, 0x7fffffff, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ry,
+                                                           (unsigned)(((int64_t)(m - m0) * ldo + n) * 4), 0,
+                                                           DIAG == 10 ? 16 : DIAG == 11 ? 1 : 17);
+                }
+                else if (write_through) {
+                    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Yb + (int64_t)m0 * ldo, 0, 0x7fffffff, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ry,
+                                                           (unsigned)(((int64_t)(m - m0) * ldo + n) * 4), 0, 16);
+                } else *dst = v;
             }
         }
     }
     __syncthreads();  // (the epilogue regions overlap the operand stages of a next tile)
     }
 }
+
+constexpr int kWriteThroughMaxRows = 3072;
 
 struct FlexChoice {
     int ra = 0, cb = 0;
@@ -457,14 +475,17 @@ hipError_t launch_gemm_flex(const float* A, int64_t lda, const float* W, const f
     const int k_len = K / ksplit;
     const int vslices = logical_slices / ksplit;  // slices a workgroup adds up itself
     const FlexChoice ch = flex_choose(M, N, k_len, ksplit, vslices > 1);
-    const int partial = partials != nullptr;
-    float* out = partial ? partials : Y;
+    const int partial = (partials != nullptr ? 1 : 0) | (M <= kWriteThroughMaxRows ? 2 : 0);  // (the kernel's out_mode)
+    float* out = partials != nullptr ? partials : Y;
 #ifdef KJARNI_TUNING
+    // (knock-out 9 with KJARNI_HIP_FLEX_STORE = 10 / 11 / 12 in the environment: the write-through store policies instead)
+    static const int store_policy = [] { const char* e = std::getenv("KJARNI_HIP_FLEX_STORE"); return e ? std::atoi(e) : 9; }();
+    const int knock = tune::flex_knockout() == 9 ? store_policy : tune::flex_knockout();
 #define KJ_FLEX_DIAG(RA_, CB_, D_)                                                                                                     \
-    if (ch.ra == RA_ && ch.cb == CB_ && tune::flex_knockout() == D_ && vslices <= 1)                                                    \
+    if (ch.ra == RA_ && ch.cb == CB_ && knock == D_ && vslices <= 1)                                                    \
         return flex_launch_one<RA_, CB_, false, D_>(A, lda, W, K, bias, R, ldr, out, ldy, M, N, k_len, ksplit, 1, (int)epi, partial, stream);
-    KJ_FLEX_DIAG(2, 9, 1) KJ_FLEX_DIAG(2, 9, 2) KJ_FLEX_DIAG(2, 9, 3) KJ_FLEX_DIAG(2, 9, 4) KJ_FLEX_DIAG(2, 9, 5) KJ_FLEX_DIAG(2, 9, 6) KJ_FLEX_DIAG(2, 9, 7) KJ_FLEX_DIAG(2, 9, 8) KJ_FLEX_DIAG(2, 9, 9)
-    KJ_FLEX_DIAG(2, 12, 1) KJ_FLEX_DIAG(2, 12, 2) KJ_FLEX_DIAG(2, 12, 3) KJ_FLEX_DIAG(2, 12, 4) KJ_FLEX_DIAG(2, 12, 5) KJ_FLEX_DIAG(2, 12, 6) KJ_FLEX_DIAG(2, 12, 7) KJ_FLEX_DIAG(2, 12, 8) KJ_FLEX_DIAG(2, 12, 9)
+    KJ_FLEX_DIAG(2, 9, 1) KJ_FLEX_DIAG(2, 9, 2) KJ_FLEX_DIAG(2, 9, 3) KJ_FLEX_DIAG(2, 9, 4) KJ_FLEX_DIAG(2, 9, 5) KJ_FLEX_DIAG(2, 9, 6) KJ_FLEX_DIAG(2, 9, 7) KJ_FLEX_DIAG(2, 9, 8) KJ_FLEX_DIAG(2, 9, 9) KJ_FLEX_DIAG(2, 9, 10) KJ_FLEX_DIAG(2, 9, 11) KJ_FLEX_DIAG(2, 9, 12)
+    KJ_FLEX_DIAG(2, 12, 1) KJ_FLEX_DIAG(2, 12, 2) KJ_FLEX_DIAG(2, 12, 3) KJ_FLEX_DIAG(2, 12, 4) KJ_FLEX_DIAG(2, 12, 5) KJ_FLEX_DIAG(2, 12, 6) KJ_FLEX_DIAG(2, 12, 7) KJ_FLEX_DIAG(2, 12, 8) KJ_FLEX_DIAG(2, 12, 9) KJ_FLEX_DIAG(2, 12, 10) KJ_FLEX_DIAG(2, 12, 11) KJ_FLEX_DIAG(2, 12, 12)
 #undef KJ_FLEX_DIAG
 #endif
 #define KJ_FLEX(RA_, CB_)                                                                                                             \

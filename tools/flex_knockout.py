@@ -15,7 +15,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 rng = np.random.default_rng(0)
 NAMES = {0: "whole kernel", 1: "no output stores", 2: "no global loads in the K-loop", 3: "MFMAs only in the K-loop", 4: "no barrier in the K-loop",
-         5: "no staging in the K-loop", 6: "staging loads sc1 (bypass L1)", 7: "staging loads sc0", 8: "staging loads nt", 9: "streaming output stores"}
+         5: "no staging in the K-loop", 6: "staging loads sc1 (bypass L1)", 7: "staging loads sc0", 8: "staging loads nt", 9: "output stores: streaming, or KJARNI_HIP_FLEX_STORE=10/11/12 (sc1 / sc0 / both)"}
 ops.linear(rng.standard_normal((4096, 384), dtype=np.float32), (rng.standard_normal((1536, 384), dtype=np.float32) * 0.05), None, None,
            ops.EPI_BIAS, iters=3000)  # clocks up
 for name, K, N, epi, cfg in (("qkv 128x144", 384, 1152, ops.EPI_BIAS, 209), ("fc1+gelu 128x192", 384, 1536, ops.EPI_BIAS_GELU, 212),
