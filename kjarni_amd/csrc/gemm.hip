@@ -98,7 +98,7 @@ __device__ __forceinline__ void mfma16(f32x16 (&acc)[2][2], const Frag& f)
     }
 }
 
-template <int EPI, int BKT, int DIAG, bool STREAM_OUT = false>
+template <int EPI, int BKT, int DIAG, int OUT_POLICY = 0>  // OUT_POLICY: 0 plain output stores, 1 streaming
 __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mfma(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* R, int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, int n_tiles, int64_t total_tiles)
@@ -335,15 +335,18 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
                 for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
             }
             if (m < M) {
-                // STREAM_OUT (outputs larger than the memory-side cache): streaming stores.  Plain ones leave the tile's 64 KB in
+                // OUT_POLICY 1 (outputs larger than the memory-side cache): streaming stores.  Plain ones leave the tile's 64 KB in
                 // the XCD's L2, where they evict the A panels and weights the neighbouring tiles are still reading -- FC1 + GELU
                 // at 262 144 rows fetched 1.31 GB for 0.41 GB of operands (PMC, profiles/r04n_traffic_ab.log: 0.43 GB with streaming
                 // stores, QKV 0.96 -> 0.50); the time is the same within 0.3 %, the HBM traffic of the layer 14 % lower.
                 // (A template parameter, not a kernel argument: the compiler merges the two stores of a run-time choice into one
                 // plain store.)
                 f32x4* dst = reinterpret_cast<f32x4*>(Y + m * ldy + n);
-                if (STREAM_OUT) __builtin_nontemporal_store(v, dst);
-                else *dst = v;
+                if (OUT_POLICY == 1) {
+                    __builtin_nontemporal_store(v, dst);
+                } else {
+                    *dst = v;
+                }
             }
         }
     }
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_generic(const float* __restri
 // Outputs from this size leave through streaming stores: nothing the size of the memory-side cache (256 MB) is found there again.
 constexpr int64_t kStreamOutBytes = (int64_t)256 << 20;
 
-template <int EPI, int BKT, int DIAG, bool STREAM_OUT>
+template <int EPI, int BKT, int DIAG, int OUT_POLICY>
 hipError_t launch_tiled_as(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
                            int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int K, hipStream_t stream)
 {
@@ -849,7 +852,7 @@ hipError_t launch_tiled_as(const float* A, int64_t lda, const float* W, const fl
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         if (!attr_set[dev & 63]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma<EPI, BKT, DIAG, STREAM_OUT>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_mfma<EPI, BKT, DIAG, OUT_POLICY>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
             if (e != hipSuccess) return e;
             attr_set[dev & 63] = true;
@@ -865,7 +868,7 @@ hipError_t launch_tiled_as(const float* A, int64_t lda, const float* W, const fl
     const int64_t resident = (int64_t)256 * T::WAVES_PER_SIMD;
     const bool persistent = EPI == EPI_BIAS && !tune::no_persistent_tile_loop();  // (GELU in the pipeline: 1.7 % slower as a persistent launch, r03l)
     dim3 grid((unsigned)(persistent ? std::min(total, resident) : total));
-    hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG, STREAM_OUT>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
+    hipLaunchKernelGGL((gemm_nt_f32_mfma<EPI, BKT, DIAG, OUT_POLICY>), grid, dim3(256), T::LDS_BYTES, stream, A, lda, W, bias,
                        R, ldr, Y, ldy, M, N, K, n_tiles, total);
     return hipGetLastError();
 }
@@ -876,8 +879,8 @@ hipError_t launch_tiled(const float* A, int64_t lda, const float* W, const float
 {
     // (in place -- R == Y -- the stores stay plain: the rows are read again as the next projection's residual)
     if (DIAG == 0 && (int64_t)M * N * 4 >= kStreamOutBytes && R != Y && !tune::no_streaming_output_stores())
-        return launch_tiled_as<EPI, BKT, 0, true>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
-    return launch_tiled_as<EPI, BKT, DIAG, false>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        return launch_tiled_as<EPI, BKT, 0, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+    return launch_tiled_as<EPI, BKT, DIAG, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
 }
 
 // ---- Calls of 257 .. 8192 rows (the reference's default batch is 32 sentences) -------------------------------------------
