@@ -12,7 +12,7 @@ for f in $(grep '^CPP_SRCS' Makefile | cut -d= -f2); do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -fsanitize=undefined -shared-libsan -Wno-option-ignored \
-  -o ../../build/asan/libkjarni_ffi.so ../../build/csrc/{gemm,gemm_split,attention,rowops,cosine,whisper_kernels,llm_kernels}.o ../../build/asan/*.o \
+  -o ../../build/asan/libkjarni_ffi.so ../../build/csrc/{gemm,gemm_flex,gemm_split,attention,rowops,cosine,whisper_kernels,llm_kernels}.o ../../build/asan/*.o \
   -Wl,-soname,libkjarni_ffi.so
 cd ../..
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
