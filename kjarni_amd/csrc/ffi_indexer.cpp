@@ -99,6 +99,20 @@ size_t device_batch_chunks()
     return 2048;
 }
 
+// KJARNI_HIP_INDEX_TIMING=1: where a run's wall time goes, per stage, on stderr (measurements)
+struct StageTimes {
+    std::atomic<int64_t> load_us{0}, blocked_us{0}, device_us{0}, write_us{0}, commit_us{0}, tok_wait_us{0}, embed_us{0};
+};
+inline int64_t now_us()
+{
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool index_timing()
+{
+    static const bool on = std::getenv("KJARNI_HIP_INDEX_TIMING") != nullptr;
+    return on;
+}
+
 using ReportFn = std::function<void(KjarniProgressStage, size_t, size_t, const char*)>;
 using CancelFn = std::function<bool()>;
 
@@ -131,13 +145,20 @@ struct KjarniIndexer {
             return count;
         }
 
-        // One device batch is in flight on a worker thread (tokenise -> GPU -> writer) while the caller keeps loading and
-        // splitting files; inside the batch the next length group is tokenised while the GPU works on the current one.
-        std::future<void> pending;
+        // Three stages: the caller keeps loading and splitting files; one device batch is in flight on a worker thread (tokenise ->
+        // GPU; inside the batch the next length group is tokenised while the GPU works on the current one); the batch before it is
+        // being written (IndexWriter::add: the BM25 postings, the segment files) on a third thread -- the writer is the slowest host
+        // stage per chunk, and serial after the GPU stage it left the device idle half of the time.  Batches are written in order;
+        // at most one waits behind the one being written.
+        StageTimes* times = nullptr;
+        std::future<void> pending;  // the device stage of the newest batch
+        std::future<void> writing;  // the write stage of the batch before it (owned by the device stage's thread while that runs)
 
         void wait()
         {
+            const int64_t t0 = now_us();
             if (pending.valid()) pending.get();  // rethrows what the batch threw
+            if (times) times->blocked_us += now_us() - t0;
         }
 
         void drain()
@@ -148,13 +169,14 @@ struct KjarniIndexer {
             auto job_metas = std::make_shared<std::vector<Metadata>>(std::move(metas));
             texts.clear();
             metas.clear();
-            pending = std::async(std::launch::async, [this, job_texts, job_metas] { process(*job_texts, *job_metas); });
+            pending = std::async(std::launch::async, [this, job_texts, job_metas] { process(job_texts, job_metas); });
         }
 
         void finish()  // everything handed over so far is on disk when this returns
         {
             drain();
             wait();
+            if (writing.valid()) writing.get();
         }
 
         ~Sink()
@@ -163,14 +185,21 @@ struct KjarniIndexer {
                 wait();
             } catch (...) {
             }
+            try {
+                if (writing.valid()) writing.get();
+            } catch (...) {
+            }
         }
 
-        void process(std::vector<std::string>& texts, std::vector<Metadata>& metas)
+        void process(std::shared_ptr<std::vector<std::string>> texts_p, std::shared_ptr<std::vector<Metadata>> metas_p)
         {
+            std::vector<std::string>& texts = *texts_p;
             const size_t n = texts.size();
             if (n == 0) return;
+            const int64_t t_dev = now_us();
             const size_t H = (size_t)ix.embedder->config().hidden;
-            std::vector<float> emb(n * H);
+            auto emb_p = std::make_shared<std::vector<float>>(n * H);
+            std::vector<float>& emb = *emb_p;
             // length-sorted groups: every group is padded to ITS longest member only
             std::vector<size_t> order(n);
             std::iota(order.begin(), order.end(), (size_t)0);
@@ -186,21 +215,35 @@ struct KjarniIndexer {
                 const size_t e = std::min(n, s + group);
                 std::vector<float> out;
                 try {
+                    const int64_t t0 = now_us();
                     const BatchEncoding be = next.get();
+                    const int64_t t1 = now_us();
                     if (e < n) next = std::async(std::launch::async, tokenize, e);
                     // Embedder::embed_batch: mean pool, L2-normalised (crates/kjarni/src/embedder/model.rs:142-160)
                     out = embed_encoding(*ix.embedder, be, POOL_MEAN, true);
+                    if (times) {
+                        times->tok_wait_us += t1 - t0;
+                        times->embed_us += now_us() - t1;
+                    }
                 } catch (const std::exception& ex) {
                     if (next.valid()) next.wait();
                     throw IndexerFailure(KJARNI_ERROR_INFERENCE_FAILED, std::string("Failed to load embedder: ") + ex.what());
                 }
                 for (size_t i = s; i < e; ++i) std::memcpy(&emb[order[i] * H], &out[(i - s) * H], H * sizeof(float));
             }
-            try {
-                for (size_t i = 0; i < n; ++i) writer.add(texts[i], &emb[i * H], H, &metas[i]);
-            } catch (const std::exception& ex) {
-                throw indexing_failed(ex.what());
-            }
+            if (times) times->device_us += now_us() - t_dev;
+            if (writing.valid()) writing.get();  // (in order, and no more than one batch waiting to be written)
+            IndexWriter* w = &writer;
+            StageTimes* tm = times;
+            writing = std::async(std::launch::async, [w, tm, texts_p, metas_p, emb_p, n, H] {
+                const int64_t t0 = now_us();
+                try {
+                    for (size_t i = 0; i < n; ++i) w->add((*texts_p)[i], &(*emb_p)[i * H], H, &(*metas_p)[i]);
+                } catch (const std::exception& ex) {
+                    throw indexing_failed(ex.what());
+                }
+                if (tm) tm->write_us += now_us() - t0;
+            });
         }
     };
 
@@ -219,7 +262,8 @@ struct KjarniIndexer {
         if (is_cancelled()) throw cancelled();
 
         const DocumentLoader doc_loader(loader);
-        Sink sink{*this, writer, std::max(device_batch_chunks(), std::max<size_t>(batch_size, 1)), {}, {}, {}};
+        StageTimes times;
+        Sink sink{*this, writer, std::max(device_batch_chunks(), std::max<size_t>(batch_size, 1)), {}, {}, index_timing() ? &times : nullptr, {}, {}};
         std::vector<std::string> batch_texts;
         std::vector<Metadata> batch_metas;
 
@@ -227,6 +271,7 @@ struct KjarniIndexer {
             if (is_cancelled()) throw cancelled();
             report(KJARNI_PROGRESS_LOADING, file_idx, total_files, files[file_idx].c_str());
             std::vector<Chunk> chunks;
+            const int64_t t_load = now_us();
             try {
                 chunks = doc_loader.load_file(files[file_idx]);
             } catch (const std::exception& e) {
@@ -234,6 +279,7 @@ struct KjarniIndexer {
                 if (!quiet) std::fprintf(stderr, "Warning: Failed to load %s: %s\n", files[file_idx].c_str(), e.what());
                 continue;
             }
+            times.load_us += now_us() - t_load;
             total_chunks += chunks.size();
             ++files_processed;
             for (Chunk& c : chunks) {
@@ -252,11 +298,17 @@ struct KjarniIndexer {
         }
         sink.finish();
         report(KJARNI_PROGRESS_COMMITTING, total_docs, total_docs, commit_msg);
+        const int64_t t_commit = now_us();
         try {
             writer.commit();
         } catch (const std::exception& e) {
             throw indexing_failed(e.what());
         }
+        times.commit_us += now_us() - t_commit;
+        if (index_timing())
+            std::fprintf(stderr, "indexer stages (ms): load + split %.1f | caller blocked on the device stage %.1f | device stage %.1f (waiting for the tokeniser %.1f, embedding %.1f) | write stage %.1f | commit %.1f\n",
+                         times.load_us / 1e3, times.blocked_us / 1e3, times.device_us / 1e3, times.tok_wait_us / 1e3, times.embed_us / 1e3, times.write_us / 1e3,
+                         times.commit_us / 1e3);
     }
 
     KjarniIndexStats create(const std::string& index_path, const std::vector<std::string>& inputs, bool force,
