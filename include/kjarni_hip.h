@@ -329,6 +329,11 @@ KjarniErrorCode kjarni_hip_cosine_search_host(int32_t device, const float* queri
  * the hits' documents and metadata, for a Searcher the query's tokenisation and embedding).  Up to n <= 4 values. */
 void kjarni_hip_search_breakdown(double* out, size_t n);
 
+/* Keyword search (BM25, host side) walks the segments of an index of at least this many documents on a few host threads
+ * (contiguous runs of segments, hits merged in segment order: the result does not depend on it).  Default 50 000; 0 = always
+ * when there are four segments or more, SIZE_MAX = never.  Process-wide. */
+void kjarni_hip_set_keyword_parallel_min_docs(size_t docs);
+
 /* ---- tokenizer -----------------------------------------------------------------
  * The reference tokenises on the host with the HF `tokenizers` crate configured at
  * load time (crates/kjarni-transformers/src/pipeline/encoder/loader.rs:98-115:

@@ -470,6 +470,7 @@ SIGNATURES = {
     "kjarni_hip_cosine_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
     "kjarni_hip_search_breakdown": (None, [POINTER(C.c_double), c_size_t]),
+    "kjarni_hip_set_keyword_parallel_min_docs": (None, [c_size_t]),
     "kjarni_hip_cosine_search_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32, c_int32]),
     "kjarni_hip_cosine_search": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                            c_void_p, c_void_p, c_void_p, c_void_p]),

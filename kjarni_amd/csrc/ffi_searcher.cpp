@@ -707,6 +707,8 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_index_search(const char* index_path, co
 // out[0] re-opening the index (revalidation of the parsed segments), out[1] the scan callback (image lookup, copies, launches,
 // wait), out[2] of it between the query's H2D copy and the hits' arrival, out[3] the whole call -- the rest is host work: BM25,
 // rank fusion, reading the hits' documents and metadata back, (for a Searcher) tokenising and embedding the query.
+KJARNI_EXPORT void kjarni_hip_set_keyword_parallel_min_docs(size_t docs) { set_keyword_parallel_min_docs(docs); }
+
 KJARNI_EXPORT void kjarni_hip_search_breakdown(double* out, size_t n)
 {
     const double v[4] = {t_breakdown.open_us, t_breakdown.scan_us, t_breakdown.device_us, t_breakdown.total_us};

@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <thread>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -793,11 +794,40 @@ std::vector<SearchHit> IndexReader::search_semantic(const float* query, size_t l
     return convert(all);
 }
 
+static std::atomic<size_t> g_keyword_parallel_min_docs{50000};
+void set_keyword_parallel_min_docs(size_t docs) { g_keyword_parallel_min_docs.store(docs, std::memory_order_relaxed); }
+
 std::vector<SearchHit> IndexReader::search_keywords(const std::string& query, size_t limit) const
 {
+    // Segments are independent (bm25.rs scores a segment's documents against that segment's statistics): a large index is
+    // walked by a few host threads, each a contiguous run of segments; the hits are merged in segment order as before.
+    const size_t nseg = segments_.size();
+    std::vector<std::vector<std::pair<size_t, float>>> per(nseg);
+    size_t docs = 0;
+    for (const auto& sg : segments_) docs += sg->doc_count();
+    size_t workers = std::min<size_t>({nseg / 2, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (docs < g_keyword_parallel_min_docs.load(std::memory_order_relaxed)) workers = 1;
+    if (workers < 2) {
+        for (size_t si = 0; si < nseg; ++si) per[si] = segments_[si]->search_keywords(query, limit);
+    } else {
+        std::vector<std::thread> pool;
+        std::vector<std::exception_ptr> errs(workers);
+        for (size_t w = 0; w < workers; ++w)
+            pool.emplace_back([&, w] {
+                try {
+                    for (size_t si = nseg * w / workers, e = nseg * (w + 1) / workers; si < e; ++si)
+                        per[si] = segments_[si]->search_keywords(query, limit);
+                } catch (...) {
+                    errs[w] = std::current_exception();
+                }
+            });
+        for (std::thread& t : pool) t.join();
+        for (const std::exception_ptr& e : errs)
+            if (e) std::rethrow_exception(e);
+    }
     std::vector<std::tuple<size_t, size_t, float>> all;
-    for (size_t si = 0; si < segments_.size(); ++si)
-        for (const auto& r : segments_[si]->search_keywords(query, limit)) all.emplace_back(si, r.first, r.second);
+    for (size_t si = 0; si < nseg; ++si)
+        for (const auto& r : per[si]) all.emplace_back(si, r.first, r.second);
     sort_desc_truncate(all, limit);
     return convert(all);
 }

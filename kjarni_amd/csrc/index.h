@@ -120,6 +120,9 @@ private:
 // (Segment::search_vectors, segment.rs:307-337).  Supplied by the GPU side, which takes the whole list so that
 // all segments of a query are enqueued before the one synchronisation.
 using SegmentHits = std::vector<std::pair<size_t, float>>;
+
+// Documents from which IndexReader::search_keywords walks the segments on several host threads (kjarni_hip.h).
+void set_keyword_parallel_min_docs(size_t docs);
 using SegmentScanFn = std::function<std::vector<SegmentHits>(const std::vector<const Segment*>& segments,
                                                              const float* query, size_t limit)>;
 

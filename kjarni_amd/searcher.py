@@ -112,6 +112,11 @@ def rrf_fuse(keyword_ids, semantic_ids, limit: int):
     return [(int(ids[i]), float(sc[i])) for i in range(n.value)]
 
 
+def set_keyword_parallel_min_docs(docs: int) -> None:
+    """Index size from which BM25 walks the segments on several host threads (kjarni_hip_set_keyword_parallel_min_docs)."""
+    lib().kjarni_hip_set_keyword_parallel_min_docs(docs)
+
+
 def search_breakdown() -> Dict[str, float]:
     """Where this thread's last search call spent its time, in microseconds (kjarni_hip_search_breakdown): re-opening the
     index, the scan over the device image, of it the device round trip, the whole call."""

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 from kjarni_amd import _ffi
-from kjarni_amd.searcher import bm25_tokenize, glob_match, index_search, rrf_fuse, search_keywords
+from kjarni_amd.searcher import (bm25_tokenize, glob_match, index_search, rrf_fuse, search_keywords,
+                                 set_keyword_parallel_min_docs)
 from oracle import search_oracle as SO
 
 
@@ -181,6 +182,29 @@ def test_keywords_repeated_terms_and_dense_matches_bit_exact(tmp_path):
     for q in ["glacier fjord basalt", "fjord fjord glacier fjord", "wool wool", "river d17 lights", "d3 d3 d4"]:
         for k in (1, 10, 2000):
             _same(search_keywords(root, q, k), orc.search_keywords(q, k))
+
+
+def test_keywords_on_several_host_threads_are_the_same_hits(tmp_path):
+    # Large indexes walk their segments on a few host threads (index.cpp, IndexReader::search_keywords): same hits, same scores,
+    # same order as one thread and as the oracle.
+    rng = np.random.default_rng(23)
+    words = ["glacier", "fjord", "basalt", "wool", "geyser", "harbour", "lights", "river"]
+    docs = [(" ".join(rng.choice(words, int(rng.integers(1, 14)))) + f" d{i}", rng.standard_normal(4).astype(np.float32),
+             {"source": f"f{i % 7}.txt"}) for i in range(1300)]
+    root = str(tmp_path / "threads")
+    SO.write_index(root, 4, docs, max_docs_per_segment=100)   # 13 segments
+    orc = SO.IndexOracle(docs, 100)
+    try:
+        for q in ["glacier fjord basalt", "wool wool", "river d17 lights", "nothing-matches"]:
+            for k in (1, 10, 2000):
+                set_keyword_parallel_min_docs(2 ** 62)
+                one = search_keywords(root, q, k)
+                set_keyword_parallel_min_docs(0)
+                many = search_keywords(root, q, k)
+                _same(many, one)
+                _same(many, orc.search_keywords(q, k))
+    finally:
+        set_keyword_parallel_min_docs(50000)
 
 
 def test_rewritten_index_is_not_served_from_the_segment_cache(tmp_path):
