@@ -13,7 +13,7 @@
 //   11  fused LayerNorm tiles as a persistent launch (two workgroups per CU)
 //   12  128 x 128 tiles: plain output stores whatever the output's size (no streaming stores for outputs >= 256 MB)
 //   14  fused LayerNorm tiles read bias / gamma / beta from global memory in the epilogue (rounds 1-2) instead of from LDS
-//   15  residual projection + LayerNorm of up to 64 rows with a long K: the 64 x 64-tile K slices instead of the few-rows kernel's
+//   15  residual projection + LayerNorm of a few rows (up to gemm_few_rows_max) with a long K: the 64 x 64-tile K slices instead of the few-rows kernel's
 //   31..34  persistent grid of the 64 x 64-tile kernel: 768 / 512 / 256 / 1 280 workgroups instead of 1 024
 //   21..26  knock-out diagnostics of the 64 x 64-tile kernel (unsliced launches): its DIAG template parameter 1..6
 //   17  f32-on-bf16 mode: the 64 x 64-tile route stays on the f32 matrix cores
