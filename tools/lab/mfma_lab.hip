@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <string>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -279,6 +280,141 @@ void run(const char* name, const float* A, const float* W, float* Y, int64_t M, 
     }
 }
 
+
+// ---- The tile with WM x 2 waves: WM = 2 is the production shape (128 x 128, two workgroups per CU), WM = 4 the 256 x 128
+// eight-wave tile (one workgroup per CU, a quarter less staging per MFMA).  Same loop for both: tile kt + 1 goes registers -> LDS
+// in phase 1 of step kt with the loads of tile kt + 2 behind it; EPI: the LDS-transposed epilogue with 16-byte stores.
+template <int WM, bool EPI>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void lab_wm_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                            float* __restrict__ Y, int64_t M, int N, int K, int n_tiles)
+{
+    constexpr int TBM = 64 * WM, TA = TBM * STRIDE, TB = BN * STRIDE, NB = 8 / WM;  // B pieces per thread (A: always 4)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;            // [2][TBM][STRIDE]
+    float* sB = smem + 2 * TA;   // [2][128][STRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, l31 = lane & 31, half = lane >> 5;
+    const int64_t nwg = gridDim.x;
+    const int64_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8, q8 = nwg / 8, r8 = nwg % 8;
+    const int64_t bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int64_t m0 = (bid / n_tiles) * TBM;
+    const int n0 = (int)(bid % n_tiles) * BN;
+    const int ld_row = tid / 8, ld_c4 = tid % 8;  // rows 0 .. 16 WM - 1
+    const float* ga_ptr[4];
+    const float* gb_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga_ptr[i] = A + (m0 + ld_row + 16 * WM * i) * K + ld_c4 * 4;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) gb_ptr[i] = W + (int64_t)(n0 + ld_row + 16 * WM * i) * K + ld_c4 * 4;
+    f32x4 ga[4], gb[NB];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ga[i] = *reinterpret_cast<const f32x4*>(ga_ptr[i] + k0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) gb[i] = *reinterpret_cast<const f32x4*>(gb_ptr[i] + k0);
+    };
+    const int st_off = ld_row * STRIDE + ld_c4 * 4;
+    auto store_tiles = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sA + stage * TA + st_off + 16 * WM * i * STRIDE) = ga[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(sB + stage * TB + st_off + 16 * WM * i * STRIDE) = gb[i];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nk = K / BK;
+    const int a_off = (wr * 64 + l31) * STRIDE + half * 4;
+    const int b_off = (wc * 64 + l31) * STRIDE + half * 4;
+    load_tiles(0);
+    store_tiles(0);
+    if (nk > 1) load_tiles(BK);
+    __syncthreads();
+    Frag fr[2];
+    read_frag(fr[0], sA + a_off, sB + b_off, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* pa = sA + cur * TA + a_off;
+        const float* pb = sB + cur * TB + b_off;
+#pragma unroll
+        for (int p = 0; p < NKK; ++p) {
+            Frag& use = fr[p & 1];
+            Frag& nxt = fr[(p + 1) & 1];
+            if (p + 1 < NKK) {
+                read_frag(nxt, pa, pb, p + 1);
+            } else {
+                __syncthreads();
+                read_frag(nxt, sA + (cur ^ 1) * TA + a_off, sB + (cur ^ 1) * TB + b_off, 0);
+            }
+            if (p == 1) {
+                store_tiles(cur ^ 1);
+                if (kt + 2 < nk) load_tiles((kt + 2) * BK);
+            }
+            mfma16(acc, use);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (EPI) {
+        constexpr int ES = 68;
+        float* sw = smem + wid * (32 * ES);  // (a 32-row round at a time: 8 waves x 32 x 68 floats fit the operand stages)
+        const int e_row = lane >> 4, e_c4 = lane & 15;
+        const int n = n0 + wc * 64 + e_c4 * 4;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * half) * ES + j * 32 + l31] = acc[i][j][r];
+            const int64_t m_base = m0 + wr * 64 + i * 32 + e_row;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * ES + e_c4 * 4);
+                *reinterpret_cast<f32x4*>(Y + (m_base + it * 4) * N + n) = v;
+            }
+        }
+        return;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    Y[(m0 + wr * 64 + l31) * N + n0 + wc * 64 + half] = s;
+}
+
+template <int WM, bool EPI>
+void run_wm(const char* name, const float* A, const float* W, float* Y, int64_t M, int N, int K)
+{
+    const int lds = 2 * (64 * WM + BN) * STRIDE * 4;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_wm_kernel<WM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int n_tiles = N / BN;
+    dim3 grid((unsigned)(M / (64 * WM) * n_tiles));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    const double flops = 2.0 * M * N * K;
+    const int iters = (int)(0.4 / (flops / 125e12)) + 1;
+    for (int rep = 0; rep < 2; ++rep) {
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((lab_wm_kernel<WM, EPI>), grid, dim3(128 * WM), lds, 0, A, W, Y, M, N, K, n_tiles);
+        CHECK(hipEventRecord(a));
+        for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((lab_wm_kernel<WM, EPI>), grid, dim3(128 * WM), lds, 0, A, W, Y, M, N, K, n_tiles);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        ms /= iters;
+        const double tf = flops / (ms * 1e-3) / 1e12;
+        printf("%-44s lds=%6d K=%5d N=%5d  %8.4f ms %7.2f TFLOP/s %5.1f%%\n", name, lds, K, N, ms, tf, tf / 157.3 * 100);
+        fflush(stdout);
+    }
+}
 
 // ---- LDS-DMA variant: global -> LDS directly (no VGPR staging, no ds_write), unpadded [128][32] tiles with the
 // 16-byte slot XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128), the swizzle applied on the SOURCE address.
@@ -725,6 +861,16 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&Y2, (size_t)M * N * 4));
     CHECK(hipMemset(Y, 0, (size_t)M * N * 4));
     CHECK(hipMemset(Y2, 0, (size_t)M * N * 4));
+    if (argc > 1 && std::string(argv[1]) == "wm") {  // the eight-wave 256 x 128 tile against the production shape, same loop
+        for (int k : {384, 1536}) {
+            run_wm<2, false>("128x128, 4 waves, 2 WG/CU, trivial epilogue", A, W, Y, M, 1536, k);
+            run_wm<4, false>("256x128, 8 waves, 1 WG/CU, trivial epilogue", A, W, Y2, M, 1536, k);
+            run_wm<2, true>("128x128, 4 waves, 2 WG/CU, LDS epilogue", A, W, Y, M, 1536, k);
+            run_wm<4, true>("256x128, 8 waves, 1 WG/CU, LDS epilogue", A, W, Y2, M, 1536, k);
+            compare_full(Y, Y2, M, 1536);
+        }
+        return 0;
+    }
     for (int n : {1536, 384}) {
         CHECK(hipMemset(Y, 0, (size_t)M * N * 4));
         CHECK(hipMemset(Y2, 0, (size_t)M * N * 4));
