@@ -32,7 +32,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   value_host_ptrs / value_ragged  (N = 1, embed) the same workload through host pointers
                 (H2D of ids/mask + D2H of the embeddings inside the timed region) and with
                 ragged lengths U{16..128}.
-  value_by_call_size  (N = 1, embed) one host-pointer call at a time of 1 / 32 / 256 sentences.
+  value_by_call_size  (N = 1, embed) one host-pointer call at a time of 1 / 8 / 32 / 64 / 256 sentences.
   value_f32_on_bf16   (N = 1, embed) the headline workload in the opt-in mode kjarni_hip_set_f32_on_bf16 (default off;
                 never part of `value`), with the largest difference of its embeddings from the default path's.
 """
@@ -499,10 +499,10 @@ def main():
         torch.cuda.synchronize()
         extras["value_ragged_padded_layout"] = round(n_local / (time.perf_counter() - t1), 1)
         enc.set_packing(1)
-        # the sizes callers make: one call at a time of 1 / 32 / 256 sentences through host pointers (the reference's default
+        # the sizes callers make: one call at a time of 1 / 8 / 32 / 64 / 256 sentences through host pointers (the reference's default
         # batch is 32, crates/kjarni-ffi/src/embedder.rs); 1 and 32 take the few-rows / mid-size GEMM routes
         by_call = {}
-        for b in (1, 32, 256):
+        for b in (1, 8, 32, 64, 256):
             reps = max(8, 2048 // b)
             enc.embed(ids_np[:b], mask_np[:b])
             t1 = time.perf_counter()
@@ -536,7 +536,7 @@ def main():
         extras["extras_note"] = ("value_host_ptrs: ids/mask handed over as host buffers, embeddings returned to the "
                                  "host (PCIe inclusive); value_ragged: lengths U{16..128} right-padded to 128, run over the kept tokens only "
                                  "(packed rows); value_ragged_padded_layout: the same batch with every [PAD] row computed; 2 steps each; "
-                                 "value_by_call_size: one host-pointer call at a time of 1 / 32 / 256 sentences x 128 tokens; "
+                                 "value_by_call_size: one host-pointer call at a time of 1 / 8 / 32 / 64 / 256 sentences x 128 tokens; "
                                  "value_f32_on_bf16: the headline workload in the opt-in mode kjarni_hip_set_f32_on_bf16 (f32 products "
                                  "from three exact bf16 pieces per operand on the bf16 matrix cores; off by default, not part of `value`)")
 
