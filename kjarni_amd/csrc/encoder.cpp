@@ -1045,18 +1045,21 @@ void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask,
              });
 }
 
-// ---- two lanes -------------------------------------------------------------------------------------------
+// ---- lanes -----------------------------------------------------------------------------------------------
 // A call of a few thousand tokens (the reference's default batch of 32) is ~43 kernels of 15-50 us, each of which pays a
 // launch gap, a prologue and an output burst that nothing overlaps: the chip idles a third of the time.
-// Sentences are independent, so such a call runs as two halves (cut where the kept tokens halve) on two workspaces and two
-// streams, the second half enqueued by a persistent helper thread: the halves drift apart by a fraction of a kernel and each
-// one's idle phases fall under the other's matrix work.  Measured (tools/overlap_probe.py): 24 / 32 / 64 sentences x 128
-// tokens 0.93 / 1.02 / 1.84 -> 0.83 / 0.94 / 1.75 ms; below ~2 300 tokens and above ~8 192 one launch sequence is faster
-// (16 x 128: 0.64 against 0.66; 128 x 128: 3.10 against 3.23), so only that range splits.  Both halves stay in the mid-size
-// projection route, where a row's result does not depend on the rows beside it: the split is invisible in the results.
-// The helper serves one call at a time; a call that finds it busy runs unsplit.
+// Sentences are independent, so such a call runs as two or three parts (cut where the kept tokens halve / third) on as many
+// workspaces and streams, the other parts enqueued by persistent helper threads: the parts drift apart by a fraction of a kernel
+// and each one's idle phases fall under the others' matrix work.  Measured (tools/overlap_probe.py, sentences x 128 tokens; one /
+// two / three parts): 24: 0.93 / 0.83 / -; 32: 1.02 / 0.89 / -; 36: 1.16 / 1.10 / 1.06; 48: 1.57 / 1.39 / 1.31; 56: 1.62 / 1.59 /
+// 1.48; 72: 2.35 / 1.94 / 1.90; 96: 2.68 / 2.54 / 2.41; 128: 3.07 / 3.23 / 3.09 ms -- below ~2 300 tokens and above ~12 300
+// one launch sequence is as fast or faster, so only that range splits.
+// Up to 8 192 tokens the whole call would take the mid-size projection route as its parts do, where a row's result does not
+// depend on the rows beside it: the split is invisible in the results, and a call that finds the helpers busy simply runs unsplit.
+// Above that the whole call would run on the large-batch tiles (another summation order): there the split is part of what the call
+// computes -- it is made whenever lanes are on, and a part whose helper is busy runs on the caller's thread after the caller's own.
 namespace {
-constexpr int64_t kTwoLaneMinTokens = 2304, kTwoLaneMaxTokens = 8192;
+constexpr int64_t kTwoLaneMinTokens = 2304, kThreeLaneMinTokens = 4608, kSameRouteMaxTokens = 8192, kLaneMaxTokens = 12288;
 }
 
 EncoderModel::Lane::~Lane()
@@ -1114,12 +1117,12 @@ void EncoderModel::Lane::wait()
     if (err) std::rethrow_exception(err);
 }
 
-// half(b0, nb): runs sentences [b0, b0 + nb) of the call.  Returns false when the call does not split (the caller runs it whole).
+// part(b0, nb): runs sentences [b0, b0 + nb) of the call.  Returns false when the call does not split (the caller runs it whole).
 template <class F>
-bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F&& half)
+bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F&& part)
 {
     if (!two_lanes_ || batch < 4 || batch * seq < kTwoLaneMinTokens) return false;
-    // kept tokens (what the packed layout computes on) and where they halve
+    // kept tokens (what the packed layout computes on) and where they halve / third
     std::vector<int64_t> upto((size_t)batch + 1, 0);
     for (int64_t b = 0; b < batch; ++b) {
         int64_t n = 0;
@@ -1128,26 +1131,68 @@ bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F
         upto[(size_t)b + 1] = upto[(size_t)b] + (packing_ >= 1 ? n : seq);
     }
     const int64_t total = upto[(size_t)batch];
-    if (total < kTwoLaneMinTokens || total > kTwoLaneMaxTokens) return false;
-    int64_t cut = 1;
-    while (cut < batch - 1 && upto[(size_t)cut] * 2 < total) ++cut;
-    // both halves on the kernels the whole call would take (the small-call attention kernel sums in another order)
-    if (seq <= 128 && std::min(cut, batch - cut) * cfg_.heads <= attention_small_call_items()) return false;
-    std::exception_ptr second;
-    if (!lane_.try_begin([&, cut] { half(cut, batch - cut); })) return false;
-    std::exception_ptr first;
-    try {
-        half(0, cut);
-    } catch (...) {
-        first = std::current_exception();
+    if (total < kTwoLaneMinTokens || total > kLaneMaxTokens) return false;
+    // every part on the kernels a mid-size call takes (the small-call attention kernel sums in another order)
+    auto cuts_ok = [&](const int64_t* cut, int parts) {
+        for (int i = 0; i < parts; ++i) {
+            const int64_t nb = cut[i + 1] - cut[i];
+            if (nb < 1 || (seq <= 128 && nb * cfg_.heads <= attention_small_call_items())) return false;
+            const int64_t tokens = upto[(size_t)cut[i + 1]] - upto[(size_t)cut[i]];
+            if (tokens > kSameRouteMaxTokens || tokens < 1024) return false;  // (a mid-size call itself: neither the few-rows nor the large-batch kernels)
+        }
+        return true;
+    };
+    auto cut_into = [&](int parts, int64_t* cut) {
+        cut[0] = 0;
+        for (int i = 1; i < parts; ++i) {
+            int64_t c = cut[i - 1] + 1;
+            while (c < batch - (parts - i) && upto[(size_t)c] * parts < total * i) ++c;
+            cut[i] = c;
+        }
+        cut[parts] = batch;
+    };
+    int64_t cut[4];
+    int parts = 0;
+    static const int max_parts = [] {  // (measurements: KJARNI_HIP_LANES_MAX=2 keeps calls of up to 8 192 tokens in two parts)
+        const char* e = std::getenv("KJARNI_HIP_LANES_MAX");
+        return e && std::atoi(e) == 2 ? 2 : 3;
+    }();
+    if (total >= kThreeLaneMinTokens && batch >= 6 && (max_parts >= 3 || total > kSameRouteMaxTokens)) {
+        cut_into(3, cut);
+        if (cuts_ok(cut, 3)) parts = 3;
     }
-    try {
-        lane_.wait();
-    } catch (...) {
-        second = std::current_exception();
+    if (parts == 0 && total <= kSameRouteMaxTokens) {
+        cut_into(2, cut);
+        if (cuts_ok(cut, 2)) parts = 2;
     }
-    if (first) std::rethrow_exception(first);
-    if (second) std::rethrow_exception(second);
+    if (parts == 0) return false;
+    const bool must = total > kSameRouteMaxTokens;  // (the parts' routes are not the whole call's: the split defines the result)
+    bool on_helper[2] = {false, false};
+    for (int i = 1; i < parts; ++i) {
+        const int64_t b0 = cut[i], nb = cut[i + 1] - cut[i];
+        on_helper[i - 1] = lane_[i - 1].try_begin([&part, b0, nb] { part(b0, nb); });
+        if (!on_helper[i - 1] && i == 1 && !must) return false;  // (nothing started yet: run unsplit, the same bits)
+    }
+    std::exception_ptr err;
+    auto run_here = [&](int i) {
+        try {
+            part(cut[i], cut[i + 1] - cut[i]);
+        } catch (...) {
+            if (!err) err = std::current_exception();
+        }
+    };
+    run_here(0);
+    for (int i = 1; i < parts; ++i)
+        if (!on_helper[i - 1]) run_here(i);  // (its helper was busy with another call)
+    for (int i = 1; i < parts; ++i) {
+        if (!on_helper[i - 1]) continue;
+        try {
+            lane_[i - 1].wait();
+        } catch (...) {
+            if (!err) err = std::current_exception();
+        }
+    }
+    if (err) std::rethrow_exception(err);
     return true;
 }
 

@@ -310,7 +310,7 @@ private:
         std::exception_ptr error_;
         bool busy_ = false, has_task_ = false, stop_ = false;
     };
-    Lane lane_;
+    Lane lane_[2];  // (a call runs as up to three parts: the caller's + two helpers')
     std::atomic<bool> two_lanes_{true};
     template <class F>
     bool run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F&& half);

@@ -167,15 +167,18 @@ def test_rerank_logits_equal_the_hf_fixtures(cross, fixtures, B, S):
 
 
 def test_two_lanes_are_invisible_in_the_results(tmp_path):
-    """Calls of 2 304 .. 8 192 kept tokens run as two halves on two streams (kjarni_hip_encoder_set_two_lanes): bit-identical to
-    the same call as one launch sequence -- full, ragged (the cut follows the kept tokens) and pair batches -- and oracle-equal."""
+    """Calls of 2 304 .. 8 192 kept tokens run as two or three parts on as many streams (kjarni_hip_encoder_set_two_lanes):
+    bit-identical to the same call as one launch sequence -- full, ragged (the cuts follow the kept tokens) and pair batches -- and
+    oracle-equal.  Calls of up to 12 288 tokens split too; there the unsplit call would take the large-batch kernels, so the two
+    forms agree to rounding and the split form is what the call computes (deterministically: twice the same bits)."""
     import kjarni_amd
     from oracle import oracle as O
     d, c = str(tmp_path / "e"), str(tmp_path / "c")
     cfg, t = synth.minilm_embedder(d, seed=3, num_hidden_layers=2)
     ccfg, ct = synth.minilm_cross_encoder(c, seed=4, num_hidden_layers=2)
     enc, ce = kjarni_amd.HipEncoder(d), kjarni_amd.HipEncoder(c)
-    for B, S, ragged in ((32, 128, False), (24, 128, True), (64, 128, True), (40, 100, False), (19, 128, False)):
+    for B, S, ragged in ((32, 128, False), (24, 128, True), (64, 128, True), (40, 100, False), (19, 128, False), (48, 128, False),
+                         (36, 128, False), (60, 128, True)):
         ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=ragged)
         two = enc.embed(ids, mask)
         enc.set_two_lanes(False)
@@ -183,6 +186,15 @@ def test_two_lanes_are_invisible_in_the_results(tmp_path):
         enc.set_two_lanes(True)
         assert np.array_equal(two, one), (B, S, ragged)
         assert float(np.abs(two - O.OracleModel(t, cfg).embed_batch(ids, mask)).max()) < 1e-4
+    for B, S, ragged in ((72, 128, False), (96, 128, False), (150, 128, True)):   # 9 216 / 12 288 / ~ 10 800 kept tokens
+        ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=ragged)
+        split = enc.embed(ids, mask)
+        assert np.array_equal(split, enc.embed(ids, mask)), (B, S, ragged)
+        enc.set_two_lanes(False)
+        one = enc.embed(ids, mask)
+        enc.set_two_lanes(True)
+        assert float(np.abs(split - one).max()) < 1e-6, (B, S, ragged)
+        assert float(np.abs(split - O.OracleModel(t, cfg).embed_batch(ids, mask)).max()) < 1e-4
     ids, mask, types = synth.synthetic_pairs(48, 96, seed=5)
     two = ce.logits(ids, mask, types)
     ce.set_two_lanes(False)

@@ -21,7 +21,8 @@ with tempfile.TemporaryDirectory() as tmp:
     synth.minilm_embedder(d, seed=0)
     enc = kjarni_amd.HipEncoder(d, 0)
     enc.set_combining(False)
-    for n in (1, 2, 4):
+    enc.set_two_lanes(False)
+    for n in (1, 2, 3, 4):
         b = B // n
         data = [synth.synthetic_ids(b, seq, seed=1 + i) for i in range(n)]
         for i in range(n):

@@ -24,7 +24,7 @@ def main():
         d = os.path.join(tmp, "m")
         synth.minilm_embedder(d, seed=5)
         enc = kjarni_amd.HipEncoder(d, 0)
-        shapes = [(1, 12), (2, 30), (5, 64), (16, 40), (32, 128), (70, 128), (100, 90), (300, 128), (3, 500)]
+        shapes = [(1, 12), (2, 30), (5, 64), (16, 40), (32, 128), (70, 128), (100, 90), (140, 128), (300, 128), (3, 500)]  # (140 x 128 ragged: ~10 000 kept tokens, always three parts)
         inputs = [synth.synthetic_ids(b, s, seed=50 + i, ragged=True) for i, (b, s) in enumerate(shapes)]
         refs = [enc.embed(i, m) for i, m in inputs]
         combining = os.environ.get("KJARNI_HIP_COMBINE", "1") != "0"
