@@ -1059,7 +1059,7 @@ void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask,
 // Above that the whole call would run on the large-batch tiles (another summation order): there the split is part of what the call
 // computes -- it is made whenever lanes are on, and a part whose helper is busy runs on the caller's thread after the caller's own.
 namespace {
-constexpr int64_t kTwoLaneMinTokens = 2304, kThreeLaneMinTokens = 4608, kSameRouteMaxTokens = 8192, kLaneMaxTokens = 12288;
+constexpr int64_t kTwoLaneMinTokens = 2304, kThreeLaneMinTokens = 4608, kLaneMaxTokens = 12288;
 }
 
 EncoderModel::Lane::~Lane()
@@ -1132,6 +1132,8 @@ bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F
     }
     const int64_t total = upto[(size_t)batch];
     if (total < kTwoLaneMinTokens || total > kLaneMaxTokens) return false;
+    // (8 192; fewer in the f32-on-bf16 mode, whose large tiles start earlier)
+    const int64_t kSameRouteMaxTokens = gemm_mid_route_max_rows();
     // every part on the kernels a mid-size call takes (the small-call attention kernel sums in another order)
     auto cuts_ok = [&](const int64_t* cut, int parts) {
         for (int i = 0; i < parts; ++i) {

@@ -1282,6 +1282,10 @@ inline int64_t mid_ln_min_rows(int N, int K) { return mid_ksplit(N, K) > 1 ? 1 :
 
 int64_t gemm_few_rows_max(int hidden) { return few_rows_max(hidden, hidden); }
 
+// The largest call whose projections all take the mid-size route (where a row's result does not depend on the rows beside it): 8 192
+// rows; in the f32-on-bf16 mode the 128 x 128 split tiles take over from split_min_rows().
+int64_t gemm_mid_route_max_rows() { return get_f32_on_bf16() ? std::min<int64_t>(kMidMaxRows, split_min_rows() - 1) : kMidMaxRows; }
+
 bool gemm_mid_layernorm_supported(int64_t M, int N, int K)
 {
     return M >= mid_ln_min_rows(N, K) && M <= kMidMaxRows && N <= 1024 && N % 4 == 0 && K % MID_BK == 0 && !tune::no_mid_route();

@@ -65,6 +65,8 @@ bool gemm_mid_layernorm_supported(int64_t M, int N, int K);
 // Calls of up to this many rows take the few-rows kernel (K over the waves of a workgroup; LayerNorm a launch of its own
 // unless the K-sliced route above applies): 256 for models up to 512 wide, 128 up to 1 024, 64 beyond.
 int64_t gemm_few_rows_max(int hidden);
+// Calls of up to this many rows run every projection on the mid-size route (gemm.hip): what the lanes of encoder.cpp rely on.
+int64_t gemm_mid_route_max_rows();
 size_t gemm_scratch_floats(int64_t max_rows, int max_narrow_n);
 hipError_t launch_gemm_residual_layernorm(const float* A, int64_t lda, const float* W, const float* bias,
                                           const float* R, int64_t ldr, const float* gamma, const float* beta, float eps,

@@ -172,6 +172,7 @@ def test_two_lanes_are_invisible_in_the_results(tmp_path):
     oracle-equal.  Calls of up to 12 288 tokens split too; there the unsplit call would take the large-batch kernels, so the two
     forms agree to rounding and the split form is what the call computes (deterministically: twice the same bits)."""
     import kjarni_amd
+    from kjarni_amd import ops
     from oracle import oracle as O
     d, c = str(tmp_path / "e"), str(tmp_path / "c")
     cfg, t = synth.minilm_embedder(d, seed=3, num_hidden_layers=2)
@@ -184,7 +185,13 @@ def test_two_lanes_are_invisible_in_the_results(tmp_path):
         enc.set_two_lanes(False)
         one = enc.embed(ids, mask)
         enc.set_two_lanes(True)
-        assert np.array_equal(two, one), (B, S, ragged)
+        # (in the opt-in f32-on-bf16 mode the large tiles take over from 6 144 rows: from there the parts' kernels are not the
+        # whole call's, as above 8 192 rows in the default mode)
+        if ops.get_f32_on_bf16() and int(mask.sum()) >= 6144:
+            assert float(np.abs(two - one).max()) < 1e-6, (B, S, ragged)
+            assert np.array_equal(two, enc.embed(ids, mask)), (B, S, ragged)
+        else:
+            assert np.array_equal(two, one), (B, S, ragged)
         assert float(np.abs(two - O.OracleModel(t, cfg).embed_batch(ids, mask)).max()) < 1e-4
     for B, S, ragged in ((72, 128, False), (96, 128, False), (150, 128, True)):   # 9 216 / 12 288 / ~ 10 800 kept tokens
         ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=ragged)
