@@ -96,10 +96,10 @@ KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on
  * (every call runs alone; environment KJARNI_HIP_COMBINE=0 does the same for every handle of the process). */
 KjarniErrorCode kjarni_hip_encoder_set_combining(KjarniHipEncoder* enc, int32_t on);
 
-/* Mid-size host-pointer calls (2 304 .. 12 288 kept tokens: the reference's default batch of 32 sentences and a few of them)
+/* Mid-size host-pointer calls (2 304 .. 24 576 kept tokens: the reference's default batch of 32 sentences and a few of them)
  * run as two or three parts on as many workspaces / streams, the other parts enqueued by helper threads of the handle: one
- * part's launch gaps, prologues and output bursts fall under the others' matrix work (32 / 48 / 72 / 96 x 128 tokens: 1.02 /
- * 1.57 / 2.35 / 2.68 -> 0.89 / 1.36 / 1.99 / 2.47 ms).  Sentences are independent.  Up to 8 192 tokens the parts take the
+ * part's launch gaps, prologues and output bursts fall under the others' matrix work (32 / 48 / 72 / 96 / 160 x 128 tokens: 1.02 /
+ * 1.57 / 2.35 / 2.68 / 4.54 -> 0.89 / 1.36 / 1.99 / 2.47 / 3.93 ms).  Sentences are independent.  Up to 8 192 tokens the parts take the
  * projection route the whole call would, so results are bit-identical to the unsplit call (and a call that finds the helpers
  * busy runs unsplit); above that the unsplit call would take the large-batch kernels, the two forms agree to rounding
  * (<= 1e-6), and the split form is what the call computes whenever this is on (deterministically: a part whose helper is busy

@@ -1050,16 +1050,18 @@ void EncoderModel::hidden_states_host(const uint32_t* ids, const uint32_t* mask,
 // launch gap, a prologue and an output burst that nothing overlaps: the chip idles a third of the time.
 // Sentences are independent, so such a call runs as two or three parts (cut where the kept tokens halve / third) on as many
 // workspaces and streams, the other parts enqueued by persistent helper threads: the parts drift apart by a fraction of a kernel
-// and each one's idle phases fall under the others' matrix work.  Measured (tools/overlap_probe.py, sentences x 128 tokens; one /
-// two / three parts): 24: 0.93 / 0.83 / -; 32: 1.02 / 0.89 / -; 36: 1.16 / 1.10 / 1.06; 48: 1.57 / 1.39 / 1.31; 56: 1.62 / 1.59 /
-// 1.48; 72: 2.35 / 1.94 / 1.90; 96: 2.68 / 2.54 / 2.41; 128: 3.07 / 3.23 / 3.09 ms -- below ~2 300 tokens and above ~12 300
-// one launch sequence is as fast or faster, so only that range splits.
+// and each one's idle phases fall under the others' matrix work.  Measured in the library (tools/mid_probe.py, sentences x 128
+// tokens; whole / two / three parts, ms): 24: 0.93 / 0.83 / -; 32: 1.02 / 0.89 / -; 36: 1.16 / 1.16 / 1.10; 48: 1.57 / 1.41 / 1.36;
+// 56: 1.62 / 1.58 / 1.56; 64: 1.85 / 1.77 / 1.77; 72: 2.35 / - / 1.99; 96: 2.68 / - / 2.47; 100: 2.73 / - / 2.66; 112: 2.95 / - / 2.84;
+// 128: 3.11 / - / 3.30 (left whole, below); 160: 4.54 / - / 3.93; 192: 4.88 / - / 4.72; a 6 x 768 model at 72 .. 192 sentences
+// - 3 .. - 6 % (160: + 3 %).  Below ~2 300 tokens one launch sequence is faster; above 24 576 three parts no longer fit the mid-size
+// route.
 // Up to 8 192 tokens the whole call would take the mid-size projection route as its parts do, where a row's result does not
 // depend on the rows beside it: the split is invisible in the results, and a call that finds the helpers busy simply runs unsplit.
 // Above that the whole call would run on the large-batch tiles (another summation order): there the split is part of what the call
 // computes -- it is made whenever lanes are on, and a part whose helper is busy runs on the caller's thread after the caller's own.
 namespace {
-constexpr int64_t kTwoLaneMinTokens = 2304, kThreeLaneMinTokens = 4608, kLaneMaxTokens = 12288;
+constexpr int64_t kTwoLaneMinTokens = 2304, kThreeLaneMinTokens = 4608, kLaneMaxTokens = 24576;
 }
 
 EncoderModel::Lane::~Lane()
@@ -1131,7 +1133,14 @@ bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F
         upto[(size_t)b + 1] = upto[(size_t)b] + (packing_ >= 1 ? n : seq);
     }
     const int64_t total = upto[(size_t)batch];
-    if (total < kTwoLaneMinTokens || total > kLaneMaxTokens) return false;
+    static const int64_t lane_max_tokens = [] {  // (measurements: KJARNI_HIP_LANES_MAX_TOKENS)
+        const char* e = std::getenv("KJARNI_HIP_LANES_MAX_TOKENS");
+        return e && std::atoll(e) > 0 ? (int64_t)std::atoll(e) : kLaneMaxTokens;
+    }();
+    if (total < kTwoLaneMinTokens || total > lane_max_tokens) return false;
+    // (where the whole call is already at its best: with the fused LayerNorm tiles -- 64 whole rows each -- 14 337 .. 16 384 rows
+    // are 225 .. 256 tiles, one per CU: 128 x 128 tokens 3.11 ms whole against 3.30 in three parts)
+    if (fuse_layernorm() && total > 14336 && total <= 16384) return false;
     // (8 192; fewer in the f32-on-bf16 mode, whose large tiles start earlier)
     const int64_t kSameRouteMaxTokens = gemm_mid_route_max_rows();
     // every part on the kernels a mid-size call takes (the small-call attention kernel sums in another order)

@@ -169,7 +169,7 @@ def test_rerank_logits_equal_the_hf_fixtures(cross, fixtures, B, S):
 def test_two_lanes_are_invisible_in_the_results(tmp_path):
     """Calls of 2 304 .. 8 192 kept tokens run as two or three parts on as many streams (kjarni_hip_encoder_set_two_lanes):
     bit-identical to the same call as one launch sequence -- full, ragged (the cuts follow the kept tokens) and pair batches -- and
-    oracle-equal.  Calls of up to 12 288 tokens split too; there the unsplit call would take the large-batch kernels, so the two
+    oracle-equal.  Calls of up to 24 576 tokens split too; there the unsplit call would take the large-batch kernels, so the two
     forms agree to rounding and the split form is what the call computes (deterministically: twice the same bits)."""
     import kjarni_amd
     from kjarni_amd import ops
@@ -193,7 +193,7 @@ def test_two_lanes_are_invisible_in_the_results(tmp_path):
         else:
             assert np.array_equal(two, one), (B, S, ragged)
         assert float(np.abs(two - O.OracleModel(t, cfg).embed_batch(ids, mask)).max()) < 1e-4
-    for B, S, ragged in ((72, 128, False), (96, 128, False), (150, 128, True)):   # 9 216 / 12 288 / ~ 10 800 kept tokens
+    for B, S, ragged in ((72, 128, False), (96, 128, False), (150, 128, True), (160, 128, False)):   # 9 216 / 12 288 / ~ 10 800 / 20 480 kept tokens
         ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=ragged)
         split = enc.embed(ids, mask)
         assert np.array_equal(split, enc.embed(ids, mask)), (B, S, ragged)
