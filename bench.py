@@ -18,7 +18,24 @@ cross-encoder (kjarni_amd.distributed.sharded_rerank_scores), all-gather of the 
 scores, and the host's stable descending sort (cross_encoder/model.rs:251-252) -- all
 inside the timed region.
 
+--in-process (with --gpus N, launched plainly): ONE process drives the N devices through the library's own
+EncoderGroup (kjarni_hip_group_embed_allgather / _logits_allgather: a host thread + stream per device, ncclAllGather
+on a ncclCommInitAll communicator) -- the arrangement a C# / Go caller of the C ABI gets; `config.arrangement` says which
+of the two produced `value`.
+
+`value` is measured with inputs and outputs RESIDENT IN HBM (device pointers in, device pointers out; `config.io`);
+the PCIe-inclusive rate of the same workload is `value_host_ptrs`.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  steps_ms      wall time of every timed step (HIP events on the launch stream, resolved after the region's final
+                synchronisation: no extra sync inside the region)
+  clock_ghz     the shader clock the chip holds at the start of every timed step and after the last one (a one-wave
+                probe on a side stream: shader cycles per 10 ns tick, kjarni_hip_clock_probe), `clock_ghz_first` /
+                `clock_ghz_last`; `gpu_sensors`: board power / temperature / sclk sampled from sysfs during the region
+                (+ rocm-smi before and after) -- what tells a slower box from a power-limited long run
+  scan          (N = 1, embed) the other half of the hot path, R14: cosine search (scan + top-10) of 1 and of 64 queries
+                over a [1 000 000, 384] corpus resident in HBM, each with its own roofline (hbm / mfma) and an oracle
+                index check on a 50 000-row prefix
   roofline      the dominant kernel, timed live with HIP events on its launch stream over
                 the timed region (libkjarni_ffi's profiler)
   rerank        (embed workload) the 100 000-pair STRONG-scaling rerank leg run after the embed region, same timing rules:
@@ -160,6 +177,167 @@ def cpu_baseline(cfg, tensors, budget_s=60.0, cap_sentences=4096):
             "variants": variants, "host": host}
 
 
+class GpuSensors:
+    """Board power / temperature / sclk of one GPU, sampled from sysfs (hwmon) by a host thread every `period` seconds while
+    a timed region runs (file reads only: nothing is enqueued, nothing synchronises), plus `rocm-smi` snapshots taken by
+    snapshot() OUTSIDE the region.  Every source is optional: what the box does not expose is left out."""
+
+    def __init__(self, index=0, period=0.5):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        amd = []
+        for c in cards:
+            try:
+                if open(os.path.join(c, "vendor")).read().strip() == "0x1002":
+                    amd.append(c)
+            except OSError:
+                pass
+        if index < len(amd):
+            for hw in glob.glob(os.path.join(amd[index], "hwmon", "hwmon*")):
+                for key, names in (("power_w", ("power1_average", "power1_input")), ("temp_c", ("temp2_input", "temp1_input")),
+                                   ("sclk_mhz", ("freq1_input",)), ("power_cap_w", ("power1_cap",))):
+                    for nm in names:
+                        f = os.path.join(hw, nm)
+                        if key not in self.files and os.path.exists(f):
+                            self.files[key] = f
+        self._scale = {"power_w": 1e-6, "temp_c": 1e-3, "sclk_mhz": 1e-6, "power_cap_w": 1e-6}
+
+    def read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                out[k] = round(int(open(f).read().strip()) * self._scale[k], 1)
+            except (OSError, ValueError):
+                pass
+        return out
+
+    def start(self):
+        import threading
+        if not self.files:
+            return
+        t0 = time.perf_counter()
+
+        def run():
+            while not self._stop.is_set():
+                r = self.read()
+                if r:
+                    r["t_s"] = round(time.perf_counter() - t0, 2)
+                    self.samples.append(r)
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=2)
+        out = {"source": "sysfs hwmon" if self.files else None, "samples": len(self.samples)}
+        for k in ("power_w", "temp_c", "sclk_mhz"):
+            v = [x[k] for x in self.samples if k in x]
+            if v:
+                q = max(1, len(v) // 4)
+                out[k] = {"first_quarter_mean": round(sum(v[:q]) / q, 1), "last_quarter_mean": round(sum(v[-q:]) / q, 1),
+                          "min": min(v), "max": max(v)}
+        cap = self.read().get("power_cap_w")
+        if cap:
+            out["power_cap_w"] = cap
+        return out
+
+    @staticmethod
+    def snapshot():
+        """One `rocm-smi` reading (power, temperature, clocks) as a flat dict; {} when the tool is missing or slow."""
+        try:
+            p = subprocess.run(["rocm-smi", "--showpower", "--showtemp", "--showclocks", "--json"], capture_output=True, text=True,
+                               timeout=20)
+            card = next(iter(json.loads(p.stdout).values()))
+            keep = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if any(w in kl for w in ("power", "temperature", "sclk", "mclk")):
+                    keep[k] = v
+            return keep
+        except Exception:
+            return {}
+
+
+def scan_leg(torch, np, dev, n_docs, check_rows=50000, dim=384, k=10):
+    """R14, the other half of the hot path (kjarni-search/src/vector.rs:131-166, kjarni-rag/src/segment.rs:307-371): cosine
+    search = scan + top-k in ONE call (kjarni_hip_cosine_search) of 1 query and of 64 queries over a unit-norm Gaussian
+    corpus [n_docs, 384] resident in HBM.  One query streams the corpus once: HBM-bound, dim x 4 algorithmic bytes per
+    document.  64 queries are 2 x 64 x dim flop per document on the f32 matrix cores against the same bytes: MFMA-bound
+    (32 flop per byte).  Each entry carries its own roofline; indices and scores are checked against the CPU oracle on a
+    prefix of `check_rows` rows (indices exact, scores to 1e-6) after the clock has stopped."""
+    from kjarni_amd import _ffi
+    from oracle import oracle as O
+    L = _ffi.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(2)
+    corpus = torch.randn((n_docs, dim), generator=g, device=dev, dtype=torch.float32)
+    corpus /= torch.linalg.vector_norm(corpus, dim=1, keepdim=True)
+    host_prefix = corpus[:check_rows].cpu().numpy()
+    out = {"corpus": f"[{n_docs}, {dim}] unit-norm Gaussian rows resident in HBM, k = {k}, Segment semantics",
+           "unit": "ms per search call (scan + top-k in one call, device pointers)"}
+    for nq in (1, 64):
+        q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
+        idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
+
+        def search(n):
+            ws = torch.empty(L.kjarni_hip_cosine_search_workspace_bytes(nq, n, dim, k), dtype=torch.uint8, device=dev)
+            _ffi.check_error(L.kjarni_hip_cosine_search(0, q.data_ptr(), nq, corpus.data_ptr(), n, dim, 1, k, ws.data_ptr(),
+                                                        idx.data_ptr(), sc.data_ptr(), stream))
+            return ws
+        ws = torch.empty(L.kjarni_hip_cosine_search_workspace_bytes(nq, n_docs, dim, k), dtype=torch.uint8, device=dev)
+
+        def call():
+            _ffi.check_error(L.kjarni_hip_cosine_search(0, q.data_ptr(), nq, corpus.data_ptr(), n_docs, dim, 1, k, ws.data_ptr(),
+                                                        idx.data_ptr(), sc.data_ptr(), stream))
+        for _ in range(5):
+            call()
+        reps = 50 if n_docs <= 2_000_000 else 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        alg_bytes, flop = n_docs * dim * 4, 2.0 * nq * n_docs * dim
+        if nq == 1:
+            roof = {"kernel": "cosine_search_stream_kernel", "bound": "hbm", "achieved": round(alg_bytes / ms / 1e6, 1),
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_call": alg_bytes}
+        else:
+            roof = {"kernel": "cosine_scan_mfma_kernel", "bound": "mfma", "achieved": round(flop / ms / 1e9, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": None, "algorithmic_flop_per_call": flop, "corpus_gbs": round(alg_bytes / ms / 1e6, 1),
+                    "bound_ms": round(max(flop / (PEAK_FP32_MFMA_TFLOPS * 1e9), alg_bytes / (PEAK_HBM_GBS * 1e6)), 3)}
+        # oracle check on the prefix (a separate, untimed call over the first check_rows rows)
+        keep = search(check_rows)
+        torch.cuda.synchronize()
+        got_i, got_s = idx.cpu().numpy(), sc.cpu().numpy()
+        qh = q.cpu().numpy()
+        same, worst = True, 0.0
+        for j in range(nq if nq == 1 else 8):   # every 8th query of the 64
+            jj = j * (nq // 8) if nq > 1 else 0
+            ri, rs = O.search(qh[jj], host_prefix, k, mode=1)
+            same = same and bool(np.array_equal(ri, got_i[jj]))
+            worst = max(worst, float(np.abs(rs - got_s[jj]).max()))
+        del keep
+        assert same, f"scan leg: top-{k} indices of {nq} quer{'y' if nq == 1 else 'ies'} differ from the oracle"
+        assert worst < 1e-6, f"scan leg: scores differ from the oracle by {worst}"
+        out[f"queries_{nq}"] = {"ms_per_call": round(ms, 4), "doc_queries_per_s": round(nq * n_docs / ms * 1e3, 0), "roofline": roof,
+                               "indices_equal_oracle_on_prefix": same, "max_abs_score_err_vs_oracle": worst,
+                               "prefix_rows_checked": check_rows}
+        del ws, idx, sc, q
+    del corpus
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children.  Nothing in this process has
     touched torch.cuda or HIP, and it never execs."""
@@ -222,11 +400,181 @@ class HostStubEncoder:
         self._view(out_ptr, batch, 1, C.c_float, np.float32)[:, 0] = np.cos(ids.sum(1) * 1e-4)
 
 
+class HostStubGroup:
+    """--dry-run-cpu --in-process: stands in for HipEncoderGroup (host buffers instead of device buffers)."""
+    hidden_size, num_labels, transport = 384, 1, "dry-run (host)"
+
+    def __init__(self, n):
+        self.size, self.devices, self._enc = n, list(range(n)), HostStubEncoder()
+
+    def shard(self, rows, i):
+        from kjarni_amd import distributed as D
+        return D.shard_rows(rows, self.size, i)
+
+    def _gather(self, run, batch_total, cols, out_ptrs):
+        import ctypes as C
+
+        import numpy as np
+        outs = [HostStubEncoder._view(p, batch_total, cols, C.c_float, np.float32) for p in out_ptrs]
+        for i in range(self.size):
+            start, count = self.shard(batch_total, i)
+            if count:
+                run(i, count, outs[i][start:start + count].ctypes.data)
+            for j in range(self.size):
+                if j != i:
+                    outs[j][start:start + count] = outs[i][start:start + count]
+
+    def embed_allgather(self, ids_ptrs, mask_ptrs, batch_total, seq, out_ptrs, **kw):
+        self._gather(lambda i, c, o: self._enc.embed_dev(ids_ptrs[i], mask_ptrs[i], c, seq, o), batch_total, self.hidden_size, out_ptrs)
+
+    def logits_allgather(self, ids_ptrs, mask_ptrs, type_ptrs, batch_total, seq, out_ptrs, **kw):
+        self._gather(lambda i, c, o: self._enc.logits_dev(ids_ptrs[i], mask_ptrs[i], 0, c, seq, o), batch_total, 1, out_ptrs)
+
+    def close(self):
+        pass
+
+
+def main_in_process(args):
+    """ONE process, all --gpus devices: the library's own multi-device arrangement (csrc/group.cpp; what a C# / Go caller of
+    kjarni_embedder_* / kjarni_reranker_* gets, here on device pointers).  A step = kjarni_hip_group_embed_allgather (every
+    replica encodes its row block on its own host thread + stream, then ONE ncclAllGather on the ncclCommInitAll communicator
+    leaves all rows in every device's buffer) -- synchronous, so steps are timed with the host clock.  Same workloads, same
+    JSON contract as the one-process-per-GPU arrangement; `config.arrangement` names this one."""
+    import numpy as np
+    import torch
+
+    from kjarni_amd import distributed as D
+    from tests import synth
+    dry, n, S = args.dry_run_cpu, args.gpus, SEQ
+    torch.set_num_threads(max(1, cpus_granted()))
+    if not dry:
+        import kjarni_amd
+        if not torch.cuda.is_available() or torch.cuda.device_count() < n or kjarni_amd.device_count() < n:
+            print(f"bench.py --in-process: {n} AMD GPUs needed (there is no CPU fallback for the product path)", file=sys.stderr)
+            return 1
+
+    def on(i):
+        return torch.device("cpu") if dry else torch.device("cuda", i)
+
+    def to(i, a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(on(i))
+
+    def load(make, seed):
+        with tempfile.TemporaryDirectory(prefix="kjarni_bench_grp_") as tmp:
+            cfg, tensors = make(tmp, seed=seed, family=args.weights)
+            grp = HostStubGroup(n) if dry else kjarni_amd.HipEncoderGroup(tmp, devices=list(range(n)))
+        return cfg, tensors, grp
+
+    def sync_all():
+        if not dry:
+            for i in range(n):
+                torch.cuda.synchronize(i)
+
+    def run_leg(rerank, n_total, steps, warmup):
+        cfg, tensors, grp = load(synth.minilm_cross_encoder if rerank else synth.minilm_embedder, 1 if rerank else 0)
+        cols = 1 if rerank else grp.hidden_size
+        blocks, ids_d, mask_d, types_d, outs = [], [], [], [], []
+        for i in range(n):
+            start, count = grp.shard(n_total, i)
+            if rerank:   # every replica builds only its rows of the one fixed pair set
+                a, b, c = synth.synthetic_pairs_rows(start, count, S, seed=1)
+                types_d.append(to(i, c))
+            else:        # weak scaling: replica i's block is the block rank i of the other arrangement encodes
+                a, b = synth.synthetic_ids(count, S, seed=i)
+            blocks.append((start, count, a, b, types_d[-1] if rerank else None))
+            ids_d.append(to(i, a))
+            mask_d.append(to(i, b))
+            outs.append(torch.empty((n_total, cols), dtype=torch.float32, device=on(i)))
+        ptr = lambda ts: [t.data_ptr() for t in ts]  # noqa: E731
+        held = {}
+
+        def step():
+            if rerank:
+                grp.logits_allgather(ptr(ids_d), ptr(mask_d), ptr(types_d), n_total, S, ptr(outs))
+                held["order"] = D.rerank_order_arrays(outs[0][:, 0])   # D2H + the host's stable descending sort
+            else:
+                grp.embed_allgather(ptr(ids_d), ptr(mask_d), n_total, S, ptr(outs))
+        for _ in range(warmup):
+            step()
+        sync_all()
+        per_step = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            step()
+            per_step.append(round((time.perf_counter() - t1) * 1e3, 2))
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        first = outs[0].cpu()
+        assert bool(torch.isfinite(first).all()), "outputs are not finite"
+        for i in range(1, n):
+            assert bool(torch.equal(outs[i].cpu(), first)), f"device {i}'s buffer differs from device 0's after the all-gather"
+        if rerank:
+            order = held["order"]
+            assert bool((order[1][:-1] >= order[1][1:]).all()), "order is not descending"
+        parity = {}
+        if not dry and not args.no_parity_check:
+            from oracle import oracle as O
+            orc = O.OracleModel(tensors, cfg, blocked_gemm=True)
+            last = n - 1   # rows of the LAST replica: they reached device 0 through the collective
+            start, count, a, b, _ = blocks[last]
+            sel = np.unique(np.concatenate([np.array([0, count - 1]), np.random.default_rng(5).choice(count, min(32, count), replace=False)]))[:32]
+            if rerank:
+                c = types_d[last].cpu().numpy().view(np.uint32)
+                ref = orc.rerank_scores(*(np.ascontiguousarray(x[sel]) for x in (a, b, c)))
+                got = first[start + torch.from_numpy(sel), 0].numpy()
+            else:
+                ref = orc.embed_batch(np.ascontiguousarray(a[sel]), np.ascontiguousarray(b[sel]))
+                got = first[start + torch.from_numpy(sel)].numpy()
+            parity = {"max_abs_err_vs_oracle": float(np.abs(got - ref).max()), "rows_checked_vs_oracle": int(len(sel)),
+                      "parity_tolerance": 1e-4}
+            assert parity["max_abs_err_vs_oracle"] < 1e-4, f"in-process output differs from the oracle: {parity}"
+        transport = grp.transport
+        fps = flops_per_sentence(grp.hidden_size, cfg["num_hidden_layers"], cfg["intermediate_size"], S)
+        grp.close()
+        return elapsed, per_step, parity, transport, fps, blocks[0][1]
+
+    rerank = args.workload == "rerank"
+    n_total = args.pairs if rerank else n * args.sentences
+    elapsed, per_step, parity, transport, fps, rows0 = run_leg(rerank, n_total, args.steps, args.warmup)
+    value = n_total * args.steps / elapsed
+    what = ("pairs/sec minilm-l6-v2-cross-encoder rerank (seq=128)", "pairs/s") if rerank else \
+        ("sentences/sec minilm-l6-v2 batch encode (seq=128)", "sentences/s")
+    result = {"metric": what[0], "value": round(value, 1), "unit": what[1], "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+              "scaling": "strong" if rerank else "weak", "vs_baseline": None, "dtype": "f32",
+              "data": "dry-run" if dry else "synthetic",
+              "config": {"workload": (f"minilm-l6-v2-cross-encoder Reranker over {n_total} synthetic query-doc pairs x {S} tokens in total "
+                                      "(BASELINE.json configs[2])" if rerank else
+                                      f"minilm-l6-v2 Embedder: {args.sentences} synthetic sentences per GPU, seq_len=128, fp32 "
+                                      "(BASELINE.json configs[1])") + "; random weights of that architecture",
+                         "rows_per_step": n_total, "rows_per_gpu": rows0, "seq_len": S,
+                         "sharding": f"rows x{n}, all-gather of the outputs into every device's buffer",
+                         "weights": f"tests/synth.py family '{args.weights}', random (no checkpoints offline)",
+                         "io": "ids / mask and the output vectors resident in HBM (device pointers, one block per device)",
+                         "arrangement": f"in-process group: one process, a host thread + stream per device (kjarni_hip_group_*_allgather), "
+                                        f"transport {transport}"},
+              "steps_ms": per_step}
+    if not dry:
+        result["e2e_frac_fp32_mfma_peak"] = round(value * fps / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n), 4)
+    result.update(parity)
+    if not rerank and not args.no_rerank_leg:
+        r_steps = args.rerank_steps or max(1, min(args.steps, 5))
+        r_el, r_ms, r_par, _, r_fps, r_rows0 = run_leg(True, args.pairs, r_steps, 1 if args.warmup else 0)
+        leg = {"pairs_per_s": round(args.pairs * r_steps / r_el, 1), "ms_per_step": round(r_el / r_steps * 1e3, 3), "n_gpus": n,
+               "scaling": "strong", "steps": r_steps, "pairs_per_step": args.pairs, "pairs_per_gpu": r_rows0, "unit": "pairs/s",
+               "steps_ms": r_ms}
+        leg.update(r_par)
+        result["rerank"] = leg
+    print(json.dumps(result), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)    # the driver's form (--steps 20 --warmup 5): builder and driver
+    ap.add_argument("--warmup", type=int, default=5)    # numbers are the same experiment
     ap.add_argument("--workload", choices=("embed", "rerank"), default="embed")
     ap.add_argument("--sentences", type=int, default=SENTENCES_PER_GPU, help="embed: sentences per GPU per step")
     ap.add_argument("--pairs", type=int, default=RERANK_PAIRS, help="rerank: pairs per step over ALL GPUs")
@@ -238,10 +586,23 @@ def main():
     ap.add_argument("--no-rerank-leg", action="store_true",
                     help="embed workload: skip the 100 000-pair strong-scaling rerank leg that follows the embed region")
     ap.add_argument("--rerank-steps", type=int, default=0, help="timed steps of the rerank leg (default min(steps, 5))")
+    ap.add_argument("--no-scan", action="store_true", help="embed workload: skip the cosine-search (R14) leg")
+    ap.add_argument("--scan-docs", type=int, default=1_000_000, help="corpus rows of the scan leg (10 000 000 on request)")
+    ap.add_argument("--no-sensors", action="store_true", help="do not sample sysfs / rocm-smi around the timed region")
+    ap.add_argument("--weights", choices=("trained", "init"), default="trained",
+                    help="tests/synth.py weight family: trained-checkpoint statistics (default) or N(0, 0.02) initialisation")
+    ap.add_argument("--in-process", action="store_true",
+                    help="one process drives all --gpus devices through the library's EncoderGroup (kjarni_hip_group_*_allgather)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing self-test without a GPU: gloo + a host stub instead of the HIP encoder")
     args = ap.parse_args()
 
+    if args.in_process:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            print("bench.py: --in-process is ONE process for all devices; do not launch it through torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+        sys.exit(main_in_process(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -306,7 +667,10 @@ def main():
     rerank = args.workload == "rerank"
     with tempfile.TemporaryDirectory(prefix=f"kjarni_bench_r{rank}_") as tmp:
         # random-init weights of the named architecture (no network for checkpoints)
-        cfg, tensors = (synth.minilm_cross_encoder if rerank else synth.minilm_embedder)(tmp, seed=1 if rerank else 0)
+        # (--weights trained: trained-checkpoint statistics -- peaked softmax, LayerNorm gain outliers, GELU tails -- so the
+        # post-clock oracle check below is a check in the regime users run, not in the uniform-softmax regime of N(0, 0.02))
+        cfg, tensors = (synth.minilm_cross_encoder if rerank else synth.minilm_embedder)(tmp, seed=1 if rerank else 0,
+                                                                                         family=args.weights)
         enc = HostStubEncoder() if dry else kjarni_amd.HipEncoder(tmp, local_rank)
     if args.chunk_tokens and not dry:
         enc.set_chunk_tokens(args.chunk_tokens)
@@ -355,12 +719,52 @@ def main():
     profile = not args.no_profile and not dry
     if profile:
         enc.profile_begin(GEMM_KINDS)
+    # Per-step wall time and shader clock WITHOUT a synchronisation inside the region: an event on the launch stream after
+    # every step, and a one-wave probe on a side stream that starts when step i starts (it waits for the event that ends step
+    # i - 1) and stamps shader cycles against the 100 MHz counter for 50 us -- the clock the chip holds under that step's load.
+    sensors = smi_before = None
+    instrument = not dry and rank == 0
+    if instrument:
+        from kjarni_amd import ops as _probe_ops
+        main_stream = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        probes = torch.zeros((args.steps + 1, 2), dtype=torch.int64, device=dev)
+        if not args.no_sensors:
+            smi_before = GpuSensors.snapshot()
+            sensors = GpuSensors(local_rank)
     sync()
+    if sensors:
+        sensors.start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if instrument:
+        evs[0].record(main_stream)
+    for i in range(args.steps):
+        if instrument:
+            side.wait_event(evs[i])
+            _probe_ops.clock_probe(probes[i].data_ptr(), 50, side.cuda_stream)
         step()
+        if instrument:
+            evs[i + 1].record(main_stream)
+    if instrument:
+        side.wait_event(evs[args.steps])
+        _probe_ops.clock_probe(probes[args.steps].data_ptr(), 50, side.cuda_stream)
     sync()
     elapsed = time.perf_counter() - t0
+    timing = {}
+    if instrument:
+        side.synchronize()
+        timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
+        pr = probes.cpu().numpy().astype(np.float64)
+        ghz = [round(float(c / t / 10.0), 3) if t > 0 else None for c, t in pr]
+        timing["clock_ghz"] = ghz
+        timing["clock_ghz_first"], timing["clock_ghz_last"] = ghz[0], ghz[-1]
+        timing["clock_note"] = ("clock_ghz[i]: shader cycles per 10 ns tick over a 50 us one-wave probe that starts with timed step i "
+                                "(side stream); the last entry follows the last step")
+        if sensors:
+            timing["gpu_sensors"] = sensors.stop()
+            timing["gpu_sensors"]["rocm_smi_before"] = smi_before
+            timing["gpu_sensors"]["rocm_smi_after"] = GpuSensors.snapshot()
     stats = enc.profile_end() if profile else []
     all_stats = []
     if profile and rank == 0 and world == 1:
@@ -416,7 +820,7 @@ def main():
     rerank_leg = None
     if not rerank and not args.no_rerank_leg:
         with tempfile.TemporaryDirectory(prefix=f"kjarni_bench_ce_r{rank}_") as tmp:
-            ce_cfg, ce_tensors = synth.minilm_cross_encoder(tmp, seed=1)
+            ce_cfg, ce_tensors = synth.minilm_cross_encoder(tmp, seed=1, family=args.weights)
             ce = HostStubEncoder() if dry else kjarni_amd.HipEncoder(tmp, local_rank)
         if args.chunk_tokens and not dry:
             ce.set_chunk_tokens(args.chunk_tokens)
@@ -545,6 +949,10 @@ def main():
                                  "value_f32_on_bf16: the headline workload in the opt-in mode kjarni_hip_set_f32_on_bf16 (f32 products "
                                  "from three exact bf16 pieces per operand on the bf16 matrix cores; off by default, not part of `value`)")
 
+    scan = None
+    if rank == 0 and world == 1 and not rerank and not dry and not args.no_scan:
+        scan = scan_leg(torch, np, dev, args.scan_docs)
+
     if rank == 0:
         total = n_total * args.steps
         value = total / elapsed
@@ -560,7 +968,7 @@ def main():
         else:
             metric, unit = "sentences/sec minilm-l6-v2 batch encode (seq=128)", "sentences/s"
             workload = ("minilm-l6-v2 Embedder: 65 536 synthetic sentences per GPU, seq_len=128, fp32 "
-                        "(BASELINE.json configs[1]); random-init weights of that architecture")
+                        "(BASELINE.json configs[1]); random weights of that architecture")
             shard = f"rows x{world}" + (" + RCCL all-gather of [N,384] outputs" if world > 1 else "")
         result = {
             "metric": metric,
@@ -576,7 +984,10 @@ def main():
             "dtype": "f32",
             "data": "dry-run" if dry else "synthetic",
             "config": {"workload": workload, "rows_per_step": n_total, "rows_per_gpu": n_local, "seq_len": S,
-                       "sharding": shard},
+                       "sharding": shard, "weights": f"tests/synth.py family '{args.weights}', random (no checkpoints offline)",
+                       "io": "ids / mask and the output vectors resident in HBM (device pointers); the PCIe-inclusive rate of the "
+                             "same workload is value_host_ptrs",
+                       "arrangement": "one process per GPU (kjarni_amd.distributed over torch.distributed; RCCL when N > 1)"},
         }
         if not dry:
             result["e2e_tflops"] = round(value * fps / 1e12, 2)
@@ -614,9 +1025,12 @@ def main():
                                 "tflops": round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 2) if s["flops"] else None,
                                 "gbs": round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1)}
                     for s in all_stats if s["launches"]}
+        result.update(timing)
         result.update(parity)
         if rerank_leg:
             result["rerank"] = rerank_leg
+        if scan:
+            result["scan"] = scan
         if comm_info:
             result["collective"] = comm_info
         result["host_threads_per_rank"] = torch.get_num_threads()  # (the rank's share of the CPUs the cgroup grants)

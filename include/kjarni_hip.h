@@ -123,6 +123,13 @@ KjarniErrorCode kjarni_hip_encoder_set_two_lanes(KjarniHipEncoder* enc, int32_t 
 int32_t kjarni_hip_set_f32_on_bf16(int32_t on);
 int32_t kjarni_hip_get_f32_on_bf16(void);
 
+/* Measurement aid (bench.py's `clock_ghz` fields; no counterpart in the reference): enqueues ONE wave on `stream` that reads the
+ * shader-cycle counter and the constant 100 MHz counter either side of a spin of `spin_us` microseconds (0 = 20; at most
+ * 10 000) and writes out_dev[0] = shader cycles, out_dev[1] = 10 ns ticks.  out_dev[0] / out_dev[1] / 10 is the shader clock in
+ * GHz the chip holds at that point of the stream -- what a power-limited run lowers while a short one does not.  Asynchronous;
+ * out_dev is a device pointer to two uint64. */
+KjarniErrorCode kjarni_hip_clock_probe(uint64_t* out_dev, uint32_t spin_us, void* stream);
+
 /* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
  * calls may be made concurrently from any number of host threads and on any streams, as on the reference's
  * handles (its model types are Send + Sync, crates/kjarni-ffi/src/lib.rs:25-32).  The weights are immutable; each

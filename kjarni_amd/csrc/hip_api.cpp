@@ -143,6 +143,14 @@ KJARNI_EXPORT int32_t kjarni_hip_set_f32_on_bf16(int32_t on)
 
 KJARNI_EXPORT int32_t kjarni_hip_get_f32_on_bf16(void) { return kjarni::get_f32_on_bf16() ? 1 : 0; }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_clock_probe(uint64_t* out_dev, uint32_t spin_us, void* stream)
+{
+    if (!out_dev) return KJARNI_ERROR_NULL_POINTER;
+    const uint32_t us = spin_us == 0 ? 20u : (spin_us > 10000u ? 10000u : spin_us);
+    return kjarni::launch_clock_probe(out_dev, us * 100u, (hipStream_t)stream) == hipSuccess ? KJARNI_OK
+                                                                                             : KJARNI_ERROR_INFERENCE_FAILED;
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
                                                                const uint32_t* mask_dev,
                                                                const uint32_t* type_ids_dev, int64_t batch,

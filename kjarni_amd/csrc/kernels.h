@@ -159,4 +159,8 @@ size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k);
 hipError_t launch_cosine_search(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode, int k,
                                 void* workspace, int64_t* out_idx, float* out_score, hipStream_t stream);
 
+// Measurement aid: one wave stamps the shader-cycle counter and the 100 MHz counter around a spin of spin_ticks x 10 ns;
+// out[0] = shader cycles, out[1] = 10 ns ticks (clock in GHz = out[0] / out[1] / 10).  rowops.hip.
+hipError_t launch_clock_probe(uint64_t* out, unsigned spin_ticks, hipStream_t stream);
+
 }  // namespace kjarni

@@ -592,4 +592,30 @@ hipError_t launch_row_softmax(const float* in, int64_t rows, int n, int sigmoid,
     return hipGetLastError();
 }
 
+// Measurement aid (bench.py): ONE wave reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) either side of a spin of `spin_ticks` 10 ns ticks: cycles / ticks x 0.1 = the shader clock in GHz that the
+// chip holds at that moment (MI355X_MICROARCH.md, "DVFS give-back" item 6).  Enqueued between steps of a timed region it
+// costs its spin (tens of microseconds) and no synchronisation; out[0] = cycles, out[1] = ticks.
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned spin_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
+hipError_t launch_clock_probe(uint64_t* out, unsigned spin_ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)out, spin_ticks);
+    return hipGetLastError();
+}
+
 }  // namespace kjarni

@@ -113,6 +113,12 @@ def set_f32_on_bf16(on: bool) -> bool:
     return bool(lib().kjarni_hip_set_f32_on_bf16(1 if on else 0))
 
 
+def clock_probe(out_dev_ptr: int, spin_us: int = 20, stream: int = 0) -> None:
+    """Enqueues the one-wave clock probe (kjarni_hip_clock_probe): out_dev_ptr -> two uint64 on the device, [shader cycles,
+    10 ns ticks]; GHz = cycles / ticks / 10."""
+    check_error(lib().kjarni_hip_clock_probe(out_dev_ptr, int(spin_us), stream))
+
+
 def get_f32_on_bf16() -> bool:
     return bool(lib().kjarni_hip_get_f32_on_bf16())
 

@@ -60,6 +60,131 @@ def bert_tensors(cfg: dict, seed: int = 0, prefix: str = "", head: str = "") -> 
     return t
 
 
+TRAINED_OUTLIER_CHANNELS = 3     # per LayerNorm: gains x5
+QK_GROWTH = 1.08
+SUBLAYER_OUT = 0.5               # out-proj / FC2 outputs relative to the residual they are added to
+TRAINED_MASSIVE_CHANNELS = 2     # shared by every LayerNorm: bias +-4 (the "massive activation" dimensions of trained BERTs)
+
+
+def trained_bert_tensors(cfg: dict, seed: int = 0, prefix: str = "", head: str = "") -> Dict[str, np.ndarray]:
+    """Seeded weights with the STATISTICS of a trained MiniLM-class checkpoint instead of N(0, 0.02) initialisation (under
+    which every attention softmax is uniform to three digits and GELU never leaves its linear part): attention logits
+    that spread over the keys of a query row with std 3-5 and reach |max| > 10 (peaked softmax), LayerNorm gains
+    log-normal over 0.2 ... 2.5 with three x5 outlier channels per LayerNorm, two channels that carry a bias of +-4 through
+    every layer, biases O(0.1 ... 1), FC1 pre-activations reaching +-6.  The matrices that read a LayerNorm's output are
+    scaled by the second moment that output has by construction (sum of gain^2 + bias^2), so every layer sits in the same
+    regime.  `regime_stats` measures what a batch actually sees; tests/golden/make_encoder_fixtures.py stores those
+    numbers next to the float64 fixtures.  Stands in for the real checkpoints the reference pins
+    (sentence_encoder/tests.rs:411-1184, cross_encoder/tests.rs:38-100), which are not available offline."""
+    rng = np.random.default_rng([seed, 0x7261696E])
+    H, L, I = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"]
+    V, P, T = cfg["vocab_size"], cfg["max_position_embeddings"], cfg["type_vocab_size"]
+    d = H // cfg["num_attention_heads"]
+    massive = rng.choice(H, size=min(TRAINED_MASSIVE_CHANNELS, H), replace=False)
+    massive_sign = rng.choice([-1.0, 1.0], size=len(massive))
+
+    def w(*shape, s):
+        return (rng.standard_normal(shape) * s).astype(np.float32)
+
+    def layer_norm():
+        g = np.clip(np.exp(rng.normal(np.log(0.8), 0.5, H)), 0.2, 2.5)
+        g[rng.choice(H, size=min(TRAINED_OUTLIER_CHANNELS, H), replace=False)] *= 5.0
+        g[massive] = 0.3                 # small gain, large bias: the value is re-created by every LayerNorm, it does not compound
+        b = rng.standard_normal(H) * 0.1
+        b[massive] += 4.0 * massive_sign
+        return g.astype(np.float32), b.astype(np.float32), float(np.sqrt((g * g + b * b).sum()))
+
+    t = {}
+    e = prefix + "embeddings."
+    t[e + "word_embeddings.weight"] = w(V, H, s=0.05)
+    t[e + "position_embeddings.weight"] = w(P, H, s=0.02)
+    t[e + "token_type_embeddings.weight"] = w(T, H, s=0.02)
+    t[e + "LayerNorm.weight"], t[e + "LayerNorm.bias"], rms = layer_norm()
+    for i in range(L):
+        p = f"{prefix}encoder.layer.{i}."
+        # q, k of std ~ 2 per component: logits = q.k / sqrt(d) then spread with std ~ 4 over the keys
+        for nm, target in (("query", 2.0 * QK_GROWTH ** i), ("key", 2.0 * QK_GROWTH ** i), ("value", 1.0)):
+            t[p + f"attention.self.{nm}.weight"] = w(H, H, s=target / rms)
+            t[p + f"attention.self.{nm}.bias"] = w(H, s=0.1 if nm != "value" else 0.3)
+            if nm != "value":   # content-addressed attention: what every token shares does not steer it
+                t[p + f"attention.self.{nm}.weight"][:, massive] *= np.float32(0.05)
+        t[p + "attention.output.dense.weight"] = w(H, H, s=0.5 * SUBLAYER_OUT / np.sqrt(H))
+        t[p + "attention.output.dense.bias"] = w(H, s=0.2)
+        t[p + "attention.output.LayerNorm.weight"], t[p + "attention.output.LayerNorm.bias"], rms = layer_norm()
+        t[p + "intermediate.dense.weight"] = w(I, H, s=1.7 / rms)
+        t[p + "intermediate.dense.bias"] = w(I, s=0.3)
+        t[p + "output.dense.weight"] = w(H, I, s=SUBLAYER_OUT / np.sqrt(I))
+        t[p + "output.dense.bias"] = w(H, s=0.2)
+        t[p + "output.LayerNorm.weight"], t[p + "output.LayerNorm.bias"], rms = layer_norm()
+    if head == "cross":
+        t["bert.pooler.dense.weight"] = w(H, H, s=0.8 / rms)
+        t["bert.pooler.dense.bias"] = w(H, s=0.1)
+        t["classifier.weight"] = w(1, H, s=0.3)
+        t["classifier.bias"] = w(1, s=0.3)
+    elif head == "plain2":
+        t["classifier.weight"] = w(2, H, s=0.3)
+        t["classifier.bias"] = w(2, s=0.3)
+    del d
+    return t
+
+
+def regime_stats(tensors: Dict[str, np.ndarray], cfg: dict, ids: np.ndarray, mask: np.ndarray, prefix: str = "",
+                 types: np.ndarray = None) -> Dict[str, float]:
+    """A float64 numpy forward of the BERT graph that reports WHICH numerical regime a weight set puts a batch in:
+    attention-logit std over the keys of a query row (largest and smallest layer) / max, the mean of the largest softmax probability per query row, the range of FC1
+    pre-activations, the largest hidden-state magnitude.  Real tokens only.  Test infrastructure (a third, independent
+    statement of the graph besides oracle/ and Hugging Face)."""
+    from scipy.special import erf
+    H, L, nh = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["num_attention_heads"]
+    d, eps = H // nh, cfg.get("layer_norm_eps", 1e-12)
+    g = lambda k: tensors[k].astype(np.float64)  # noqa: E731
+
+    def ln(x, pre):
+        mu = x.mean(-1, keepdims=True)
+        var = ((x - mu) ** 2).mean(-1, keepdims=True)
+        return (x - mu) / np.sqrt(var + eps) * g(pre + ".weight") + g(pre + ".bias")
+
+    B, S = ids.shape
+    e = prefix + "embeddings."
+    ty = np.zeros_like(ids) if types is None else types
+    x = g(e + "word_embeddings.weight")[ids] + g(e + "position_embeddings.weight")[:S][None] + g(e + "token_type_embeddings.weight")[ty]
+    x = ln(x, e + "LayerNorm")
+    real = mask.astype(bool)
+    pair = real[:, None, :, None] & real[:, None, None, :]
+    st = dict(logit_std=0.0, logit_absmax=0.0, softmax_top_mean=1.0, fc1_min=0.0, fc1_max=0.0, fc1_std=0.0, hidden_absmax=0.0)
+    tops, per_layer = [], []
+    for i in range(L):
+        p = f"{prefix}encoder.layer.{i}."
+        lin = lambda a, nm: a @ g(p + nm + ".weight").T + g(p + nm + ".bias")  # noqa: E731
+        split = lambda a: a.reshape(B, S, nh, d).transpose(0, 2, 1, 3)  # noqa: E731
+        q, k, v = (split(lin(x, "attention.self." + nm)) for nm in ("query", "key", "value"))
+        logits = q @ k.transpose(0, 1, 3, 2) / np.sqrt(d)
+        sel = logits[np.broadcast_to(pair, logits.shape)]
+        cnt = real.sum(-1)[:, None, None, None]
+        row_mean = np.where(real[:, None, None, :], logits, 0.0).sum(-1, keepdims=True) / cnt
+        within = (logits - row_mean)[np.broadcast_to(pair, logits.shape)]   # spread over the keys of one query row
+        per_layer.append((float(within.std()), float(np.abs(sel).max())))
+        st["logit_std"] = max(st["logit_std"], float(within.std()))
+        st["logit_absmax"] = max(st["logit_absmax"], float(np.abs(sel).max()))
+        logits = np.where(real[:, None, None, :], logits, -1e9)
+        pr = np.exp(logits - logits.max(-1, keepdims=True))
+        pr /= pr.sum(-1, keepdims=True)
+        tops.append(float(pr.max(-1)[np.broadcast_to(real[:, None, :], pr.shape[:3])].mean()))
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, S, H)
+        x = ln(lin(ctx, "attention.output.dense") + x, p + "attention.output.LayerNorm")
+        a = lin(x, "intermediate.dense")
+        ar = a[real]
+        st["fc1_min"], st["fc1_max"] = min(st["fc1_min"], float(ar.min())), max(st["fc1_max"], float(ar.max()))
+        st["fc1_std"] = max(st["fc1_std"], float(ar.std()))
+        a = 0.5 * a * (1.0 + erf(a / np.sqrt(2.0)))
+        x = ln(lin(a, "output.dense") + x, p + "output.LayerNorm")
+        st["hidden_absmax"] = max(st["hidden_absmax"], float(np.abs(x[real]).max()))
+    st["softmax_top_mean"] = float(np.mean(tops))
+    st["logit_std_min_layer"] = min(a for a, _ in per_layer)
+    st["last_hidden"] = x
+    return st
+
+
 def distilbert_tensors(cfg: dict, seed: int = 0) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     H, L, I = cfg["dim"], cfg["n_layers"], cfg["hidden_dim"]
@@ -130,21 +255,23 @@ def shard_model_dir(path: str, n_shards: int = 3) -> Dict[str, str]:
     return weight_map
 
 
-def minilm_embedder(path: str, seed: int = 0, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+def minilm_embedder(path: str, seed: int = 0, family: str = "init", **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+    """family: "init" = N(0, 0.02) initialisation; "trained" = trained-checkpoint statistics (trained_bert_tensors)."""
     cfg = dict(MINILM, model_type="bert", hidden_act="gelu", layer_norm_eps=1e-12,
                architectures=["BertModel"])
     cfg.update(over)
-    t = bert_tensors(cfg, seed)
+    t = trained_bert_tensors(cfg, seed) if family == "trained" else bert_tensors(cfg, seed)
     write_model_dir(path, cfg, t)
     return cfg, t
 
 
-def minilm_cross_encoder(path: str, seed: int = 1, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+def minilm_cross_encoder(path: str, seed: int = 1, family: str = "init", **over) -> Tuple[dict, Dict[str, np.ndarray]]:
     cfg = dict(MINILM, model_type="bert", hidden_act="gelu", layer_norm_eps=1e-12,
                architectures=["BertForSequenceClassification"], id2label={"0": "LABEL_0"},
                label2id={"LABEL_0": 0})
     cfg.update(over)
-    t = bert_tensors(cfg, seed, prefix="bert.", head="cross")
+    make = trained_bert_tensors if family == "trained" else bert_tensors
+    t = make(cfg, seed, prefix="bert.", head="cross")
     write_model_dir(path, cfg, t)
     return cfg, t
 

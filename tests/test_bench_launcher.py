@@ -72,3 +72,29 @@ def test_eight_ranks_as_the_driver_launches_them():
     leg = r["rerank"]
     assert leg["n_gpus"] == 8 and leg["scaling"] == "strong" and leg["pairs_per_step"] == 100003 and leg["pairs_per_gpu"] == 12501
     assert 1 <= r["host_threads_per_rank"] <= max(1, (os.cpu_count() or 8) // 8)
+
+
+def test_in_process_arrangement_drives_every_device_from_one_process():
+    """--in-process: ONE process, the library's EncoderGroup arrangement (kjarni_hip_group_*_allgather; what FFI callers get).
+    On the CPU stub: weak embed rows (N x sentences), the strong rerank leg over uneven blocks, every device's buffer holding
+    every row, and the JSON naming the arrangement that produced `value`."""
+    r = _run(["--gpus", "3", "--in-process", "--steps", "2", "--warmup", "1", "--dry-run-cpu", "--sentences", "21", "--pairs", "100"])
+    assert r["n_gpus"] == 3 and r["scaling"] == "weak" and r["config"]["rows_per_step"] == 63 and r["config"]["rows_per_gpu"] == 21
+    assert r["config"]["arrangement"].startswith("in-process group") and len(r["steps_ms"]) == 2
+    assert "collective" not in r   # no torch.distributed communicator in this arrangement
+    leg = r["rerank"]
+    assert leg["scaling"] == "strong" and leg["pairs_per_step"] == 100 and leg["pairs_per_gpu"] == 34 and leg["n_gpus"] == 3
+    r = _run(["--gpus", "2", "--in-process", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--workload", "rerank", "--pairs", "9"])
+    assert r["unit"] == "pairs/s" and r["config"]["rows_per_gpu"] == 5 and "rerank" not in r
+
+
+def test_in_process_refuses_a_multi_process_launch():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--in-process", "--dry-run-cpu"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode == 2 and "ONE process" in p.stderr
+
+
+def test_the_line_names_the_arrangement_and_the_io():
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--sentences", "10", "--no-rerank-leg"])
+    assert r["config"]["arrangement"].startswith("one process per GPU") and "resident in HBM" in r["config"]["io"]

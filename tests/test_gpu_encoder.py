@@ -5,30 +5,46 @@ import pytest
 
 from oracle import oracle as O
 from tests import synth
+from tests.parity_report import report
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+# Hidden states are not O(1) in the trained family (LayerNorm gains up to 12.5: values reach 30); the bar for THEM is 1e-4 of the
+# largest value, as for any f32 quantity.  Embeddings (unit vectors) and logits keep the absolute 1e-4 of north_star.
+FAMILIES = {"init": "", "trained": "trained_"}
+
+
+@pytest.fixture(scope="module", params=list(FAMILIES))
+def family(request):
+    """tests/synth.py: "init" = N(0, 0.02) weights (uniform softmax), "trained" = trained-checkpoint statistics (peaked softmax,
+    LayerNorm gain outliers, GELU tails) -- the stand-in for the reference's real-weight goldens
+    (sentence_encoder/tests.rs:411-1184, cross_encoder/tests.rs:38-100)."""
+    return request.param
 
 
 @pytest.fixture(scope="module")
-def minilm(tmp_path_factory):
+def minilm(tmp_path_factory, family):
     import kjarni_amd
     d = str(tmp_path_factory.mktemp("minilm"))
-    cfg, t = synth.minilm_embedder(d, seed=0)
+    cfg, t = synth.minilm_embedder(d, seed=0, family=family)
     enc = kjarni_amd.HipEncoder(d, 0)
     yield enc, O.OracleModel(t, cfg)
     enc.close()
 
 
 @pytest.fixture(scope="module")
-def cross(tmp_path_factory):
+def cross(tmp_path_factory, family):
     import kjarni_amd
     d = str(tmp_path_factory.mktemp("cross"))
-    cfg, t = synth.minilm_cross_encoder(d, seed=1)
+    cfg, t = synth.minilm_cross_encoder(d, seed=1, family=family)
     enc = kjarni_amd.HipEncoder(d, 0)
     yield enc, O.OracleModel(t, cfg)
     enc.close()
+
+
+def hidden_tol(ref):
+    return TOL * max(1.0, float(np.nanmax(np.abs(ref))) / 4.0)   # init family: |h| <= ~8 -> 1e-4 .. 2e-4 as before
 
 
 def test_model_info(minilm):
@@ -39,7 +55,7 @@ def test_model_info(minilm):
 
 @pytest.mark.parametrize("B,S,ragged", [(1, 8, False), (3, 8, True), (3, 128, True), (16, 128, False),
                                         (2, 37, True), (5, 200, True)])
-def test_hidden_states_parity(minilm, B, S, ragged):
+def test_hidden_states_parity(minilm, family, B, S, ragged):
     import kjarni_amd
     enc, orc = minilm
     ids, mask = synth.synthetic_ids(B, S, seed=B * 1000 + S, ragged=ragged)
@@ -48,20 +64,21 @@ def test_hidden_states_parity(minilm, B, S, ragged):
         ref = orc.forward(ids, mask, None, mv)
         assert got.shape == ref.shape
         assert np.isfinite(got).all()
-        assert np.abs(got - ref).max() < TOL
+        tol = TOL if family == "init" else hidden_tol(ref)
+        assert report(f"encoder/{family}/hidden_states", np.abs(got - ref).max(), tol) < tol
 
 
 @pytest.mark.parametrize("B,S", [(1, 8), (3, 8), (64, 128), (3, 128), (4, 300)])
-def test_embed_parity(minilm, B, S):
+def test_embed_parity(minilm, family, B, S):
     enc, orc = minilm
     ids, mask = synth.synthetic_ids(B, S, seed=7 * B + S, ragged=True)
     got = enc.embed(ids, mask)  # mean + L2 = encode_batch_flat, AUTO mask fill
     ref = orc.embed_batch(ids, mask)
-    assert np.abs(got - ref).max() < TOL
+    assert report(f"encoder/{family}/embed", np.abs(got - ref).max(), TOL) < TOL
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
 
 
-def test_pooling_modes(minilm):
+def test_pooling_modes(minilm, family):
     enc, orc = minilm
     ids, mask = synth.synthetic_ids(4, 32, seed=11, ragged=True)
     h = orc.forward(ids, mask, None, O.strategy_mask_value(4 * 32))
@@ -69,12 +86,13 @@ def test_pooling_modes(minilm):
     for name, ref in (("mean", O.mean_pool(h, mf)), ("cls", O.cls_pool(h)), ("max", O.max_pool(h, mf)),
                       ("last_token", O.last_token_pool(h, mf))):
         got = enc.embed(ids, mask, pooling=name, normalize=False)
-        assert np.abs(got - ref).max() < TOL, name
+        tol = hidden_tol(ref)   # unnormalised pooled hidden states
+        assert report(f"encoder/{family}/pool_{name}_raw", np.abs(got - ref).max(), tol) < tol, name
         gotn = enc.embed(ids, mask, pooling=name, normalize=True)
         assert np.abs(gotn - O.l2_normalize(ref)).max() < TOL, name
 
 
-def test_type_ids_and_rerank_logits(cross):
+def test_type_ids_and_rerank_logits(cross, family):
     enc, orc = cross
     assert enc.num_labels == 1
     for B, S in ((1, 16), (3, 64), (8, 128)):
@@ -82,7 +100,7 @@ def test_type_ids_and_rerank_logits(cross):
         got = enc.logits(ids, mask, types)
         ref = orc.rerank_scores(ids, mask, types)
         assert got.shape == (B, 1)
-        assert np.abs(got[:, 0] - ref).max() < TOL
+        assert report(f"encoder/{family}/rerank_logits", np.abs(got[:, 0] - ref).max(), TOL) < TOL
 
 
 def test_chunking_is_invisible(minilm):
@@ -119,7 +137,7 @@ def test_out_of_vocab_ids_leave_zero_rows(minilm):
     ids[0, 3] = 40000  # >= vocab: embeddings/mod.rs:232-236 leaves zeros
     got = enc.hidden_states(ids, mask)
     ref = orc.forward(ids, mask, None, O.strategy_mask_value(16))
-    assert np.abs(got - ref).max() < TOL
+    assert np.abs(got - ref).max() < hidden_tol(ref)
 
 
 def test_errors(minilm):
@@ -147,23 +165,24 @@ def fixtures():
 
 
 @pytest.mark.parametrize("B,S", FIXTURE_CASES)
-def test_embeddings_equal_the_hf_fixtures(minilm, fixtures, B, S):
-    enc, _ = minilm  # synth.minilm_embedder(seed=0): the weights the fixtures were made with (digest checked on the CPU side)
-    tag = f"embed_{B}x{S}"
+def test_embeddings_equal_the_hf_fixtures(minilm, family, fixtures, B, S):
+    enc, _ = minilm  # synth.minilm_embedder(seed=0, family): the weights the fixtures were made with (digest checked on the CPU side)
+    tag = f"{FAMILIES[family]}embed_{B}x{S}"
     got = enc.embed(fixtures[tag + "_ids"], fixtures[tag + "_mask"])
-    assert float(np.abs(got - fixtures[tag + "_embeddings"]).max()) < TOL
+    assert report(f"encoder/{family}/embed_vs_hf_float64", np.abs(got - fixtures[tag + "_embeddings"]).max(), TOL) < TOL
     if tag + "_hidden" in fixtures:
         h = enc.hidden_states(fixtures[tag + "_ids"], fixtures[tag + "_mask"])
         real = fixtures[tag + "_mask"].astype(bool)
-        assert float(np.abs(h - fixtures[tag + "_hidden"])[real].max()) < TOL
+        tol = TOL if family == "init" else hidden_tol(fixtures[tag + "_hidden"][real])
+        assert report(f"encoder/{family}/hidden_vs_hf_float64", np.abs(h - fixtures[tag + "_hidden"])[real].max(), tol) < tol
 
 
 @pytest.mark.parametrize("B,S", FIXTURE_CASES)
-def test_rerank_logits_equal_the_hf_fixtures(cross, fixtures, B, S):
-    enc, _ = cross   # synth.minilm_cross_encoder(seed=1)
-    tag = f"pairs_{B}x{S}"
+def test_rerank_logits_equal_the_hf_fixtures(cross, family, fixtures, B, S):
+    enc, _ = cross   # synth.minilm_cross_encoder(seed=1, family)
+    tag = f"{FAMILIES[family]}pairs_{B}x{S}"
     got = enc.logits(fixtures[tag + "_ids"], fixtures[tag + "_mask"], fixtures[tag + "_types"])
-    assert float(np.abs(got - fixtures[tag + "_logits"]).max()) < TOL
+    assert report(f"encoder/{family}/rerank_logits_vs_hf_float64", np.abs(got - fixtures[tag + "_logits"]).max(), TOL) < TOL
 
 
 def test_two_lanes_are_invisible_in_the_results(tmp_path):

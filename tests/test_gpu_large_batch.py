@@ -16,6 +16,7 @@ import pytest
 
 from oracle import oracle as O
 from tests import synth
+from tests.parity_report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -28,41 +29,50 @@ def _oracle(tensors, cfg):
     return O.OracleModel(tensors, cfg, blocked_gemm=True)
 
 
+@pytest.fixture(scope="module", params=["init", "trained"])
+def family(request):
+    """tests/synth.py weight families: "init" = N(0, 0.02) (uniform softmax, GELU in its linear part); "trained" = the statistics
+    of a trained checkpoint (attention logits spreading with std 3-5 and |max| > 10, LayerNorm gain outliers x5, FC1
+    pre-activations beyond +-6) -- the stand-in for the real-weight goldens of sentence_encoder/tests.rs:411-1184 and
+    cross_encoder/tests.rs:38-100.  Every model-level test of (a), (c), (d) runs on both."""
+    return request.param
+
+
 @pytest.fixture(scope="module")
-def minilm2(tmp_path_factory):
+def minilm2(tmp_path_factory, family):
     import kjarni_amd
     d = str(tmp_path_factory.mktemp("minilm2"))
-    cfg, t = synth.minilm_embedder(d, seed=5, num_hidden_layers=2)
+    cfg, t = synth.minilm_embedder(d, seed=5, family=family, num_hidden_layers=2)
     enc = kjarni_amd.HipEncoder(d, 0)
     yield enc, _oracle(t, cfg)
     enc.close()
 
 
 @pytest.fixture(scope="module")
-def cross2(tmp_path_factory):
+def cross2(tmp_path_factory, family):
     import kjarni_amd
     d = str(tmp_path_factory.mktemp("cross2"))
-    cfg, t = synth.minilm_cross_encoder(d, seed=6, num_hidden_layers=2)
+    cfg, t = synth.minilm_cross_encoder(d, seed=6, family=family, num_hidden_layers=2)
     enc = kjarni_amd.HipEncoder(d, 0)
     yield enc, _oracle(t, cfg)
     enc.close()
 
 
 @pytest.fixture(scope="module")
-def minilm6(tmp_path_factory):
+def minilm6(tmp_path_factory, family):
     import kjarni_amd
     d = str(tmp_path_factory.mktemp("minilm6"))
-    cfg, t = synth.minilm_embedder(d, seed=0)
+    cfg, t = synth.minilm_embedder(d, seed=0, family=family)
     enc = kjarni_amd.HipEncoder(d, 0)
     yield enc, _oracle(t, cfg)
     enc.close()
 
 
 @pytest.fixture(scope="module")
-def cross6(tmp_path_factory):
+def cross6(tmp_path_factory, family):
     import kjarni_amd
     d = str(tmp_path_factory.mktemp("cross6"))
-    cfg, t = synth.minilm_cross_encoder(d, seed=1)
+    cfg, t = synth.minilm_cross_encoder(d, seed=1, family=family)
     enc = kjarni_amd.HipEncoder(d, 0)
     yield enc, _oracle(t, cfg)
     enc.close()
@@ -81,7 +91,7 @@ def products(request):
 
 # ------------------------------------------------------------------------------------------------ (a)
 @pytest.mark.parametrize("B,S,ragged", [(2100, 128, True), (300, 100, True), (2048, 128, False)])
-def test_whole_chunk_and_tail_embed_every_row(minilm2, products, B, S, ragged):
+def test_whole_chunk_and_tail_embed_every_row(minilm2, family, products, B, S, ragged):
     """2 100 x 128 = one full 2 048-sentence chunk (18 432 QKV tiles, 24 576 attention items) + a 52-sentence tail on the
     mid-size route; 300 x 100 = 30 000 tokens in one chunk with a sequence length that is not a tile multiple."""
     enc, orc = minilm2
@@ -90,10 +100,10 @@ def test_whole_chunk_and_tail_embed_every_row(minilm2, products, B, S, ragged):
     ref = orc.embed_batch(ids, mask)
     err = np.abs(got - ref).max(axis=1)
     assert np.isfinite(got).all()
-    assert float(err.max()) < TOL, (int(err.argmax()), float(err.max()))
+    assert report(f"large/{family}/{products}/chunk_embed_every_row", err.max(), TOL) < TOL, (int(err.argmax()), float(err.max()))
 
 
-def test_whole_chunk_and_tail_rerank_logits_every_row(cross2, products):
+def test_whole_chunk_and_tail_rerank_logits_every_row(cross2, family, products):
     enc, orc = cross2
     ids, mask, types = synth.synthetic_pairs(2060, 128, seed=9)
     rng = np.random.default_rng(9)
@@ -105,10 +115,10 @@ def test_whole_chunk_and_tail_rerank_logits_every_row(cross2, products):
     got = enc.logits(ids, mask, types)[:, 0]
     ref = orc.rerank_scores(ids, mask, types)
     err = np.abs(got - ref)
-    assert float(err.max()) < TOL, (int(err.argmax()), float(err.max()))
+    assert report(f"large/{family}/{products}/chunk_rerank_logits_every_row", err.max(), TOL) < TOL, (int(err.argmax()), float(err.max()))
 
 
-def test_hidden_states_of_a_large_call(minilm2):
+def test_hidden_states_of_a_large_call(minilm2, family):
     """hidden_states writes the layer outputs straight into the caller's buffer (no pooling): 80 x 128 = 10 240 tokens
     is above the 8 192-row boundary, so the fused LayerNorm tile kernel produces what is compared."""
     import kjarni_amd
@@ -117,7 +127,9 @@ def test_hidden_states_of_a_large_call(minilm2):
     for fill, mv in ((kjarni_amd.MASK_NEG_1E9, O.MASK_ALLOC), (kjarni_amd.MASK_NEG_INF, O.MASK_NOALLOC)):
         got = enc.hidden_states(ids, mask, fill=fill)
         ref = orc.forward(ids, mask, None, mv)
-        assert float(np.abs(got - ref).max()) < TOL
+        # hidden states reach ~30 in the trained family (LayerNorm gains up to 12.5): 1e-4 of the largest value / 4 there
+        tol = TOL * max(1.0, float(np.abs(ref).max()) / 4.0)
+        assert report(f"large/{family}/hidden_states_10240_tokens", np.abs(got - ref).max(), tol) < tol
 
 
 # ------------------------------------------------------------------------------------------------ (b)
@@ -192,7 +204,7 @@ def test_attention_on_the_item_loop(B, S, d):
 
 
 # ------------------------------------------------------------------------------------------------ (c)
-def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6, products):
+def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6, family, products):
     """BASELINE.json configs[1] once: 65 536 x 128 through one call (32 chunks).  64 sampled rows (chunk edges included)
     against the oracle; those and 192 more re-encoded in 64-sentence calls (mid-size route) agree to 1e-5; another
     chunk size gives the same vectors."""
@@ -209,11 +221,11 @@ def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6, products
     for s in range(0, len(rows), 64):
         sel = rows[s:s + 64]
         small = enc.embed(np.ascontiguousarray(ids[sel]), np.ascontiguousarray(mask[sel]))
-        assert float(np.abs(small - full[sel]).max()) < 1e-5
+        assert report(f"large/{family}/{products}/configs1_64_sentence_calls_vs_one_call", np.abs(small - full[sel]).max(), 1e-5) < 1e-5
     sel = np.concatenate([edge, rows[::5]])[:64]
     ref = orc.embed_batch(np.ascontiguousarray(ids[sel]), np.ascontiguousarray(mask[sel]))
     err = np.abs(full[sel] - ref).max(axis=1)
-    assert float(err.max()) < TOL, (int(sel[err.argmax()]), float(err.max()))
+    assert report(f"large/{family}/{products}/configs1_embed_65536x128", err.max(), TOL) < TOL, (int(sel[err.argmax()]), float(err.max()))
     enc.set_chunk_tokens(128 * 1000)   # 1 000-sentence chunks: 65 full ones and a 536-sentence tail
     try:
         other = enc.embed(ids, mask)
@@ -222,7 +234,7 @@ def test_full_embed_config_rows_against_oracle_and_small_calls(minilm6, products
     assert float(np.abs(other - full).max()) < 1e-5
 
 
-def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6, products):
+def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6, family, products):
     """BASELINE.json configs[2] on one GPU: 100 000 pairs x 128."""
     enc, orc = cross6
     N, S = 100000, 128
@@ -235,17 +247,19 @@ def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6, products
     for s in range(0, len(rows), 64):
         sel = rows[s:s + 64]
         small = enc.logits(*(np.ascontiguousarray(a[sel]) for a in (ids, mask, types)))[:, 0]
-        assert float(np.abs(small - full[sel]).max()) < 1e-5
+        # logits of a few units in the trained family: route-to-route rounding scales with them
+        small_tol = 1e-5 * max(1.0, float(np.abs(full).max()))
+        assert report(f"large/{family}/{products}/configs2_64_pair_calls_vs_one_call", np.abs(small - full[sel]).max(), small_tol) < small_tol
     sel = np.concatenate([edge, rows[::3]])[:48]
     ref = orc.rerank_scores(*(np.ascontiguousarray(a[sel]) for a in (ids, mask, types)))
     err = np.abs(full[sel] - ref)
-    assert float(err.max()) < TOL, (int(sel[err.argmax()]), float(err.max()))
+    assert report(f"large/{family}/{products}/configs2_rerank_100000x128", err.max(), TOL) < TOL, (int(sel[err.argmax()]), float(err.max()))
     order = np.argsort(-full, kind="stable")
     assert (full[order][:-1] >= full[order][1:]).all()
 
 
 # ------------------------------------------------------------------------------------------------ (d)
-def test_call_size_sweep_against_the_oracle(minilm2):
+def test_call_size_sweep_against_the_oracle(minilm2, family):
     """Seeded sweep over (sentences, padded length): the three projection routes (<= 256 tokens, 257 .. 8 192, more), both
     attention kernels, ragged masks."""
     enc, orc = minilm2
@@ -258,7 +272,7 @@ def test_call_size_sweep_against_the_oracle(minilm2):
         ids, mask = synth.synthetic_ids(b, seq, seed=100 + i, ragged=True)
         got = enc.embed(ids, mask)
         ref = orc.embed_batch(ids, mask)
-        err = float(np.abs(got - ref).max())
+        err = report(f"large/{family}/call_size_sweep", np.abs(got - ref).max(), TOL)
         worst = max(worst, err)
         assert err < TOL, (i, b, seq, err)
     assert worst > 0.0
