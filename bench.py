@@ -182,21 +182,25 @@ class GpuSensors:
     a timed region runs (file reads only: nothing is enqueued, nothing synchronises), plus `rocm-smi` snapshots taken by
     snapshot() OUTSIDE the region.  Every source is optional: what the box does not expose is left out."""
 
-    def __init__(self, index=0, period=0.5):
+    def __init__(self, pci_bus_id=None, period=0.5):
+        """pci_bus_id: "0000:bb:dd.f" of the device (a box shows every GPU of the host under /sys/class/drm, whatever the
+        container may use); None = the first AMD card."""
         import glob
         import threading
         self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
-        self.files = {}
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        self.files, self.card = {}, None
         amd = []
-        for c in cards:
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             try:
-                if open(os.path.join(c, "vendor")).read().strip() == "0x1002":
-                    amd.append(c)
+                if open(os.path.join(c, "vendor")).read().strip() != "0x1002":
+                    continue
             except OSError:
-                pass
-        if index < len(amd):
-            for hw in glob.glob(os.path.join(amd[index], "hwmon", "hwmon*")):
+                continue
+            if pci_bus_id is None or os.path.basename(os.path.realpath(c)).lower() == pci_bus_id.lower():
+                amd.append(c)
+        if amd:
+            self.card = os.path.basename(os.path.realpath(amd[0]))
+            for hw in glob.glob(os.path.join(amd[0], "hwmon", "hwmon*")):
                 for key, names in (("power_w", ("power1_average", "power1_input")), ("temp_c", ("temp2_input", "temp1_input")),
                                    ("sclk_mhz", ("freq1_input",)), ("power_cap_w", ("power1_cap",))):
                     for nm in names:
@@ -234,7 +238,7 @@ class GpuSensors:
         self._stop.set()
         if self._thread:
             self._thread.join(timeout=2)
-        out = {"source": "sysfs hwmon" if self.files else None, "samples": len(self.samples)}
+        out = {"source": f"sysfs hwmon of {self.card}" if self.files else None, "samples": len(self.samples)}
         for k in ("power_w", "temp_c", "sclk_mhz"):
             v = [x[k] for x in self.samples if k in x]
             if v:
@@ -470,7 +474,11 @@ def main_in_process(args):
             for i in range(n):
                 torch.cuda.synchronize(i)
 
+    def say(msg):
+        print(f"bench.py --in-process: {msg}", file=sys.stderr, flush=True)
+
     def run_leg(rerank, n_total, steps, warmup):
+        say(f"{'rerank' if rerank else 'embed'} leg: {n_total} rows over {n} device(s), {warmup} + {steps} steps")
         cfg, tensors, grp = load(synth.minilm_cross_encoder if rerank else synth.minilm_embedder, 1 if rerank else 0)
         cols = 1 if rerank else grp.hidden_size
         blocks, ids_d, mask_d, types_d, outs = [], [], [], [], []
@@ -530,6 +538,7 @@ def main_in_process(args):
                       "parity_tolerance": 1e-4}
             assert parity["max_abs_err_vs_oracle"] < 1e-4, f"in-process output differs from the oracle: {parity}"
         transport = grp.transport
+        say(f"leg done in {elapsed:.2f} s, transport {transport}")
         fps = flops_per_sentence(grp.hidden_size, cfg["num_hidden_layers"], cfg["intermediate_size"], S)
         grp.close()
         return elapsed, per_step, parity, transport, fps, blocks[0][1]
@@ -732,7 +741,12 @@ def main():
         probes = torch.zeros((args.steps + 1, 2), dtype=torch.int64, device=dev)
         if not args.no_sensors:
             smi_before = GpuSensors.snapshot()
-            sensors = GpuSensors(local_rank)
+            try:
+                pr_ = torch.cuda.get_device_properties(local_rank)
+                bus = f"{pr_.pci_domain_id:04x}:{pr_.pci_bus_id:02x}:{pr_.pci_device_id:02x}.0"
+            except Exception:
+                bus = None
+            sensors = GpuSensors(bus)
     sync()
     if sensors:
         sensors.start()
