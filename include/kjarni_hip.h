@@ -86,14 +86,17 @@ KjarniErrorCode kjarni_hip_encoder_set_chunk_tokens(KjarniHipEncoder* enc, int64
  *      matter more than asynchrony (1.76 x on lengths U{16..128}). */
 KjarniErrorCode kjarni_hip_encoder_set_packing(KjarniHipEncoder* enc, int32_t on);
 
-/* Concurrent small calls on one handle.  The reference serialises nothing on a handle (kjarni-ffi/src/lib.rs:25-32): N
- * threads may each embed or classify one sentence at once.  A single-sentence forward is ~45 dependent launches on a fraction
- * of the chip, so by default the HOST-pointer entry points (and everything built on them: the string-level handles, groups)
- * COMBINE small calls (<= 8 rows, <= 1 024 tokens) that arrive while another small call of the same kind is on the device: a
- * call that finds the handle idle runs at once exactly as before; calls that queue up behind it ride along with the next
- * leader as ONE packed batch (one forward per round instead of one per thread).  A combined call's result equals the solo
- * call's to rounding (<= 1e-6: the rows take the packed layout and another tile route), not bit for bit.  0 turns it off
- * (every call runs alone; environment KJARNI_HIP_COMBINE=0 does the same for every handle of the process). */
+/* Concurrent small calls on one handle -- OPT-IN, default off.  The reference serialises nothing on a handle
+ * (kjarni-ffi/src/lib.rs:25-32) and gives every call its own deterministic result; so does this library by default: N threads
+ * that each embed or classify one sentence run N independent forwards (on up to four workspaces / streams at once), each
+ * bit-identical to the same call made alone.  A single-sentence forward is ~45 dependent launches on a fraction of the chip,
+ * so a service that prefers throughput over bit-reproducibility can turn COMBINING on (1 here, or KJARNI_HIP_COMBINE=1 in the
+ * environment for every handle the process loads, the string-level handles and groups included): small host-pointer calls
+ * (<= 8 rows, <= 1 024 tokens) that arrive while another small call of the same kind is on the device then ride along with the
+ * next leader as ONE packed batch (16 threads: 9.7 k -> 28 k encodes/s).  A call that finds the handle idle still runs at once.
+ * What it costs: a combined call's result equals the solo call's to rounding (<= 1e-6: the rows take the packed layout and
+ * possibly another tile route), not bit for bit, and WHICH calls share a forward depends on arrival times.  If a shared
+ * forward fails, each of its calls is run again alone, so only the call that fails by itself reports an error. */
 KjarniErrorCode kjarni_hip_encoder_set_combining(KjarniHipEncoder* enc, int32_t on);
 
 /* Mid-size host-pointer calls (2 304 .. 24 576 kept tokens: the reference's default batch of 32 sentences and a few of them)

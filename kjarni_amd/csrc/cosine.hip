@@ -1244,14 +1244,21 @@ size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k)
     (void)dim;
     const size_t fused = (size_t)(2048 * 256 + 2 * 2048) * sizeof(uint64_t);
     size_t two = pad256((size_t)nq * (size_t)n_docs * sizeof(float)) + pad256(cosine_topk_workspace_bytes(nq, n_docs, k));
-    // the fused many-query scan: candidate list, counters, the sample's best k per query
-    two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4);
+    // the fused many-query scan (nq >= 20 only): candidate list, counters, the sample's best k per query
+    if (nq >= 20) two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4);
     return fused > two ? fused : two;
 }
 
-// Per-query top-k of cosine(query, corpus row): out_idx / out_score [nq, k], score descending, ties by ascending row index
-// (VectorStore::search, kjarni-search/src/vector.rs:150-166; Segment::search_vectors, kjarni-rag/src/segment.rs:307-337);
-// slots past the corpus hold -1 / -inf.  One query takes the fused pass (no score array); otherwise scores + selection.
+// For callers whose query and corpus pointers are 16-byte aligned by construction (the Searcher's device image and staging
+// buffers): ONE query over a width the fused pass covers needs the workgroups' candidate lists only (4 MB) -- not the
+// [1, n_docs] score array and the two-call selection buffers the general bound above includes.
+size_t cosine_search_one_query_workspace_bytes(int64_t n_docs, int dim, int k)
+{
+    const int R = stream_rows(dim, false);
+    if (k <= 256 && R > 0 && n_docs >= R && !tune::scan_two_launches()) return (size_t)(2048 * 256 + 2 * 2048) * sizeof(uint64_t);
+    return cosine_search_workspace_bytes(1, n_docs, dim, k);
+}
+
 hipError_t launch_cosine_search(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode, int k,
                                 void* workspace, int64_t* out_idx, float* out_score, hipStream_t stream)
 {

@@ -210,7 +210,8 @@ std::unique_ptr<EncoderModel> EncoderModel::load(const std::string& dir, int dev
 
     std::unique_ptr<EncoderModel> m(new EncoderModel());
     m->device_ = device;
-    if (const char* e = std::getenv("KJARNI_HIP_COMBINE")) m->combining_ = !(e[0] == '0' && e[1] == '\0');
+    // (opt-in: a combined call's bits depend on who else happened to call -- off unless asked for)
+    if (const char* e = std::getenv("KJARNI_HIP_COMBINE")) m->combining_ = e[0] != '\0' && !(e[0] == '0' && e[1] == '\0');
     if (const char* e = std::getenv("KJARNI_HIP_TWO_LANES")) m->two_lanes_ = !(e[0] == '0' && e[1] == '\0');
     EncoderConfig& c = m->cfg_;
     c.config_json = read_file(dir + "/config.json");
@@ -1125,13 +1126,25 @@ bool EncoderModel::run_two_lanes(const uint32_t* mask, int64_t batch, int seq, F
 {
     if (!two_lanes_ || batch < 4 || batch * seq < kTwoLaneMinTokens) return false;
     // kept tokens (what the packed layout computes on) and where they halve / third
+    // (plan_packing's own test: ONE row that cannot be packed -- mask values above 1, or a row whose first token is masked --
+    // puts the whole call on the padded layout.  A part without that row would still pack, so the parts would not compute what
+    // the unsplit call computes and the result would depend on whether a helper was free: such a call does not split.)
     std::vector<int64_t> upto((size_t)batch + 1, 0);
+    bool packable = packing_ >= 1 && seq > 1;
     for (int64_t b = 0; b < batch; ++b) {
         int64_t n = 0;
+        uint32_t over = 0;
         const uint32_t* row = mask + b * seq;
-        for (int s = 0; s < seq; ++s) n += row[s] != 0u;
-        upto[(size_t)b + 1] = upto[(size_t)b] + (packing_ >= 1 ? n : seq);
+        for (int s = 0; s < seq; ++s) {
+            n += row[s] != 0u;
+            over |= row[s];
+        }
+        if (over > 1u || row[0] == 0u) packable = false;
+        upto[(size_t)b + 1] = upto[(size_t)b] + n;
     }
+    if (packing_ >= 1 && !packable) return false;
+    if (!packable)
+        for (int64_t b = 0; b < batch; ++b) upto[(size_t)b + 1] = (b + 1) * (int64_t)seq;  // padded layout: every row computes seq tokens
     const int64_t total = upto[(size_t)batch];
     static const int64_t lane_max_tokens = [] {  // (measurements: KJARNI_HIP_LANES_MAX_TOKENS)
         const char* e = std::getenv("KJARNI_HIP_LANES_MAX_TOKENS");
@@ -1317,39 +1330,51 @@ void EncoderModel::submit_small(CombineReq& req)
     std::unique_lock<std::mutex> lock(combine_mu_);
     combine_queue_.push_back(&req);
     while (!req.done) {
-        if (combine_leaders_ >= combine_leaders() || combine_queue_.empty()) {
+        // A call whose own request is already in some leader's batch only waits for it: leading another batch now would put
+        // other callers' work in front of its own return.
+        if (req.taken || combine_leaders_ >= combine_leaders() || combine_queue_.empty()) {
             combine_cv_.wait(lock);
             continue;
         }
-        // lead: the oldest queued call and every compatible one behind it, within the batch bounds
+        // lead: the oldest queued call and every compatible one behind it, within the batch bounds (rows, and rows x the
+        // LONGEST sequence taken so far: what the combined batch is padded to before the packed layout drops the padding)
         ++combine_leaders_;
         std::vector<CombineReq*> take;
-        int64_t rows = 0, tokens = 0;
+        int64_t rows = 0;
+        int max_seq = 0;
         for (auto it = combine_queue_.begin(); it != combine_queue_.end();) {
             CombineReq* r = *it;
-            const int seq = take.empty() ? r->seq : std::max(r->seq, take.front()->seq);
-            if ((take.empty() || (r->compatible(*take.front()) && rows + r->batch <= kCombineMaxBatchRows &&
-                                  (rows + r->batch) * seq <= kCombineMaxBatchTokens))) {
+            const int seq = std::max(max_seq, r->seq);
+            if (take.empty() || (r->compatible(*take.front()) && rows + r->batch <= kCombineMaxBatchRows &&
+                                 (rows + r->batch) * seq <= kCombineMaxBatchTokens)) {
                 take.push_back(r);
+                r->taken = true;
                 rows += r->batch;
-                tokens = rows * seq;
+                max_seq = seq;
                 it = combine_queue_.erase(it);
             } else {
                 ++it;
             }
         }
-        (void)tokens;
         lock.unlock();
-        std::exception_ptr err;
+        std::vector<std::exception_ptr> errs(take.size());
         try {
             run_combined(take);
         } catch (...) {
-            err = std::current_exception();
+            // The shared forward failed: every rider runs again ALONE, so that only the caller whose input (or whose own
+            // forward) fails sees an error -- as on the reference, where calls do not know of each other.
+            for (size_t i = 0; i < take.size(); ++i) {
+                try {
+                    run_combined(std::vector<CombineReq*>{take[i]});
+                } catch (...) {
+                    errs[i] = std::current_exception();
+                }
+            }
         }
         lock.lock();
-        for (CombineReq* r : take) {
-            r->error = err;
-            r->done = true;
+        for (size_t i = 0; i < take.size(); ++i) {
+            take[i]->error = errs[i];
+            take[i]->done = true;
         }
         --combine_leaders_;
         combine_cv_.notify_all();
@@ -1363,7 +1388,7 @@ void EncoderModel::embed_host(const uint32_t* ids, const uint32_t* mask, const u
 {
     if (batch <= 0 || seq <= 0) return;
     if (combining_ && batch <= kCombineMaxCallRows && batch * seq <= kCombineMaxCallTokens) {
-        CombineReq r{0, ids, mask, type_ids, batch, seq, (int)pool, normalize, mask_value, out, (size_t)cfg_.hidden, false, nullptr};
+        CombineReq r{0, ids, mask, type_ids, batch, seq, (int)pool, normalize, mask_value, out, (size_t)cfg_.hidden, false, false, nullptr};
         submit_small(r);
         return;
     }
@@ -1376,7 +1401,7 @@ void EncoderModel::logits_host(const uint32_t* ids, const uint32_t* mask, const 
     if (cfg_.head_kind == 0) throw std::runtime_error("model has no classification head");
     if (batch <= 0 || seq <= 0) return;
     if (combining_ && batch <= kCombineMaxCallRows && batch * seq <= kCombineMaxCallTokens) {
-        CombineReq r{1, ids, mask, type_ids, batch, seq, 0, false, mask_value, out, (size_t)cfg_.num_labels, false, nullptr};
+        CombineReq r{1, ids, mask, type_ids, batch, seq, 0, false, mask_value, out, (size_t)cfg_.num_labels, false, false, nullptr};
         submit_small(r);
         return;
     }

@@ -267,7 +267,7 @@ private:
     size_t weight_bytes_ = 0;
     std::atomic<int64_t> chunk_tokens_{262144};
     std::atomic<int> packing_{1};
-    std::atomic<bool> combining_{true};
+    std::atomic<bool> combining_{false};  // opt-in (kjarni_hip_encoder_set_combining / KJARNI_HIP_COMBINE=1)
 
     // ---- combining of concurrent small host-pointer calls (encoder.cpp, "call combining") ----
     struct CombineReq {
@@ -281,6 +281,7 @@ private:
         float* out;
         size_t out_per_row;
         bool done = false;
+        bool taken = false;  // in some leader's batch (its owner then only waits)
         std::exception_ptr error;
         bool compatible(const CombineReq& o) const
         {

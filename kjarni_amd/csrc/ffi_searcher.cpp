@@ -163,7 +163,9 @@ public:
 
         ContextLease lease(*this);
         Context& c = lease.ctx();
-        const size_t need = cosine_search_workspace_bytes(1, (int64_t)total, (int)query_dim, k);
+        // (image->vectors and c.io come from hipMalloc: 256-byte aligned, so the one-query bound applies -- 4 MB per context on
+        // the fused pass instead of 36 MB + 4 bytes per document)
+        const size_t need = cosine_search_one_query_workspace_bytes((int64_t)total, (int)query_dim, k);
         if (need > c.work_bytes) {
             if (c.work) {
                 hip_check(hipStreamSynchronize(c.stream), "hipStreamSynchronize");
@@ -233,6 +235,7 @@ private:
         float* vectors = nullptr;
         size_t bytes = 0, dim = 0;
         uint64_t last_used = 0;
+        bool ready = false, failed = false;  // (under the scanner's mu_) uploaded / its upload threw
         ~Image()
         {
             if (vectors) (void)hipFree(vectors);  // (runs on a thread whose current device is the scanner's)
@@ -284,58 +287,84 @@ private:
         Context* c_;
     };
 
-    // The image of this segment list: the resident one, or a new upload (other queries wait for it under the lock: the
-    // first query against an index pays the copy once).
+    // The image of this segment list: the resident one, or a new upload.  The upload (hipMalloc + a synchronous copy of the
+    // whole index) runs OUTSIDE mu_: the new image is registered first as a placeholder (`ready` false) that later queries
+    // against the SAME index wait on, while queries against images that are already resident keep being served.
     std::shared_ptr<Image> image_for(const std::vector<const Segment*>& segs, const std::vector<size_t>& use,
                                      const std::vector<uint64_t>& uids, size_t dim)
     {
-        std::lock_guard<std::mutex> lock(mu_);
-        const uint64_t tick = ++tick_;
-        for (auto& im : images_)
-            if (im->dim == dim && im->uids == uids) {
-                im->last_used = tick;
-                return im;
+        std::shared_ptr<Image> im;
+        {
+            std::unique_lock<std::mutex> lock(mu_);
+            const uint64_t tick = ++tick_;
+            for (auto& x : images_)
+                if (x->dim == dim && x->uids == uids) {
+                    x->last_used = tick;
+                    std::shared_ptr<Image> found = x;
+                    image_cv_.wait(lock, [&] { return found->ready || found->failed; });
+                    if (found->failed) break;  // its upload failed in another thread: try again below
+                    return found;
+                }
+            im = std::make_shared<Image>();
+            im->uids = uids;
+            im->dim = dim;
+            im->offsets.push_back(0);
+            for (size_t u : use) {
+                im->dirs.push_back(segs[u]->dir());
+                im->offsets.push_back(im->offsets.back() + segs[u]->doc_count());
             }
-        auto im = std::make_shared<Image>();
-        im->uids = uids;
-        im->dim = dim;
-        im->offsets.push_back(0);
-        for (size_t u : use) {
-            im->dirs.push_back(segs[u]->dir());
-            im->offsets.push_back(im->offsets.back() + segs[u]->doc_count());
+            im->bytes = im->offsets.back() * dim * sizeof(float);
+            // a superseded image of the same index (a segment was added: the old list is a prefix or shares directories) goes
+            // first, then least-recently-used ones until the new image fits the budget (images still uploading are kept)
+            for (auto it = images_.begin(); it != images_.end();) {
+                bool same_index = (*it)->failed;
+                for (const std::string& d : (*it)->dirs) same_index = same_index || d == im->dirs.front();
+                it = (same_index && ((*it)->ready || (*it)->failed)) ? images_.erase(it) : std::next(it);
+            }
+            while (budget_bytes_ && !images_.empty()) {
+                size_t held = 0;
+                for (const auto& x : images_) held += x->bytes;
+                if (held + im->bytes <= budget_bytes_) break;
+                auto victim = images_.end();
+                for (auto it = images_.begin(); it != images_.end(); ++it)
+                    if ((*it)->ready && (victim == images_.end() || (*it)->last_used < (*victim)->last_used)) victim = it;
+                if (victim == images_.end()) break;
+                images_.erase(victim);
+            }
+            im->last_used = tick;
+            images_.push_back(im);
         }
-        im->bytes = im->offsets.back() * dim * sizeof(float);
-        // a superseded image of the same index (a segment was added: the old list is a prefix or shares directories) goes first,
-        // then least-recently-used ones until the new image fits the budget
-        for (auto it = images_.begin(); it != images_.end();) {
-            bool same_index = false;
-            for (const std::string& d : (*it)->dirs) same_index = same_index || d == im->dirs.front();
-            it = same_index ? images_.erase(it) : std::next(it);
-        }
-        while (budget_bytes_ && !images_.empty()) {
-            size_t held = 0;
-            for (const auto& x : images_) held += x->bytes;
-            if (held + im->bytes <= budget_bytes_) break;
-            auto victim = images_.begin();
+        try {
+            hip_check(hipMalloc((void**)&im->vectors, im->bytes ? im->bytes : 4), "hipMalloc(index image)");
+            for (size_t i = 0; i < use.size(); ++i) {
+                const Segment& seg = *segs[use[i]];
+                hip_check(hipMemcpy(im->vectors + im->offsets[i] * dim, seg.vectors(), seg.doc_count() * dim * sizeof(float),
+                                    hipMemcpyHostToDevice),
+                          "H2D segment vectors");
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(mu_);
+            im->failed = true;
             for (auto it = images_.begin(); it != images_.end(); ++it)
-                if ((*it)->last_used < (*victim)->last_used) victim = it;
-            images_.erase(victim);
+                if (*it == im) {
+                    images_.erase(it);
+                    break;
+                }
+            image_cv_.notify_all();
+            throw;
         }
-        hip_check(hipMalloc((void**)&im->vectors, im->bytes ? im->bytes : 4), "hipMalloc(index image)");
-        for (size_t i = 0; i < use.size(); ++i) {
-            const Segment& seg = *segs[use[i]];
-            hip_check(hipMemcpy(im->vectors + im->offsets[i] * dim, seg.vectors(), seg.doc_count() * dim * sizeof(float),
-                                hipMemcpyHostToDevice),
-                      "H2D segment vectors");
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            im->ready = true;
         }
-        im->last_used = tick;
-        images_.push_back(im);
+        image_cv_.notify_all();
         return im;
     }
 
     int device_;
     mutable std::mutex mu_;
     std::condition_variable ctx_cv_;
+    std::condition_variable image_cv_;  // an image's upload finished (or failed)
     std::vector<std::shared_ptr<Image>> images_;
     std::vector<std::unique_ptr<Context>> contexts_;
     size_t budget_bytes_ = 0;

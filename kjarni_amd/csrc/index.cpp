@@ -538,17 +538,20 @@ struct SegmentStamp {
     bool operator==(const SegmentStamp& o) const { return std::memcmp(v, o.v, sizeof v) == 0; }
 };
 // What a query re-checks of a parsed segment: the segment DIRECTORY (a file created, removed or renamed in it changes its
-// mtime; a directory removed and re-created is another inode), segment.json and vectors.bin.  Segments are immutable once
-// written -- the reference's writer and this one create a segment directory and never touch it again
-// (kjarni-rag/src/segment.rs:90-170) -- so this is enough to see an index deleted, rebuilt or extended; an in-place edit of
-// docs.bin / bm25.bin behind the library's back is not a case either implementation supports.  Three stat calls per segment
-// and query instead of seven system calls.
+// mtime; a directory removed and re-created is another inode), segment.json, vectors.bin -- and docs.bin and metadata.jsonl,
+// which stay MAPPED for the lifetime of the cached Segment: a truncation or rewrite of those by another process would
+// otherwise end in SIGBUS (or stale text) instead of the reference's "corrupt offsets" error on the next query.  Segments are
+// immutable once written -- the reference's writer and this one create a segment directory and never touch it again
+// (kjarni-rag/src/segment.rs:90-170).  Five stat calls per segment and query (no open / pread / close per hit).
 bool stamp_of(const std::string& dir, SegmentStamp& out)
 {
-    static const char* const kFiles[3] = {"", "/segment.json", "/vectors.bin"};
-    for (int i = 0; i < 3; ++i) {
+    static const char* const kFiles[5] = {"", "/segment.json", "/vectors.bin", "/docs.bin", "/metadata.jsonl"};
+    for (int i = 0; i < 5; ++i) {
         struct stat st;
-        if (::stat((dir + kFiles[i]).c_str(), &st) != 0) return false;  // Segment::open would throw
+        if (::stat((dir + kFiles[i]).c_str(), &st) != 0) {
+            if (i < 3) return false;  // Segment::open would throw
+            continue;                 // (read lazily: a missing file is that lookup's error; its stamp stays zero)
+        }
         out.v[4 * i] = (uint64_t)st.st_size;
         out.v[4 * i + 1] = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
         out.v[4 * i + 2] = (uint64_t)st.st_ctim.tv_sec * 1000000000ull + (uint64_t)st.st_ctim.tv_nsec;

@@ -156,6 +156,8 @@ hipError_t launch_cosine_topk(const float* scores, int nq, int64_t n_docs, int k
 // registers, the scores never exist in memory -- plus one small merge launch; everything else runs launch_cosine_scores +
 // launch_cosine_topk inside the workspace.  out_idx / out_score: [nq, k].
 size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k);
+// nq = 1 with 16-byte aligned query / corpus pointers (the caller's promise): the fused pass's 4 MB where it applies.
+size_t cosine_search_one_query_workspace_bytes(int64_t n_docs, int dim, int k);
 hipError_t launch_cosine_search(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode, int k,
                                 void* workspace, int64_t* out_idx, float* out_score, hipStream_t stream);
 

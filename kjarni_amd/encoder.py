@@ -70,7 +70,7 @@ class HipEncoder:
 
     def set_combining(self, on: bool):
         """Small host-array calls that arrive while another is on the device ride along with the next one as one packed batch
-        (default on; kjarni_hip.h: kjarni_hip_encoder_set_combining)."""
+        (opt-in, default off; kjarni_hip.h: kjarni_hip_encoder_set_combining)."""
         check_error(lib().kjarni_hip_encoder_set_combining(self._h, 1 if on else 0))
 
     def set_two_lanes(self, on: bool):

@@ -227,3 +227,29 @@ def test_two_lanes_are_invisible_in_the_results(tmp_path):
     one = ce.logits(ids, mask, types)
     assert np.array_equal(two, one)
     assert float(np.abs(two[:, 0] - O.OracleModel(ct, ccfg).rerank_scores(ids, mask, types)).max()) < 1e-4
+
+
+def test_a_call_with_an_unpackable_row_is_the_same_with_and_without_lanes(tmp_path):
+    """One mask row that cannot be packed (first token masked, or a mask value above 1) puts the WHOLE call on the padded layout
+    (plan_packing); parts cut from such a call would pack on their own and so compute something else than the unsplit call --
+    and whether a call splits depends on a helper thread being free.  Such a call therefore never splits: same bits either way,
+    oracle-equal."""
+    import kjarni_amd
+    d = str(tmp_path / "e")
+    cfg, t = synth.minilm_embedder(d, seed=3, num_hidden_layers=2)
+    enc = kjarni_amd.HipEncoder(d)
+    orc = O.OracleModel(t, cfg)
+    for kind in ("first_token_masked", "mask_value_2"):
+        ids, mask = synth.synthetic_ids(40, 128, seed=11, ragged=True)
+        if kind == "first_token_masked":
+            mask[7, 0] = 0
+        else:
+            mask[7, 3] = 2
+        on = enc.embed(ids, mask)
+        enc.set_two_lanes(False)
+        off = enc.embed(ids, mask)
+        enc.set_two_lanes(True)
+        assert np.array_equal(on, off), kind
+        ref = orc.embed_batch(ids, mask)   # (`as f32`: a mask value of 2 weighs that token twice in the mean pool, traits.rs:71)
+        assert float(np.abs(on - ref).max()) < TOL, kind
+    enc.close()

@@ -346,8 +346,9 @@ def main():
               "kjarni_embedder_encode, 16 threads on one handle": concurrent(lambda: emb.encode(sentence), threads=16),
               "kjarni_classifier_classify, 4 threads on one handle": concurrent(lambda: clf.classify(sentence)),
               "kjarni_classifier_classify, 16 threads on one handle": concurrent(lambda: clf.classify(sentence), threads=16),
-              "note": "small calls that arrive while another is on the device are combined into one packed forward "
-                      "(kjarni_hip_encoder_set_combining, default on)"})
+              "combining": os.environ.get("KJARNI_HIP_COMBINE", "0") not in ("", "0"),
+              "note": "with KJARNI_HIP_COMBINE=1 small calls that arrive while another is on the device are combined into one "
+                      "packed forward (kjarni_hip_encoder_set_combining: opt-in, default off)"})
         del emb, clf
 
     if "indexer" in which:

@@ -1,7 +1,7 @@
 """Concurrency soak of one encoder handle: N host threads issue calls of mixed sizes (all three projection routes, workspaces
 growing and being reused, two lanes, call combining) for a while.  Every result must equal the single-threaded result bit for
 bit -- except small calls (<= 8 rows, <= 1 024 tokens) while combining is on (the default): those share a forward with whatever
-else is queued and are held to 1e-6 (KJARNI_HIP_COMBINE=0: bit for bit again):
+else is queued and are held to 1e-6 (without KJARNI_HIP_COMBINE=1, the default: bit for bit):
 python tools/stress_encoder.py [threads] [seconds]."""
 import os
 import sys
@@ -27,7 +27,7 @@ def main():
         shapes = [(1, 12), (2, 30), (5, 64), (16, 40), (32, 128), (70, 128), (100, 90), (140, 128), (300, 128), (3, 500)]  # (140 x 128 ragged: ~10 000 kept tokens, always three parts)
         inputs = [synth.synthetic_ids(b, s, seed=50 + i, ragged=True) for i, (b, s) in enumerate(shapes)]
         refs = [enc.embed(i, m) for i, m in inputs]
-        combining = os.environ.get("KJARNI_HIP_COMBINE", "1") != "0"
+        combining = os.environ.get("KJARNI_HIP_COMBINE", "0") not in ("", "0")   # (opt-in)
         small = [combining and b <= 8 and b * s <= 1024 for b, s in shapes]
         worst = [0.0]
         errors, calls = [], [0] * n_threads
