@@ -259,6 +259,19 @@ KjarniErrorCode kjarni_hip_op_linear_bf16_weights(int32_t device, const float* x
 KjarniErrorCode kjarni_hip_op_attention(int32_t device, const float* qkv, const uint32_t* mask, int64_t batch,
                                         int32_t seq, int32_t heads, int32_t head_dim, float mask_value,
                                         float* ctx, int32_t iters, float* ms_out);
+/* The operator with the reference's full argument list (EncoderSelfAttention::forward / forward_noalloc,
+ * cpu/encoder/encoder_self_attention.rs:57-140, 143-307): position_bias = NULL or an additive f32 [heads, bias_seq, bias_seq]
+ * (bias_seq >= seq; broadcast over sentences; added after the 1/sqrt(head_dim) scale and before the padding mask), scale_qk = 0
+ * skips the scale.  No encoder of the registry passes a bias, so models never take this entry: it runs the any-shape kernel and
+ * exists so that the reference's own layer goldens (encoder_layer.rs:349-448: hidden 4, 2 heads, a position bias) run on the GPU. */
+KjarniErrorCode kjarni_hip_op_attention_biased(int32_t device, const float* qkv, const uint32_t* mask, const float* position_bias,
+                                               int32_t bias_seq, int64_t batch, int32_t seq, int32_t heads, int32_t head_dim,
+                                               int32_t scale_qk, float mask_value, float* ctx);
+/* Pooling of hidden states [batch, seq, hidden] under a u32 mask [batch, seq] (NULL = all ones), optionally followed by L2
+ * normalisation: mean / cls / max / last-token pooling as kjarni-transformers/src/pooling/mod.rs:11-68 and
+ * cpu/encoder/traits.rs:66-139 (l2_normalize_inplace).  out: [batch, hidden]; hidden <= 1024. */
+KjarniErrorCode kjarni_hip_op_pool(int32_t device, const float* hidden_states, const uint32_t* mask, int64_t batch, int32_t seq,
+                                   int32_t hidden, KjarniHipPooling pooling, int32_t normalize, float* out);
 KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const float* gamma, const float* beta,
                                          float eps, int64_t rows, int32_t hidden, float* y, int32_t iters,
                                          float* ms_out);

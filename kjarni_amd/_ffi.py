@@ -442,6 +442,9 @@ SIGNATURES = {
                                                     _f32p, c_int32, _f32p]),
     "kjarni_hip_op_attention": (c_int32, [c_int32, _f32p, _u32p, c_int64, c_int32, c_int32, c_int32, c_float,
                                           _f32p, c_int32, _f32p]),
+    "kjarni_hip_op_pool": (c_int32, [c_int32, _f32p, _u32p, c_int64, c_int32, c_int32, c_int32, c_int32, _f32p]),
+    "kjarni_hip_op_attention_biased": (c_int32, [c_int32, _f32p, _u32p, _f32p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                                 c_float, _f32p]),
     "kjarni_hip_op_layer_norm": (c_int32, [c_int32, _f32p, _f32p, _f32p, c_float, c_int64, c_int32, _f32p,
                                            c_int32, _f32p]),
     "kjarni_hip_op_linear_layer_norm": (c_int32, [c_int32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, c_float, c_int64,

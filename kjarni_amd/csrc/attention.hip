@@ -742,7 +742,8 @@ __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __re
                                                                const uint32_t* __restrict__ mask,
                                                                int seq, int heads, int head_dim,
                                                                float scale, float mask_value,
-                                                               const int32_t* __restrict__ cu, float* __restrict__ ctx)
+                                                               const int32_t* __restrict__ cu, float* __restrict__ ctx,
+                                                               const float* __restrict__ pos_bias, int bias_seq)
 {
     extern __shared__ float srow[];  // [seq]
     const int lane = threadIdx.x;
@@ -765,6 +766,9 @@ __global__ __launch_bounds__(64) void attention_generic_kernel(const float* __re
         float s = 0.0f;
         for (int d = 0; d < head_dim; ++d) s = fmaf(qv[d], kv[d], s);
         s *= scale;
+        // additive position bias [heads, bias_seq, bias_seq], broadcast over sentences: after the scale, before the mask
+        // (encoder_self_attention.rs:110-116, 250-257)
+        if (pos_bias) s += pos_bias[((int64_t)h * bias_seq + q) * bias_seq + j];
         if (mask && mask[row0 + j] == 0u) s = mask_value;
         srow[j] = s;
         mx = fmaxf(mx, s);
@@ -876,6 +880,27 @@ hipError_t launch_d(const float* qkv, const uint32_t* mask, int64_t batch, int s
 // kernels): callers that cut a batch in two keep both halves above it so that the cut does not change a bit of the result.
 int attention_small_call_items() { return kSplitMaxItems; }
 
+namespace {
+hipError_t launch_generic(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads, int head_dim, float mask_value,
+                          float* ctx, hipStream_t stream, const int32_t* cu, const float* pos_bias, int bias_seq, bool scale_qk)
+{
+    const float scale = scale_qk ? 1.0f / sqrtf((float)head_dim) : 1.0f;
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+        const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
+        dim3 grid((unsigned)seq, (unsigned)heads, (unsigned)nb);
+        if (cu)
+            hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream, qkv, nullptr, seq, heads,
+                               head_dim, scale, mask_value, cu + b0, ctx, pos_bias, bias_seq);
+        else
+            hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream,
+                               qkv + b0 * seq * 3 * (int64_t)heads * head_dim,
+                               mask ? mask + b0 * seq : nullptr, seq, heads, head_dim, scale, mask_value, nullptr,
+                               ctx + b0 * seq * (int64_t)heads * head_dim, pos_bias, bias_seq);
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batch, int seq, int heads,
                             int head_dim, float mask_value, float* ctx, hipStream_t stream, const int32_t* cu)
 {
@@ -884,20 +909,15 @@ hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batc
                          ((reinterpret_cast<uintptr_t>(ctx) & 15) == 0);  // (16-byte loads of qkv, 16-byte stores of ctx)
     if (head_dim == 32 && aligned) return launch_d<32>(qkv, mask, batch, seq, heads, mask_value, ctx, stream, cu);
     if (head_dim == 64 && aligned) return launch_d<64>(qkv, mask, batch, seq, heads, mask_value, ctx, stream, cu);
-    const float scale = 1.0f / sqrtf((float)head_dim);
-    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
-        const int64_t nb = (batch - b0 < 65535) ? (batch - b0) : 65535;
-        dim3 grid((unsigned)seq, (unsigned)heads, (unsigned)nb);
-        if (cu)
-            hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream, qkv, nullptr, seq, heads,
-                               head_dim, scale, mask_value, cu + b0, ctx);
-        else
-            hipLaunchKernelGGL(attention_generic_kernel, grid, dim3(64), seq * sizeof(float), stream,
-                               qkv + b0 * seq * 3 * (int64_t)heads * head_dim,
-                               mask ? mask + b0 * seq : nullptr, seq, heads, head_dim, scale, mask_value, nullptr,
-                               ctx + b0 * seq * (int64_t)heads * head_dim);
-    }
-    return hipGetLastError();
+    return launch_generic(qkv, mask, batch, seq, heads, head_dim, mask_value, ctx, stream, cu, nullptr, 0, true);
+}
+
+hipError_t launch_attention_biased(const float* qkv, const uint32_t* mask, const float* pos_bias, int bias_seq, int64_t batch, int seq,
+                                   int heads, int head_dim, bool scale_qk, float mask_value, float* ctx, hipStream_t stream)
+{
+    if (batch <= 0 || seq <= 0) return hipSuccess;
+    if (pos_bias && bias_seq < seq) return hipErrorInvalidValue;
+    return launch_generic(qkv, mask, batch, seq, heads, head_dim, mask_value, ctx, stream, nullptr, pos_bias, bias_seq, scale_qk);
 }
 
 }  // namespace kjarni

@@ -479,6 +479,54 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_attention(int32_t device, const floa
     });
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_attention_biased(int32_t device, const float* qkv, const uint32_t* mask,
+                                                             const float* position_bias, int32_t bias_seq, int64_t batch,
+                                                             int32_t seq, int32_t heads, int32_t head_dim, int32_t scale_qk,
+                                                             float mask_value, float* ctx)
+{
+    if (!qkv || !ctx) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (batch < 0 || seq <= 0 || heads <= 0 || head_dim <= 0) throw InvalidConfig("invalid attention dimensions");
+        if (position_bias && bias_seq < seq) throw InvalidConfig("position bias is smaller than the sequence");
+        use_device(device);
+        if (batch == 0) return;
+        const size_t T = (size_t)batch * seq, H = (size_t)heads * head_dim;
+        const size_t bias_bytes = position_bias ? (size_t)heads * bias_seq * bias_seq * 4 : 4;
+        DeviceBuf qd(T * 3 * H * 4), md(T * 4), cd(T * H * 4), bd(bias_bytes);
+        hip_check(hipMemcpy(qd.p, qkv, T * 3 * H * 4, hipMemcpyHostToDevice), "H2D qkv");
+        if (mask) hip_check(hipMemcpy(md.p, mask, T * 4, hipMemcpyHostToDevice), "H2D mask");
+        if (position_bias) hip_check(hipMemcpy(bd.p, position_bias, bias_bytes, hipMemcpyHostToDevice), "H2D position bias");
+        hip_check(launch_attention_biased((const float*)qd.p, mask ? (const uint32_t*)md.p : nullptr,
+                                          position_bias ? (const float*)bd.p : nullptr, bias_seq, batch, seq, heads, head_dim,
+                                          scale_qk != 0, mask_value, (float*)cd.p, nullptr),
+                  "attention (position bias)");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        hip_check(hipMemcpy(ctx, cd.p, T * H * 4, hipMemcpyDeviceToHost), "D2H ctx");
+    });
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_pool(int32_t device, const float* hidden_states, const uint32_t* mask, int64_t batch,
+                                                 int32_t seq, int32_t hidden, KjarniHipPooling pooling, int32_t normalize, float* out)
+{
+    if (!hidden_states || !out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (batch < 0 || seq <= 0 || hidden <= 0 || hidden > 1024) throw InvalidConfig("invalid pooling dimensions");
+        use_device(device);
+        if (batch == 0) return;
+        const size_t T = (size_t)batch * seq;
+        DeviceBuf hd(T * hidden * 4), md(T * 4), od((size_t)batch * hidden * 4);
+        hip_check(hipMemcpy(hd.p, hidden_states, T * hidden * 4, hipMemcpyHostToDevice), "H2D hidden states");
+        std::vector<uint32_t> ones;
+        if (!mask) ones.assign(T, 1u);
+        hip_check(hipMemcpy(md.p, mask ? mask : ones.data(), T * 4, hipMemcpyHostToDevice), "H2D mask");
+        hip_check(launch_pool((const float*)hd.p, (const uint32_t*)md.p, batch, seq, hidden, (PoolMode)pooling, normalize,
+                              (float*)od.p, nullptr),
+                  "pool");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        hip_check(hipMemcpy(out, od.p, (size_t)batch * hidden * 4, hipMemcpyDeviceToHost), "D2H pooled");
+    });
+}
+
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_layer_norm(int32_t device, const float* x, const float* gamma,
                                                        const float* beta, float eps, int64_t rows, int32_t hidden,
                                                        float* y, int32_t iters, float* ms_out)

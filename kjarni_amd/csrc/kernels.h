@@ -119,6 +119,14 @@ hipError_t launch_attention(const float* qkv, const uint32_t* mask, int64_t batc
                             int heads, int head_dim, float mask_value, float* ctx,
                             hipStream_t stream, const int32_t* cu = nullptr);
 
+// The reference's full operator signature (EncoderSelfAttention::forward / forward_noalloc, encoder_self_attention.rs:57-140,
+// 143-307): an optional ADDITIVE position bias [heads, bias_seq, bias_seq] (broadcast over sentences; added after the scale and
+// before the padding mask) and the scale_qk switch.  None of the registry's encoders passes a bias, so
+// the model path never comes here: this is the any-shape kernel (one wave per query row), kept for the reference's own layer
+// goldens (encoder_layer.rs:349-448), which use one.
+hipError_t launch_attention_biased(const float* qkv, const uint32_t* mask, const float* pos_bias, int bias_seq, int64_t batch, int seq,
+                                   int heads, int head_dim, bool scale_qk, float mask_value, float* ctx, hipStream_t stream);
+
 int attention_small_call_items();  // calls of up to this many (sentence, head) items take the small-call attention kernel
 
 // RoPE on the Q and K thirds of qkv [tokens, 3*hidden] in place, position = token index within its sentence

@@ -12,6 +12,7 @@ from . import _ffi
 from ._ffi import check_error, lib
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_NEW, EPI_BIAS_RELU, EPI_BIAS_TANH, EPI_BIAS_RESIDUAL, EPI_BIAS_MUL_SILU = range(7)
+POOL_MEAN, POOL_CLS, POOL_MAX, POOL_LAST = 0, 1, 2, 3
 
 
 def _f(a):
@@ -70,6 +71,38 @@ def attention(qkv, mask, heads: int, mask_value: float = -1e9, iters: int = 0, d
                                               b, s, heads, hidden // heads, float(mask_value), _f(ctx), iters,
                                               C.byref(ms)))
     return ctx, (float(ms.value) if iters > 0 else None)
+
+
+def pool(hidden_states, mask=None, pooling: int = 0, normalize: bool = False, device: int = 0) -> np.ndarray:
+    """hidden_states [B, S, H] -> [B, H] (kjarni_hip_op_pool): pooling 0 mean, 1 cls, 2 max, 3 last token; optional L2."""
+    h = _c(hidden_states)
+    b, s, d = h.shape
+    mask = None if mask is None else np.ascontiguousarray(mask, np.uint32)
+    out = np.empty((b, d), np.float32)
+    check_error(lib().kjarni_hip_op_pool(device, _f(h), None if mask is None else mask.ctypes.data_as(_ffi._u32p), b, s, d,
+                                         int(pooling), 1 if normalize else 0, _f(out)))
+    return out
+
+
+def attention_biased(qkv, mask, heads: int, position_bias=None, scale_qk: bool = True, mask_value: float = -1e9,
+                     device: int = 0) -> np.ndarray:
+    """EncoderSelfAttention with the reference's full argument list (kjarni_hip_op_attention_biased): position_bias
+    [1, heads, S', S'] or [heads, S', S'] with S' >= seq, added after the scale and before the padding mask."""
+    qkv = _c(qkv)
+    b, s, h3 = qkv.shape
+    hidden = h3 // 3
+    mask = None if mask is None else np.ascontiguousarray(mask, np.uint32)
+    bias, bias_seq = None, 0
+    if position_bias is not None:
+        bias = np.ascontiguousarray(position_bias, np.float32)
+        bias = bias.reshape(bias.shape[-3:])
+        assert bias.shape[0] == heads and bias.shape[1] == bias.shape[2]
+        bias_seq = int(bias.shape[1])
+    ctx = np.empty((b, s, hidden), np.float32)
+    check_error(lib().kjarni_hip_op_attention_biased(device, _f(qkv), None if mask is None else mask.ctypes.data_as(_ffi._u32p),
+                                                     None if bias is None else _f(bias), bias_seq, b, s, heads, hidden // heads,
+                                                     1 if scale_qk else 0, float(mask_value), _f(ctx)))
+    return ctx
 
 
 def layer_norm(x, gamma, beta, eps: float, iters: int = 0, device: int = 0) -> Tuple[np.ndarray, Optional[float]]:
