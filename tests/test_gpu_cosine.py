@@ -104,7 +104,10 @@ def test_near_ties_may_swap_only_within_rounding():
     a, b = int(ridx[2]), int(ridx[3])
     twin = corpus[a].astype(np.float64)
     bump = np.random.default_rng(3).standard_normal(dim)
-    bump -= (bump @ q.astype(np.float64)) * q.astype(np.float64)          # orthogonal to the query: the cosine moves in second order
+    qd = q.astype(np.float64)
+    bump -= (bump @ qd) * qd                                                # orthogonal to the query ...
+    t_perp = twin - (twin @ qd) * qd
+    bump -= (bump @ t_perp) / (t_perp @ t_perp) * t_perp                    # ... and to the twin: the cosine moves in second order
     corpus[b] = (twin + 2e-4 * bump / np.linalg.norm(bump)).astype(np.float32)
     full = O.cosine_scan(q, corpus, 0)
     assert abs(float(full[a]) - float(full[b])) < 2e-6 and not np.array_equal(corpus[a], corpus[b])
