@@ -314,12 +314,21 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
     // per-lane offsets, no 64-bit vector address arithmetic and no per-lane predication in the item loop -- rows at
     // or past `seq` fall outside the descriptor and read as zeros / are not written (hardware bounds check).  The
     // vector ALU is the resource the f32 MFMAs run on here, so address math there is matrix time lost.
+    // Staging map (key row, 16-byte column) of piece `it` of this thread, chosen for the LDS: a half-wave holds 16 consecutive
+    // rows x two neighbouring columns.  V goes into LDS TRANSPOSED by 4-byte stores at [4 col + c][row] with a row stride of
+    // 132 floats, i.e. bank (16 col + 4 c + row) mod 32: 16 rows x (an even and an odd column) are 32 different banks.  With the
+    // row-major map (8 or 16 lanes along a row) the half-wave's eight columns fell on two banks per row -- 4-way conflicts on
+    // every one of the 16 transposing stores per item, a third of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT 9.4e6 of
+    // SQ_LDS_IDX_ACTIVE 2.9e7, profiles/r04m_pmc_pipeline_summary.txt).  K's 16-byte stores (8 lanes = 8 consecutive rows of one
+    // column: banks 4 (row + col) .. + 3) and every fragment read stay conflict-free; a global load still covers 64
+    // contiguous bytes of a row (lanes l, l + 16, l + 32, l + 48).
+    constexpr int COL_QUADS = V4_PER_ROW / 4;  // groups of four 16-byte columns per row
+    auto stage_row = [&](int it) { return 64 * (it / COL_QUADS) + 16 * wid + (lane & 15); };
+    auto stage_col = [&](int it) { return 4 * (it % COL_QUADS) + 2 * (lane >> 5) + ((lane >> 4) & 1); };
     uint32_t off_kv[STAGE_ITERS];
 #pragma unroll
-    for (int it = 0; it < STAGE_ITERS; ++it) {
-        const int f = tid + it * 256;
-        off_kv[it] = (uint32_t)(((int64_t)(f / V4_PER_ROW) * row_stride + (f % V4_PER_ROW) * 4) * 4);
-    }
+    for (int it = 0; it < STAGE_ITERS; ++it)
+        off_kv[it] = (uint32_t)(((int64_t)stage_row(it) * row_stride + stage_col(it) * 4) * 4);
     const uint32_t off_q = (uint32_t)(((int64_t)q_row * row_stride + half * 4) * 4);
     const uint32_t off_o = (uint32_t)(((int64_t)(wid * 32 + 4 * half) * hidden + l31) * 4);
     auto span_in_of = [&](int len) { return (int)((((int64_t)len - 1) * row_stride + D) * 4); };  // bytes of one head's rows of Q, K or V
@@ -439,8 +448,7 @@ __global__ __launch_bounds__(256, D >= 64 ? 2 : 3) void attention_pipe_kernel(co
         if (DIAG != 2 || item == (int64_t)first)
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
-            const int f = tid + it * 256;
-            const int r = f / V4_PER_ROW, c4 = f % V4_PER_ROW;
+            const int r = stage_row(it), c4 = stage_col(it);
             *reinterpret_cast<f32x4*>(sK + r * SM::K_STRIDE + c4 * 4) = kreg[it];
 #pragma unroll
             for (int c = 0; c < 4; ++c) sVt[(c4 * 4 + c) * SM::VT_STRIDE + r] = vreg[it][c];
