@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <atomic>
 
+#include <type_traits>
+
 #include "device_utils.h"
 #include "kernels.h"
 #include "tuning.h"
@@ -778,7 +780,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int MQ_Q = 64, MQ_D = 256, MQ_BK = 16, MQ_STRIDE = MQ_BK + 4;
 constexpr int MQ_STAGE_FLOATS = (MQ_Q + MQ_D) * MQ_STRIDE;
-constexpr int MQ_LDS_BYTES = (2 * MQ_STAGE_FLOATS + 2 * MQ_D + 2 * MQ_Q) * 4;
+constexpr int MQ_LDS_BYTES = (2 * MQ_STAGE_FLOATS + 2 * MQ_D + 3 * MQ_Q) * 4;
 
 // Selection inside the scan (FUSED).  VectorStore::search keeps the best k of every query (vector.rs:150-166); written out,
 // 64 queries x 10^7 documents are 2.56 GB of scores that the selection reads back (2.1 of 7.5 ms).  With a per-query lower
@@ -799,7 +801,13 @@ struct ScanFuse {
 
 // tile_stride > 1 (the sample pass, not FUSED): tiles 0, tile_stride, 2 tile_stride, ... are scanned and their scores written
 // compactly ([nq, n_tiles * 256]).  run_flag != null: the launch runs only if *run_flag != 0.
-template <int MODE, bool FUSED>
+// KIND: 0 scores out; 1 FUSED (selection inside the scan); 2 the sample pass of a fused search with a small k: instead of the
+// sampled tiles' scores only the MAXIMUM of every (query, tile, wave) -- 64 documents -- goes out ([nq, n_tiles * 4]): the k-th
+// largest of a query's maxima is a score that at least k documents reach, i.e. a valid bound, and for k far below the number of
+// maxima it is as tight as the k-th best of all sampled scores (P(max of 64 >= T) ~ 64 P(score >= T)) -- at a 64th of the
+// bytes and without the two-level selection over the sample (200 us of a 0.84 ms search of 10^6 documents).
+constexpr int SCAN_SCORES = 0, SCAN_FUSED = 1, SCAN_SAMPLE_MAX = 2;
+template <int MODE, int KIND>
 __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* __restrict__ queries, int nq,
                                                                   const float* __restrict__ corpus, int64_t n_docs, int dim,
                                                                   const float* __restrict__ qn2, float* __restrict__ scores,
@@ -812,6 +820,8 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     float* sDn = smem + 2 * MQ_STAGE_FLOATS;            // [2][256]: ||doc||^2 of a tile, by tile parity
     float* sQn = sDn + 2 * MQ_D;                        // [64]: sqrt(||q||^2)
     float* sThr = sQn + MQ_Q;                           // [64]: FUSED: the query's score bound
+    float* sTq = sThr + MQ_Q;                           // [64]: FUSED: the same bound for dot / ||doc|| (see the epilogue)
+    constexpr bool FUSED = KIND == SCAN_FUSED;
     if (run_flag != nullptr && *run_flag == 0u) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -821,8 +831,11 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     // two buffer descriptors and the loop state -- and every spilled one is a v_readlane in the K-loop)
     const int nt = (int)n_tiles, grid = (int)gridDim.x;
     if ((int)blockIdx.x >= nt) return;
+#ifdef KJARNI_TUNING
+    const bool same_tile = tile_stride < 0;
+    if (same_tile) tile_stride = 1;
+#endif
     const int my_tiles = (nt - 1 - (int)blockIdx.x) / grid + 1;
-    const int steps = my_tiles * nk;
 
     // staging: thread -> (row, 16-byte column); lanes 0-3 take row r, lanes 4-7 row r + 4 (see gemm_nt_f32_mfma_ln)
     const int ld_grp = tid >> 3;
@@ -840,51 +853,61 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) offD[i] = (uint32_t)(((int64_t)(ld_row + 64 * i) * dim + ld_c4 * 4) * 4);
 
-    // the staging side of the flat loop runs two steps ahead of the matrix side
+    // The staging side of the flat loop runs two steps ahead of the matrix side.  Everything a K-step does is STRAIGHT-LINE
+    // code -- no branch around a load, a store or the tile bookkeeping: the instruction groups below (sched_group_barrier:
+    // LDS writes and global loads dealt out between the MFMAs) only order instructions inside one basic block, and the
+    // compiler counts outstanding loads exactly only along straight-line code (with `if (last step of the tile)` branches in
+    // the body every K-step waited for ALL its loads, wrote its LDS stage and only then issued its first MFMA: 63 % of the
+    // f32 MFMA peak; rounds 3-4).  So: the tile of the next request advances by scalar selects, a request past the
+    // workgroup's last tile goes through a descriptor without extent (zeros, no traffic), and the once-per-tile work (norms,
+    // epilogue) sits between the K-step loops, not inside them.
     int s_tile = (int)blockIdx.x;  // tile of the step to be requested next
-    int s_k = 0, s_par = 0;        // its K-step; parity of the tile whose rows sit in the registers
+    int s_k = 0, s_par = 0;        // its K-step; parity of the tile whose rows the store side is on
     auto tile_rsrc = [&](int tile) {
-        const int64_t d0 = (int64_t)tile * tile_stride * MQ_D;
-        const int64_t rows = n_docs - d0 < MQ_D ? n_docs - d0 : MQ_D;   // documents past n_docs: zeros
+        int64_t d0 = (int64_t)tile * tile_stride * MQ_D;
+#ifdef KJARNI_TUNING
+        if (same_tile) d0 = 0;  // (diagnostic, cosine variant 3: every tile reads the corpus' first 256 rows -- no HBM stream)
+#endif
+        int64_t rows = n_docs - d0 < MQ_D ? n_docs - d0 : MQ_D;   // documents past n_docs: zeros
+        rows = (tile < nt && rows > 0) ? rows : 0;                // past the workgroup's last tile: no extent at all
+
         return rsrc(corpus + d0 * dim, rows * dim * 4);
     };
     __amdgpu_buffer_rsrc_t rD = tile_rsrc(s_tile);
     f32x4 gq, gd[4];
-    auto request = [&]() {  // the next step's rows -> registers
+    auto request = [&]() {  // the next step's rows -> registers; then on to the following step (branch-free)
         const int soff = s_k * MQ_BK * 4;
         gq = ld16(rQ, offQ, soff);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gd[i] = ld16(rD, offD[i], soff);
-        if (++s_k == nk) {
-            s_k = 0;
-            s_tile += grid;
-            if (s_tile < nt) rD = tile_rsrc(s_tile);
-        }
+        const bool wrap = s_k + 1 == nk;
+        s_k = wrap ? 0 : s_k + 1;
+        s_tile = wrap ? s_tile + grid : s_tile;
+        rD = tile_rsrc(s_tile);
     };
-    float sumsq[4] = {0.f, 0.f, 0.f, 0.f};
-    int st_k = 0;  // K-step of the rows in the registers
+    // ||doc||^2 on packed pairs (v_pk_fma_f32: two of a piece's four squares per instruction -- the K-loop's only vector
+    // arithmetic, and the f32 MFMAs do not hide it): even and odd elements accumulate apart and meet at the tile's end
+    f32x2 sumsq[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     auto store = [&](int stage) {  // registers -> LDS stage; the documents' squared norms on the way
         *reinterpret_cast<f32x4*>(sQ + stage * MQ_STAGE_FLOATS + st_off) = gq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<f32x4*>(sD + stage * MQ_STAGE_FLOATS + st_off + 64 * i * MQ_STRIDE) = gd[i];
-            sumsq[i] = fmaf(gd[i][0], gd[i][0], sumsq[i]);
-            sumsq[i] = fmaf(gd[i][1], gd[i][1], sumsq[i]);
-            sumsq[i] = fmaf(gd[i][2], gd[i][2], sumsq[i]);
-            sumsq[i] = fmaf(gd[i][3], gd[i][3], sumsq[i]);
+            const f32x2 lo = {gd[i][0], gd[i][1]}, hi = {gd[i][2], gd[i][3]};
+            sumsq[i] = __builtin_elementwise_fma(lo, lo, sumsq[i]);
+            sumsq[i] = __builtin_elementwise_fma(hi, hi, sumsq[i]);
         }
-        if (++st_k == nk) {  // the tile's last K-step: its norms are complete
-            st_k = 0;
+    };
+    auto finish_norms = [&]() {  // after the store of a tile's LAST K-step: its norms are complete
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = sumsq[i];
-                v += __shfl_xor(v, 1, kWave);
-                v += __shfl_xor(v, 2, kWave);
-                if (ld_c4 == 0) sDn[s_par * MQ_D + ld_row + 64 * i] = v;
-                sumsq[i] = 0.0f;
-            }
-            s_par ^= 1;
+        for (int i = 0; i < 4; ++i) {
+            float v = sumsq[i][0] + sumsq[i][1];
+            v += __shfl_xor(v, 1, kWave);
+            v += __shfl_xor(v, 2, kWave);
+            if (ld_c4 == 0) sDn[s_par * MQ_D + ld_row + 64 * i] = v;
+            sumsq[i] = f32x2{0.0f, 0.0f};
         }
+        s_par ^= 1;
     };
 
     if (tid < MQ_Q) {
@@ -894,6 +917,16 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
             if (tid < nq && fuse.thr_idx[(int64_t)(fuse.q_base + tid) * fuse.thr_k + fuse.thr_k - 1] >= 0)
                 t = fuse.thr_score[(int64_t)(fuse.q_base + tid) * fuse.thr_k + fuse.thr_k - 1];
             sThr[tid] = t;
+            // The cheap test of the epilogue: cosine >= t  <=>  dot / ||doc|| >= t ||q||  (norms above 1e-4: no clamp applies),
+            // relaxed by 4e-6 of its magnitude so that rounding can only ADMIT a score the exact comparison then rejects.  No
+            // bound (or a query too small for the rule): -inf, everything goes to the exact comparison; rows past nq: +inf.
+            float tq = INFINITY;
+            if (tid < nq) {
+                const float qn = sqrtf(qn2[tid]);
+                const float b = t * qn;
+                tq = (t == -INFINITY || !(qn >= 1e-4f) || b != b) ? -INFINITY : b - 4e-6f * fabsf(b) - 1e-30f;
+            }
+            sTq[tid] = tq;
         }
     }
 
@@ -931,19 +964,29 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     // prologue: step 0 -> LDS stage 0, step 1 in flight in the registers, fragments kk = 0 of step 0
     request();
     store(0);
-    if (steps > 1) request();
+    request();
     __syncthreads();
     Frag fr[2];
     read_frag(fr[0], 0, 0);
 
+    // FUSED: this lane's 32 bounds (query = accumulator register x lane half) in registers for the whole launch
+    float tq[FUSED ? 32 : 1];
+    if (FUSED) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tq[i * 16 + r] = sTq[i * 32 + acc_row(r, half)];  // (written before the prologue's barrier)
+    }
+
     int c_tile = (int)blockIdx.x;  // tile the matrix side is on
-    int c_k = 0, c_par = 0;
-    for (int g = 0; g < steps; ++g) {
-        const int cur = g & 1;
-        // phase 0: fragments of the second half of this step; step g + 1 -> the other LDS stage; request step g + 2
+    int c_par = 0, cur = 0;        // parity of its norms; LDS stage of the step being multiplied
+    // One K-step (straight-line).  NORMS: the rows stored in this step are a tile's last K-step.
+    auto kstep = [&](auto norms_tag) {
+        constexpr bool NORMS = decltype(norms_tag)::value;
+        // phase 0: fragments of the second half of this step; the next step -> the other LDS stage; request the one after
         read_frag(fr[1], cur, 1);
-        if (g + 1 < steps) store(cur ^ 1);
-        if (g + 2 < steps) request();
+        store(cur ^ 1);
+        request();
         mfma16(fr[0]);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 4 fragment reads first
 #pragma unroll
@@ -954,12 +997,20 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (NORMS) finish_norms();
         // phase 1: everyone has read stage cur and written stage cur ^ 1
         __syncthreads();
-        if (g + 1 < steps) read_frag(fr[0], cur ^ 1, 0);
+        read_frag(fr[0], cur ^ 1, 0);
         mfma16(fr[1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (++c_k == nk) {
+        cur ^= 1;
+    };
+    for (int t = 0; t < my_tiles; ++t) {
+        // K-steps 0 .. nk - 3; nk - 2 (whose store completes this tile's rows: norms); nk - 1 (stores the next tile's first step)
+        for (int ks = 0; ks + 2 < nk; ++ks) kstep(std::false_type{});
+        kstep(std::true_type{});
+        kstep(std::false_type{});
+        {
             // The tile is complete: cosines out, accumulators cleared.  dot / den as one v_rcp_f32 + a Newton step on the
             // quotient (r = 1 / den to 1 ulp, v = dot r, v += (dot - den v) r): the IEEE division sequence without its
             // range scaling, which den = ||q|| ||doc|| never needs; 6 vector instructions per score instead of 15 -- the
@@ -967,64 +1018,130 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
             const int64_t d_base = (int64_t)c_tile * MQ_D + wid * 64 + l31;          // where the score goes (compact in a sample pass)
             const int64_t a_base = (int64_t)c_tile * tile_stride * MQ_D + wid * 64 + l31;  // the document's index
             const bool whole = nq == MQ_Q && ((int64_t)c_tile * tile_stride + 1) * MQ_D <= n_docs;  // no row or column of the tile is cut
+            auto cosine_of = [&](float dot, float qn, float dn) {
+                const float den = MODE == 0 ? fmaxf(qn * dn, 1e-9f) : qn * dn;   // vector.rs:131-148 | segment.rs:355-371
+                const float rc = __builtin_amdgcn_rcpf(den);
+                float v = dot * rc;
+                v = fmaf(fmaf(-den, v, dot), rc, v);
+                if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
+                return v;
+            };
+            if (KIND == SCAN_SCORES) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int64_t d = d_base + j * 32, ad = a_base + j * 32;
-                const float dn = sqrtf(sDn[c_par * MQ_D + wid * 64 + j * 32 + l31]);
-                float* out = scores + d;
-                bool hit[FUSED ? 32 : 1];
-                float val[FUSED ? 32 : 1];
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t d = d_base + j * 32, ad = a_base + j * 32;
+                    const float dn = sqrtf(sDn[c_par * MQ_D + wid * 64 + j * 32 + l31]);
+                    float* out = scores + d;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int q = i * 32 + acc_row(r, half);
+                            const float v = cosine_of(acc[i][j][r], sQn[q], dn);
+                            if (whole || (q < nq && ad < n_docs)) out[(int64_t)q * stride] = v;
+                            acc[i][j][r] = 0.0f;
+                        }
+                }
+            } else if (KIND == SCAN_SAMPLE_MAX) {
+                // the largest cosine of each of this lane-half's 32 queries over the wave's 64 documents (a NaN never wins)
+                const float dn0 = sqrtf(sDn[c_par * MQ_D + wid * 64 + l31]), dn1 = sqrtf(sDn[c_par * MQ_D + wid * 64 + 32 + l31]);
+                const bool ok0 = a_base < n_docs, ok1 = a_base + 32 < n_docs;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int q = i * 32 + acc_row(r, half);
                         const float qn = sQn[q];
-                        const float dot = acc[i][j][r];
-                        const float den = MODE == 0 ? fmaxf(qn * dn, 1e-9f) : qn * dn;   // vector.rs:131-148 | segment.rs:355-371
-                        const float rc = __builtin_amdgcn_rcpf(den);
-                        float v = dot * rc;
-                        v = fmaf(fmaf(-den, v, dot), rc, v);
-                        if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
-                        if (FUSED) {
-                            // (not below the bound: ties and NaN scores go to the exact comparison of the selection)
-                            hit[i * 16 + r] = (whole || (q < nq && ad < n_docs)) && !(v < sThr[q]);
-                            val[i * 16 + r] = v;
-                        } else if (whole || (q < nq && ad < n_docs)) {
-                            out[(int64_t)q * stride] = v;
-                        }
-                        acc[i][j][r] = 0.0f;
+                        const float v0 = cosine_of(acc[i][0][r], qn, dn0), v1 = cosine_of(acc[i][1][r], qn, dn1);
+                        float m = fmaxf(ok0 ? v0 : -INFINITY, ok1 ? v1 : -INFINITY);
+                        m = fmaxf(m, __shfl_xor(m, 1, kWave));
+                        m = fmaxf(m, __shfl_xor(m, 2, kWave));
+                        m = fmaxf(m, __shfl_xor(m, 4, kWave));
+                        m = fmaxf(m, __shfl_xor(m, 8, kWave));
+                        m = fmaxf(m, __shfl_xor(m, 16, kWave));
+                        if (l31 == 0 && q < nq) scores[(int64_t)q * stride + (int64_t)c_tile * 4 + wid] = m;
+                        acc[i][0][r] = 0.0f;
+                        acc[i][1][r] = 0.0f;
                     }
-                if (FUSED) {
-                    // one vote per 32 x 64 block of scores; the appends (rare once the bounds are in place) run per score: the two
-                    // half-waves of a register belong to two queries, each half appends to its query's list with one atomic
-                    bool any = false;
+            } else {
+                // FUSED.  Nearly every score is below its query's bound, so the common path decides that with ONE multiply and
+                // one compare per score -- dot x (1 / ||doc||) against the bound in that domain (tq, relaxed: it may admit, never
+                // reject, what the exact comparison would keep; a NaN passes; a document too small for the rule passes) -- and
+                // only a block of 32 x 64 scores in which some lane saw a pass computes cosines, compares exactly and appends:
+                // the two half-waves of a register belong to two queries, each half appends to its query's list with one atomic.
 #pragma unroll
-                    for (int e = 0; e < 32; ++e) any = any || hit[e];
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t ad = a_base + j * 32;
+                    const float dn2 = sDn[c_par * MQ_D + wid * 64 + j * 32 + l31];
+                    const float dn = sqrtf(dn2);
+                    const bool small_doc = !(dn >= 1e-4f);
+                    const float idn = __builtin_amdgcn_rcpf(dn);
+                    bool any = small_doc;
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) any = any || !(acc[e >> 4][j][e & 15] * idn < tq[e]);
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int e = 0; e < 32; ++e) {
-                            const uint64_t m = __ballot(hit[e]);
+                            int q = (e >> 4) * 32 + acc_row(e & 15, half);
+                            // (opaque: otherwise the 32 list addresses below are hoisted out of the K-loop into 64 registers)
+                            asm volatile("" : "+v"(q));
+                            const float v = cosine_of(acc[e >> 4][j][e & 15], sQn[q], dn);
+                            // (not below the bound: ties and NaN scores go to the exact comparison of the selection)
+                            const bool hit = (whole || (q < nq && ad < n_docs)) && !(v < sThr[q]);
+                            const uint64_t m = __ballot(hit);
                             if (m == 0ull) continue;
-                            const int q = (e >> 4) * 32 + acc_row(e & 15, half);
                             const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
                             const int leader = (half << 5) + (mh ? __ffs((int)mh) - 1 : 0);
                             unsigned base = 0;
                             if (mh != 0u && lane == leader) base = atomicAdd(fuse.cand_count + 1 + fuse.q_base + q, (unsigned)__popc(mh));
                             base = (unsigned)__shfl((int)base, leader, kWave);
-                            if (hit[e]) {
+                            if (hit) {
                                 const unsigned at = base + (unsigned)__popc(mh & ((1u << l31) - 1u));
-                                if (at < fuse.cap) fuse.cand_key[(size_t)(fuse.q_base + q) * fuse.cap + at] = make_key(val[e], (uint32_t)ad);
+                                if (at < fuse.cap) fuse.cand_key[(size_t)(fuse.q_base + q) * fuse.cap + at] = make_key(v, (uint32_t)ad);
                                 else fuse.cand_count[0] = 1u;  // overflow: the two-call form behind this launch takes over
                             }
                         }
                     }
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) acc[e >> 4][j][e & 15] = 0.0f;
                 }
             }
-            c_k = 0;
             c_par ^= 1;
             c_tile += grid;
         }
+    }
+}
+
+// The bound of a fused search from the sample pass's maxima (SCAN_SAMPLE_MAX): the k-th largest of a query's `n` maxima, or
+// "no bound" (index -1) when fewer than k of them are finite.  One block per query, n <= 4 096: the maxima stay in registers as
+// 32-bit orderable keys and the k-th largest is found bit by bit from the top -- the largest x with at least k keys >= x --
+// 32 counting rounds (sixteen ballots + four LDS words each) instead of a sort.
+__global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ maxima, int n, int64_t stride, int k,
+                                                           float* __restrict__ thr_score, int64_t* __restrict__ thr_idx)
+{
+    __shared__ int wave_count[2][4];
+    const int tid = threadIdx.x, q = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t key[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int at = tid + 256 * i;
+        const float v = at < n ? maxima[(int64_t)q * stride + at] : -INFINITY;
+        key[i] = (v > -INFINITY) ? orderable(v) : 0u;   // (-inf, NaN and padding: 0; a finite score's key is never 0)
+    }
+    uint32_t found = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = found | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += __popcll(__ballot(key[i] >= cand));   // (the wave's count: wave-uniform)
+        if (lane == 0) wave_count[bit & 1][wid] = c;
+        __syncthreads();   // (two alternating slots: one barrier per round)
+        const int total = wave_count[bit & 1][0] + wave_count[bit & 1][1] + wave_count[bit & 1][2] + wave_count[bit & 1][3];
+        if (total >= k) found = cand;
+    }
+    if (tid == 0) {
+        thr_idx[q] = found == 0u ? -1 : 0;
+        thr_score[q] = found == 0u ? -INFINITY : from_orderable(found);
     }
 }
 
@@ -1036,9 +1153,10 @@ hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_
 //   tile_stride > 1: the sample pass (scores of every tile_stride-th tile, compact, row length `score_stride`)
 //   fuse != null:    selection inside the scan (no scores): candidates into fuse's list
 //   run_flag:        the launches run only if *run_flag != 0
+//   sample_max:      (with tile_stride) per-(query, tile, wave) maxima [nq, n_tiles * 4] into `scores` instead of the scores
 hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
                      float* scores, hipStream_t stream, int tile_stride = 1, int64_t score_stride = -1, const ScanFuse* fuse = nullptr,
-                     const unsigned* run_flag = nullptr)
+                     const unsigned* run_flag = nullptr, bool sample_max = false)
 {
     float* qn2 = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&qn2), (size_t)(nq + 8) * sizeof(float), stream);
@@ -1053,15 +1171,18 @@ hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t 
         ScanFuse f = fuse ? *fuse : ScanFuse{};
         f.q_base = q0;
         float* sc = scores ? scores + (int64_t)q0 * score_stride : nullptr;
-#define KJ_SCAN(MODE_, FUSED_)                                                                                                      \
-    hipLaunchKernelGGL((cosine_scan_mfma_kernel<MODE_, FUSED_>), dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, \
-                       m, corpus, n_docs, dim, qn2 + q0, sc, score_stride, n_tiles, tile_stride, run_flag, f)
+#define KJ_SCAN(MODE_, KIND_)                                                                                                       \
+    hipLaunchKernelGGL((cosine_scan_mfma_kernel<MODE_, KIND_>), dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, \
+                       m, corpus, n_docs, dim, qn2 + q0, sc, score_stride, n_tiles, (tune::scan_same_tile() && tile_stride == 1) ? -1 : tile_stride, run_flag, f)
         if (fuse) {
-            if (mode == 0) KJ_SCAN(0, true);
-            else KJ_SCAN(1, true);
+            if (mode == 0) KJ_SCAN(0, SCAN_FUSED);
+            else KJ_SCAN(1, SCAN_FUSED);
+        } else if (sample_max) {
+            if (mode == 0) KJ_SCAN(0, SCAN_SAMPLE_MAX);
+            else KJ_SCAN(1, SCAN_SAMPLE_MAX);
         } else {
-            if (mode == 0) KJ_SCAN(0, false);
-            else KJ_SCAN(1, false);
+            if (mode == 0) KJ_SCAN(0, SCAN_SCORES);
+            else KJ_SCAN(1, SCAN_SCORES);
         }
 #undef KJ_SCAN
         e = hipGetLastError();
@@ -1236,6 +1357,7 @@ void final_lists(int kpad, const uint64_t* keys, int lists, int k, int64_t* out_
 namespace {
 constexpr size_t kManyCandCap = (size_t)4 << 20;       // candidate keys of the fused many-query scan over all its queries (32 MB)
 constexpr int64_t kManyFusedMinDocs = 400000;           // below: the two-call form (its selection is a small share there)
+constexpr int kSampleMaxK = 128;                        // up to this k the sample pass hands over per-wave maxima, not scores
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 }  // namespace
 
@@ -1308,11 +1430,22 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         const int64_t ns = (all_tiles + ts - 1) / ts;
         const int64_t last_rows = std::min<int64_t>(MQ_D, n_docs - (ns - 1) * ts * (int64_t)MQ_D);
         const int64_t n_sample = (ns - 1) * MQ_D + last_rows;
-        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, n_sample);
-        if (e != hipSuccess) return e;
-        e = cosine_topk_impl(scores, nq, n_sample, k, topk_ws, thr_idx, thr_score, stream, nullptr);
-        if (e != hipSuccess) return e;
-        ScanFuse f{thr_score, thr_idx, k, cand_key, counters, cap_q, 0};
+        int thr_k = k;
+        if (k <= kSampleMaxK && ns * 4 <= 4096 && ns * 4 >= 8 * (int64_t)k) {
+            // a small k: the bound is the k-th largest of the sampled tiles' per-wave maxima (SCAN_SAMPLE_MAX) -- no sample scores
+            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, ns * 4, nullptr, nullptr, true);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)(ns * 4), ns * 4, k, thr_score, thr_idx);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            thr_k = 1;
+        } else {
+            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, n_sample);
+            if (e != hipSuccess) return e;
+            e = cosine_topk_impl(scores, nq, n_sample, k, topk_ws, thr_idx, thr_score, stream, nullptr);
+            if (e != hipSuccess) return e;
+        }
+        ScanFuse f{thr_score, thr_idx, thr_k, cand_key, counters, cap_q, 0};
         e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, nullptr, stream, 1, -1, &f);
         if (e != hipSuccess) return e;
         const int kpad = kpad_for(k);

@@ -35,6 +35,7 @@
 // cosine variant (kjarni_hip_set_cosine_variant):
 //    1  streaming passes only (no GEMM route for many queries)
 //    2  one query: scores + selection as separate launches instead of the fused pass
+//    3  many queries (diagnostic, results meaningless): every tile of the matrix-core scan reads the corpus' first 256 rows -- the kernel without its HBM stream
 #pragma once
 
 #ifdef KJARNI_TUNING
@@ -85,6 +86,7 @@ inline bool no_split_attention() { return attention() == 22 || attention() == 21
 
 inline bool scan_streaming_only() { return cosine() == 1; }
 inline bool scan_two_launches() { return cosine() == 2; }
+inline bool scan_same_tile() { return cosine() == 3; }
 
 }  // namespace tune
 }  // namespace kjarni

@@ -295,19 +295,21 @@ def test_one_call_search_equals_scores_plus_topk(n, dim, k):
             assert np.abs(sa[:kk] - rsc).max() < 1e-4
 
 
+@pytest.mark.parametrize("k", [12, 200])
 @pytest.mark.parametrize("case", ["random", "ascending", "overflow"])
-def test_many_queries_one_call_selects_inside_the_scan(case):
+def test_many_queries_one_call_selects_inside_the_scan(case, k):
     """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries selects inside the matrix-core scan: a strided
     sample of the corpus gives every query a lower bound of its k-th best score, the full scan appends only scores at or above
     it to a candidate list, a per-query selection finishes -- no [queries, documents] score array.  Same indices and score bits
     as kjarni_hip_cosine_scores + kjarni_hip_cosine_topk: on random rows; on rows whose scores ascend with the index (the sample
     under-estimates every bound); and when the candidate list overflows (identical queries, every sampled tile anti-correlated,
-    every other row correlated: 28 M candidates against a 4 M list), where the queued two-call form takes over."""
+    every other row correlated: 28 M candidates against a 4 M list), where the queued two-call form takes over.
+    k = 12: the bound comes from the sampled tiles' per-wave maxima (k <= 128); k = 200: from the sample's own top-k."""
     import torch
     from kjarni_amd import _ffi
     L = _ffi.lib()
     dev = torch.device("cuda", 0)
-    n, dim, nq, k = 450_123, 384, 70, 12
+    n, dim, nq = 450_123, 384, 70
     g = torch.Generator(device=dev).manual_seed(11)
     corpus = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
     q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)

@@ -10,6 +10,6 @@ B, S, heads, d = (a + [32, 2048, 12, 64][len(a):])[:4]
 rng = np.random.default_rng(0)
 qkv = (rng.standard_normal((B, S, 3 * heads * d)) * 0.5).astype(np.float32)
 mask = np.ones((B, S), np.uint32)
-out, ms = ops.attention(qkv, mask, heads, iters=5)
+out, ms = ops.attention(qkv, mask, heads, iters=50)
 fl = 4.0 * B * S * S * heads * d
 print(f"attention d={d} B={B} S={S}: {ms:.3f} ms, {fl / ms / 1e9:.1f} TFLOP/s")

@@ -12,6 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0   # (tuning build: kjarni_hip_set_cosine_variant)
 dim = 384
 L = _ffi.lib()
 dev = torch.device("cuda", 0)
@@ -22,6 +23,9 @@ ws = torch.empty(L.kjarni_hip_cosine_search_workspace_bytes(nq, n, dim, k), dtyp
 idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
 sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
+if variant:
+    from kjarni_amd import ops
+    ops.set_cosine_variant(variant)
 
 
 def run():
@@ -37,4 +41,4 @@ for _ in range(reps):
     run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-print(f"n {n} nq {nq} k {k}: {dt * 1e3:.3f} ms per search", flush=True)
+print(f"n {n} nq {nq} k {k}{' variant ' + str(variant) if variant else ''}: {dt * 1e3:.3f} ms per search", flush=True)
