@@ -823,7 +823,6 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     float* sTq = sThr + MQ_Q;                           // [64]: FUSED: the same bound for dot / ||doc|| (see the epilogue)
     constexpr bool FUSED = KIND == SCAN_FUSED;
     if (run_flag != nullptr && *run_flag == 0u) return;
-
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int nk = dim / MQ_BK;
@@ -832,8 +831,14 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
     const int nt = (int)n_tiles, grid = (int)gridDim.x;
     if ((int)blockIdx.x >= nt) return;
 #ifdef KJARNI_TUNING
-    const bool same_tile = tile_stride < 0;
-    if (same_tile) tile_stride = 1;
+    // (diagnostics, cosine variants 3 / 4 / 5: -1 every tile reads the corpus' first 256 rows; -2 that and no epilogue;
+    // -3 that and no norm arithmetic in the K-loop)
+    // -4 / -5: the real corpus stream without the epilogue / without the norm arithmetic
+    const bool same_tile = tile_stride < 0 && tile_stride >= -3, diag_no_epilogue = tile_stride == -2 || tile_stride == -4,
+               diag_no_norms = tile_stride == -3 || tile_stride == -5;
+    if (tile_stride < 0) tile_stride = 1;
+#else
+    constexpr bool diag_no_epilogue = false, diag_no_norms = false;
 #endif
     const int my_tiles = (nt - 1 - (int)blockIdx.x) / grid + 1;
 
@@ -893,9 +898,11 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<f32x4*>(sD + stage * MQ_STAGE_FLOATS + st_off + 64 * i * MQ_STRIDE) = gd[i];
-            const f32x2 lo = {gd[i][0], gd[i][1]}, hi = {gd[i][2], gd[i][3]};
-            sumsq[i] = __builtin_elementwise_fma(lo, lo, sumsq[i]);
-            sumsq[i] = __builtin_elementwise_fma(hi, hi, sumsq[i]);
+            if (!diag_no_norms) {
+                const f32x2 lo = {gd[i][0], gd[i][1]}, hi = {gd[i][2], gd[i][3]};
+                sumsq[i] = __builtin_elementwise_fma(lo, lo, sumsq[i]);
+                sumsq[i] = __builtin_elementwise_fma(hi, hi, sumsq[i]);
+            }
         }
     };
     auto finish_norms = [&]() {  // after the store of a tile's LAST K-step: its norms are complete
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
             if (tid < nq) {
                 const float qn = sqrtf(qn2[tid]);
                 const float b = t * qn;
-                tq = (t == -INFINITY || !(qn >= 1e-4f) || b != b) ? -INFINITY : b - 4e-6f * fabsf(b) - 1e-30f;
+                tq = (t == -INFINITY || !(qn >= 1e-4f && qn < INFINITY) || b != b) ? -INFINITY : b - 4e-6f * fabsf(b) - 1e-30f;
             }
             sTq[tid] = tq;
         }
@@ -1026,7 +1033,19 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                 if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
                 return v;
             };
-            if (KIND == SCAN_SCORES) {
+            if (diag_no_epilogue) {
+                float keep = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            keep += acc[i][j][r];
+                            acc[i][j][r] = 0.0f;
+                        }
+                if (keep == 123456.789f) scores[0] = keep;
+            } else if (KIND == SCAN_SCORES) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int64_t d = d_base + j * 32, ad = a_base + j * 32;
@@ -1074,14 +1093,27 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                     const int64_t ad = a_base + j * 32;
                     const float dn2 = sDn[c_par * MQ_D + wid * 64 + j * 32 + l31];
                     const float dn = sqrtf(dn2);
-                    const bool small_doc = !(dn >= 1e-4f);
+                    const bool odd_doc = !(dn >= 1e-4f && dn < INFINITY);   // too small for the rule, or not finite: exact path
                     const float idn = __builtin_amdgcn_rcpf(dn);
-                    bool any = small_doc;
+                    // margin of every score over its bound, two per instruction (v_pk_fma_f32 / v_pk_max_f32); a pass is a
+                    // margin >= 0.  (A NaN margin would be dropped by the max: a NaN dot product needs a non-finite document --
+                    // odd_doc -- or a non-finite query, whose bound is -inf: margin +inf.)
+                    const f32x2 idn2 = {idn, idn};
+                    f32x2 top = {-INFINITY, -INFINITY};
 #pragma unroll
-                    for (int e = 0; e < 32; ++e) any = any || !(acc[e >> 4][j][e & 15] * idn < tq[e]);
+                    for (int e = 0; e < 32; e += 2) {
+                        const f32x2 dots = {acc[e >> 4][j][e & 15], acc[e >> 4][j][(e & 15) + 1]};
+                        const f32x2 margin = __builtin_elementwise_fma(dots, idn2, f32x2{-tq[e], -tq[e + 1]});
+                        top = __builtin_elementwise_max(top, margin);
+                    }
+                    const bool any = odd_doc || fmaxf(top[0], top[1]) >= 0.0f;
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int e = 0; e < 32; ++e) {
+                            // (the cheap test again, per register: at ~1e-4 passes per score a block that has one has ONE, and
+                            // the exact cosine + list bookkeeping below run for that register only, not for all 32)
+                            const float margin = fmaf(acc[e >> 4][j][e & 15], idn, -tq[e]);
+                            if (__ballot(odd_doc || margin >= 0.0f) == 0ull) continue;
                             int q = (e >> 4) * 32 + acc_row(e & 15, half);
                             // (opaque: otherwise the 32 list addresses below are hoisted out of the K-loop into 64 registers)
                             asm volatile("" : "+v"(q));
@@ -1173,7 +1205,7 @@ hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t 
         float* sc = scores ? scores + (int64_t)q0 * score_stride : nullptr;
 #define KJ_SCAN(MODE_, KIND_)                                                                                                       \
     hipLaunchKernelGGL((cosine_scan_mfma_kernel<MODE_, KIND_>), dim3(grid), dim3(256), MQ_LDS_BYTES, stream, queries + (int64_t)q0 * dim, \
-                       m, corpus, n_docs, dim, qn2 + q0, sc, score_stride, n_tiles, (tune::scan_same_tile() && tile_stride == 1) ? -1 : tile_stride, run_flag, f)
+                       m, corpus, n_docs, dim, qn2 + q0, sc, score_stride, n_tiles, (tune::scan_diag() && tile_stride == 1) ? -tune::scan_diag() : tile_stride, run_flag, f)
         if (fuse) {
             if (mode == 0) KJ_SCAN(0, SCAN_FUSED);
             else KJ_SCAN(1, SCAN_FUSED);
