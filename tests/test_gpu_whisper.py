@@ -29,7 +29,11 @@ def audio():
     return synth.synthetic_audio(30.0, seed=1)
 
 
-def test_log_mel(env, audio):
+def test_log_mel_values_unpinned_in_the_reference_held_to_the_restatement(env, audio):
+    """The reference's tests pin only the SHAPE of the log-mel spectrogram (crates/kjarni-models/src/models/whisper tests: (80,
+    3000), no value golden), so this stage's parity is pinned by construction, not by the reference: the HIP front end is held to
+    oracle/whisper_oracle.py's restatement of the same f32 DFT at 2e-4 (that restatement to a float64 evaluation at 2e-3,
+    tests/test_whisper_oracle.py)."""
     for a in (audio, audio[:100_000], synth.synthetic_audio(0.05, seed=2)):
         ref = W.log_mel(a)
         got = env["gpu"].log_mel(a)
