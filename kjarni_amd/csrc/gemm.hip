@@ -287,6 +287,10 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
     // That is the plain epilogue's scheme (the persistent launch: QKV +0.5 %).  Epilogues with arithmetic (GELU, ...) run one
     // workgroup per tile and keep ONE round of 64 rows over the whole operand area: sixteen independent 16-byte pieces per
     // thread in flight through the activation instead of eight (FC1 + GELU measured 1.7 % slower in two rounds).
+    // (Round 5 measured the alternative without the transpose -- operands swapped so that a lane holds one output row and four
+    // registers a 16-byte piece of it, stores straight from the accumulators: bit-identical, 10 % SLOWER; a store instruction
+    // then covers 32 rows x 32 bytes instead of 4 rows x 256.  Where a K = 384 tile's epilogue goes (tuning build, gemm variants
+    // 9 / 52): the global stores 4.5-5 % of the kernel, the LDS transpose + bias 1.5 %, the GELU arithmetic 5 % more.)
     constexpr bool kSplitRounds = EPI == EPI_BIAS;
     constexpr int EROWS = kSplitRounds ? 32 : 64;
     static_assert(2 * 32 * EPI_STRIDE <= TILE_FLOATS, "two waves' epilogue regions must fit one operand stage");
@@ -334,7 +338,9 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = epilogue<EPI>(v[c]);
             }
-            if (m < M) {
+            if (DIAG == 2) {  // (diagnostic: the epilogue's LDS transpose and arithmetic without its global stores)
+                if (v[0] + v[1] + v[2] + v[3] == 123456.789f) Y[0] = v[0];
+            } else if (m < M) {
                 // OUT_POLICY 1 (outputs larger than the memory-side cache): streaming stores.  Plain ones leave the tile's 64 KB in
                 // the XCD's L2, where they evict the A panels and weights the neighbouring tiles are still reading -- FC1 + GELU
                 // at 262 144 rows fetched 1.31 GB for 0.41 GB of operands (PMC, profiles/r04n_traffic_ab.log: 0.43 GB with streaming
@@ -1262,6 +1268,7 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
     if (aligned) {
 #ifdef KJARNI_TUNING
         if (tune::tiles_without_epilogue()) return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        if (tune::tiles_without_stores()) return launch_tiled<EPI, 32, 2>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
 #endif
         if (get_f32_on_bf16() && K % 64 == 0) return launch_gemm_split(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, (GemmEpilogue)EPI, stream);
         return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);

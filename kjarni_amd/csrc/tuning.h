@@ -17,6 +17,7 @@
 //   31..34  persistent grid of the 64 x 64-tile kernel: 768 / 512 / 256 / 1 280 workgroups instead of 1 024
 //   21..26  knock-out diagnostics of the 64 x 64-tile kernel (unsliced launches): its DIAG template parameter 1..6
 //   17  f32-on-bf16 mode: the 64 x 64-tile route stays on the f32 matrix cores
+//   52  128 x 128 tiles: the epilogue without its global stores (diagnostic)
 // 100000 + r  f32-on-bf16 mode: the split kernel takes calls from r rows (instead of 6 144: gemm.hip, split_min_rows()) in place of the 64 x 64-tile route
 // 1000 + r  the few-rows kernel takes calls of up to r rows (sweeps of the few-rows / 64 x 64-tile crossover), r < 1000
 //    8  mid-size calls on the 64 x 64 tiles of gemm.hip instead of gemm_flex.hip's per-call tile
@@ -78,6 +79,7 @@ inline bool flex_any_rows() { return gemm() < 100000 && gemm() % 10000 >= 5000 &
 inline int flex_knockout() { return gemm() >= 12000 && gemm() < 100000 && flex_config_override() ? gemm() / 10000 : 0; }
 inline bool no_flex_route() { return gemm() == 8; }
 inline bool no_streaming_output_stores() { return gemm() == 12; }
+inline bool tiles_without_stores() { return gemm() == 52; }
 
 inline bool no_pipelined_attention() { return attention() == 1; }
 inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }
