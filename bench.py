@@ -965,7 +965,11 @@ def main():
 
     scan = None
     if rank == 0 and world == 1 and not rerank and not dry and not args.no_scan:
-        scan = scan_leg(torch, np, dev, args.scan_docs)
+        try:
+            scan = scan_leg(torch, np, dev, args.scan_docs)
+        except Exception as e:  # (an auxiliary leg must not take the headline line down with it; the failure is in the line)
+            print(f"bench.py: scan leg failed: {e!r}", file=sys.stderr, flush=True)
+            scan = {"error": repr(e)}
 
     if rank == 0:
         total = n_total * args.steps
