@@ -767,18 +767,21 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = {}
     if instrument:
-        side.synchronize()
-        timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
-        pr = probes.cpu().numpy().astype(np.float64)
-        ghz = [round(float(c / t / 10.0), 3) if t > 0 else None for c, t in pr]
-        timing["clock_ghz"] = ghz
-        timing["clock_ghz_first"], timing["clock_ghz_last"] = ghz[0], ghz[-1]
-        timing["clock_note"] = ("clock_ghz[i]: shader cycles per 10 ns tick over a 50 us one-wave probe that starts with timed step i "
-                                "(side stream); the last entry follows the last step")
-        if sensors:
-            timing["gpu_sensors"] = sensors.stop()
-            timing["gpu_sensors"]["rocm_smi_before"] = smi_before
-            timing["gpu_sensors"]["rocm_smi_after"] = GpuSensors.snapshot()
+        try:
+            side.synchronize()
+            timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
+            pr = probes.cpu().numpy().astype(np.float64)
+            ghz = [round(float(c / t / 10.0), 3) if t > 0 else None for c, t in pr]
+            timing["clock_ghz"] = ghz
+            timing["clock_ghz_first"], timing["clock_ghz_last"] = ghz[0], ghz[-1]
+            timing["clock_note"] = ("clock_ghz[i]: shader cycles per 10 ns tick over a 50 us one-wave probe that starts with timed step i "
+                                    "(side stream); the last entry follows the last step")
+            if sensors:
+                timing["gpu_sensors"] = sensors.stop()
+                timing["gpu_sensors"]["rocm_smi_before"] = smi_before
+                timing["gpu_sensors"]["rocm_smi_after"] = GpuSensors.snapshot()
+        except Exception as e:  # (diagnostics only: never at the price of the line)
+            timing["instrumentation_error"] = repr(e)
     stats = enc.profile_end() if profile else []
     all_stats = []
     if profile and rank == 0 and world == 1:
