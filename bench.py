@@ -29,8 +29,8 @@ the PCIe-inclusive rate of the same workload is `value_host_ptrs`.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   steps_ms      wall time of every timed step (HIP events on the launch stream, resolved after the region's final
                 synchronisation: no extra sync inside the region)
-  clock_ghz     the shader clock the chip holds at the start of every timed step and after the last one (a one-wave
-                probe on a side stream: shader cycles per 10 ns tick, kjarni_hip_clock_probe), `clock_ghz_first` /
+  clock_ghz     the shader clock the chip holds in front of every timed step and after the last one (a one-wave, 20 us
+                probe on the launch stream: shader cycles per 10 ns tick, kjarni_hip_clock_probe), `clock_ghz_first` /
                 `clock_ghz_last`; `gpu_sensors`: board power / temperature / sclk sampled from sysfs during the region
                 (+ rocm-smi before and after) -- what tells a slower box from a power-limited long run
   scan          (N = 1, embed) the other half of the hot path, R14: cosine search (scan + top-10) of 1 and of 64 queries
@@ -598,6 +598,7 @@ def main():
     ap.add_argument("--no-scan", action="store_true", help="embed workload: skip the cosine-search (R14) leg")
     ap.add_argument("--scan-docs", type=int, default=1_000_000, help="corpus rows of the scan leg (10 000 000 on request)")
     ap.add_argument("--no-sensors", action="store_true", help="do not sample sysfs / rocm-smi around the timed region")
+    ap.add_argument("--no-instrument", action="store_true", help="no per-step events, clock probes or sensors at all")
     ap.add_argument("--weights", choices=("trained", "init"), default="trained",
                     help="tests/synth.py weight family: trained-checkpoint statistics (default) or N(0, 0.02) initialisation")
     ap.add_argument("--in-process", action="store_true",
@@ -729,14 +730,15 @@ def main():
     if profile:
         enc.profile_begin(GEMM_KINDS)
     # Per-step wall time and shader clock WITHOUT a synchronisation inside the region: an event on the launch stream after
-    # every step, and a one-wave probe on a side stream that starts when step i starts (it waits for the event that ends step
-    # i - 1) and stamps shader cycles against the 100 MHz counter for 50 us -- the clock the chip holds under that step's load.
+    # every step, and in front of every step a one-wave probe ON THE SAME STREAM that stamps shader cycles against the 100 MHz
+    # counter for 20 us (0.0014 % of a step) -- the clock the power controller holds at that point of the run.  (Not on a side
+    # stream: the first torch.cuda.Stream() of a process creates torch's pool of 32 streams, and with those in the process the
+    # library's own streams share hardware queues -- a 64-sentence call, three parts on three streams, went 1.77 -> 2.02 ms.)
     sensors = smi_before = None
-    instrument = not dry and rank == 0
+    instrument = not dry and rank == 0 and not args.no_instrument
     if instrument:
         from kjarni_amd import ops as _probe_ops
         main_stream = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         probes = torch.zeros((args.steps + 1, 2), dtype=torch.int64, device=dev)
         if not args.no_sensors:
@@ -755,27 +757,24 @@ def main():
         evs[0].record(main_stream)
     for i in range(args.steps):
         if instrument:
-            side.wait_event(evs[i])
-            _probe_ops.clock_probe(probes[i].data_ptr(), 50, side.cuda_stream)
+            _probe_ops.clock_probe(probes[i].data_ptr(), 20, main_stream.cuda_stream)
         step()
         if instrument:
             evs[i + 1].record(main_stream)
     if instrument:
-        side.wait_event(evs[args.steps])
-        _probe_ops.clock_probe(probes[args.steps].data_ptr(), 50, side.cuda_stream)
+        _probe_ops.clock_probe(probes[args.steps].data_ptr(), 20, main_stream.cuda_stream)
     sync()
     elapsed = time.perf_counter() - t0
     timing = {}
     if instrument:
         try:
-            side.synchronize()
             timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
             pr = probes.cpu().numpy().astype(np.float64)
             ghz = [round(float(c / t / 10.0), 3) if t > 0 else None for c, t in pr]
             timing["clock_ghz"] = ghz
             timing["clock_ghz_first"], timing["clock_ghz_last"] = ghz[0], ghz[-1]
-            timing["clock_note"] = ("clock_ghz[i]: shader cycles per 10 ns tick over a 50 us one-wave probe that starts with timed step i "
-                                    "(side stream); the last entry follows the last step")
+            timing["clock_note"] = ("clock_ghz[i]: shader cycles per 10 ns tick over a 20 us one-wave probe enqueued on the launch stream "
+                                    "in front of timed step i; the last entry follows the last step")
             if sensors:
                 timing["gpu_sensors"] = sensors.stop()
                 timing["gpu_sensors"]["rocm_smi_before"] = smi_before

@@ -276,13 +276,41 @@ def minilm_cross_encoder(path: str, seed: int = 1, family: str = "init", **over)
     return cfg, t
 
 
-def distilbert_sentiment(path: str, seed: int = 2, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+def trained_distilbert_tensors(cfg: dict, seed: int = 0) -> Dict[str, np.ndarray]:
+    """trained_bert_tensors in DistilBERT's layout (no token types; q_lin / k_lin / v_lin / out_lin, sa_layer_norm, ffn.lin1 /
+    lin2, output_layer_norm; pre_classifier + classifier head)."""
+    bert_cfg = dict(hidden_size=cfg["dim"], num_hidden_layers=cfg["n_layers"], num_attention_heads=cfg["n_heads"],
+                    intermediate_size=cfg["hidden_dim"], vocab_size=cfg["vocab_size"],
+                    max_position_embeddings=cfg["max_position_embeddings"], type_vocab_size=1)
+    b = trained_bert_tensors(bert_cfg, seed)
+    rng = np.random.default_rng([seed, 0x64697374])
+    H = cfg["dim"]
+    t = {}
+    e = "distilbert.embeddings."
+    t[e + "word_embeddings.weight"] = b["embeddings.word_embeddings.weight"]
+    t[e + "position_embeddings.weight"] = b["embeddings.position_embeddings.weight"]
+    t[e + "LayerNorm.weight"], t[e + "LayerNorm.bias"] = b["embeddings.LayerNorm.weight"], b["embeddings.LayerNorm.bias"]
+    ren = {"attention.self.query": "attention.q_lin", "attention.self.key": "attention.k_lin", "attention.self.value": "attention.v_lin",
+           "attention.output.dense": "attention.out_lin", "attention.output.LayerNorm": "sa_layer_norm",
+           "intermediate.dense": "ffn.lin1", "output.dense": "ffn.lin2", "output.LayerNorm": "output_layer_norm"}
+    for i in range(cfg["n_layers"]):
+        for old, new in ren.items():
+            for part in ("weight", "bias"):
+                t[f"distilbert.transformer.layer.{i}.{new}.{part}"] = b[f"encoder.layer.{i}.{old}.{part}"]
+    t["pre_classifier.weight"] = (rng.standard_normal((H, H)) * (0.8 / np.sqrt(H))).astype(np.float32)
+    t["pre_classifier.bias"] = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    t["classifier.weight"] = (rng.standard_normal((2, H)) * 0.3).astype(np.float32)
+    t["classifier.bias"] = (rng.standard_normal(2) * 0.3).astype(np.float32)
+    return t
+
+
+def distilbert_sentiment(path: str, seed: int = 2, family: str = "init", **over) -> Tuple[dict, Dict[str, np.ndarray]]:
     cfg = dict(model_type="distilbert", dim=768, n_layers=6, n_heads=12, hidden_dim=3072, vocab_size=30522,
                max_position_embeddings=512, activation="gelu",
                architectures=["DistilBertForSequenceClassification"],
                id2label={"0": "NEGATIVE", "1": "POSITIVE"}, label2id={"NEGATIVE": 0, "POSITIVE": 1})
     cfg.update(over)
-    t = distilbert_tensors(cfg, seed)
+    t = trained_distilbert_tensors(cfg, seed) if family == "trained" else distilbert_tensors(cfg, seed)
     write_model_dir(path, cfg, t)
     return cfg, t
 

@@ -167,3 +167,30 @@ def test_registry_names_reach_the_new_families(tmp_path):
     with pytest.raises(kjarni_amd.KjarniException) as ei:  # a seq2seq model is not an embedder
         kjarni_amd.Embedder("flan-t5-base", cache_dir=str(cache))
     assert ei.value.code == kjarni_amd.KjarniError.LOAD_FAILED and "not compatible" in str(ei.value)
+
+
+def test_distilbert_classifier_logits_in_the_trained_regime(tmp_path):
+    """BASELINE.json configs[0]'s architecture (distilbert-sentiment: 6 x 768, pre_classifier + ReLU + classifier) on weights
+    with the statistics of a trained checkpoint (tests/synth.py: trained_distilbert_tensors -- peaked softmax, LayerNorm gain
+    outliers, GELU tails): token-level logits and string-level probabilities against the oracle at 1e-4, logits of several
+    units.  (The N(0, 0.02) family is tests/test_gpu_ffi.py::test_classifier_distilbert_softmax_labels_and_multilabel.)"""
+    import kjarni_amd
+    from tests.parity_report import report
+    d = str(tmp_path / "sst2")
+    cfg, t = synth.distilbert_sentiment(d, seed=5, family="trained", n_layers=3)   # 3 of 6 layers keep the CPU oracle quick
+    synth.add_tokenizer(d)
+    orc = O.OracleModel(t, cfg, blocked_gemm=True)
+    enc = kjarni_amd.HipEncoder(d)
+    for B, S in ((1, 28), (8, 128), (40, 64)):
+        ids, mask = synth.synthetic_ids(B, S, seed=B + S, ragged=True)
+        want = orc.head_logits(orc.forward(ids, mask, None, O.strategy_mask_value(ids.size)))
+        got = enc.logits(ids, mask)
+        assert float(np.abs(want).max()) > 1.0
+        assert report("families/trained/distilbert_logits", np.abs(got - want).max(), TOL) < TOL, (B, S)
+    tok = kjarni_amd.Tokenizer(os.path.join(d, "tokenizer.json"), 512)
+    clf = kjarni_amd.Classifier(model_path=d)
+    for text in ("this movie was surprisingly good", "a dull, lifeless two hours"):
+        ids, mask, _ = tok.encode_batch([text])
+        probs = O.softmax_rows(orc.head_logits(orc.forward(ids, mask, None, O.MASK_ALLOC)))[0]
+        got = dict(clf.classify(text))
+        assert abs(got["NEGATIVE"] - probs[0]) < TOL and abs(got["POSITIVE"] - probs[1]) < TOL
