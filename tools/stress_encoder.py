@@ -1,7 +1,7 @@
 """Concurrency soak of one encoder handle: N host threads issue calls of mixed sizes (all three projection routes, workspaces
 growing and being reused, two lanes, call combining) for a while.  Every result must equal the single-threaded result bit for
-bit -- except small calls (<= 8 rows, <= 1 024 tokens) while combining is on (the default): those share a forward with whatever
-else is queued and are held to 1e-6 (without KJARNI_HIP_COMBINE=1, the default: bit for bit):
+bit -- except small calls (<= 8 rows, <= 1 024 tokens) while combining is opted in (KJARNI_HIP_COMBINE=1): those share a forward
+with whatever else is queued and are held to 1e-6 (by default, without it: bit for bit):
 python tools/stress_encoder.py [threads] [seconds]."""
 import os
 import sys
