@@ -315,7 +315,8 @@ def distilbert_sentiment(path: str, seed: int = 2, family: str = "init", **over)
     return cfg, t
 
 
-def roberta_classifier(path: str, seed: int = 3, labels=("negative", "neutral", "positive"), **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+def roberta_classifier(path: str, seed: int = 3, labels=("negative", "neutral", "positive"), family: str = "init",
+                       **over) -> Tuple[dict, Dict[str, np.ndarray]]:
     """RobertaForSequenceClassification layout (sequence_classifier/configs.rs:149-280): "roberta."-prefixed BERT layers,
     514 positions (offset 2), one token type, classifier.dense + tanh + classifier.out_proj."""
     cfg = dict(model_type="roberta", hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
@@ -323,7 +324,7 @@ def roberta_classifier(path: str, seed: int = 3, labels=("negative", "neutral", 
                architectures=["RobertaForSequenceClassification"], id2label={str(i): l for i, l in enumerate(labels)},
                label2id={l: i for i, l in enumerate(labels)})
     cfg.update(over)
-    t = bert_tensors(cfg, seed, prefix="roberta.")
+    t = (trained_bert_tensors if family == "trained" else bert_tensors)(cfg, seed, prefix="roberta.")
     rng = np.random.default_rng(seed + 100)
     H = cfg["hidden_size"]
     t["classifier.dense.weight"] = (rng.standard_normal((H, H)) * 0.05).astype(np.float32)
@@ -334,14 +335,32 @@ def roberta_classifier(path: str, seed: int = 3, labels=("negative", "neutral", 
     return cfg, t
 
 
-def mpnet_embedder(path: str, seed: int = 4, **over) -> Tuple[dict, Dict[str, np.ndarray]]:
+def mpnet_embedder(path: str, seed: int = 4, family: str = "init", **over) -> Tuple[dict, Dict[str, np.ndarray]]:
     """MPNet layout (sentence_encoder/configs.rs:393-470), including the relative-attention-bias tensor of real
-    checkpoints, which the reference never reads."""
+    checkpoints, which the reference never reads.  family "trained": trained_bert_tensors under MPNet's names."""
     cfg = dict(model_type="mpnet", hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
                hidden_act="gelu", max_position_embeddings=514, vocab_size=30527, layer_norm_eps=1e-5,
                architectures=["MPNetModel"], relative_attention_num_buckets=32)
     cfg.update(over)
     rng = np.random.default_rng(seed)
+    if family == "trained":
+        b = trained_bert_tensors(dict(cfg, type_vocab_size=1), seed)
+        H = cfg["hidden_size"]
+        t = {"embeddings.word_embeddings.weight": b["embeddings.word_embeddings.weight"],
+             "embeddings.position_embeddings.weight": b["embeddings.position_embeddings.weight"],
+             "embeddings.LayerNorm.weight": b["embeddings.LayerNorm.weight"], "embeddings.LayerNorm.bias": b["embeddings.LayerNorm.bias"],
+             "encoder.relative_attention_bias.weight": (rng.standard_normal((32, cfg["num_attention_heads"])) * 0.5).astype(np.float32),
+             "pooler.dense.weight": (rng.standard_normal((H, H)) * 0.02).astype(np.float32),
+             "pooler.dense.bias": (rng.standard_normal(H) * 0.05).astype(np.float32)}
+        ren = {"attention.self.query": "attention.attn.q", "attention.self.key": "attention.attn.k", "attention.self.value": "attention.attn.v",
+               "attention.output.dense": "attention.attn.o", "attention.output.LayerNorm": "attention.LayerNorm",
+               "intermediate.dense": "intermediate.dense", "output.dense": "output.dense", "output.LayerNorm": "output.LayerNorm"}
+        for i in range(cfg["num_hidden_layers"]):
+            for old, new in ren.items():
+                for part in ("weight", "bias"):
+                    t[f"encoder.layer.{i}.{new}.{part}"] = b[f"encoder.layer.{i}.{old}.{part}"]
+        write_model_dir(path, cfg, t)
+        return cfg, t
     H, L, I, V, P = cfg["hidden_size"], cfg["num_hidden_layers"], cfg["intermediate_size"], cfg["vocab_size"], cfg["max_position_embeddings"]
     w = lambda *shape, s=0.02: (rng.standard_normal(shape) * s).astype(np.float32)  # noqa: E731
     g = lambda n: (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)  # noqa: E731

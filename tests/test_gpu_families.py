@@ -22,10 +22,11 @@ def _tokenizer(d, name):
     return os.path.join(d, "tokenizer.json")
 
 
-def test_roberta_classifier_matches_oracle(tmp_path):
+@pytest.mark.parametrize("family", ["init", "trained"])
+def test_roberta_classifier_matches_oracle(tmp_path, family):
     import kjarni_amd
     d = str(tmp_path / "roberta")
-    cfg, t = synth.roberta_classifier(d)
+    cfg, t = synth.roberta_classifier(d, family=family)
     tok = kjarni_amd.Tokenizer(_tokenizer(d, "roberta"), cfg["max_position_embeddings"])
     orc = O.OracleModel(t, cfg)
     clf = kjarni_amd.Classifier(model_path=d)
@@ -53,10 +54,11 @@ def test_roberta_classifier_matches_oracle(tmp_path):
     assert np.abs(want0[valid] - want[valid]).max() > 1e-2
 
 
-def test_mpnet_embedder_matches_oracle(tmp_path):
+@pytest.mark.parametrize("family", ["init", "trained"])
+def test_mpnet_embedder_matches_oracle(tmp_path, family):
     import kjarni_amd
     d = str(tmp_path / "mpnet")
-    cfg, t = synth.mpnet_embedder(d)
+    cfg, t = synth.mpnet_embedder(d, family=family)
     tok = kjarni_amd.Tokenizer(_tokenizer(d, "mpnet"), cfg["max_position_embeddings"])
     orc = O.OracleModel(t, cfg)
     emb = kjarni_amd.Embedder(model_path=d)
