@@ -602,7 +602,9 @@ __global__ void clock_probe_kernel(unsigned long long* out, unsigned spin_ticks)
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long r1 = r0;
-    while (r1 - r0 < spin_ticks) {
+    // (bounded: 512 shader cycles per round, so even at 100 MHz a round is <= 512 ticks -- a counter that did not advance could
+    // not hang the launch)
+    for (unsigned round = 0; r1 - r0 < spin_ticks && round < spin_ticks + 4096u; ++round) {
         __builtin_amdgcn_s_sleep(8);
         r1 = __builtin_amdgcn_s_memrealtime();
     }
