@@ -545,19 +545,26 @@ struct SegmentStamp {
 // (kjarni-rag/src/segment.rs:90-170).  Five stat calls per segment and query (no open / pread / close per hit).
 bool stamp_of(const std::string& dir, SegmentStamp& out)
 {
-    static const char* const kFiles[5] = {"", "/segment.json", "/vectors.bin", "/docs.bin", "/metadata.jsonl"};
-    for (int i = 0; i < 5; ++i) {
+    // (the directory is resolved ONCE -- O_PATH -- and its files are stat'ed relative to it: five path walks down a deep
+    // index tree become one)
+    static const char* const kFiles[5] = {"", "segment.json", "vectors.bin", "docs.bin", "metadata.jsonl"};
+    const int dfd = ::open(dir.c_str(), O_PATH | O_DIRECTORY | O_CLOEXEC);
+    if (dfd < 0) return false;  // Segment::open would throw
+    bool ok = true;
+    for (int i = 0; i < 5 && ok; ++i) {
         struct stat st;
-        if (::stat((dir + kFiles[i]).c_str(), &st) != 0) {
-            if (i < 3) return false;  // Segment::open would throw
-            continue;                 // (read lazily: a missing file is that lookup's error; its stamp stays zero)
+        const int rc = i == 0 ? ::fstat(dfd, &st) : ::fstatat(dfd, kFiles[i], &st, 0);
+        if (rc != 0) {
+            if (i < 3) ok = false;  // Segment::open would throw
+            continue;               // (read lazily: a missing file is that lookup's error; its stamp stays zero)
         }
         out.v[4 * i] = (uint64_t)st.st_size;
         out.v[4 * i + 1] = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
         out.v[4 * i + 2] = (uint64_t)st.st_ctim.tv_sec * 1000000000ull + (uint64_t)st.st_ctim.tv_nsec;
         out.v[4 * i + 3] = (uint64_t)st.st_ino;
     }
-    return true;
+    ::close(dfd);
+    return ok;
 }
 struct CachedSegment {
     SegmentStamp stamp;
