@@ -346,6 +346,16 @@ def scan_leg(torch, np, dev, n_docs, check_rows=50000, dim=384, k=10):
     return out
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator is made; on a pipe that buffer is flushed at process
+    exit, i.e. AFTER the JSON line.  Flushing it right after the communicator exists keeps the JSON line the last line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children.  Nothing in this process has
     touched torch.cuda or HIP, and it never execs."""
@@ -542,6 +552,7 @@ def main_in_process(args):
                       "parity_tolerance": 1e-4}
             assert parity["max_abs_err_vs_oracle"] < 1e-4, f"in-process output differs from the oracle: {parity}"
         transport = grp.transport
+        flush_c_stdio()
         say(f"leg done in {elapsed:.2f} s, transport {transport}")
         fps = flops_per_sentence(grp.hidden_size, cfg["num_hidden_layers"], cfg["intermediate_size"], S)
         grp.close()
@@ -579,6 +590,7 @@ def main_in_process(args):
                "steps_ms": r_ms}
         leg.update(r_par)
         result["rerank"] = leg
+    flush_c_stdio()
     print(json.dumps(result), flush=True)
     return 0
 
@@ -673,6 +685,7 @@ def main():
                 pass
         comm_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_version": version,
                      "allreduce_of_ones": int(ones.item())}
+        flush_c_stdio()
         if rank == 0:
             print(f"bench.py: {comm_info['backend']} communicator over {comm_info['ranks']} ranks"
                   f" (RCCL {version}); all-reduce of ones = {comm_info['allreduce_of_ones']}", file=sys.stderr, flush=True)
