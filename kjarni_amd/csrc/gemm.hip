@@ -361,6 +361,324 @@ __global__ __launch_bounds__(256, Tile<BKT>::WAVES_PER_SIMD) void gemm_nt_f32_mf
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same 128 x 128 tiles as ONE continuous K-stream per workgroup (the headline's K = 384 projections: QKV and FC1 + GELU
+// at >= 10^5 rows, where a tile is only 12 K-steps and its edges are what the kernel above loses -- r05 knock-outs: a tile
+// without an epilogue runs at the K = 1536 rate, the output stores alone cost 4.5-5 %).
+//
+// Vector-memory operations of a wave complete in issue order (loads and stores share `vmcnt`), so the first operand load
+// a wave issues AFTER its sixteen output stores cannot be consumed before those stores are acknowledged by the L2
+// (600-3 000 cycles under load).  In the kernel above that load is the next tile's prologue: the wave sits out the store
+// round trip AND its own load latency once per tile.  Here a workgroup's tiles form one stream of K-blocks: the last two
+// K-steps of a tile request and stage the first two blocks of the NEXT tile exactly as any other step does (another buffer
+// descriptor, nothing else), so there is no prologue after the first tile, the blocks consumed right after an epilogue were
+// requested before its stores, and the first load issued behind the stores is not needed until a whole K-step
+// (4 096 matrix cycles) later.  Bias and activation run on the accumulators in place (64 independent values per lane, before
+// the transpose); the transpose uses the second operand stage, free from the last K-step's barrier until the next tile's
+// first K-step stages into it -- the one barrier that closes a tile.
+// Same K order per output as the kernel above: bit-identical results.
+template <int EPI, int DIAG, int OUT_POLICY>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_stream(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ Y, int64_t ldy, int64_t M,
+                                                             int K, int n_tiles, int64_t total_tiles)
+{
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU, "epilogues without a residual operand");
+    using T = Tile<32>;
+    constexpr int BK = T::BK, NKK = T::NKK, STRIDE = T::STRIDE, TILE_FLOATS = T::TILE_FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                    // [2][128][STRIDE]
+    float* sB = smem + 2 * TILE_FLOATS;  // [2][128][STRIDE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // tile order: as in gemm_nt_f32_mfma (every XCD walks one contiguous run of tiles, N fastest)
+    const unsigned nwg = (unsigned)total_tiles;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u;
+    struct Where {
+        int64_t m0;
+        int n0;
+    };
+    auto tile_of = [&](unsigned wg) {
+        const unsigned xcd = wg & 7u, slot = wg >> 3;
+        const unsigned bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        const unsigned m_tile = bid / (unsigned)n_tiles;
+        return Where{(int64_t)m_tile * BM, (int)(bid - m_tile * (unsigned)n_tiles) * BN};
+    };
+    // (descriptors of a tile that does not exist have no extent: its loads return zeros and move nothing)
+    auto rsrc_a = [&](Where w, bool live) {
+        const int64_t rows = (M - w.m0 < BM) ? (M - w.m0) : BM;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + w.m0 * lda), 0, live ? (int)(((rows - 1) * lda + K) * 4) : 0, 0x00020000);
+    };
+    auto rsrc_w = [&](Where w, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (int64_t)w.n0 * K), 0, live ? (int)((int64_t)BN * K * 4) : 0, 0x00020000);
+    };
+
+    const int ld_row = tid / T::V4_PER_ROW, ld_c4 = tid % T::V4_PER_ROW;
+    uint32_t offA[T::LOADS], offW[T::LOADS];
+#pragma unroll
+    for (int i = 0; i < T::LOADS; ++i) {
+        const int64_t r = ld_row + T::ROWS_PER_PASS * i;
+        offA[i] = (uint32_t)((r * lda + ld_c4 * 4) * 4);
+        offW[i] = (uint32_t)((r * K + ld_c4 * 4) * 4);
+    }
+    f32x4 ga[T::LOADS], gb[T::LOADS];
+    auto ld16 = [](__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, int k0) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, k0 * 4, 0));
+    };
+    const int st_off = ld_row * STRIDE + ld_c4 * 4;
+    auto store_piece = [&](int stage, int i) {
+        if (i < T::LOADS)
+            *reinterpret_cast<f32x4*>(sA + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * i * STRIDE) = ga[i];
+        else
+            *reinterpret_cast<f32x4*>(sB + stage * TILE_FLOATS + st_off + T::ROWS_PER_PASS * (i - T::LOADS) * STRIDE) = gb[i - T::LOADS];
+    };
+    auto load_piece = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int i, int k0) {
+        if (i < T::LOADS)
+            ga[i] = ld16(ra, offA[i], k0);
+        else
+            gb[i - T::LOADS] = ld16(rw, offW[i - T::LOADS], k0);
+    };
+
+    const int nk = K / BK;  // (even and >= 4: the launcher)
+    const int a_off = (wr * 64 + l31) * STRIDE + half * 4;
+    const int b_off = (wc * 64 + l31) * STRIDE + half * 4;
+
+    unsigned wg = blockIdx.x;
+    Where here = tile_of(wg);
+    __amdgpu_buffer_rsrc_t rA = rsrc_a(here, true), rW = rsrc_w(here, true);
+    // the one prologue of the workgroup: block 0 -> LDS[0], block 1 in registers, the first fragments
+#pragma unroll
+    for (int i = 0; i < T::PIECES; ++i) load_piece(rA, rW, i, 0);
+#pragma unroll
+    for (int i = 0; i < T::PIECES; ++i) store_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < T::PIECES; ++i) load_piece(rA, rW, i, BK);
+    __syncthreads();
+    Frag fr[2];
+    read_frag<STRIDE>(fr[0], sA + a_off, sB + b_off, 0);
+
+    f32x16 acc[2][2];
+    float* sw = (wid < 2 ? sA : sB) + TILE_FLOATS + (wid & 1) * (32 * EPI_STRIDE);  // this wave's transpose region, second stage
+    static_assert(2 * 32 * EPI_STRIDE <= TILE_FLOATS, "two waves' epilogue regions must fit one operand stage");
+    const int e_row = lane >> 4, e_c4 = lane & 15;
+    // Outputs and bias through descriptors as well: rows past M are dropped by the bounds check and a missing bias reads as
+    // zeros, so that NO vector-memory instruction of the tile loop sits under a branch -- the compiler then counts `vmcnt`
+    // exactly across the tile edge (a store under `if (m < M)` makes it assume the stores were not issued, and the waits of the
+    // K-steps behind them would then include them after all).
+    const uint32_t off_y = (uint32_t)((((int64_t)wr * 64 + e_row) * ldy + wc * 64 + e_c4 * 4) * 4);
+    // K-step kt of a tile: matrix work on block kt from LDS[kt & 1]; the block in the registers (kt + 1, or the next tile's
+    // first) goes to the other stage and the registers take the block after that, described by (ra, rw, k0).
+    // DRAIN (the first K-step after an epilogue): the previous tile's sixteen output pieces leave from `hold`, four per phase,
+    // dealt out between the MFMAs like the staging pieces.
+    f32x4 hold[16];
+    __amdgpu_buffer_rsrc_t rY_prev = __builtin_amdgcn_make_buffer_rsrc(Y, 0, 0, 0x00020000);
+    auto put = [&](int piece_of_tile) {
+        // piece 8 i + it of a tile: rows i * 32 + it * 4 + (lane >> 4) of the wave's 64, 16 bytes of each
+        // (OUT_POLICY 1: streaming stores, as in the kernel above -- cache-policy bit 1 = nt)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, hold[piece_of_tile]), rY_prev,
+                                               off_y, (int)((int64_t)(piece_of_tile * 4) * ldy * 4), OUT_POLICY == 1 && DIAG != 5 ? 2 : 0);
+    };
+    auto step = [&](auto drain_tag, int kt, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, int k0) {
+        constexpr bool DRAIN = decltype(drain_tag)::value && (DIAG == 0 || DIAG >= 3);
+        const int cur = kt & 1;
+        const float* pa = sA + cur * TILE_FLOATS + a_off;
+        const float* pb = sB + cur * TILE_FLOATS + b_off;
+#pragma unroll
+        for (int p = 0; p < NKK; ++p) {
+            Frag& use = fr[p & 1];
+            Frag& nxt = fr[(p + 1) & 1];
+            if (p + 1 < NKK) {
+                read_frag<STRIDE>(nxt, pa, pb, p + 1);
+            } else {
+                __syncthreads();
+                read_frag<STRIDE>(nxt, sA + (cur ^ 1) * TILE_FLOATS + a_off, sB + (cur ^ 1) * TILE_FLOATS + b_off, 0);
+            }
+            constexpr int PP = T::PIECES_PER_PHASE;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const int piece = p * PP + i;
+                if (p + 1 < NKK && piece < T::PIECES) {
+                    store_piece(cur ^ 1, piece);
+                    load_piece(ra, rw, piece, k0);
+                }
+            }
+            // (all sixteen in the phases before the barrier, 6 + 5 + 5: the waits of the NEXT K-step are the loop's static counts and
+            // take in every store issued before them -- the later a store, the less time its acknowledgement has had)
+            const int first_out = p == 0 ? 0 : 1 + 5 * p, n_out = p + 1 < NKK ? (p == 0 ? 6 : 5) : 0;
+            if (DRAIN) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    if (q < n_out) put(first_out + q);
+            }
+            mfma16(acc, use);
+            if (p + 1 < NKK) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // 4 x DS read first
+            int drained = 0;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const int piece = p * PP + i;
+                if (p + 1 < NKK && piece < T::PIECES) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, DRAIN ? 2 : 4, 0);  // MFMA x 4
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // DS write
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // VMEM read
+                    if (DRAIN) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
+                        ++drained;
+                    }
+                }
+            }
+            if (DRAIN) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    if (q >= drained && q < n_out) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // VMEM write
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert((NKK & 1) == 0, "fragment double-buffer parity must repeat every K-step");
+    static_assert(NKK == 4, "the drain deals 6 + 5 + 5 output pieces over three phases");
+    using TT = std::true_type;
+    using FF = std::false_type;
+
+    const uint32_t off_bias = (uint32_t)((wc * 64 + l31) * 4);
+    const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? n_tiles * BN * 4 : 0, 0x00020000);
+    auto rsrc_y = [&](Where w) {
+        const int64_t rows = (M - w.m0 < BM) ? (M - w.m0) : BM;
+        return __builtin_amdgcn_make_buffer_rsrc(Y + w.m0 * ldy + w.n0, 0, (int)(((rows - 1) * ldy + BN) * 4), 0x00020000);
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    };
+    auto bias_of = [&](Where w, int j) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_bias, off_bias + j * 128, w.n0 * 4, 0));
+    };
+
+    unsigned wg_next = wg + gridDim.x;
+    bool more = wg_next < nwg;
+    Where next = tile_of(more ? wg_next : wg);
+    __amdgpu_buffer_rsrc_t rAn = rsrc_a(next, more), rWn = rsrc_w(next, more);
+    float b0 = bias_of(here, 0), b1 = bias_of(here, 1);
+    zero_acc();
+    // (DIAG 3, tuning build: shader cycles this wave spends in the K-steps / between them, summed over its tiles)
+    uint64_t t_loop = 0, t_edge = 0, t_mark = DIAG == 3 ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned tiles_done = 0;
+    step(FF{}, 0, rA, rW, 2 * BK);
+    for (;;) {
+        // (K-step 1 apart from the loop: its waits are then counted exactly behind the drained stores, and the loop's static
+        // counts -- which take in every older store -- start a whole K-step after the last of them)
+        step(FF{}, 1, rA, rW, 3 * BK);
+        int kt = 2;
+        for (; kt + 2 < nk; ++kt) step(FF{}, kt, rA, rW, (kt + 2) * BK);
+        step(FF{}, kt++, rAn, rWn, 0);
+        step(FF{}, kt, rAn, rWn, BK);
+        if (DIAG == 3) {
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            t_loop += t - t_mark;
+            t_mark = t;
+            ++tiles_done;
+        }
+
+        if (DIAG == 1) {
+            // Diagnostic build only (tools/kernel_bench.py): no epilogue; keeps the accumulators live.
+            float sacc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+            if (sacc == 123456.789f) Y[0] = sacc;
+        } else {
+            // bias (+ activation) on the accumulators, then the transpose into `hold`: 16 bytes of four rows per register quad
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 v = f32x2{acc[i][j][r], acc[i][j][r + 1]} + (j ? b1 : b0);
+                        if (EPI == EPI_BIAS_GELU) v = gelu_erf_fast2(v);
+                        acc[i][j][r] = v[0];
+                        acc[i][j][r + 1] = v[1];
+                    }
+            rY_prev = rsrc_y(DIAG == 5 ? Where{(int64_t)(blockIdx.x / (unsigned)n_tiles) * BM, (int)(blockIdx.x % (unsigned)n_tiles) * BN} : here);  // (5: every tile of a workgroup to the same place)
+            if (DIAG == 4) {
+                // (diagnostic: the same stores without the LDS transpose and without the barrier -- the values land in the wrong places)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    hold[q] = f32x4{acc[q >> 3][(q >> 2) & 1][(q & 3) * 4], acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 1],
+                                    acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 2], acc[q >> 3][(q >> 2) & 1][(q & 3) * 4 + 3]};
+            } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sw[acc_row(r, half) * EPI_STRIDE + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    hold[i * 8 + it] = *reinterpret_cast<const f32x4*>(sw + (it * 4 + e_row) * EPI_STRIDE + e_c4 * 4);
+            }
+            }
+            if (DIAG == 2) {  // (diagnostic: everything but the global stores)
+                f32x4 t = hold[0];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) t += hold[q];
+                if (t[0] + t[1] + t[2] + t[3] == 123456.789f) Y[0] = t[0];
+            }
+        }
+        if (!more) {
+            if (DIAG == 0 || DIAG >= 3) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) put(q);
+            }
+            if (DIAG == 3) {
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                if (tid == 0) {
+                    float* o = Y + (int64_t)blockIdx.x * 4;
+                    o[0] = (float)t_loop;
+                    o[1] = (float)t_edge;
+                    o[2] = (float)tiles_done;
+                }
+            }
+            break;
+        }
+        if (DIAG != 4) __syncthreads();  // every wave has read its transpose region: the next K-step stages into that LDS
+        if (DIAG == 3) {
+            const uint64_t t = __builtin_amdgcn_s_memtime();
+            t_edge += t - t_mark;
+            t_mark = t;
+        }
+        wg = wg_next;
+        here = next;
+        rA = rAn;
+        rW = rWn;
+        wg_next = wg + gridDim.x;
+        more = wg_next < nwg;
+        next = tile_of(more ? wg_next : wg);
+        rAn = rsrc_a(next, more);
+        rWn = rsrc_w(next, more);
+        b0 = bias_of(here, 0);
+        b1 = bias_of(here, 1);
+        zero_acc();
+        step(TT{}, 0, rA, rW, 2 * BK);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Residual GEMM with the LayerNorm folded into its epilogue:
 //     Y = LayerNorm(A W^T + bias + R) * gamma + beta          (R == Y allowed)
 // replaces out-proj / FC2 + residual add + LayerNorm of the post-norm layer
@@ -845,6 +1163,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_generic(const float* __restri
 
 // Outputs from this size leave through streaming stores: nothing the size of the memory-side cache (256 MB) is found there again.
 constexpr int64_t kStreamOutBytes = (int64_t)256 << 20;
+// K-steps (of 32) up to which a tile's edges are worth the continuous-stream kernel (gemm_nt_f32_stream): K <= 768
+constexpr int kStreamMaxKSteps = 24;
 
 template <int EPI, int BKT, int DIAG, int OUT_POLICY>
 hipError_t launch_tiled_as(const float* A, int64_t lda, const float* W, const float* bias, const float* R,
@@ -868,6 +1188,26 @@ hipError_t launch_tiled_as(const float* A, int64_t lda, const float* W, const fl
     const int64_t m_tiles = (M + BM - 1) / BM;
     const int64_t total = m_tiles * n_tiles;
     if (total > 0x7fffffff) return hipErrorInvalidValue;  // (the kernel's tile index is 32-bit; a chunk is <= 262 144 rows)
+    // Short K and many tiles per workgroup (the headline's QKV and FC1): the tiles as one continuous K-stream.
+    if constexpr ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && BKT == 32) {
+        const int nk = K / 32;
+        if (R == nullptr && nk >= 6 && (nk & 1) == 0 && nk <= kStreamMaxKSteps && (int64_t)BM * ldy * 4 < ((int64_t)1 << 31) && total >= 4 * (int64_t)256 * T::WAVES_PER_SIMD &&
+            !tune::no_k_stream_tiles()) {
+            static bool attr_set[64] = {};
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
+            if (e != hipSuccess) return e;
+            if (!attr_set[dev & 63]) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_f32_stream<EPI, DIAG, OUT_POLICY>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+                if (e != hipSuccess) return e;
+                attr_set[dev & 63] = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_f32_stream<EPI, DIAG, OUT_POLICY>), dim3((unsigned)((int64_t)256 * T::WAVES_PER_SIMD)), dim3(256),
+                               T::LDS_BYTES, stream, A, lda, W, bias, Y, ldy, M, K, n_tiles, total);
+            return hipGetLastError();
+        }
+    }
     // The kernel walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  With the plain epilogue a grid of the workgroups the
     // chip holds at once measured +2.2 % (QKV shape: no dispatch between a workgroup's tiles); with the GELU epilogue -1.1 %
     // (the barrier that ends a tile waits for the slowest wave's epilogue), so those launch one workgroup per tile.
@@ -1269,6 +1609,9 @@ hipError_t launch_epi(const float* A, int64_t lda, const float* W, const float* 
 #ifdef KJARNI_TUNING
         if (tune::tiles_without_epilogue()) return launch_tiled<EPI, 32, 1>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
         if (tune::tiles_without_stores()) return launch_tiled<EPI, 32, 2>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        if (tune::tiles_with_cycle_counts()) return launch_tiled<EPI, 32, 3>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        if (tune::tiles_without_transpose()) return launch_tiled<EPI, 32, 4>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
+        if (tune::tiles_stored_in_place()) return launch_tiled<EPI, 32, 5>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);
 #endif
         if (get_f32_on_bf16() && K % 64 == 0) return launch_gemm_split(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, (GemmEpilogue)EPI, stream);
         return launch_tiled<EPI, 32, 0>(A, lda, W, bias, R, ldr, Y, ldy, M, N, K, stream);

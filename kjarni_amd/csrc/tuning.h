@@ -18,6 +18,13 @@
 //   21..26  knock-out diagnostics of the 64 x 64-tile kernel (unsliced launches): its DIAG template parameter 1..6
 //   17  f32-on-bf16 mode: the 64 x 64-tile route stays on the f32 matrix cores
 //   52  128 x 128 tiles: the epilogue without its global stores (diagnostic)
+//   53  128 x 128 tiles: one launch-resident workgroup per tile sequence WITH a prologue per tile (gemm_nt_f32_mfma) where the
+//       continuous K-stream kernel (gemm_nt_f32_stream) would run
+//   54  gemm_nt_f32_stream: wave 0 of every workgroup leaves (cycles in K-steps, cycles between them, tiles) in the first floats of
+//       the output (diagnostic; the output is then not the product)
+//   56  gemm_nt_f32_stream: every tile of a workgroup stored over the workgroup's first (plain stores: the output stays in the L2;
+//       diagnostic -- what the stores cost as instructions, without their memory traffic)
+//   55  gemm_nt_f32_stream: the output stores without the LDS transpose and the barrier behind it (diagnostic: values in the wrong places)
 // 100000 + r  f32-on-bf16 mode: the split kernel takes calls from r rows (instead of 6 144: gemm.hip, split_min_rows()) in place of the 64 x 64-tile route
 // 1000 + r  the few-rows kernel takes calls of up to r rows (sweeps of the few-rows / 64 x 64-tile crossover), r < 1000
 //    8  mid-size calls on the 64 x 64 tiles of gemm.hip instead of gemm_flex.hip's per-call tile
@@ -80,6 +87,10 @@ inline int flex_knockout() { return gemm() >= 12000 && gemm() < 100000 && flex_c
 inline bool no_flex_route() { return gemm() == 8; }
 inline bool no_streaming_output_stores() { return gemm() == 12; }
 inline bool tiles_without_stores() { return gemm() == 52; }
+inline bool no_k_stream_tiles() { return gemm() == 53; }
+inline bool tiles_with_cycle_counts() { return gemm() == 54; }
+inline bool tiles_without_transpose() { return gemm() == 55; }
+inline bool tiles_stored_in_place() { return gemm() == 56; }
 
 inline bool no_pipelined_attention() { return attention() == 1; }
 inline int attention_knockout() { return attention() >= 11 && attention() <= 16 ? attention() - 10 : 0; }
