@@ -30,12 +30,15 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   steps_ms      wall time of every timed step (HIP events on the launch stream, resolved after the region's final
                 synchronisation: no extra sync inside the region)
   roofline.frac_of_peak_at_that_clock / e2e_frac_of_peak_at_that_clock
-                the same fractions against the matrix-core peak at the clock THIS box held (mean of clock_ghz over the
-                region; 157.3 TFLOP/s is the 2.4 GHz figure): 0.88-0.90 / 0.85-0.87 on every box seen, where `frac` ranges
-                over 0.83-0.88 with the box
-  clock_ghz     the shader clock the chip holds in front of every timed step and after the last one (a one-wave, 20 us
-                probe on the launch stream: shader cycles per 10 ns tick, kjarni_hip_clock_probe), `clock_ghz_first` /
-                `clock_ghz_last`; `gpu_sensors`: board power / temperature / sclk sampled from sysfs during the region
+                the same fractions against the matrix-core peak at the clock the chip held UNDER THE WORK (mean of
+                clock_ghz; 157.3 TFLOP/s is the 2.4 GHz figure).  f32 matrix-core kernels run the board at its power cap and
+                the clock settles well below 2.4 GHz there; `frac` stays the contract's figure against the fixed peak
+  clock_ghz     the shader clock under load, one value per timed step: a one-wave kernel on a stream of its own beside the
+                launch stream (kjarni_hip_clock_trace, asleep between its reads) stamps shader cycles against the 100 MHz
+                counter over 16 consecutive windows per step; `clock_ghz_min` / `clock_ghz_max` over all windows;
+                `clock_ghz_idle`: the same reading with nothing else running, before the region (what a probe BETWEEN
+                two kernels of the launch stream reads: rounds 1-5 quoted that, 2.3-2.4 GHz).
+                `gpu_sensors`: board power / temperature / sclk sampled from sysfs during the region
                 (+ rocm-smi before and after) -- what tells a slower box from a power-limited long run
   scan          (N = 1, embed) the other half of the hot path, R14: cosine search (scan + top-10) of 1 and of 64 queries
                 over a [1 000 000, 384] corpus resident in HBM, each with its own roofline (hbm / mfma) and an oracle
@@ -746,18 +749,32 @@ def main():
     profile = not args.no_profile and not dry
     if profile:
         enc.profile_begin(GEMM_KINDS)
-    # Per-step wall time and shader clock WITHOUT a synchronisation inside the region: an event on the launch stream after
-    # every step, and in front of every step a one-wave probe ON THE SAME STREAM that stamps shader cycles against the 100 MHz
-    # counter for 20 us (0.0014 % of a step) -- the clock the power controller holds at that point of the run.  (Not on a side
-    # stream: the first torch.cuda.Stream() of a process creates torch's pool of 32 streams, and with those in the process the
-    # library's own streams share hardware queues -- a 64-sentence call, three parts on three streams, went 1.77 -> 2.02 ms.)
+    # Per-step wall time and the shader clock UNDER LOAD, without a synchronisation inside the region: an event on the launch
+    # stream after every step; beside it, on the library's own non-blocking stream, one one-wave kernel per step that stamps shader
+    # cycles against the 100 MHz counter over 16 windows of ~1/16 step (asleep in between).  The host enqueues far ahead of
+    # the device, so the trace kernels simply follow each other: trace i covers roughly step i (each is 3 % shorter than a step,
+    # so the last one ends inside the region).  (A probe on the launch stream between two steps reads an IDLE chip: the power
+    # controller lets the clock back up within microseconds -- that is `clock_ghz_idle`.  And not a torch side stream: the first
+    # torch.cuda.Stream() of a process creates torch's pool of 32 streams, with which the library's own streams share hardware
+    # queues -- a 64-sentence call, three parts on three streams, went 1.77 -> 2.02 ms.)
     sensors = smi_before = None
     instrument = not dry and rank == 0 and not args.no_instrument
     if instrument:
         from kjarni_amd import ops as _probe_ops
         main_stream = torch.cuda.current_stream()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-        probes = torch.zeros((args.steps + 1, 2), dtype=torch.int64, device=dev)
+        TRACE_WINDOWS = 16
+        probes = torch.zeros((args.steps, TRACE_WINDOWS, 2), dtype=torch.int64, device=dev)
+        idle_probe = torch.zeros((2,), dtype=torch.int64, device=dev)
+        side_stream = _probe_ops.measurement_stream()
+        # one more untimed step for the window length (and the idle reading in front of it)
+        _probe_ops.clock_probe(idle_probe.data_ptr(), 200, main_stream.cuda_stream)
+        sync()
+        t_est = time.perf_counter()
+        step()
+        sync()
+        est_us = (time.perf_counter() - t_est) * 1e6
+        window_us = int(min(1_000_000, max(10, 0.97 * est_us / TRACE_WINDOWS)))
         if not args.no_sensors:
             smi_before = GpuSensors.snapshot()
             try:
@@ -773,25 +790,28 @@ def main():
     if instrument:
         evs[0].record(main_stream)
     for i in range(args.steps):
-        if instrument:
-            _probe_ops.clock_probe(probes[i].data_ptr(), 20, main_stream.cuda_stream)
+        if instrument and side_stream:
+            _probe_ops.clock_trace(probes[i].data_ptr(), TRACE_WINDOWS, window_us, side_stream)
         step()
         if instrument:
             evs[i + 1].record(main_stream)
-    if instrument:
-        _probe_ops.clock_probe(probes[args.steps].data_ptr(), 20, main_stream.cuda_stream)
     sync()
     elapsed = time.perf_counter() - t0
     timing = {}
     if instrument:
         try:
             timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
+            torch.cuda.synchronize()  # (the side stream's last trace)
             pr = probes.cpu().numpy().astype(np.float64)
-            ghz = [round(float(c / t / 10.0), 3) if t > 0 else None for c, t in pr]
-            timing["clock_ghz"] = ghz
-            timing["clock_ghz_first"], timing["clock_ghz_last"] = ghz[0], ghz[-1]
-            timing["clock_note"] = ("clock_ghz[i]: shader cycles per 10 ns tick over a 20 us one-wave probe enqueued on the launch stream "
-                                    "in front of timed step i; the last entry follows the last step")
+            win = np.where(pr[..., 1] > 0, pr[..., 0] / np.maximum(pr[..., 1], 1) / 10.0, np.nan)  # GHz per window
+            if np.isfinite(win).any():
+                timing["clock_ghz"] = [round(float(np.nanmean(w)), 3) if np.isfinite(w).any() else None for w in win]
+                timing["clock_ghz_min"], timing["clock_ghz_max"] = round(float(np.nanmin(win)), 3), round(float(np.nanmax(win)), 3)
+            ip = idle_probe.cpu().numpy().astype(np.float64)
+            timing["clock_ghz_idle"] = round(float(ip[0] / ip[1] / 10.0), 3) if ip[1] > 0 else None
+            timing["clock_note"] = (f"clock_ghz[i]: shader cycles per 10 ns tick, mean of {TRACE_WINDOWS} windows of {window_us} us read by a one-wave "
+                                    "kernel on a stream of its own while timed step i runs (the clock UNDER the work); clock_ghz_idle: the "
+                                    "same reading over 200 us with nothing else running")
             if sensors:
                 timing["gpu_sensors"] = sensors.stop()
                 timing["gpu_sensors"]["rocm_smi_before"] = smi_before
@@ -1056,10 +1076,10 @@ def main():
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "flops_per_launch": d["flops"] / d["launches"],
             }
-            # The same fraction against the peak AT THE CLOCK THIS BOX HELD (the matrix-core peak scales with the shader clock;
-            # 157.3 TFLOP/s is the 2.4 GHz figure): boxes reach 2.22-2.41 GHz at the same power cap, and this is the number that
-            # is the same on all of them -- `frac` stays the contract's figure against the fixed peak.
-            ghz = [g for g in (timing.get("clock_ghz") or [])[1:-1] if g]
+            # The same fraction against the peak AT THE CLOCK THE CHIP HELD UNDER THIS WORK (the matrix-core peak scales with the
+            # shader clock; 157.3 TFLOP/s is the 2.4 GHz figure): the board runs these kernels at its power cap and the clock it
+            # settles at there is what the kernels' rate is a fraction of -- `frac` stays the contract's figure against the fixed peak.
+            ghz = [g for g in (timing.get("clock_ghz") or []) if g]
             if ghz:
                 mean_ghz = sum(ghz) / len(ghz)
                 result["roofline"]["clock_ghz_mean"] = round(mean_ghz, 3)

@@ -132,6 +132,15 @@ int32_t kjarni_hip_get_f32_on_bf16(void);
  * GHz the chip holds at that point of the stream -- what a power-limited run lowers while a short one does not.  Asynchronous;
  * out_dev is a device pointer to two uint64. */
 KjarniErrorCode kjarni_hip_clock_probe(uint64_t* out_dev, uint32_t spin_us, void* stream);
+/* The same reading over `samples` consecutive windows of `window_us` microseconds (1 .. 4096 windows of 10 .. 1 000 000 us, at
+ * most ten seconds per launch): out_dev[2 s] = shader cycles, out_dev[2 s + 1] = 10 ns ticks of window s.  Enqueued on a stream
+ * of its OWN beside the work being measured (one wave, asleep between its reads) it is the clock the chip holds UNDER that work:
+ * f32 matrix-core kernels run the board at its power cap and the clock it settles at there -- not the 2.4 GHz of the data sheet
+ * -- is what their rate is a fraction of.  A probe between two kernels of the busy stream reads an idle chip's clock instead. */
+KjarniErrorCode kjarni_hip_clock_trace(uint64_t* out_dev, uint32_t samples, uint32_t window_us, void* stream);
+/* A non-blocking stream of the library's own for such readings (one per process, made on first use on the current device, never
+ * destroyed; NULL if it cannot be made).  hipStreamSynchronize / a later blocking copy from out_dev orders the caller behind it. */
+void* kjarni_hip_measurement_stream(void);
 
 /* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
  * calls may be made concurrently from any number of host threads and on any streams, as on the reference's

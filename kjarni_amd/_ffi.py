@@ -424,6 +424,8 @@ SIGNATURES = {
     "kjarni_hip_set_f32_on_bf16": (c_int32, [c_int32]),
     "kjarni_hip_get_f32_on_bf16": (c_int32, []),
     "kjarni_hip_clock_probe": (c_int32, [c_void_p, C.c_uint32, c_void_p]),
+    "kjarni_hip_clock_trace": (c_int32, [c_void_p, C.c_uint32, C.c_uint32, c_void_p]),
+    "kjarni_hip_measurement_stream": (c_void_p, []),
     "kjarni_hip_encoder_hidden_states": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                                    c_int32, c_void_p, c_void_p]),
     "kjarni_hip_encoder_embed": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

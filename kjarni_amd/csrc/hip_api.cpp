@@ -1,4 +1,5 @@
 // Token-level C ABI (include/kjarni_hip.h).
+#include <mutex>
 #include <sys/stat.h>
 
 #include <cmath>
@@ -149,6 +150,26 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_clock_probe(uint64_t* out_dev, uint32_t
     const uint32_t us = spin_us == 0 ? 20u : (spin_us > 10000u ? 10000u : spin_us);
     return kjarni::launch_clock_probe(out_dev, us * 100u, (hipStream_t)stream) == hipSuccess ? KJARNI_OK
                                                                                              : KJARNI_ERROR_INFERENCE_FAILED;
+}
+
+KJARNI_EXPORT void* kjarni_hip_measurement_stream(void)
+{
+    // one non-blocking stream per process, made on first use and kept (a measurement aid: see kjarni_hip_clock_trace)
+    static std::mutex mu;
+    static hipStream_t stream = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
+    return stream;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_clock_trace(uint64_t* out_dev, uint32_t samples, uint32_t window_us, void* stream)
+{
+    if (!out_dev) return KJARNI_ERROR_NULL_POINTER;
+    // (one launch stays below ten seconds: 1 .. 4096 windows of 10 us .. 1 s)
+    if (samples == 0 || samples > 4096u || window_us < 10u || window_us > 1000000u || (uint64_t)samples * window_us > 10000000ull)
+        return KJARNI_ERROR_INVALID_CONFIG;
+    return kjarni::launch_clock_trace(out_dev, samples, window_us * 100u, (hipStream_t)stream) == hipSuccess ? KJARNI_OK
+                                                                                                           : KJARNI_ERROR_INFERENCE_FAILED;
 }
 
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_encoder_hidden_states(KjarniHipEncoder* enc, const uint32_t* ids_dev,
@@ -410,11 +431,16 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* 
         use_device(device);
         if (m == 0) return;
         const size_t xb = (size_t)m * k * 4, wb = (size_t)n * k * 4, yb = (size_t)m * n * 4;
-        DeviceBuf xd(xb), wd(wb), bd((size_t)n * 4), rd(residual ? yb : 4), yd(yb);
+        // A guard band of one tile's rows behind the output: the tile kernels compute whole 128-row tiles and leave the rows past m
+        // to a bounds check (a predicate, or the extent of a buffer descriptor) -- a wrong one would write here, silently.
+        const size_t guard_floats = (size_t)128 * n;
+        DeviceBuf xd(xb), wd(wb), bd((size_t)n * 4), rd(residual ? yb : 4), yd(yb + guard_floats * 4);
         hip_check(hipMemcpy(xd.p, x, xb, hipMemcpyHostToDevice), "H2D x");
         hip_check(hipMemcpy(wd.p, w, wb, hipMemcpyHostToDevice), "H2D w");
         if (bias) hip_check(hipMemcpy(bd.p, bias, (size_t)n * 4, hipMemcpyHostToDevice), "H2D bias");
         if (residual) hip_check(hipMemcpy(rd.p, residual, yb, hipMemcpyHostToDevice), "H2D residual");
+        constexpr uint32_t kGuard = 0x7fc0beefu;  // (a NaN no epilogue produces)
+        hip_check(hipMemsetD32((hipDeviceptr_t)((char*)yd.p + yb), (int)kGuard, guard_floats), "guard band");
         // the scratch slab the encoder lends its GEMMs, so that the op takes the route the model takes at this row count
         const size_t sf = gemm_scratch_floats(m, n);
         DeviceBuf sd(sf * 4);
@@ -426,6 +452,10 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_linear(int32_t device, const float* 
                       "gemm");
         });
         hip_check(hipMemcpy(y, yd.p, yb, hipMemcpyDeviceToHost), "D2H y");
+        std::vector<uint32_t> guard(guard_floats);
+        hip_check(hipMemcpy(guard.data(), (char*)yd.p + yb, guard_floats * 4, hipMemcpyDeviceToHost), "D2H guard band");
+        for (size_t i = 0; i < guard_floats; ++i)
+            if (guard[i] != kGuard) throw std::runtime_error("GEMM wrote past the last output row (guard band touched at float " + std::to_string(i) + ")");
     });
 }
 

@@ -172,5 +172,6 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
 // Measurement aid: one wave stamps the shader-cycle counter and the 100 MHz counter around a spin of spin_ticks x 10 ns;
 // out[0] = shader cycles, out[1] = 10 ns ticks (clock in GHz = out[0] / out[1] / 10).  rowops.hip.
 hipError_t launch_clock_probe(uint64_t* out, unsigned spin_ticks, hipStream_t stream);
+hipError_t launch_clock_trace(uint64_t* out, unsigned samples, unsigned window_ticks, hipStream_t stream);
 
 }  // namespace kjarni

@@ -614,6 +614,33 @@ __global__ void clock_probe_kernel(unsigned long long* out, unsigned spin_ticks)
     out[1] = r1 - r0;
 }
 
+// The same reading repeated: `samples` consecutive windows of `window_ticks` (10 ns each), one (cycles, ticks) pair per window.
+// Launched on a stream of its own beside the work being measured, it is the clock the chip holds UNDER that work (one wave,
+// asleep between its reads; a probe between two kernels of the busy stream reads the clock of an idle chip instead).
+__global__ void clock_trace_kernel(unsigned long long* out, unsigned samples, unsigned window_ticks)
+{
+    if (threadIdx.x != 0) return;
+    for (unsigned s = 0; s < samples; ++s) {
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long r1 = r0;
+        for (unsigned round = 0; r1 - r0 < window_ticks && round < window_ticks + 4096u; ++round) {  // (bounded as above)
+            __builtin_amdgcn_s_sleep(64);
+            r1 = __builtin_amdgcn_s_memrealtime();
+        }
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        r1 = __builtin_amdgcn_s_memrealtime();
+        out[2 * s] = c1 - c0;
+        out[2 * s + 1] = r1 - r0;
+    }
+}
+
+hipError_t launch_clock_trace(uint64_t* out, unsigned samples, unsigned window_ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(clock_trace_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)out, samples, window_ticks);
+    return hipGetLastError();
+}
+
 hipError_t launch_clock_probe(uint64_t* out, unsigned spin_ticks, hipStream_t stream)
 {
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)out, spin_ticks);

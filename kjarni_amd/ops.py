@@ -152,6 +152,17 @@ def clock_probe(out_dev_ptr: int, spin_us: int = 20, stream: int = 0) -> None:
     check_error(lib().kjarni_hip_clock_probe(out_dev_ptr, int(spin_us), stream))
 
 
+def clock_trace(out_dev_ptr: int, samples: int, window_us: int, stream: int) -> None:
+    """Enqueues the repeated clock reading (kjarni_hip_clock_trace) on `stream` -- a stream of its own beside the work being
+    measured: out_dev_ptr -> samples x [shader cycles, 10 ns ticks] uint64 on the device."""
+    check_error(lib().kjarni_hip_clock_trace(out_dev_ptr, int(samples), int(window_us), stream))
+
+
+def measurement_stream() -> int:
+    """The library's own non-blocking stream for clock traces (kjarni_hip_measurement_stream); 0 if it cannot be made."""
+    return int(lib().kjarni_hip_measurement_stream() or 0)
+
+
 def get_f32_on_bf16() -> bool:
     return bool(lib().kjarni_hip_get_f32_on_bf16())
 

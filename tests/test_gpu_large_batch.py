@@ -319,3 +319,31 @@ def test_projection_shape_sweep_against_float64():
             ref = (v - mu) / np.sqrt(((v - mu) ** 2).mean(axis=1, keepdims=True) + 1e-12) * g + beta
         err = float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max()))
         assert err < 2e-5, (i, kind, m, n, k, err)
+
+
+@pytest.mark.parametrize("m,n,k,epi,with_bias", [
+    (30001, 1152, 384, "bias", True),      # 2 115 tiles over 512 workgroups (4 or 5 each), the last row tile 49 rows
+    (40077, 1536, 384, "gelu", True),
+    (33000, 1152, 768, "bias", False),     # 24 K-steps (the longest the kernel takes), no bias
+    (70001, 512, 192, "gelu", True),       # 6 K-steps (the shortest)
+    (262144 + 5, 1152, 384, "bias", True),  # the headline's chunk + a 5-row tail tile
+])
+def test_k_stream_tiles_whole_output_against_float64(m, n, k, epi, with_bias):
+    """The continuous K-stream tile kernel (gemm.hip, gemm_nt_f32_stream: K <= 768, >= 2 048 tiles, no residual operand) on
+    ragged row counts: every output element against a float64 evaluation (sampled rows + all of the last row tile for the
+    largest case); kjarni_hip_op_linear also fails if anything was written behind the last row (its guard band)."""
+    from kjarni_amd import ops
+    from scipy.special import erf
+    rng = np.random.default_rng(m + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32) if with_bias else None
+    got, _ = ops.linear(x, w, b, None, ops.EPI_BIAS_GELU if epi == "gelu" else ops.EPI_BIAS)
+    rows = np.arange(m) if m <= 80000 else np.unique(np.concatenate([rng.choice(m, 4096, replace=False), np.arange(m - 200, m), np.arange(0, 200)]))
+    ref = x[rows].astype(np.float64) @ w.astype(np.float64).T + (b.astype(np.float64) if b is not None else 0.0)
+    if epi == "gelu":
+        ref = 0.5 * ref * (1.0 + erf(ref / np.sqrt(2.0)))
+    err = float(np.abs(got[rows] - ref).max())
+    report(f"large/k_stream_tiles_{m}x{n}x{k}_{epi}", err, 2e-5)
+    assert err < 2e-5, err
+    assert np.isfinite(got).all()

@@ -203,3 +203,21 @@ def test_layer_norm_parity(rows, hidden):
     for eps in (1e-12, 1e-5):
         got, _ = ops.layer_norm(x, g, b, eps)
         assert np.abs(got - O.layer_norm(x, g, b, eps)).max() < 1e-5
+
+
+def test_clock_trace_reads_a_shader_clock():
+    """kjarni_hip_clock_trace (bench.py's clock_ghz): windows of shader cycles against the 100 MHz counter on the library's own
+    measurement stream -- every window a plausible clock (0.1 .. 3 GHz), window lengths as asked (within 20 %)."""
+    import torch
+    from kjarni_amd import ops
+    out = torch.zeros((8, 2), dtype=torch.int64, device="cuda:0")
+    stream = ops.measurement_stream()
+    assert stream != 0
+    ops.clock_trace(out.data_ptr(), 8, 500, stream)
+    torch.cuda.synchronize()
+    v = out.cpu().numpy().astype(np.float64)
+    ghz = v[:, 0] / v[:, 1] / 10.0
+    assert ((ghz > 0.1) & (ghz < 3.0)).all(), ghz
+    assert ((v[:, 1] >= 50_000) & (v[:, 1] < 60_000)).all(), v[:, 1]  # 500 us = 50 000 ticks of 10 ns
+    with pytest.raises(Exception):
+        ops.clock_trace(out.data_ptr(), 0, 500, stream)
