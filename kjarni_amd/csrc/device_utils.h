@@ -39,44 +39,47 @@ __device__ __forceinline__ float gelu_erf(float x)
     return 0.5f * x * (1.0f + erff(x * 0.7071067811865475f));
 }
 
-// erf-GELU for the GEMM epilogue.  erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, the
-// same approximation the reference's own GPU shader uses: gpu_ops/blocks/ffn/fc1.wgsl:57-71):
-// 2 transcendentals + ~12 VALU per element instead of ~34 for the libm-grade erff, which matters
-// because FC1's epilogue runs once per 384 MFMA-flops-deep output element.
+// erf-GELU for the GEMM epilogues (activations.rs:56-59: 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x)), with ONE transcendental:
+//     GELU(x) = max(x, 0) - g(|x|),   g(a) = a Phi(-a) = a 2^-P(a),   P(a) = -log2 Phi(-a)
+// P is smooth (1 at 0, ~ a^2 / (2 ln 2) far out) and a degree-6 polynomial, fitted on [0, 6] with the error weighted by g ln 2
+// (what an error of P does to g; tools/fit_gelu.py), reproduces GELU in f32 to 2.8e-7 absolute over |x| <= 12 -- the
+// rounding of the result itself near |x| = 4; beyond a = 6, g < 6e-9 and a is clamped.  Rounds 1-4 used Abramowitz & Stegun
+// 7.1.26 (a reciprocal AND an exponential per element, 4.7e-7): FC1's epilogue runs once per 384 MFMA-flops-deep output
+// element on the FP32 lanes the f32 matrix instructions also use, and the quarter-rate transcendentals were over half of it.
+// max(x, 0) as 0.5 (x + |x|) (exact) so that a NaN stays a NaN.
+constexpr float kGeluP0 = 0.999993085861206f, kGeluP1 = 1.1512017250061035f, kGeluP2 = 0.4587709307670593f, kGeluP3 = 0.05341215059161186f,
+                kGeluP4 = -0.008080747909843922f, kGeluP5 = 0.0007692292565479875f, kGeluP6 = -3.3093903766712174e-05f;
 __device__ __forceinline__ float gelu_erf_fast(float x)
 {
-    const float z = fabsf(x) * 0.7071067811865475f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = fmaf(-p, e, 1.0f);
-    const float erf_v = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_v);
+    const float ax = fabsf(x);
+    const float a = fminf(ax, 6.0f);
+    float p = fmaf(kGeluP6, a, kGeluP5);
+    p = fmaf(p, a, kGeluP4);
+    p = fmaf(p, a, kGeluP3);
+    p = fmaf(p, a, kGeluP2);
+    p = fmaf(p, a, kGeluP1);
+    p = fmaf(p, a, kGeluP0);
+    const float g = a * __builtin_amdgcn_exp2f(-p);
+    return fmaf(x + ax, 0.5f, -g);
 }
 
-// The same on four elements, with the polynomial on packed pairs (v_pk_fma_f32 / v_pk_mul_f32:
-// two elements per VALU instruction) -- the epilogue has no MFMA to hide behind.
+// The same on a pair, with the polynomial on packed pairs (v_pk_fma_f32 / v_pk_mul_f32: two elements per VALU instruction;
+// the same operations in the same order as above: the same bits) -- the epilogue has no MFMA to hide behind.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x)
 {
     const f32x2 ax = __builtin_elementwise_abs(x);
-    const f32x2 z = ax * 0.7071067811865475f;
-    const f32x2 d = __builtin_elementwise_fma(z, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
-    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
-    p = p * t;
-    const f32x2 a = z * z * -1.4426950408889634f;
-    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-    const f32x2 erf_abs = __builtin_elementwise_fma(-p, e, f32x2{1.0f, 1.0f});  // erf(|x|/sqrt2) in [0,1]
-    // 0.5*x*(1 + sign(x)*erf_abs) = 0.5*(x + |x|*erf_abs)
-    return __builtin_elementwise_fma(ax, erf_abs, x) * 0.5f;
+    const f32x2 a = {fminf(ax[0], 6.0f), fminf(ax[1], 6.0f)};
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 p = __builtin_elementwise_fma(k2(kGeluP6), a, k2(kGeluP5));
+    p = __builtin_elementwise_fma(p, a, k2(kGeluP4));
+    p = __builtin_elementwise_fma(p, a, k2(kGeluP3));
+    p = __builtin_elementwise_fma(p, a, k2(kGeluP2));
+    p = __builtin_elementwise_fma(p, a, k2(kGeluP1));
+    p = __builtin_elementwise_fma(p, a, k2(kGeluP0));
+    const f32x2 e = {__builtin_amdgcn_exp2f(-p[0]), __builtin_amdgcn_exp2f(-p[1])};
+    const f32x2 g = a * e;
+    return __builtin_elementwise_fma(x + ax, k2(0.5f), -g);
 }
 
 // activations.rs:62-66
