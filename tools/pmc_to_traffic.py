@@ -19,10 +19,12 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
             "kjarni::(anonymous namespace)::", "").split("(")[0]
         if name.startswith("gemm_nt_f32_mfma_ln"):
             name = "gemm_nt_f32_mfma_ln"
-        elif name.startswith("gemm_nt_f32_mfma<"):
+        elif name.startswith(("gemm_nt_f32_mfma<", "gemm_nt_f32_stream<")):
             epi = int(name.split("<")[1].split(",")[0].rstrip(">"))
-            name = f"gemm_nt_f32_mfma<{EPI.get(epi, epi)}>"
+            name = f"{name.split('<')[0]}<{EPI.get(epi, epi)}>"
         name = name.split("<")[0] if name.startswith(("attention", "pool")) else name
+        if not name.startswith(("gemm_", "attention", "embed_", "pool", "layernorm", "cosine", "mid_", "small_linear")):
+            continue  # (torch's fills / reductions around the step, the clock probes)
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, c in acc.items():
