@@ -802,6 +802,7 @@ def main():
         try:
             timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
             torch.cuda.synchronize()  # (the side stream's last trace)
+            _probe_ops.measurement_stream_release()  # (or one of the encoder's lane streams may share a hardware queue with it)
             pr = probes.cpu().numpy().astype(np.float64)
             win = np.where(pr[..., 1] > 0, pr[..., 0] / np.maximum(pr[..., 1], 1) / 10.0, np.nan)  # GHz per window
             if np.isfinite(win).any():

@@ -141,6 +141,10 @@ KjarniErrorCode kjarni_hip_clock_trace(uint64_t* out_dev, uint32_t samples, uint
 /* A non-blocking stream of the library's own for such readings (one per process, made on first use on the current device, never
  * destroyed; NULL if it cannot be made).  hipStreamSynchronize / a later blocking copy from out_dev orders the caller behind it. */
 void* kjarni_hip_measurement_stream(void);
+/* Waits for it and destroys it (the next kjarni_hip_measurement_stream() makes a new one).  A process has a handful of hardware
+ * queues and HIP deals its streams over them: release the stream once the readings are in, or one of an encoder's own streams may
+ * share a queue with it. */
+void kjarni_hip_measurement_stream_release(void);
 
 /* Thread safety (every entry point of a KjarniHipEncoder / KjarniHipEncoderGroup, device- and host-pointer forms):
  * calls may be made concurrently from any number of host threads and on any streams, as on the reference's

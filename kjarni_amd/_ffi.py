@@ -426,6 +426,7 @@ SIGNATURES = {
     "kjarni_hip_clock_probe": (c_int32, [c_void_p, C.c_uint32, c_void_p]),
     "kjarni_hip_clock_trace": (c_int32, [c_void_p, C.c_uint32, C.c_uint32, c_void_p]),
     "kjarni_hip_measurement_stream": (c_void_p, []),
+    "kjarni_hip_measurement_stream_release": (None, []),
     "kjarni_hip_encoder_hidden_states": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                                    c_int32, c_void_p, c_void_p]),
     "kjarni_hip_encoder_embed": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

@@ -163,6 +163,11 @@ def measurement_stream() -> int:
     return int(lib().kjarni_hip_measurement_stream() or 0)
 
 
+def measurement_stream_release() -> None:
+    """Waits for the measurement stream and destroys it (kjarni_hip_measurement_stream_release)."""
+    lib().kjarni_hip_measurement_stream_release()
+
+
 def get_f32_on_bf16() -> bool:
     return bool(lib().kjarni_hip_get_f32_on_bf16())
 

@@ -221,3 +221,6 @@ def test_clock_trace_reads_a_shader_clock():
     assert ((v[:, 1] >= 50_000) & (v[:, 1] < 60_000)).all(), v[:, 1]  # 500 us = 50 000 ticks of 10 ns
     with pytest.raises(Exception):
         ops.clock_trace(out.data_ptr(), 0, 500, stream)
+    ops.measurement_stream_release()
+    assert ops.measurement_stream() != 0  # (a new one)
+    ops.measurement_stream_release()
