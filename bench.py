@@ -767,13 +767,17 @@ def main():
         probes = torch.zeros((args.steps, TRACE_WINDOWS, 2), dtype=torch.int64, device=dev)
         idle_probe = torch.zeros((2,), dtype=torch.int64, device=dev)
         side_stream = _probe_ops.measurement_stream()
-        # one more untimed step for the window length (and the idle reading in front of it)
-        _probe_ops.clock_probe(idle_probe.data_ptr(), 200, main_stream.cuda_stream)
+        _probe_ops.clock_probe(idle_probe.data_ptr(), 200, main_stream.cuda_stream)  # (the idle reading: nothing else is running)
+    # One more untimed step on EVERY rank (a step holds the output all-gather at N > 1: all ranks or none), timed on the host: the
+    # length of a clock-trace window.
+    est_us = 0.0
+    if not args.no_instrument:  # (--dry-run-cpu included: the gloo tests then cover that every rank makes the same collectives)
         sync()
         t_est = time.perf_counter()
         step()
         sync()
         est_us = (time.perf_counter() - t_est) * 1e6
+    if instrument:
         window_us = int(min(1_000_000, max(10, 0.97 * est_us / TRACE_WINDOWS)))
         if not args.no_sensors:
             smi_before = GpuSensors.snapshot()
