@@ -216,6 +216,19 @@ int32_t kjarni_hip_group_num_labels(const KjarniHipEncoderGroup* group);
 /* Row block [*start_out, *start_out + *count_out) of `rows` rows that replica i owns. */
 KjarniErrorCode kjarni_hip_group_shard(const KjarniHipEncoderGroup* group, int64_t rows, size_t i, int64_t* start_out,
                                        int64_t* count_out);
+/* The collective that kjarni_hip_group_*_allgather issues for `rows` rows of `width` floats over n devices, as a list (host
+ * arithmetic only: no device, no group needed): rank `rank` calls ncclAllGather in place (root = -1; equal blocks) or one
+ * ncclBroadcast per non-empty block (root >= 0; blocks that differ by a row) on `floats` values at float offset `offset` of
+ * its full output buffer.  Writes up to `cap` operations to ops_out, the total count to *count_out (n for equal blocks,
+ * n x non-empty blocks otherwise). */
+typedef struct KjarniHipGatherOp {
+    int32_t rank;
+    int32_t root;
+    int64_t offset;
+    int64_t floats;
+} KjarniHipGatherOp;
+KjarniErrorCode kjarni_hip_group_gather_plan(int64_t rows, size_t n, int64_t width, KjarniHipGatherOp* ops_out, size_t cap,
+                                             size_t* count_out);
 /* Host pointers: every device stages, encodes and returns its block straight into `out` ([batch, hidden] /
  * [batch, num_labels]); the mask fill follows the size of the whole call. */
 KjarniErrorCode kjarni_hip_group_embed_host(KjarniHipEncoderGroup* group, const uint32_t* ids, const uint32_t* mask,

@@ -459,6 +459,7 @@ SIGNATURES = {
     "kjarni_hip_group_hidden_size": (c_int32, [c_void_p]),
     "kjarni_hip_group_num_labels": (c_int32, [c_void_p]),
     "kjarni_hip_group_shard": (c_int32, [c_void_p, c_int64, c_size_t, POINTER(c_int64), POINTER(c_int64)]),
+    "kjarni_hip_group_gather_plan": (c_int32, [c_int64, c_size_t, c_int64, c_void_p, c_size_t, POINTER(c_size_t)]),
     "kjarni_hip_group_embed_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                               _f32p]),
     "kjarni_hip_group_logits_host": (c_int32, [c_void_p, _u32p, _u32p, _u32p, c_int64, c_int32, c_int32, _f32p]),

@@ -984,6 +984,17 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) tq[i * 16 + r] = sTq[i * 32 + acc_row(r, half)];  // (written before the prologue's barrier)
     }
+    // FUSED: does one of this lane-half's 32 queries hold a NaN or an infinity?  Its dot products are then NaN (or inf - inf once
+    // the -inf bound is added), which the packed max below drops: such a lane takes the exact path for every tile, where a NaN
+    // score is "not below the bound", is appended, overflows the list and leaves the query to the two-call form -- whose result
+    // (k rows with NaN scores) is the reference's.
+    bool odd_query = false;
+    if (FUSED) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) odd_query = odd_query || !(sQn[i * 32 + acc_row(r, half)] < INFINITY);
+    }
 
     int c_tile = (int)blockIdx.x;  // tile the matrix side is on
     int c_par = 0, cur = 0;        // parity of its norms; LDS stage of the step being multiplied
@@ -1096,8 +1107,8 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                     const bool odd_doc = !(dn >= 1e-4f && dn < INFINITY);   // too small for the rule, or not finite: exact path
                     const float idn = __builtin_amdgcn_rcpf(dn);
                     // margin of every score over its bound, two per instruction (v_pk_fma_f32 / v_pk_max_f32); a pass is a
-                    // margin >= 0.  (A NaN margin would be dropped by the max: a NaN dot product needs a non-finite document --
-                    // odd_doc -- or a non-finite query, whose bound is -inf: margin +inf.)
+                    // margin that is not negative.  (A NaN margin is dropped by the max: a NaN dot product needs a non-finite
+                    // document -- odd_doc -- or a non-finite query -- odd_query; both take the exact path.)
                     const f32x2 idn2 = {idn, idn};
                     f32x2 top = {-INFINITY, -INFINITY};
 #pragma unroll
@@ -1106,14 +1117,14 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                         const f32x2 margin = __builtin_elementwise_fma(dots, idn2, f32x2{-tq[e], -tq[e + 1]});
                         top = __builtin_elementwise_max(top, margin);
                     }
-                    const bool any = odd_doc || fmaxf(top[0], top[1]) >= 0.0f;
+                    const bool any = odd_doc || odd_query || fmaxf(top[0], top[1]) >= 0.0f;
                     if (__ballot(any) != 0ull) {
 #pragma unroll
                         for (int e = 0; e < 32; ++e) {
                             // (the cheap test again, per register: at ~1e-4 passes per score a block that has one has ONE, and
                             // the exact cosine + list bookkeeping below run for that register only, not for all 32)
                             const float margin = fmaf(acc[e >> 4][j][e & 15], idn, -tq[e]);
-                            if (__ballot(odd_doc || margin >= 0.0f) == 0ull) continue;
+                            if (__ballot(odd_doc || !(margin < 0.0f)) == 0ull) continue;   // (a NaN margin passes)
                             int q = (e >> 4) * 32 + acc_row(e & 15, half);
                             // (opaque: otherwise the 32 list addresses below are hoisted out of the K-loop into 64 registers)
                             asm volatile("" : "+v"(q));

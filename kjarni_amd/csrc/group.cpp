@@ -272,6 +272,24 @@ const char* EncoderGroup::transport()
     return transport_note_.empty() ? "memcpy" : transport_note_.c_str();
 }
 
+std::vector<EncoderGroup::GatherOp> EncoderGroup::gather_plan(int64_t rows_total, size_t parts, int64_t width)
+{
+    std::vector<GatherOp> ops;
+    if (parts == 0 || rows_total < 0 || width <= 0) return ops;
+    std::vector<int64_t> start(parts), count(parts);
+    for (size_t i = 0; i < parts; ++i) shard(rows_total, parts, i, &start[i], &count[i]);
+    const bool even = rows_total % (int64_t)parts == 0;
+    for (size_t i = 0; i < parts; ++i) {
+        if (even) {
+            ops.push_back({(int32_t)i, -1, start[i] * width, count[i] * width});
+        } else {
+            for (size_t root = 0; root < parts; ++root)
+                if (count[root] > 0) ops.push_back({(int32_t)i, (int32_t)root, start[root] * width, count[root] * width});
+        }
+    }
+    return ops;
+}
+
 // Every out_dev[i] holds block i (rows shard(rows_total, n, i)) at its place; afterwards every buffer holds all
 // blocks.  Called with the compute of block i already enqueued on streams_[i].
 void EncoderGroup::gather(float* const* out_dev, int64_t rows_total, int64_t width)
@@ -281,7 +299,7 @@ void EncoderGroup::gather(float* const* out_dev, int64_t rows_total, int64_t wid
     for (size_t i = 0; i < n; ++i) shard(rows_total, n, i, &start[i], &count[i]);
     if (ensure_rccl()) {
         const RcclApi& r = *static_cast<RcclApi*>(rccl_);
-        const bool even = rows_total % (int64_t)n == 0;
+        const std::vector<GatherOp> plan = gather_plan(rows_total, n, width);
         nccl_check(r, r.GroupStart(), "ncclGroupStart");
         // Nothing throws between GroupStart and GroupEnd: the first failure is remembered, the bracket is always closed
         // and the streams drained, so a failed collective leaves neither an open RCCL group on this thread nor
@@ -294,18 +312,16 @@ void EncoderGroup::gather(float* const* out_dev, int64_t rows_total, int64_t wid
                 first_what = what;
             }
         };
-        for (size_t i = 0; i < n && first == ncclSuccess; ++i) {
+        for (const GatherOp& op : plan) {
+            if (first != ncclSuccess) break;
+            const size_t i = (size_t)op.rank;
             ncclComm_t comm = static_cast<ncclComm_t>(comms_[i]);
-            if (even) {
+            if (op.root < 0) {
                 // in place: the send buffer is this rank's slot of the receive buffer
-                note(r.AllGather(out_dev[i] + start[i] * width, out_dev[i], (size_t)(count[i] * width), ncclFloat, comm, streams_[i]),
-                     "ncclAllGather");
+                note(r.AllGather(out_dev[i] + op.offset, out_dev[i], (size_t)op.floats, ncclFloat, comm, streams_[i]), "ncclAllGather");
             } else {
-                for (size_t root = 0; root < n && first == ncclSuccess; ++root)
-                    if (count[root] > 0)
-                        note(r.Broadcast(out_dev[i] + start[root] * width, out_dev[i] + start[root] * width,
-                                         (size_t)(count[root] * width), ncclFloat, (int)root, comm, streams_[i]),
-                             "ncclBroadcast");
+                note(r.Broadcast(out_dev[i] + op.offset, out_dev[i] + op.offset, (size_t)op.floats, ncclFloat, op.root, comm, streams_[i]),
+                     "ncclBroadcast");
             }
         }
         note(r.GroupEnd(), "ncclGroupEnd");

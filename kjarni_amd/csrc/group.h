@@ -40,6 +40,17 @@ public:
 
     // Balanced contiguous partition of `rows` over `parts`: floor(rows/parts) each, the first rows % parts one more.
     static void shard(int64_t rows, size_t parts, size_t i, int64_t* start, int64_t* count);
+    // The collective of the device-resident form as a list of operations (pure host arithmetic, testable without a device):
+    // rank `rank` of `parts` receives `floats` values of root `root`'s block at float offset `offset` of its full buffer.  Blocks
+    // of equal size: ONE in-place all-gather per rank (root = -1, its own block's offset and size); otherwise one broadcast per
+    // non-empty block and rank, in root order.  Every rank's operations cover [0, rows * width) exactly once.
+    struct GatherOp {
+        int32_t rank;     // the communicator rank that issues the call
+        int32_t root;     // -1: ncclAllGather (in place); >= 0: ncclBroadcast from this root
+        int64_t offset;   // in floats, into out_dev[rank] (send buffer for the all-gather / root, receive buffer otherwise)
+        int64_t floats;   // element count of the call
+    };
+    static std::vector<GatherOp> gather_plan(int64_t rows_total, size_t parts, int64_t width);
     // Replicas a batch of `batch` sentences is spread over (a device's share is never below kMinRowsPerDevice,
     // so a single sentence does not pay a thread hop per GPU).
     size_t fanout(int64_t batch) const;

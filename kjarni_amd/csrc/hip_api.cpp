@@ -154,16 +154,20 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_clock_probe(uint64_t* out_dev, uint32_t
 
 namespace {
 std::mutex g_measurement_mu;
-hipStream_t g_measurement_stream = nullptr;
+constexpr int kMaxMeasurementDevices = 64;
+hipStream_t g_measurement_stream[kMaxMeasurementDevices] = {};   // one per device, made on first use on that device
 }  // namespace
 
 KJARNI_EXPORT void* kjarni_hip_measurement_stream(void)
 {
-    // one non-blocking stream per process, made on first use (a measurement aid: see kjarni_hip_clock_trace)
+    // one non-blocking stream per DEVICE, made on first use with that device current (a measurement aid: see
+    // kjarni_hip_clock_trace); a caller whose current device differs gets that device's own stream, never another's
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxMeasurementDevices) return nullptr;
     std::lock_guard<std::mutex> lock(g_measurement_mu);
-    if (!g_measurement_stream && hipStreamCreateWithFlags(&g_measurement_stream, hipStreamNonBlocking) != hipSuccess)
-        g_measurement_stream = nullptr;
-    return g_measurement_stream;
+    if (!g_measurement_stream[dev] && hipStreamCreateWithFlags(&g_measurement_stream[dev], hipStreamNonBlocking) != hipSuccess)
+        g_measurement_stream[dev] = nullptr;
+    return g_measurement_stream[dev];
 }
 
 KJARNI_EXPORT void kjarni_hip_measurement_stream_release(void)
@@ -171,11 +175,16 @@ KJARNI_EXPORT void kjarni_hip_measurement_stream_release(void)
     // (a process has a handful of hardware queues and HIP deals its streams over them: while this stream exists, one of the
     // encoder's own streams may share a queue with it -- a 64-sentence call, three parts on three streams, 1.72 -> 2.07 ms)
     std::lock_guard<std::mutex> lock(g_measurement_mu);
-    if (g_measurement_stream) {
-        (void)hipStreamSynchronize(g_measurement_stream);
-        (void)hipStreamDestroy(g_measurement_stream);
-        g_measurement_stream = nullptr;
+    int before = -1;
+    (void)hipGetDevice(&before);
+    for (int dev = 0; dev < kMaxMeasurementDevices; ++dev) {
+        if (!g_measurement_stream[dev]) continue;
+        (void)hipSetDevice(dev);
+        (void)hipStreamSynchronize(g_measurement_stream[dev]);
+        (void)hipStreamDestroy(g_measurement_stream[dev]);
+        g_measurement_stream[dev] = nullptr;
     }
+    if (before >= 0) (void)hipSetDevice(before);
 }
 
 KJARNI_EXPORT KjarniErrorCode kjarni_hip_clock_trace(uint64_t* out_dev, uint32_t samples, uint32_t window_us, void* stream)
@@ -314,6 +323,17 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_shard(const KjarniHipEncoderGroup
     if (!g || !start_out || !count_out) return KJARNI_ERROR_NULL_POINTER;
     if (i >= g->group->size() || rows < 0) return KJARNI_ERROR_INVALID_CONFIG;
     EncoderGroup::shard(rows, g->group->size(), i, start_out, count_out);
+    return KJARNI_OK;
+}
+
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_group_gather_plan(int64_t rows, size_t n, int64_t width, KjarniHipGatherOp* ops_out, size_t cap,
+                                                           size_t* count_out)
+{
+    if (!count_out || (cap && !ops_out)) return KJARNI_ERROR_NULL_POINTER;
+    if (rows < 0 || n == 0 || n > 4096 || width <= 0) return KJARNI_ERROR_INVALID_CONFIG;
+    const std::vector<EncoderGroup::GatherOp> plan = EncoderGroup::gather_plan(rows, n, width);
+    *count_out = plan.size();
+    for (size_t i = 0; i < plan.size() && i < cap; ++i) ops_out[i] = KjarniHipGatherOp{plan[i].rank, plan[i].root, plan[i].offset, plan[i].floats};
     return KJARNI_OK;
 }
 
@@ -557,6 +577,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_pool(int32_t device, const float* hi
     if (!hidden_states || !out) return KJARNI_ERROR_NULL_POINTER;
     return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
         if (batch < 0 || seq <= 0 || hidden <= 0 || hidden > 1024) throw InvalidConfig("invalid pooling dimensions");
+        const PoolMode mode = pool_mode(pooling);   // (throws InvalidConfig for a value outside the enum)
         use_device(device);
         if (batch == 0) return;
         const size_t T = (size_t)batch * seq;
@@ -565,7 +586,7 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_op_pool(int32_t device, const float* hi
         std::vector<uint32_t> ones;
         if (!mask) ones.assign(T, 1u);
         hip_check(hipMemcpy(md.p, mask ? mask : ones.data(), T * 4, hipMemcpyHostToDevice), "H2D mask");
-        hip_check(launch_pool((const float*)hd.p, (const uint32_t*)md.p, batch, seq, hidden, (PoolMode)pooling, normalize,
+        hip_check(launch_pool((const float*)hd.p, (const uint32_t*)md.p, batch, seq, hidden, mode, normalize,
                               (float*)od.p, nullptr),
                   "pool");
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");

@@ -157,3 +157,39 @@ def sharded_cosine_topk(local_idx: torch.Tensor, local_score: torch.Tensor, row_
     idx_c, sc_c = idx_c[o1], sc_c[o1]
     o2 = torch.sort(sc_c, descending=True, stable=True).indices[:k]
     return idx_c[o2], sc_c[o2]
+
+
+def sharded_cosine_topk_batch(local_idx: torch.Tensor, local_score: torch.Tensor, row_offset: int, k: int, group=None
+                              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The many-query form of sharded_cosine_topk: local_idx / local_score are [nq, k] (what kjarni_hip_cosine_search returns for
+    this rank's rows of the corpus; -1 / anything where a query has fewer than k hits).  ONE all-gather of the [nq, k] index
+    block and one of the score block (G * nq * k * 12 bytes over xGMI), then every query's G * k candidates are merged on the
+    host: score descending, ties by ascending GLOBAL index (the reference's stable sort over the whole corpus,
+    vector.rs:150-166).  Returns ([nq, k] int64 global indices, -1 past a query's hits; [nq, k] float32 scores, -inf there)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    assert local_idx.dim() == 2 and local_idx.shape == local_score.shape and local_idx.shape[1] <= k
+    nq = local_idx.shape[0]
+    gidx = torch.full((nq, k), -1, dtype=torch.int64, device=local_idx.device)
+    gsc = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=local_idx.device)
+    li = local_idx.to(torch.int64)
+    gidx[:, :li.shape[1]] = torch.where(li < 0, torch.full_like(li, -1), li + row_offset)
+    gsc[:, :li.shape[1]] = torch.where(li < 0, torch.full_like(local_score, float("-inf")), local_score.to(torch.float32))
+    if world > 1:
+        idx_all = torch.empty((world * nq, k), dtype=torch.int64, device=gidx.device)     # (rank-major concatenation)
+        sc_all = torch.empty((world * nq, k), dtype=torch.float32, device=gidx.device)
+        dist.all_gather_into_tensor(idx_all, gidx.contiguous(), group=group)
+        dist.all_gather_into_tensor(sc_all, gsc.contiguous(), group=group)
+        idx_c = idx_all.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k).cpu()
+        sc_c = sc_all.view(world, nq, k).permute(1, 0, 2).reshape(nq, world * k).cpu()
+    else:
+        idx_c, sc_c = gidx.cpu(), gsc.cpu()
+    missing = idx_c < 0
+    key_i = torch.where(missing, torch.full_like(idx_c, torch.iinfo(torch.int64).max), idx_c)
+    o1 = torch.sort(key_i, dim=1, stable=True).indices                   # by global index ...
+    idx_c, sc_c, missing = idx_c.gather(1, o1), sc_c.gather(1, o1), missing.gather(1, o1)
+    # ... then stable by score: a missing slot sorts after every hit whatever its score field holds (NaN scores keep their place
+    # among the hits as the largest key, which is where the scan's own 64-bit keys put them)
+    key_s = torch.where(missing, torch.full_like(sc_c, float("-inf")), torch.nan_to_num(sc_c, nan=float("inf")))
+    o2 = torch.sort(key_s, dim=1, descending=True, stable=True).indices[:, :k]
+    out_i, out_s, out_m = idx_c.gather(1, o2), sc_c.gather(1, o2), missing.gather(1, o2)
+    return torch.where(out_m, torch.full_like(out_i, -1), out_i), torch.where(out_m, torch.full_like(out_s, float("-inf")), out_s)

@@ -36,6 +36,11 @@ def test_plain_invocation_spawns_its_ranks(workload, extra):
         leg = r["rerank"]
         assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["pairs_per_step"] == 100000
         assert leg["pairs_per_gpu"] == 50000 and leg["pairs_per_s"] > 0 and leg["ms_per_step"] > 0 and leg["steps"] == 2
+        # ... and the third sharded path of SURVEY.md section 8(e): the cosine scan over a corpus sharded by rows (local search,
+        # ONE all-gather of the candidate lists, merge by (score, global index)); the leg asserts its own result
+        sh = r["scan_sharded"]
+        assert sh["n_gpus"] == 2 and sh["scaling"] == "weak" and sh["queries_1"]["ms_per_search"] > 0
+        assert sh["queries_64"]["doc_queries_per_s"] > 0 and sh["queries_64"]["steps"] == 2
     # the communicator the ranks built spans exactly --gpus ranks (gloo here, RCCL on the GPU path)
     assert r["collective"]["ranks"] == 2 and r["collective"]["allreduce_of_ones"] == 2
     assert r["value"] > 0 and r["higher_is_better"] is True and r["vs_baseline"] is None
@@ -57,7 +62,7 @@ def test_world_size_mismatch_is_an_error():
 
 def test_single_rank_has_no_collective_and_can_skip_the_rerank_leg():
     r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--sentences", "10", "--no-rerank-leg"])
-    assert r["n_gpus"] == 1 and "collective" not in r and "rerank" not in r
+    assert r["n_gpus"] == 1 and "collective" not in r and "rerank" not in r and "scan_sharded" not in r
     r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--sentences", "10", "--pairs", "77"])
     assert r["rerank"]["pairs_per_step"] == 77 and r["rerank"]["n_gpus"] == 1
 
@@ -72,6 +77,7 @@ def test_eight_ranks_as_the_driver_launches_them():
     leg = r["rerank"]
     assert leg["n_gpus"] == 8 and leg["scaling"] == "strong" and leg["pairs_per_step"] == 100003 and leg["pairs_per_gpu"] == 12501
     assert 1 <= r["host_threads_per_rank"] <= max(1, (os.cpu_count() or 8) // 8)
+    assert r["scan_sharded"]["n_gpus"] == 8 and r["scan_sharded"]["corpus"].startswith("[8 x ")
 
 
 def test_in_process_arrangement_drives_every_device_from_one_process():

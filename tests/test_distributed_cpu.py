@@ -134,6 +134,29 @@ def _worker(rank, world, port, n_list, q):
         idx, sc = D.sharded_cosine_topk(o, loc[o], start, k)
         ref_o = torch.sort(scores, descending=True, stable=True).indices[:k]
         ok &= idx.tolist() == ref_o.tolist() and bool(torch.equal(sc, scores[ref_o]))
+        # the many-query form: [nq, k] local lists (one query with ties across the shard boundary, one with fewer than k hits on a
+        # rank), ONE all-gather per array, merged per query by (score descending, global index ascending)
+        nq = 5
+        g = torch.Generator().manual_seed(7)
+        full = torch.randn((nq, 1001), generator=g)
+        full[1] = torch.round(full[1] * 2) / 2                       # many exact ties, also across ranks
+        loc2 = full[:, start:start + count]
+        o2 = torch.sort(loc2, dim=1, descending=True, stable=True).indices[:, :k]
+        li, ls = o2.clone(), loc2.gather(1, o2)
+        if rank == world - 1:
+            li[3, 2:], ls[3, 2:] = -1, 123.0                         # this rank found only two hits for query 3
+        bi, bs = D.sharded_cosine_topk_batch(li, ls, start, k)
+        for j in range(nq):
+            row = full[j].clone()
+            if j == 3:                                               # the last rank's rows beyond its two best do not exist
+                s2, c2 = D.shard_rows(1001, world, world - 1)
+                keep = torch.sort(row[s2:s2 + c2], descending=True, stable=True).indices[:2] + s2
+                m = torch.ones(1001, dtype=torch.bool)
+                m[s2:s2 + c2] = False
+                m[keep] = True
+                row[~m] = float("-inf")
+            ref = torch.sort(row, descending=True, stable=True).indices[:k]
+            ok &= bi[j].tolist() == ref.tolist() and bool(torch.equal(bs[j], row[ref]))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -167,3 +190,66 @@ def test_world_size_3_uneven_rows_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True), (2, True)]
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("rows", [7, 16, 100003, 0])
+def test_in_process_group_gather_plan(n, rows):
+    """EncoderGroup::gather (csrc/group.cpp) issues its RCCL calls from EncoderGroup::gather_plan, pure host arithmetic exported
+    as kjarni_hip_group_gather_plan: equal blocks -> ONE in-place ncclAllGather per rank; blocks that differ by a row (N % n != 0:
+    the path a `--in-process` run with 100 003 rows takes) -> one ncclBroadcast per non-empty block and rank.  The plan is executed
+    here on host arrays with the collectives' semantics: every rank must end with every block at its place, every call of one
+    collective must agree on root / count across ranks, and no call may touch floats outside its block."""
+    import ctypes as C
+
+    import numpy as np
+
+    from kjarni_amd import _ffi
+
+    class Op(C.Structure):
+        _fields_ = [("rank", C.c_int32), ("root", C.c_int32), ("offset", C.c_int64), ("floats", C.c_int64)]
+
+    L = _ffi.lib()
+    width = 5
+    ops = (Op * (n * n + 1))()
+    cnt = C.c_size_t(0)
+    assert L.kjarni_hip_group_gather_plan(rows, n, width, C.cast(ops, C.c_void_p), len(ops), C.byref(cnt)) == 0
+    plan = [(o.rank, o.root, o.offset, o.floats) for o in ops[:cnt.value]]
+    shards = [D.shard_rows(rows, n, i) for i in range(n)]          # the same partition as EncoderGroup::shard
+    assert sum(c for _, c in shards) == rows and all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(n - 1))
+    # every rank's buffer holds ITS block (value = 1000 * rank + position) and NaN elsewhere
+    bufs = []
+    for i, (s, c) in enumerate(shards):
+        b = np.full(rows * width, np.nan, np.float64)
+        b[s * width:(s + c) * width] = 1000.0 * i + np.arange(c * width)
+        bufs.append(b)
+    even = rows % n == 0
+    per_rank = [[p for p in plan if p[0] == i] for i in range(n)]
+    if even:
+        assert all(len(p) == 1 and p[0][1] == -1 for p in per_rank)
+        counts = {p[0][3] for p in per_rank}
+        assert len(counts) == 1                                      # ncclAllGather: the same sendcount on every rank
+        for i, (s, c) in enumerate(shards):
+            assert per_rank[i][0][2] == s * width and per_rank[i][0][3] == c * width    # in place: send = own slot of recv
+        sends = [bufs[i][per_rank[i][0][2]:per_rank[i][0][2] + per_rank[i][0][3]].copy() for i in range(n)]
+        for b in bufs:
+            b[:] = np.concatenate(sends) if rows else b
+    else:
+        seqs = [[(p[1], p[3]) for p in pr] for pr in per_rank]
+        assert all(sq == seqs[0] for sq in seqs)                     # every rank issues the same broadcasts in the same order
+        assert [r for r, _ in seqs[0]] == [i for i, (_, c) in enumerate(shards) if c > 0]
+        for step in range(len(seqs[0])):
+            root = per_rank[0][step][1]
+            s, c = shards[root]
+            assert all(pr[step][2] == s * width and pr[step][3] == c * width for pr in per_rank)
+            data = bufs[root][s * width:(s + c) * width].copy()
+            assert not np.isnan(data).any()
+            for b in bufs:
+                b[s * width:(s + c) * width] = data
+    want = np.concatenate([1000.0 * i + np.arange(c * width) for i, (s, c) in enumerate(shards)]) if rows else np.zeros(0)
+    for b in bufs:
+        assert np.array_equal(b, want)
+    # bad arguments are refused, a short output array still reports the full count
+    assert L.kjarni_hip_group_gather_plan(-1, n, width, None, 0, C.byref(cnt)) == 7
+    assert L.kjarni_hip_group_gather_plan(rows, 0, width, None, 0, C.byref(cnt)) == 7
+    assert L.kjarni_hip_group_gather_plan(rows, n, width, None, 0, C.byref(cnt)) == 0 and cnt.value == len(plan)

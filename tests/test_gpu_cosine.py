@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from tests.parity_report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -295,8 +296,32 @@ def test_one_call_search_equals_scores_plus_topk(n, dim, k):
             assert np.abs(sa[:kk] - rsc).max() < 1e-4
 
 
+def test_fused_many_query_search_against_the_oracle_at_its_own_size():
+    """The route that selects INSIDE the matrix-core scan (>= 20 queries, >= 400 000 documents) held to the ORACLE directly, at a
+    size where it engages: 450 000 x 384, 64 queries, k = 12, k + 1 planted neighbours per query at cosines 0.9, 0.88, ... (the
+    expected indices are a property of the data) -- indices exact, scores 1e-4, both zero-norm conventions (vector.rs:146,
+    segment.rs:355-371), zero row and zero query included.  (segment.rs:307-337, vector.rs:150-166)"""
+    import kjarni_amd
+    n, dim, nq, k = 450_000, 384, 64, 12
+    corpus, queries = _many_query_inputs(n, dim, nq, k, 0)
+    for mode, js in ((1, range(nq)), (0, range(0, nq, 4))):
+        idx, sc = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
+        assert idx.shape == (nq, k)
+        worst = 0.0
+        for j in js:
+            if mode == 1 and j == 2:           # zero query: Segment mode returns no hits for it
+                assert (idx[j] == -1).all()
+                continue
+            ridx, rsc = O.search(queries[j], corpus, k, mode=mode)
+            if j != 2:
+                assert _oracle_gaps(queries[j], corpus, k, mode) > GAP
+            assert list(idx[j]) == list(ridx), (mode, j, idx[j], ridx)
+            worst = max(worst, float(np.abs(sc[j] - rsc).max()))
+        assert report(f"cosine/fused_many_query_450000x384_mode{mode}", worst, 1e-4) < 1e-4
+
+
 @pytest.mark.parametrize("k", [12, 200])
-@pytest.mark.parametrize("case", ["random", "ascending", "overflow"])
+@pytest.mark.parametrize("case", ["random", "ascending", "overflow", "nonfinite"])
 def test_many_queries_one_call_selects_inside_the_scan(case, k):
     """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries selects inside the matrix-core scan: a strided
     sample of the corpus gives every query a lower bound of its k-th best score, the full scan appends only scores at or above
@@ -304,7 +329,9 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
     as kjarni_hip_cosine_scores + kjarni_hip_cosine_topk: on random rows; on rows whose scores ascend with the index (the sample
     under-estimates every bound); and when the candidate list overflows (identical queries, every sampled tile anti-correlated,
     every other row correlated: 28 M candidates against a 4 M list), where the queued two-call form takes over.
-    k = 12: the bound comes from the sampled tiles' per-wave maxima (k <= 128); k = 200: from the sample's own top-k."""
+    k = 12: the bound comes from the sampled tiles' per-wave maxima (k <= 128); k = 200: from the sample's own top-k.
+    "nonfinite": one query holds a NaN, another an infinity -- their scores are NaN, which the cheap bound test must not drop:
+    those queries come back as the two-call form returns them (k rows, NaN scores), the other 68 unchanged."""
     import torch
     from kjarni_amd import _ffi
     L = _ffi.lib()
@@ -323,6 +350,9 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
         sampled = (row_tile % ts) == 0
         corpus[sampled] = -q[0] + 0.01 * corpus[sampled]
         corpus[~sampled] = q[0] + 0.05 * corpus[~sampled]
+    if case == "nonfinite":
+        q[5, 7] = float("nan")
+        q[9, 0] = float("inf")
     corpus[1000] = 0.0
     for mode in (0, 1):
         st = torch.cuda.current_stream().cuda_stream
@@ -339,7 +369,16 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
         _ffi.check_error(L.kjarni_hip_cosine_search(0, q.data_ptr(), nq, corpus.data_ptr(), n, dim, mode, k, ws1.data_ptr(),
                                                     idx1.data_ptr(), sc1.data_ptr(), st))
         torch.cuda.synchronize()
-        assert bool(torch.equal(idx1, idx2)), (case, mode)
-        assert bool(torch.equal(sc1.view(torch.int32), sc2.view(torch.int32))), (case, mode)
-        assert bool((sc1[:, :-1] >= sc1[:, 1:]).all())
+        if case == "nonfinite":
+            odd = torch.zeros(nq, dtype=torch.bool, device=dev)
+            odd[5] = odd[9] = True
+            assert bool(torch.isnan(sc2[odd]).all()) and bool((idx2[odd] >= 0).all()), "the two-call form: k rows with NaN scores"
+            assert bool(torch.isnan(sc1[odd]).all()) and bool((idx1[odd] >= 0).all()), (case, mode, sc1[odd][:, :4], idx1[odd][:, :4])
+            assert bool(torch.equal(idx1[~odd], idx2[~odd])), (case, mode)
+            assert bool(torch.equal(sc1[~odd].view(torch.int32), sc2[~odd].view(torch.int32))), (case, mode)
+            assert bool((sc1[~odd][:, :-1] >= sc1[~odd][:, 1:]).all())
+        else:
+            assert bool(torch.equal(idx1, idx2)), (case, mode)
+            assert bool(torch.equal(sc1.view(torch.int32), sc2.view(torch.int32))), (case, mode)
+            assert bool((sc1[:, :-1] >= sc1[:, 1:]).all())
         del ws1

@@ -43,8 +43,10 @@ def cross(tmp_path_factory, family):
     enc.close()
 
 
-def hidden_tol(ref):
-    return TOL * max(1.0, float(np.nanmax(np.abs(ref))) / 4.0)   # init family: |h| <= ~8 -> 1e-4 .. 2e-4 as before
+def rel_err(got, ref):
+    """max |got - ref| / max |ref| -- reported beside the absolute figure (hidden states reach ~50 in the trained family),
+    never what a test is held to: the bar is the north star's flat 1e-4 absolute."""
+    return float(np.nanmax(np.abs(got - ref)) / max(1.0, float(np.nanmax(np.abs(ref)))))
 
 
 def test_model_info(minilm):
@@ -64,8 +66,8 @@ def test_hidden_states_parity(minilm, family, B, S, ragged):
         ref = orc.forward(ids, mask, None, mv)
         assert got.shape == ref.shape
         assert np.isfinite(got).all()
-        tol = TOL if family == "init" else hidden_tol(ref)
-        assert report(f"encoder/{family}/hidden_states", np.abs(got - ref).max(), tol) < tol
+        report(f"encoder/{family}/hidden_states_relative", rel_err(got, ref), TOL)
+        assert report(f"encoder/{family}/hidden_states", np.abs(got - ref).max(), TOL) < TOL
 
 
 @pytest.mark.parametrize("B,S", [(1, 8), (3, 8), (64, 128), (3, 128), (4, 300)])
@@ -86,8 +88,7 @@ def test_pooling_modes(minilm, family):
     for name, ref in (("mean", O.mean_pool(h, mf)), ("cls", O.cls_pool(h)), ("max", O.max_pool(h, mf)),
                       ("last_token", O.last_token_pool(h, mf))):
         got = enc.embed(ids, mask, pooling=name, normalize=False)
-        tol = hidden_tol(ref)   # unnormalised pooled hidden states
-        assert report(f"encoder/{family}/pool_{name}_raw", np.abs(got - ref).max(), tol) < tol, name
+        assert report(f"encoder/{family}/pool_{name}_raw", np.abs(got - ref).max(), TOL) < TOL, name   # unnormalised pooled hidden states
         gotn = enc.embed(ids, mask, pooling=name, normalize=True)
         assert np.abs(gotn - O.l2_normalize(ref)).max() < TOL, name
 
@@ -137,7 +138,7 @@ def test_out_of_vocab_ids_leave_zero_rows(minilm):
     ids[0, 3] = 40000  # >= vocab: embeddings/mod.rs:232-236 leaves zeros
     got = enc.hidden_states(ids, mask)
     ref = orc.forward(ids, mask, None, O.strategy_mask_value(16))
-    assert np.abs(got - ref).max() < hidden_tol(ref)
+    assert np.abs(got - ref).max() < TOL
 
 
 def test_errors(minilm):
@@ -173,8 +174,8 @@ def test_embeddings_equal_the_hf_fixtures(minilm, family, fixtures, B, S):
     if tag + "_hidden" in fixtures:
         h = enc.hidden_states(fixtures[tag + "_ids"], fixtures[tag + "_mask"])
         real = fixtures[tag + "_mask"].astype(bool)
-        tol = TOL if family == "init" else hidden_tol(fixtures[tag + "_hidden"][real])
-        assert report(f"encoder/{family}/hidden_vs_hf_float64", np.abs(h - fixtures[tag + "_hidden"])[real].max(), tol) < tol
+        report(f"encoder/{family}/hidden_vs_hf_float64_relative", rel_err(h[real], fixtures[tag + "_hidden"][real]), TOL)
+        assert report(f"encoder/{family}/hidden_vs_hf_float64", np.abs(h - fixtures[tag + "_hidden"])[real].max(), TOL) < TOL
 
 
 @pytest.mark.parametrize("B,S", FIXTURE_CASES)

@@ -127,9 +127,10 @@ def test_hidden_states_of_a_large_call(minilm2, family):
     for fill, mv in ((kjarni_amd.MASK_NEG_1E9, O.MASK_ALLOC), (kjarni_amd.MASK_NEG_INF, O.MASK_NOALLOC)):
         got = enc.hidden_states(ids, mask, fill=fill)
         ref = orc.forward(ids, mask, None, mv)
-        # hidden states reach ~30 in the trained family (LayerNorm gains up to 12.5): 1e-4 of the largest value / 4 there
-        tol = TOL * max(1.0, float(np.abs(ref).max()) / 4.0)
-        assert report(f"large/{family}/hidden_states_10240_tokens", np.abs(got - ref).max(), tol) < tol
+        # hidden states reach ~50 in the trained family (LayerNorm gains up to 12.5); the bar stays the flat 1e-4 absolute, the
+        # relative figure is recorded beside it
+        report(f"large/{family}/hidden_states_10240_tokens_relative", float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())), TOL)
+        assert report(f"large/{family}/hidden_states_10240_tokens", np.abs(got - ref).max(), TOL) < TOL
 
 
 # ------------------------------------------------------------------------------------------------ (b)
@@ -247,8 +248,8 @@ def test_full_rerank_config_rows_against_oracle_and_small_calls(cross6, family, 
     for s in range(0, len(rows), 64):
         sel = rows[s:s + 64]
         small = enc.logits(*(np.ascontiguousarray(a[sel]) for a in (ids, mask, types)))[:, 0]
-        # logits of a few units in the trained family: route-to-route rounding scales with them
-        small_tol = 1e-5 * max(1.0, float(np.abs(full).max()))
+        # two routes of the same model (64-pair calls vs one 100 000-pair call): a flat 2e-5, five times under the oracle bar
+        small_tol = 2e-5
         assert report(f"large/{family}/{products}/configs2_64_pair_calls_vs_one_call", np.abs(small - full[sel]).max(), small_tol) < small_tol
     sel = np.concatenate([edge, rows[::3]])[:48]
     ref = orc.rerank_scores(*(np.ascontiguousarray(a[sel]) for a in (ids, mask, types)))

@@ -8,6 +8,7 @@ Infinity-Cache hits are included in both counters (they are fabric-side)."""
 import collections, csv, glob, json, os, sys
 
 root, out = sys.argv[1], sys.argv[2]
+round_label = sys.argv[3] if len(sys.argv) > 3 else "unlabelled passes"   # e.g. "round 6, passes r06c"
 EPI = {0: "EPI_BIAS", 1: "EPI_BIAS_GELU", 2: "EPI_BIAS_GELU_NEW", 3: "EPI_BIAS_RELU", 4: "EPI_BIAS_TANH",
        5: "EPI_BIAS_RESIDUAL"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -33,7 +34,7 @@ for k, c in acc.items():
         w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
         res[k] = {"fetch_size_kib_raw": f, "write_size_kib": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
                   "launches_sampled": len(c["FETCH_SIZE"])}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+json.dump({"round": round_label, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
                      "`python bench.py --steps 1 --warmup 1 --sentences 16384 --no-extras` (chunks of 2 048 sentences = "
                      "262 144 tokens, the launch shape of the full run)", "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
