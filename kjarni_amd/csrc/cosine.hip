@@ -1159,8 +1159,10 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
 // "no bound" (index -1) when fewer than k of them are finite.  One block per query, n <= 4 096: the maxima stay in registers as
 // 32-bit orderable keys and the k-th largest is found bit by bit from the top -- the largest x with at least k keys >= x --
 // 32 counting rounds (sixteen ballots + four LDS words each) instead of a sort.
+// Also zeroes the search's candidate counters ([0] overflow word, [1 + q] list lengths): the launch in front of the fused scan.
 __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ maxima, int n, int64_t stride, int k,
-                                                           float* __restrict__ thr_score, int64_t* __restrict__ thr_idx)
+                                                           float* __restrict__ thr_score, int64_t* __restrict__ thr_idx,
+                                                           unsigned* __restrict__ counters)
 {
     __shared__ int wave_count[2][4];
     const int tid = threadIdx.x, q = blockIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1185,6 +1187,8 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
     if (tid == 0) {
         thr_idx[q] = found == 0u ? -1 : 0;
         thr_score[q] = found == 0u ? -INFINITY : from_orderable(found);
+        counters[1 + q] = 0u;
+        if (q == 0) counters[0] = 0u;
     }
 }
 
@@ -1197,14 +1201,23 @@ hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_
 //   fuse != null:    selection inside the scan (no scores): candidates into fuse's list
 //   run_flag:        the launches run only if *run_flag != 0
 //   sample_max:      (with tile_stride) per-(query, tile, wave) maxima [nq, n_tiles * 4] into `scores` instead of the scores
+//   qn2_given:       the queries' squared norms [nq] (query_sqnorms below), computed once by a caller that makes several passes
+hipError_t query_sqnorms(const float* queries, int nq, int dim, float* qn2, hipStream_t stream)
+{
+    return scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);  // (mode 2: squared norms of the rows; query operand unused)
+}
+
 hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
                      float* scores, hipStream_t stream, int tile_stride = 1, int64_t score_stride = -1, const ScanFuse* fuse = nullptr,
-                     const unsigned* run_flag = nullptr, bool sample_max = false)
+                     const unsigned* run_flag = nullptr, bool sample_max = false, const float* qn2_given = nullptr)
 {
-    float* qn2 = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&qn2), (size_t)(nq + 8) * sizeof(float), stream);
-    if (e != hipSuccess) return e;
-    e = scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);  // squared norms of the queries (query operand unused)
+    float* qn2 = const_cast<float*>(qn2_given);
+    hipError_t e = hipSuccess;
+    if (!qn2_given) {
+        e = hipMallocAsync(reinterpret_cast<void**>(&qn2), (size_t)(nq + 8) * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+        e = query_sqnorms(queries, nq, dim, qn2, stream);
+    }
     const int64_t all_tiles = (n_docs + MQ_D - 1) / MQ_D;
     const int64_t n_tiles = (all_tiles + tile_stride - 1) / tile_stride;
     if (score_stride < 0) score_stride = n_docs;
@@ -1230,7 +1243,7 @@ hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t 
 #undef KJ_SCAN
         e = hipGetLastError();
     }
-    const hipError_t fe = hipFreeAsync(qn2, stream);
+    const hipError_t fe = qn2_given ? hipSuccess : hipFreeAsync(qn2, stream);
     return e != hipSuccess ? e : fe;
 }
 
@@ -1410,7 +1423,9 @@ size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k)
     const size_t fused = (size_t)(2048 * 256 + 2 * 2048) * sizeof(uint64_t);
     size_t two = pad256((size_t)nq * (size_t)n_docs * sizeof(float)) + pad256(cosine_topk_workspace_bytes(nq, n_docs, k));
     // the fused many-query scan (nq >= 20 only): candidate list, counters, the sample's best k per query
-    if (nq >= 20) two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4);
+    if (nq >= 20)
+        two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4) +
+               pad256((size_t)(nq + 8) * 4);   // (+ the queries' squared norms, shared by the passes of one search)
     return fused > two ? fused : two;
 }
 
@@ -1465,31 +1480,41 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         int64_t* thr_idx = reinterpret_cast<int64_t*>(p);
         p += pad256((size_t)nq * k * 8);
         float* thr_score = reinterpret_cast<float*>(p);
+        p += pad256((size_t)nq * k * 4);
+        float* qn2 = reinterpret_cast<float*>(p);   // the queries' squared norms: ONE launch for the sample, the scan and the fallback
         const unsigned cap_q = (unsigned)(kManyCandCap / (size_t)nq);
-        hipError_t e = hipMemsetAsync(counters, 0, counter_bytes, stream);
+        hipError_t e = query_sqnorms(queries, nq, dim, qn2, stream);
         if (e != hipSuccess) return e;
         const int64_t all_tiles = (n_docs + MQ_D - 1) / MQ_D;
-        const int ts = (int)std::max<int64_t>(1, all_tiles / 256);           // ~256-511 sampled tiles, spread over the corpus
+        // 128-256 sampled tiles (up to 512 for large corpora, below), spread over the corpus: ONE tile per CU, so the sample pass is a single round of workgroups that
+        // each have a CU's four matrix pipes to themselves (with 256-511 tiles it was two per CU and took twice as long: 63 us of a
+        // 0.59 ms search over 10^6 documents); ~50 000 sampled documents still bound k = 10 at ~160 candidates per query there.
+        // (from ~2 M documents on the sample pass is < 2 % of the search and the candidates it leaves are what costs: two tiles per CU)
+        const int64_t sample_tiles = all_tiles >= 8192 ? 512 : 256;
+        const int ts = (int)std::max<int64_t>(1, (all_tiles + sample_tiles - 1) / sample_tiles);
         const int64_t ns = (all_tiles + ts - 1) / ts;
         const int64_t last_rows = std::min<int64_t>(MQ_D, n_docs - (ns - 1) * ts * (int64_t)MQ_D);
         const int64_t n_sample = (ns - 1) * MQ_D + last_rows;
         int thr_k = k;
         if (k <= kSampleMaxK && ns * 4 <= 4096 && ns * 4 >= 8 * (int64_t)k) {
             // a small k: the bound is the k-th largest of the sampled tiles' per-wave maxima (SCAN_SAMPLE_MAX) -- no sample scores
-            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, ns * 4, nullptr, nullptr, true);
+            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, ns * 4, nullptr, nullptr, true, qn2);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)(ns * 4), ns * 4, k, thr_score, thr_idx);
+            hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)(ns * 4), ns * 4, k, thr_score, thr_idx,
+                               counters);   // (and zeroes the candidate counters)
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             thr_k = 1;
         } else {
-            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, n_sample);
+            e = hipMemsetAsync(counters, 0, counter_bytes, stream);
+            if (e != hipSuccess) return e;
+            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, n_sample, nullptr, nullptr, false, qn2);
             if (e != hipSuccess) return e;
             e = cosine_topk_impl(scores, nq, n_sample, k, topk_ws, thr_idx, thr_score, stream, nullptr);
             if (e != hipSuccess) return e;
         }
         ScanFuse f{thr_score, thr_idx, thr_k, cand_key, counters, cap_q, 0};
-        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, nullptr, stream, 1, -1, &f);
+        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, nullptr, stream, 1, -1, &f, nullptr, false, qn2);
         if (e != hipSuccess) return e;
         const int kpad = kpad_for(k);
 #define KJ_CAND(KP_)                                                                                                          \
@@ -1508,7 +1533,7 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         // the two-call form, run only if the candidate list overflowed
-        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, 1, -1, nullptr, counters);
+        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, 1, -1, nullptr, counters, false, qn2);
         if (e != hipSuccess) return e;
         return cosine_topk_impl(scores, nq, n_docs, k, topk_ws, out_idx, out_score, stream, counters);
     }
