@@ -251,11 +251,21 @@ void LlmModel::pass(const uint32_t* ids_dev, int n, bool device_pos)
     const LlmConfig& c = cfg_;
     const int H = c.hidden, d = c.head_dim, kv = c.kv_heads * d, I = c.inter;
     const int* pp = device_pos ? pos_ : nullptr;
-    hip_check(launch_llm_embed(ids_dev, n, H, c.vocab, embed_, bf16_ ? 1 : 0, h_, s), "embed");
+    // one token: the first layer's projection gathers the embedding row itself (one launch fewer per step)
+    bool embed_in_qkv = n == 1 && H <= 8192 && !layers_.empty() && llm_qkv_rope_embeds(H, layers_[0].ln1, layers_[0].wqkv, embed_);
+#ifdef KJARNI_TUNING
+    static const bool no_fold = std::getenv("KJARNI_HIP_LLM_NO_FOLD") != nullptr;  // measurements: the embedding gather as its own launch
+    if (no_fold) embed_in_qkv = false;
+#endif
+    if (!embed_in_qkv) hip_check(launch_llm_embed(ids_dev, n, H, c.vocab, embed_, bf16_ ? 1 : 0, h_, s), "embed");
+    bool first_layer = true;
     for (const Layer& L : layers_) {
         if (n == 1 && H <= 8192) {  // decode step: norm + projection + rotation in one launch
+            const bool emb = embed_in_qkv && first_layer;
             hip_check(launch_llm_qkv_rope(h_, L.ln1, c.eps, L.wqkv, bf16_ ? 1 : 0, L.bqkv, H, c.heads, c.kv_heads, d, cos_, sin_, q_,
-                                          L.k_cache, L.v_cache, cache_len_, pp, s), "norm + qkv + rope");
+                                          L.k_cache, L.v_cache, cache_len_, pp, s, emb ? ids_dev : nullptr, emb ? embed_ : nullptr,
+                                          c.vocab, emb ? h_ : nullptr), "norm + qkv + rope");
+            first_layer = false;
         } else {
         LlmGemvArgs a;  // RMSNorm + Q | K | V (decoder_attention.rs:61-82): K / V rows land in the cache
         a.X = h_; a.ldx = H; a.rows = n; a.gamma = L.ln1; a.eps = c.eps; a.W = L.wqkv; a.bf16 = bf16_; a.bias = L.bqkv;

@@ -43,9 +43,13 @@ void set_llm_gemv_variant(int variant);  // 0 = default (single-row kernel for r
 
 // One new token: RMSNorm + Q|K|V projection + RoPE in one launch; Q -> Q[n_heads*head_dim], K / V -> row `pos`
 // (or *pos_ptr) of the caches [*, n_kv_heads*head_dim].  W is the fused [Q;K;V] matrix.
+// embed_ids != null (only where llm_qkv_rope_embeds() says so): the input row is gathered from the embedding `table` (row
+// *embed_ids, the weights' dtype; an id >= vocab leaves zeros) instead of read from X, and stored to x_raw_out (the residual stream).
 hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, const void* W, int bf16, const float* bias, int k,
                                int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
-                               float* Vc, int pos, const int* pos_ptr, hipStream_t stream);
+                               float* Vc, int pos, const int* pos_ptr, hipStream_t stream, const uint32_t* embed_ids = nullptr,
+                               const void* table = nullptr, int vocab = 0, float* x_raw_out = nullptr);
+bool llm_qkv_rope_embeds(int k, const float* gamma, const void* W, const void* table);
 
 // Prefill: Y[M, N] = A[M, K] . W[N, K]^T + bias (+ R) on the fp32 matrix cores, W bf16 or f32; K % 32 == 0.  R may alias Y.
 // split_scratch (prefill_gemm_scratch_floats() floats, or null): short prompts split K over up to 8 workgroups per tile.

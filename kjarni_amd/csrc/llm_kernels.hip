@@ -662,13 +662,18 @@ __global__ __launch_bounds__(256) void llm_qkv_rope_kernel(const float* __restri
 // The same step in the weight-streaming form (K = 2048 / 4096 / 8192): one WAVE owns the pair of output columns, the row is
 // normalised once per workgroup into LDS, and every request (x, gamma, position, the pair's two weight rows, bias, the
 // rotation's cos / sin) is issued before anything is waited for.
-template <typename WT, int CH>
+// EMBED (the first layer of a one-token step): the input row is not read from X but gathered here from the embedding table, as
+// llm_embed_kernel does (row *embed_ids, widened; an id >= vocab leaves zeros), by every workgroup for itself; workgroup 0 also
+// stores it to x_raw_out, the residual stream the output projection adds to.  One launch fewer per token.
+template <typename WT, int CH, bool EMBED = false>
 __global__ __launch_bounds__(256) void llm_qkv_rope_stream_kernel(const float* __restrict__ X, const float* __restrict__ gamma, float eps,
                                                                   const WT* __restrict__ W, const float* __restrict__ bias,
                                                                   int n_heads, int n_kv_heads, int head_dim,
                                                                   const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                   float* __restrict__ Q, float* __restrict__ Kc, float* __restrict__ Vc,
-                                                                  int pos, const int* __restrict__ pos_ptr)
+                                                                  int pos, const int* __restrict__ pos_ptr,
+                                                                  const uint32_t* __restrict__ embed_ids, const WT* __restrict__ table,
+                                                                  int vocab, float* __restrict__ x_raw_out)
 {
     constexpr bool BF16 = sizeof(WT) == 2;
     constexpr int K = CH * 512;
@@ -696,11 +701,33 @@ __global__ __launch_bounds__(256) void llm_qkv_rope_stream_kernel(const float* _
         n_b = n_a + 1;
     }
     f32x4 xv[XV], gv[XV];
+    if (EMBED) {
+        const uint32_t id = embed_ids[0];
 #pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        xv[i] = *reinterpret_cast<const f32x4*>(X + (tid + i * 256) * 4);
-        gv[i] = *reinterpret_cast<const f32x4*>(gamma + (tid + i * 256) * 4);
+        for (int i = 0; i < XV; ++i) {
+            xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (id < (uint32_t)vocab) {
+                const WT* src = table + (int64_t)id * K + (tid + i * 256) * 4;
+                if (BF16) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(src);
+                    xv[i] = f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000u), __uint_as_float(r[1] << 16),
+                                  __uint_as_float(r[1] & 0xFFFF0000u)};
+                } else {
+                    xv[i] = *reinterpret_cast<const f32x4*>(src);
+                }
+            }
+        }
+        if (blockIdx.x == 0 && x_raw_out) {
+#pragma unroll
+            for (int i = 0; i < XV; ++i) *reinterpret_cast<f32x4*>(x_raw_out + (tid + i * 256) * 4) = xv[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) xv[i] = *reinterpret_cast<const f32x4*>(X + (tid + i * 256) * 4);
     }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) gv[i] = *reinterpret_cast<const f32x4*>(gamma + (tid + i * 256) * 4);
     const int p = pos_ptr ? *pos_ptr : pos;
     const int col = kind == 0 ? n_a : (kind == 1 ? n_a - q_dim : n_a - q_dim - kv_dim);
     const int ri = kind == 2 ? 0 : col % head_dim;  // < half
@@ -1630,18 +1657,34 @@ hipError_t launch_swiglu_mul(float* gate, const float* up, size_t n, hipStream_t
     return hipGetLastError();
 }
 
+bool llm_qkv_rope_embeds(int k, const float* gamma, const void* W, const void* table)
+{
+    return (k == 2048 || k == 4096 || k == 8192) && gamma && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(table) & 15) == 0 && g_llm_gemv_variant != 8 && g_llm_gemv_variant != 1;
+}
+
 hipError_t launch_llm_qkv_rope(const float* X, const float* gamma, float eps, const void* W, int bf16, const float* bias, int k,
                                int n_heads, int n_kv_heads, int head_dim, const float* cos_t, const float* sin_t, float* Q, float* Kc,
-                               float* Vc, int pos, const int* pos_ptr, hipStream_t stream)
+                               float* Vc, int pos, const int* pos_ptr, hipStream_t stream, const uint32_t* embed_ids, const void* table,
+                               int vocab, float* x_raw_out)
 {
     if ((k & 7) || k > 8192 || (head_dim & 1)) return hipErrorInvalidValue;
     const int tasks = (n_heads * head_dim + 2 * n_kv_heads * head_dim) / 2;
+    if (embed_ids && !llm_qkv_rope_embeds(k, gamma, W, table)) return hipErrorInvalidValue;
     if ((k == 2048 || k == 4096 || k == 8192) && gamma && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && g_llm_gemv_variant != 8 &&
         g_llm_gemv_variant != 1) {
         const dim3 sgrid((unsigned)((tasks + 3) / 4));
 #define KJ_QKVS(WT, CH)                                                                                                              \
-    hipLaunchKernelGGL((llm_qkv_rope_stream_kernel<WT, CH>), sgrid, dim3(256), 0, stream, X, gamma, eps, static_cast<const WT*>(W),  \
-                       bias, n_heads, n_kv_heads, head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr)
+    do {                                                                                                                             \
+        if (embed_ids)                                                                                                               \
+            hipLaunchKernelGGL((llm_qkv_rope_stream_kernel<WT, CH, true>), sgrid, dim3(256), 0, stream, X, gamma, eps,                \
+                               static_cast<const WT*>(W), bias, n_heads, n_kv_heads, head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr, \
+                               embed_ids, static_cast<const WT*>(table), vocab, x_raw_out);                                          \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((llm_qkv_rope_stream_kernel<WT, CH, false>), sgrid, dim3(256), 0, stream, X, gamma, eps,               \
+                               static_cast<const WT*>(W), bias, n_heads, n_kv_heads, head_dim, cos_t, sin_t, Q, Kc, Vc, pos, pos_ptr, \
+                               nullptr, nullptr, 0, nullptr);                                                                        \
+    } while (0)
         if (bf16) {
             if (k == 2048) KJ_QKVS(uint16_t, 4);
             else if (k == 4096) KJ_QKVS(uint16_t, 8);

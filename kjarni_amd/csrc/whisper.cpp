@@ -546,8 +546,22 @@ void WhisperModel::decoder_pass(const uint32_t* ids_dev, int n, bool device_pos)
     hipStream_t s = stream_;
     const int H = cfg_.d_model, heads = cfg_.heads, d = H / heads, I = cfg_.decoder_ffn;
     const int* pos_ptr = device_pos ? dpos_ : nullptr;
-    hip_check(launch_decoder_embed(ids_dev, n, H, cfg_.vocab, tok_emb_, dec_pos_, cfg_.max_target_positions, cache_len_, pos_ptr,
-                                   cfg_.scale_embedding ? 1 : 0, dh_, s), "decoder embed");
+    // One token: the first projection builds the embedded row itself and the vocabulary head folds the final LayerNorm in (two
+    // launches fewer per step; the same arithmetic, element for element) -- where the one-row kernel takes the row (512 / 2048 floats).
+    GemvArgs probe;
+    probe.rows = 1; probe.k = H; probe.gamma = dec_ln_g_; probe.beta = dec_ln_b_; probe.W = lm_head_; probe.embed_ids = ids_dev;
+    bool fold = n == 1 && gemv_rows_takes_row_extras(probe) && H == 512;
+    bool fold_head = fold;
+#ifdef KJARNI_TUNING
+    static const char* no_fold = std::getenv("KJARNI_HIP_WHISPER_NO_FOLD");  // measurements: "1" neither, "embed" / "head" not that one
+    if (no_fold && no_fold[0] == '1') fold = fold_head = false;
+    if (no_fold && no_fold[0] == 'e') fold = false;
+    if (no_fold && no_fold[0] == 'h') fold_head = false;
+#endif
+    if (!fold)
+        hip_check(launch_decoder_embed(ids_dev, n, H, cfg_.vocab, tok_emb_, dec_pos_, cfg_.max_target_positions, cache_len_, pos_ptr,
+                                       cfg_.scale_embedding ? 1 : 0, dh_, s), "decoder embed");
+    bool first_layer = true;
     auto gemv = [&](const float* X, int64_t ldx, const float* g, const float* b, const float* W, const float* bias, const float* R,
                     int n_out, int k, float* Y, GemmEpilogue epi, const char* what) {
         GemvArgs a;
@@ -562,6 +576,13 @@ void WhisperModel::decoder_pass(const uint32_t* ids_dev, int n, bool device_pos)
             a.X = dh_; a.ldx = H; a.rows = n; a.gamma = L.ln1_g; a.beta = L.ln1_b; a.eps = 1e-5f; a.W = L.wqkv; a.bias = L.bqkv;
             a.n_out = 3 * H; a.k = H; a.seg = H; a.Y0 = dq_; a.ldy0 = H; a.Y1 = L.self_k; a.Y2 = L.self_v; a.ldy12 = H;
             a.row_off = cache_len_; a.row_off_ptr = pos_ptr; a.epi = EPI_BIAS;
+            if (fold && first_layer) {
+                a.embed_ids = ids_dev; a.embed_word = tok_emb_; a.embed_pos_table = dec_pos_; a.embed_vocab = cfg_.vocab;
+                a.embed_max_pos = cfg_.max_target_positions; a.embed_pos = cache_len_; a.embed_pos_ptr = pos_ptr;
+                a.embed_scale = cfg_.scale_embedding ? std::sqrt((float)H) : 1.0f;
+                a.x_raw_out = dh_;
+            }
+            first_layer = false;
             hip_check(launch_gemv_rows(a, s), "ln1 + qkv");
         }
         // one token: the output projections merge the attention's per-split slabs themselves (no combine launches)
@@ -582,10 +603,15 @@ void WhisperModel::decoder_pass(const uint32_t* ids_dev, int n, bool device_pos)
         gemv(dh_, H, L.ln3_g, L.ln3_b, L.w1, L.b1, nullptr, I, H, dmid_, EPI_BIAS_GELU, "ln3 + fc1");
         gemv(dmid_, I, nullptr, nullptr, L.w2, L.b2, dh_, H, I, dh_, EPI_BIAS_RESIDUAL, "fc2");
     }
-    hip_check(launch_layernorm(dh_, dec_ln_g_, dec_ln_b_, 1e-5f, n, H, dlast_, s), "final ln");
     GemvArgs a;
-    a.X = dlast_ + (size_t)(n - 1) * H; a.ldx = H; a.rows = 1; a.W = lm_head_; a.n_out = cfg_.vocab; a.k = H; a.Y0 = logits_;
+    a.ldx = H; a.rows = 1; a.W = lm_head_; a.n_out = cfg_.vocab; a.k = H; a.Y0 = logits_;
     a.ldy0 = cfg_.vocab; a.epi = EPI_BIAS;
+    if (fold_head) {
+        a.X = dh_; a.gamma = dec_ln_g_; a.beta = dec_ln_b_; a.eps = 1e-5f; a.x_norm_out = dlast_;
+    } else {
+        hip_check(launch_layernorm(dh_, dec_ln_g_, dec_ln_b_, 1e-5f, n, H, dlast_, s), "final ln");
+        a.X = dlast_ + (size_t)(n - 1) * H;
+    }
     hip_check(launch_gemv_rows(a, s), "lm head");
 }
 

@@ -47,7 +47,19 @@ struct GemvArgs {
     int row_off = 0;
     const int* row_off_ptr = nullptr;
     GemmEpilogue epi = EPI_BIAS;
+    // One row of 512 / 2048 floats only (gemv_rows_takes_row_extras): the kernel can build its input row itself as
+    // launch_decoder_embed would (embed_ids != null: word[*embed_ids] * embed_scale + pos_table[*embed_pos_ptr | embed_pos]; X is
+    // then unused; LayerNorm + EPI_BIAS, 512-float rows) and leave copies of it: x_raw_out = the row as read / built (the residual
+    // stream), x_norm_out = the row after the LayerNorm (the model's last hidden state when the vocabulary head folds the final
+    // norm in).
+    const uint32_t* embed_ids = nullptr;
+    const float *embed_word = nullptr, *embed_pos_table = nullptr;
+    int embed_vocab = 0, embed_max_pos = 0, embed_pos = 0;
+    const int* embed_pos_ptr = nullptr;
+    float embed_scale = 1.0f;
+    float *x_raw_out = nullptr, *x_norm_out = nullptr;
 };
+bool gemv_rows_takes_row_extras(const GemvArgs& args);
 hipError_t launch_gemv_rows(const GemvArgs& args, hipStream_t stream);
 #ifdef KJARNI_TUNING
 void set_gemv_rows_variant(int variant);  // 0 = rows staged in LDS when there are several, 1 = always the per-wave kernel

@@ -261,13 +261,27 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 // normalisation and the dot product run on registers.  A decode step is a chain of ~5 us launches, each a chain of memory
 // round trips: the general kernel pays one for the row, a second for the weights and a third for the residual.  Same
 // lane-to-chunk map, LayerNorm arithmetic and summation order: results are bit-identical to gemv_rows_kernel's.
-template <int EPI, bool LN, int KCH>
+// EMBED (the first projection of a one-token decoder step): the input row is not read from X but built here, as
+// decoder_embed_kernel builds it -- word[id] * scale + pos[p] (id = *emb.ids, p = *emb.pos_ptr or emb.pos; ids >= vocab and
+// positions >= max_pos leave zeros) -- by every wave for itself; the wave of column 0 also stores it to x_raw_out (the residual
+// stream the later projections add to).  x_norm_out (LN only): the wave of column 0 stores the NORMALISED row there (the model's
+// last hidden state when the vocabulary head folds the final LayerNorm in).  One launch fewer each, the same arithmetic.
+struct GemvEmbed {
+    const uint32_t* ids;
+    const float *word, *pos_table;
+    int vocab, max_pos, pos;
+    const int* pos_ptr;
+    float scale;
+};
+
+template <int EPI, bool LN, int KCH, bool EMBED = false>
 __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, const float* __restrict__ W,
                                                             const float* __restrict__ bias, const float* R, int n_out,
                                                             int seg, float* Y0, float* __restrict__ Y1,
                                                             float* __restrict__ Y2, int64_t ldy12, int row_off,
-                                                            const int* __restrict__ row_off_ptr)
+                                                            const int* __restrict__ row_off_ptr, float* __restrict__ x_raw_out,
+                                                            float* __restrict__ x_norm_out, GemvEmbed emb)
 {
     constexpr int K = 256 * KCH;
     const int lane = threadIdx.x & 63;
@@ -275,8 +289,32 @@ __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restr
     if (n >= n_out) return;
     const f32x4* w4 = reinterpret_cast<const f32x4*>(W + n * (int64_t)K);
     f32x4 x[KCH], w[KCH], g[KCH], bt[KCH];
+    if (EMBED) {
+        const uint32_t id = emb.ids[0];
+        const int p = emb.pos_ptr ? *emb.pos_ptr : emb.pos;
 #pragma unroll
-    for (int j = 0; j < KCH; ++j) x[j] = *reinterpret_cast<const f32x4*>(X + (lane + 64 * j) * 4);
+        for (int j = 0; j < KCH; ++j) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (id < (uint32_t)emb.vocab) {
+                v = *reinterpret_cast<const f32x4*>(emb.word + (int64_t)id * K + (lane + 64 * j) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = v[c] * emb.scale;
+            }
+            if (emb.pos_table && p < emb.max_pos) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(emb.pos_table + (int64_t)p * K + (lane + 64 * j) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += pv[c];
+            }
+            x[j] = v;
+        }
+        if (n == 0 && x_raw_out) {
+#pragma unroll
+            for (int j = 0; j < KCH; ++j) *reinterpret_cast<f32x4*>(x_raw_out + (lane + 64 * j) * 4) = x[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) x[j] = *reinterpret_cast<const f32x4*>(X + (lane + 64 * j) * 4);
+    }
     if (LN) {
 #pragma unroll
         for (int j = 0; j < KCH; ++j) {
@@ -305,6 +343,10 @@ __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restr
         for (int j = 0; j < KCH; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[j][c] = (x[j][c] - mu) * rstd * g[j][c] + bt[j][c];
+        if (n == 0 && x_norm_out) {
+#pragma unroll
+            for (int j = 0; j < KCH; ++j) *reinterpret_cast<f32x4*>(x_norm_out + (lane + 64 * j) * 4) = x[j];
+        }
     }
     float acc = 0.0f;
 #pragma unroll
@@ -970,9 +1012,20 @@ constexpr int g_gemv_rows_variant = 0;
 void set_gemv_rows_variant(int v) { g_gemv_rows_variant = v; }
 #endif
 
+// The one-row kernel for 512- / 2048-float rows is the only one that honours embed_* / x_raw_out / x_norm_out.
+bool gemv_rows_takes_row_extras(const GemvArgs& a)
+{
+    const int kch = a.k / 256;
+    const bool ln = a.gamma != nullptr;
+    return a.rows == 1 && a.k % 256 == 0 && (kch == 2 || kch == 8) && g_gemv_rows_variant == 0 && (!ln || a.beta) &&
+           (!ln || ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0) && (a.k & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 && (a.embed_ids || ((a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0));
+}
+
 hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
 {
     if (a.rows <= 0 || a.n_out <= 0) return hipSuccess;
+    if ((a.embed_ids || a.x_raw_out || a.x_norm_out) && !gemv_rows_takes_row_extras(a)) return hipErrorInvalidValue;
     const bool simple = !a.gamma && a.seg <= 0;
     if (a.rows > GEMV_MAX_ROWS || (a.k & 3) || (a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.X) & 15) ||
         (reinterpret_cast<uintptr_t>(a.W) & 15)) {
@@ -1026,9 +1079,17 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
     const int kch = a.k / 256;
     if (a.rows == 1 && a.k % 256 == 0 && (kch == 2 || kch == 8) && g_gemv_rows_variant == 0 && (!ln || a.beta) &&
         (!ln || ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0)) {
+        const GemvEmbed emb{a.embed_ids, a.embed_word, a.embed_pos_table, a.embed_vocab, a.embed_max_pos, a.embed_pos, a.embed_pos_ptr,
+                            a.embed_scale};
+        if (a.embed_ids) {  // the first projection of a one-token step builds its input row itself (LN + Q | K | V, 512-float rows)
+            if (!(ln && a.epi == EPI_BIAS && kch == 2)) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((gemv_row_fast_kernel<EPI_BIAS, true, 2, true>), grid, dim3(256), 0, stream, a.X, a.gamma, a.beta, a.eps, a.W,
+                               a.bias, a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr, a.x_raw_out, a.x_norm_out, emb);
+            return hipGetLastError();
+        }
 #define KJ_FAST2(EPI, LN, KCH)                                                                                                    \
     hipLaunchKernelGGL((gemv_row_fast_kernel<EPI, LN, KCH>), grid, dim3(256), 0, stream, a.X, a.gamma, a.beta, a.eps, a.W, a.bias, \
-                       a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr)
+                       a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr, a.x_raw_out, a.x_norm_out, emb)
 #define KJ_FAST(EPI, LN)                                                                                                          \
     do {                                                                                                                          \
         if (kch == 2) KJ_FAST2(EPI, LN, 2);                                                                                       \

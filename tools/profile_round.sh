@@ -6,9 +6,9 @@ set -u
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 python bench.py 2>gpurun_out/bench.err | tee gpurun_out/bench.json
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-scan --no-rerank-leg 2>>gpurun_out/bench.err | tee gpurun_out/bench_steps3.json
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-scan --no-rerank-leg --no-models 2>>gpurun_out/bench.err | tee gpurun_out/bench_steps3.json
 rm -rf gpurun_out/prof gpurun_out/pmcb
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-scan --no-sensors --no-rerank-leg --no-parity-check > gpurun_out/bench_prof.json 2>gpurun_out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-scan --no-sensors --no-rerank-leg --no-parity-check --no-models > gpurun_out/bench_prof.json 2>gpurun_out/prof.err
 find gpurun_out/prof -name "*kernel_trace.csv" -delete   # gpurun_out travels back: keep the summaries only
 find gpurun_out/prof -name "*kernel_stats*"
 bash tools/pmc_bench.sh > gpurun_out/pmcb.log 2>&1

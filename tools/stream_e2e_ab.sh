@@ -1,7 +1,7 @@
 #!/bin/bash
 # Whole-step A/B on one box: the K-stream tile kernel (variant 0) against the per-tile-prologue kernel (53), alternating processes.
 export KJARNI_FFI_LIB=$PWD/kjarni_amd/lib/libkjarni_ffi_tuning.so
-F="--steps 6 --warmup 3 --no-scan --no-sensors --no-cpu-baseline --no-extras --no-rerank-leg --no-parity-check"
+F="--steps 6 --warmup 3 --no-scan --no-sensors --no-cpu-baseline --no-extras --no-rerank-leg --no-parity-check --no-models"
 for round in 1 2 3; do
   for v in 53 0; do
     python tools/bench_variant.py $v $F 2>/dev/null | tail -1 | python -c "
