@@ -10,19 +10,90 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
 
-__device__ __forceinline__ float wave_sum(float v)
+// ---- cross-lane reductions without the LDS crossbar ---------------------------------------------------------------------------
+// `__shfl_xor` compiles to ds_bpermute_b32: ~100 cycles of latency per butterfly step, six steps per wave-wide sum -- the
+// longest chain inside a one-token decode stage (tools/lab/stage_lab.hip, profiles/r06h_stage_lab.log: a LayerNorm + GEMV
+// stage 2.61 -> 2.19 us with the forms below).  The forms below give the SAME VALUES bit for bit (addition and max are
+// commutative, and wherever a step reads a lane other than i ^ n that lane holds what lane i ^ n holds):
+//   i ^ 32, i ^ 16   v_permlane32_swap / v_permlane16_swap of the register with a copy of itself (gfx950): the two results
+//                    hold {v[i], v[i ^ n]} in some order -- combine them with a commutative op;
+//   i ^ 2, i ^ 1     DPP quad permutations (exact for any data);
+//   i ^ 8            DPP row_ror:8 (exact for any data: (i + 8) % 16 == i ^ 8 within the 16-lane row);
+//   i ^ 4 etc.       a DPP rotation / mirror of the row, valid once the lanes it confuses are equal (see each helper).
+// All of them need the lanes they read to be active: use them where the wave (or at least the 16-lane row) runs unmasked.
+// They are VECTOR-ALU instructions where ds_bpermute_b32 is an LDS-pipe one: the kernels bound by the f32 matrix cores (whose
+// MFMAs share the FP32 lanes with the VALU) keep their `__shfl_xor` -- the pipelined attention kernel lost 8 % with
+// max_xor32 / sum_xor32 in its softmax (profiles/r06i); the latency-bound kernels (decode steps, row kernels, small calls) gain.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141;
+constexpr int kDppRowRor = 0x120;  // + n, n in 1..15
+
+// {a[i], b[i]} = {v[i], v[i ^ 32]} (i < 32: a = own, b = partner; i >= 32: the other way round)
+__device__ __forceinline__ void xor32_pair(float v, float& a, float& b)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(v);
+    const u32x2 t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __uint_as_float(t[0]);
+    b = __uint_as_float(t[1]);
+}
+// {a[i], b[i]} = {v[i], v[i ^ 16]} in some order
+__device__ __forceinline__ void xor16_pair(float v, float& a, float& b)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned u = __float_as_uint(v);
+    const u32x2 t = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    a = __uint_as_float(t[0]);
+    b = __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) { float a, b; xor32_pair(v, a, b); return a + b; }     // v[i] + v[i ^ 32]
+__device__ __forceinline__ float sum_xor16(float v) { float a, b; xor16_pair(v, a, b); return a + b; }     // v[i] + v[i ^ 16]
+__device__ __forceinline__ float max_xor32(float v) { float a, b; xor32_pair(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float max_xor16(float v) { float a, b; xor16_pair(v, a, b); return fmaxf(a, b); }
+
+// Sum over the 16-lane row in the butterfly order 8, 4, 2, 1 (row_ror:n reads lane (i + n) % 16, which after the steps before it
+// holds what lane i ^ n holds): == v += shfl_xor(v, 8); ... ; v += shfl_xor(v, 1), bit for bit.
+__device__ __forceinline__ float row16_sum_desc(float v)
+{
+    v += dpp_mov<kDppRowRor + 8>(v);
+    v += dpp_mov<kDppRowRor + 4>(v);
+    v += dpp_mov<kDppRowRor + 2>(v);
+    v += dpp_mov<kDppRowRor + 1>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max_desc(float v)
+{
+    v = fmaxf(v, dpp_mov<kDppRowRor + 8>(v));
+    v = fmaxf(v, dpp_mov<kDppRowRor + 4>(v));
+    v = fmaxf(v, dpp_mov<kDppRowRor + 2>(v));
+    v = fmaxf(v, dpp_mov<kDppRowRor + 1>(v));
+    return v;
+}
+// Sum over aligned groups of 8 lanes in the butterfly order 1, 2, 4 (the quad permutations are exact; once a quad is uniform,
+// row_half_mirror's lane 7 - i of the half row holds what lane i ^ 4 holds): == v += shfl_xor(v, 1); 2; 4, bit for bit.
+__device__ __forceinline__ float group8_sum_asc(float v)
+{
+    v += dpp_mov<kDppQuadXor1>(v);
+    v += dpp_mov<kDppQuadXor2>(v);
+    v += dpp_mov<kDppRowHalfMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float group8_max_asc(float v)
+{
+    v = fmaxf(v, dpp_mov<kDppQuadXor1>(v));
+    v = fmaxf(v, dpp_mov<kDppQuadXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppRowHalfMirror>(v));
     return v;
 }
 
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
-    return v;
-}
+// Wave-wide sum / max in the butterfly order 32, 16, 8, 4, 2, 1: the values `for (off = 32; off; off >>= 1) v += shfl_xor(v, off)`
+// gives, bit for bit, in every lane.
+__device__ __forceinline__ float wave_sum(float v) { return row16_sum_desc(sum_xor16(sum_xor32(v))); }
+__device__ __forceinline__ float wave_max(float v) { return row16_max_desc(max_xor16(max_xor32(v))); }
 
 // Workgroups are dealt round-robin over the 8 XCDs (a private L2 each).  The unit workgroup `wg` of a launch of `total`
 // workgroups should take so that every XCD owns ONE contiguous run of units (bijective for any total): the projections' tile

@@ -1114,8 +1114,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __r
             vis[j] = valid && (k0 + kg + 8 * j) <= limit;
             if (vis[j]) tile_max = fmaxf(tile_max, acc[j]);
         }
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) tile_max = fmaxf(tile_max, __shfl_xor(tile_max, off, kWave));
+        tile_max = group8_max_asc(tile_max);  // (the query's 8 lanes)
         const float m_new = fmaxf(m_run, tile_max);
         float psum = 0.0f;
 #pragma unroll
@@ -1124,8 +1123,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const float* __r
             psum += p;
             sP[qi * (PA_K + 4) + kg + 8 * j] = p;
         }
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) psum += __shfl_xor(psum, off, kWave);
+        psum = group8_sum_asc(psum);
         const float alpha = (m_new == -INFINITY || m_run == -INFINITY) ? (m_run == -INFINITY ? 0.0f : 1.0f) : expf(m_run - m_new);
         l_run = l_run * alpha + psum;
 #pragma unroll

@@ -725,7 +725,9 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
             float dot = 0.0f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) dot = fmaf(qv[c], kr[j][c], dot);
-            for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+            if (lpk == 16) dot = row16_sum_desc(dot);  // (d = 64: a key's 16 lanes are a DPP row; the same sum as the loop below)
+            else
+                for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
             float v = dot * scale;
             if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
             sv[j] = t < t1 ? v : -INFINITY;
@@ -746,7 +748,9 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
             float dot = 0.0f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) dot = fmaf(qv[c], kv[c], dot);
-            for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+            if (lpk == 16) dot = row16_sum_desc(dot);  // (d = 64: a key's 16 lanes are a DPP row; the same sum as the loop below)
+            else
+                for (int off = lpk >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, kWave);
             float v = dot * scale;
             if (causal_base >= 0 && t > causal_base + s) v = kMaskValue;
             if (l == 0) sc[t - t0] = v;
@@ -767,9 +771,14 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
         }
     }
     // sum of exp * V over the workgroup: the lane groups of a wave by shuffles, the four waves through LDS
-    for (int off = lpk; off < 64; off <<= 1) {
+    if (lpk == 16) {  // (d = 64: the lane groups are the wave's four rows -- i ^ 16, then i ^ 32, without the LDS crossbar)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, kWave);
+        for (int c = 0; c < 4; ++c) acc[c] = sum_xor32(sum_xor16(acc[c]));
+    } else {
+        for (int off = lpk; off < 64; off <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], off, kWave);
+        }
     }
     if (lane < lpk) accs[wave * lpk + lane] = acc;
     __syncthreads();
