@@ -660,6 +660,12 @@ __global__ __launch_bounds__(256) void gemv_rows_head_kernel(const float* __rest
 // causal >= 0 (or the pointer): query row s sees keys <= base + s (apply_causal_mask, utils/masks.rs:103-113: masked scores
 // are OVERWRITTEN with -1e9, which exp() then turns into exactly 0 next to any real score).
 // Slab layout per (row, head, split): [max, sum, 0, 0, acc[head_dim]] (16-byte aligned pieces).
+#ifdef KJARNI_TUNING
+// Measurements (tuning build): shader cycles the decode attention's register path spends per phase, summed over workgroups --
+// [0] entry -> scores (the loads' round trips + the dots), [1] -> block max, [2] -> exp, weighted V, block sum, [3] -> slab
+// stored, [4] workgroups counted.  kjarni_hip_attention_stamps reads / resets them.
+__device__ unsigned long long g_att_stamp[8];
+#endif
 constexpr int ATT_MAX_CHUNK = 512;
 constexpr int ATT_FAST = 8;  // keys per lane group that the short-range path holds in registers (128 keys per split at d = 64)
 
@@ -709,6 +715,11 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
 
     float mx = -INFINITY, sum = 0.0f;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef KJARNI_TUNING
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st1 = 0, st2 = 0, st3 = 0;
+    const bool fast_path = t1 - t0 <= ATT_FAST * groups;
+#endif
     if (t1 - t0 <= ATT_FAST * groups) {
         // Short ranges (a decode step over a few hundred cached keys is a chain of latencies, not of bytes): every K and V
         // row of the range is requested at once and held in registers -- one memory round trip instead of one per pass.
@@ -733,7 +744,13 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
             sv[j] = t < t1 ? v : -INFINITY;
             mx = fmaxf(mx, sv[j]);
         }
+#ifdef KJARNI_TUNING
+        st1 = __builtin_amdgcn_s_memtime();
+#endif
         mx = block_max(mx);
+#ifdef KJARNI_TUNING
+        st2 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int j = 0; j < ATT_FAST; ++j) {
             const float e = t0 + g + j * groups < t1 ? expf(sv[j] - mx) : 0.0f;
@@ -742,6 +759,9 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
             for (int c = 0; c < 4; ++c) acc[c] = fmaf(e, vr[j][c], acc[c]);
         }
         sum = block_sum(sum);
+#ifdef KJARNI_TUNING
+        st3 = __builtin_amdgcn_s_memtime();
+#endif
     } else {
         for (int t = t0 + g; t < t1; t += groups) {
             const f32x4 kv = *reinterpret_cast<const f32x4*>(K + (int64_t)t * ldk + col);
@@ -785,7 +805,18 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
     float* out = part + (((int64_t)s * gridDim.x + h) * splits + sp) * (head_dim + 4);
     if (tid < lpk) *reinterpret_cast<f32x4*>(out + 4 + tid * 4) = (accs[tid] + accs[lpk + tid]) + (accs[2 * lpk + tid] + accs[3 * lpk + tid]);
     if (tid == 0) *reinterpret_cast<f32x4*>(out) = f32x4{(t1 > t0) ? mx : -INFINITY, (t1 > t0) ? sum : 0.0f, 0.0f, 0.0f};
+#ifdef KJARNI_TUNING
+    if (tid == 0 && fast_path) {
+        const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_att_stamp[0], st1 - st0);
+        atomicAdd(&g_att_stamp[1], st2 - st1);
+        atomicAdd(&g_att_stamp[2], st3 - st2);
+        atomicAdd(&g_att_stamp[3], st4 - st3);
+        atomicAdd(&g_att_stamp[4], 1ull);
+    }
+#endif
 }
+
 
 __global__ __launch_bounds__(128) void decode_attention_combine_kernel(const float* __restrict__ part, int heads, int splits,
                                                                        int head_dim, float* __restrict__ ctx, int64_t ldc)
@@ -951,6 +982,16 @@ __global__ void pick_finalize_kernel(unsigned long long* __restrict__ best, int 
 }
 
 }  // namespace
+
+#ifdef KJARNI_TUNING
+hipError_t attention_stamps(unsigned long long* out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_att_stamp), 8 * sizeof(unsigned long long));
+    if (e != hipSuccess || !reset) return e;
+    static const unsigned long long zeros[8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamp), zeros, sizeof(zeros));
+}
+#endif
 
 // ---- launchers --------------------------------------------------------------------------------------
 
