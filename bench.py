@@ -33,16 +33,22 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 the same fractions against the matrix-core peak at the clock the chip held UNDER THE WORK (mean of
                 clock_ghz; 157.3 TFLOP/s is the 2.4 GHz figure).  f32 matrix-core kernels run the board at its power cap and
                 the clock settles well below 2.4 GHz there; `frac` stays the contract's figure against the fixed peak
-  clock_ghz     the shader clock under load, one value per timed step: a one-wave kernel on a stream of its own beside the
+  clock_ghz     the shader clock under load, one value per step of a pass of up to five UNTIMED steps right in front of the
+                timed region: a one-wave kernel on a stream of its own beside the
                 launch stream (kjarni_hip_clock_trace, asleep between its reads) stamps shader cycles against the 100 MHz
-                counter over 16 consecutive windows per step; `clock_ghz_min` / `clock_ghz_max` over all windows;
+                counter over 16 consecutive windows per step (beside the timed steps themselves it cost 1.2 % of `value`:
+                profiles/r06r_instrument_ab.log); `clock_ghz_min` / `clock_ghz_max` over all windows;
                 `clock_ghz_idle`: the same reading with nothing else running, before the region (what a probe BETWEEN
                 two kernels of the launch stream reads: rounds 1-5 quoted that, 2.3-2.4 GHz).
                 `gpu_sensors`: board power / temperature / sclk sampled from sysfs during the region
                 (+ rocm-smi before and after) -- what tells a slower box from a power-limited long run
-  scan          (N = 1, embed) the other half of the hot path, R14: cosine search (scan + top-10) of 1 and of 64 queries
-                over a [1 000 000, 384] corpus resident in HBM, each with its own roofline (hbm / mfma) and an oracle
-                index check on a 50 000-row prefix
+  scan / scan_1e7  (N = 1, embed) the other half of the hot path, R14: cosine search (scan + top-10) of 1 and of 64 queries
+                over a [1 000 000, 384] and a [10 000 000, 384] corpus resident in HBM, each with its own roofline (hbm /
+                mfma) and an oracle check of the TIMED call's own output (scores, order, no miss over a random subset)
+  whisper / llm_decode  (N = 1, embed) BASELINE.json configs[3] / configs[4]: Whisper-base shape transcribe of 30 s, Llama-3.2-1B
+                shape greedy decode -- each with its own roofline (hbm), oracle check after its clock, cpu_baseline
+  scan_sharded  (N > 1, embed) the cosine search over a corpus sharded by rows: local search, one all-gather of the candidate
+                lists, merge on the host
   roofline      the dominant kernel, timed live with HIP events on its launch stream over
                 the timed region (libkjarni_ffi's profiler)
   rerank        (embed workload) the 100 000-pair STRONG-scaling rerank leg run after the embed region, same timing rules:
@@ -843,6 +849,7 @@ def main():
                     help="embed workload: skip the Whisper-base (configs[3]) and Llama-1B decode (configs[4]) legs")
     ap.add_argument("--no-sensors", action="store_true", help="do not sample sysfs / rocm-smi around the timed region")
     ap.add_argument("--no-instrument", action="store_true", help="no per-step events, clock probes or sensors at all")
+    ap.add_argument("--no-clock-trace", action="store_true", help="no clock-trace kernel beside the timed steps (events and sensors stay)")
     ap.add_argument("--weights", choices=("trained", "init"), default="trained",
                     help="tests/synth.py weight family: trained-checkpoint statistics (default) or N(0, 0.02) initialisation")
     ap.add_argument("--in-process", action="store_true",
@@ -971,17 +978,17 @@ def main():
     # the launches of a chunk cost ~2.5 % throughput).  The full per-kernel table comes from one
     # extra, untimed step below.
     GEMM_KINDS = ("gemm_qkv", "gemm_out_proj", "gemm_fc1", "gemm_fc2")
-    profile = not args.no_profile and not dry
-    if profile:
-        enc.profile_begin(GEMM_KINDS)
-    # Per-step wall time and the shader clock UNDER LOAD, without a synchronisation inside the region: an event on the launch
-    # stream after every step; beside it, on the library's own non-blocking stream, one one-wave kernel per step that stamps shader
-    # cycles against the 100 MHz counter over 16 windows of ~1/16 step (asleep in between).  The host enqueues far ahead of
-    # the device, so the trace kernels simply follow each other: trace i covers roughly step i (each is 3 % shorter than a step,
-    # so the last one ends inside the region).  (A probe on the launch stream between two steps reads an IDLE chip: the power
-    # controller lets the clock back up within microseconds -- that is `clock_ghz_idle`.  And not a torch side stream: the first
-    # torch.cuda.Stream() of a process creates torch's pool of 32 streams, with which the library's own streams share hardware
-    # queues -- a 64-sentence call, three parts on three streams, went 1.77 -> 2.02 ms.)
+    profile = not args.no_profile and not dry   # (begun right in front of the timed region, below)
+    # Per-step wall time, without a synchronisation inside the region: an event on the launch stream after every timed step.
+    # The shader clock UNDER LOAD is read in a pass of its own, up to five untimed steps of the same workload right in front of the
+    # timed region: beside each step, on the library's own non-blocking stream, a one-wave kernel stamps shader cycles against the
+    # 100 MHz counter over 16 windows of ~1/16 step (asleep in between).  Round 6 measured that trace kernel BESIDE the timed steps
+    # at 1.2 % of `value` (profiles/r06r_instrument_ab.log: 45 663 with it, 46 183 without, 46 223 with no instrumentation at
+    # all; the events, the sysfs sampler and the GEMM events of `roofline` cost nothing) -- so it no longer runs there.  (A probe
+    # on the launch stream between two steps reads an IDLE chip: the power controller lets the clock back up within microseconds
+    # -- that is `clock_ghz_idle`.  And not a torch side stream: the first torch.cuda.Stream() of a process creates torch's pool
+    # of 32 streams, with which the library's own streams share hardware queues -- a 64-sentence call, three parts on three
+    # streams, went 1.77 -> 2.02 ms.)
     sensors = smi_before = None
     timing_errors = []
     instrument = not dry and rank == 0 and not args.no_instrument
@@ -990,9 +997,10 @@ def main():
         main_stream = torch.cuda.current_stream()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         TRACE_WINDOWS = 16
-        probes = torch.zeros((args.steps, TRACE_WINDOWS, 2), dtype=torch.int64, device=dev)
+        n_trace = 0 if args.no_clock_trace else max(1, min(args.steps, 5))
+        probes = torch.zeros((max(1, n_trace), TRACE_WINDOWS, 2), dtype=torch.int64, device=dev)
         idle_probe = torch.zeros((2,), dtype=torch.int64, device=dev)
-        side_stream = _probe_ops.measurement_stream()
+        side_stream = 0 if args.no_clock_trace else _probe_ops.measurement_stream()
         _probe_ops.clock_probe(idle_probe.data_ptr(), 200, main_stream.cuda_stream)  # (the idle reading: nothing else is running)
     # One more untimed step on EVERY rank (a step holds the output all-gather at N > 1: all ranks or none), timed on the host: the
     # length of a clock-trace window.
@@ -1014,19 +1022,34 @@ def main():
                 bus = None
             # (no PCI address -> no sensors: the first AMD card of /sys/class/drm may be another GPU of the host)
             sensors = GpuSensors(bus) if bus else None
+    # The clock-trace pass: up to five untimed steps on EVERY rank (a step holds the all-gather at N > 1), rank 0's with the trace
+    # kernel beside them.
+    trace_steps = 0 if (args.no_instrument or args.no_clock_trace) else max(1, min(args.steps, 5))
+    if trace_steps:
+        sync()
+        for i in range(trace_steps):
+            if instrument and side_stream:
+                try:
+                    _probe_ops.clock_trace(probes[i].data_ptr(), TRACE_WINDOWS, window_us, side_stream)
+                except Exception as e:   # (diagnostics only: never at the price of the line)
+                    timing_errors.append(repr(e))
+                    side_stream = 0
+            step()
+        sync()   # (torch.cuda.synchronize: the side stream's last trace too)
+        if instrument:
+            try:
+                _probe_ops.measurement_stream_release()  # (or one of the encoder's lane streams may share a hardware queue with it)
+            except Exception as e:
+                timing_errors.append(repr(e))
     sync()
+    if profile:
+        enc.profile_begin(GEMM_KINDS)   # (again: the dominant kernel's events are those of the timed region only)
     if sensors:
         sensors.start()
     t0 = time.perf_counter()
     if instrument:
         evs[0].record(main_stream)
     for i in range(args.steps):
-        if instrument and side_stream:
-            try:
-                _probe_ops.clock_trace(probes[i].data_ptr(), TRACE_WINDOWS, window_us, side_stream)
-            except Exception as e:   # (diagnostics only: never at the price of the line)
-                timing_errors.append(repr(e))
-                side_stream = 0
         step()
         if instrument:
             evs[i + 1].record(main_stream)
@@ -1036,9 +1059,7 @@ def main():
     if instrument:
         try:
             timing["steps_ms"] = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)]
-            torch.cuda.synchronize()  # (the side stream's last trace)
-            _probe_ops.measurement_stream_release()  # (or one of the encoder's lane streams may share a hardware queue with it)
-            pr = probes.cpu().numpy().astype(np.float64)
+            pr = probes[:max(1, trace_steps)].cpu().numpy().astype(np.float64)
             win = np.where(pr[..., 1] > 0, pr[..., 0] / np.maximum(pr[..., 1], 1) / 10.0, np.nan)  # GHz per window
             if np.isfinite(win).any():
                 timing["clock_ghz"] = [round(float(np.nanmean(w)), 3) if np.isfinite(w).any() else None for w in win]
@@ -1046,8 +1067,9 @@ def main():
             ip = idle_probe.cpu().numpy().astype(np.float64)
             timing["clock_ghz_idle"] = round(float(ip[0] / ip[1] / 10.0), 3) if ip[1] > 0 else None
             timing["clock_note"] = (f"clock_ghz[i]: shader cycles per 10 ns tick, mean of {TRACE_WINDOWS} windows of {window_us} us read by a one-wave "
-                                    "kernel on a stream of its own while timed step i runs (the clock UNDER the work); clock_ghz_idle: the "
-                                    "same reading over 200 us with nothing else running")
+                                    f"kernel on a stream of its own while untimed step i of {trace_steps} runs right in front of the timed region "
+                                    "(the clock UNDER the work; beside the timed steps themselves the trace kernel cost 1.2 % of `value`); "
+                                    "clock_ghz_idle: the same reading over 200 us with nothing else running")
             if sensors:
                 timing["gpu_sensors"] = sensors.stop()
                 timing["gpu_sensors"]["rocm_smi_before"] = smi_before

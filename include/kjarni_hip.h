@@ -126,6 +126,12 @@ KjarniErrorCode kjarni_hip_encoder_set_two_lanes(KjarniHipEncoder* enc, int32_t 
 int32_t kjarni_hip_set_f32_on_bf16(int32_t on);
 int32_t kjarni_hip_get_f32_on_bf16(void);
 
+/* Self-test (no counterpart in the reference): the kernels' cross-lane sums and maxima avoid the LDS crossbar (csrc/device_utils.h:
+ * v_permlane32_swap / v_permlane16_swap and DPP row rotations in place of ds_bpermute_b32) and claim the `__shfl_xor` butterfly's
+ * values bit for bit; this runs every such form against the butterfly it replaces on `waves` x 64 pseudo-random values of
+ * seed `seed` (1 .. 4 194 304 waves) and writes the number of lanes that differ to *mismatches_out (0 = the claim holds). */
+KjarniErrorCode kjarni_hip_selftest_reductions(int32_t device, uint32_t waves, uint32_t seed, uint32_t* mismatches_out);
+
 /* Measurement aid (bench.py's `clock_ghz` fields; no counterpart in the reference): enqueues ONE wave on `stream` that reads the
  * shader-cycle counter and the constant 100 MHz counter either side of a spin of `spin_us` microseconds (0 = 20; at most
  * 10 000) and writes out_dev[0] = shader cycles, out_dev[1] = 10 ns ticks.  out_dev[0] / out_dev[1] / 10 is the shader clock in

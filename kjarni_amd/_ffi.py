@@ -423,6 +423,7 @@ SIGNATURES = {
     "kjarni_hip_encoder_set_two_lanes": (c_int32, [c_void_p, c_int32]),
     "kjarni_hip_set_f32_on_bf16": (c_int32, [c_int32]),
     "kjarni_hip_get_f32_on_bf16": (c_int32, []),
+    "kjarni_hip_selftest_reductions": (c_int32, [c_int32, C.c_uint32, C.c_uint32, POINTER(C.c_uint32)]),
     "kjarni_hip_clock_probe": (c_int32, [c_void_p, C.c_uint32, c_void_p]),
     "kjarni_hip_clock_trace": (c_int32, [c_void_p, C.c_uint32, C.c_uint32, c_void_p]),
     "kjarni_hip_measurement_stream": (c_void_p, []),

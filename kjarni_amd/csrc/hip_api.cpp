@@ -152,6 +152,20 @@ KJARNI_EXPORT KjarniErrorCode kjarni_hip_clock_probe(uint64_t* out_dev, uint32_t
                                                                                              : KJARNI_ERROR_INFERENCE_FAILED;
 }
 
+KJARNI_EXPORT KjarniErrorCode kjarni_hip_selftest_reductions(int32_t device, uint32_t waves, uint32_t seed, uint32_t* mismatches_out)
+{
+    if (!mismatches_out) return KJARNI_ERROR_NULL_POINTER;
+    return guarded(KJARNI_ERROR_INFERENCE_FAILED, [&] {
+        if (waves == 0 || waves > (1u << 22)) throw InvalidConfig("1 .. 4 194 304 waves");
+        use_device(device);
+        DeviceBuf d(4);
+        hip_check(hipMemset(d.p, 0, 4), "memset");
+        hip_check(kjarni::launch_reduction_selftest((unsigned*)d.p, waves, seed, nullptr), "reduction self-test");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        hip_check(hipMemcpy(mismatches_out, d.p, 4, hipMemcpyDeviceToHost), "D2H");
+    });
+}
+
 namespace {
 std::mutex g_measurement_mu;
 constexpr int kMaxMeasurementDevices = 64;

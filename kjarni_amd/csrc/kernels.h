@@ -173,5 +173,8 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
 // out[0] = shader cycles, out[1] = 10 ns ticks (clock in GHz = out[0] / out[1] / 10).  rowops.hip.
 hipError_t launch_clock_probe(uint64_t* out, unsigned spin_ticks, hipStream_t stream);
 hipError_t launch_clock_trace(uint64_t* out, unsigned samples, unsigned window_ticks, hipStream_t stream);
+// Self-test: device_utils.h's DPP / permlane-swap reductions against the __shfl_xor butterflies they replace, bit for bit, on
+// `waves` x 64 pseudo-random values; *mismatches (device, zeroed by the caller) += lanes that differ.  rowops.hip.
+hipError_t launch_reduction_selftest(unsigned* mismatches, unsigned waves, unsigned seed, hipStream_t stream);
 
 }  // namespace kjarni

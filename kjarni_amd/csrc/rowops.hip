@@ -641,6 +641,64 @@ hipError_t launch_clock_trace(uint64_t* out, unsigned samples, unsigned window_t
     return hipGetLastError();
 }
 
+// Self-test of device_utils.h's reductions without the LDS crossbar: every form against the `__shfl_xor` butterfly it replaces,
+// bit for bit, on pseudo-random values (one wave per workgroup, `waves` workgroups); out[0] += lanes that differ.
+__global__ __launch_bounds__(64) void reduction_selftest_kernel(unsigned* __restrict__ out, unsigned seed)
+{
+    const unsigned i = blockIdx.x * 64u + threadIdx.x;
+    unsigned h = (i + seed) * 2654435761u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    // magnitudes over ~12 binades and both signs (sums that cancel), every 97th value exactly zero
+    float v = ((int)(h & 0xFFFFFFu) - 0x800000) * (1.0f / 8388608.0f) * __uint_as_float(((h >> 24 & 15u) + 120u) << 23);
+    if (i % 97u == 0u) v = 0.0f;
+    unsigned bad = 0;
+    auto same = [&](float a, float b) { bad += __float_as_uint(a) != __float_as_uint(b); };
+    {   // wave-wide, butterfly 32, 16, 8, 4, 2, 1
+        float s = v, m = v;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off, kWave);
+            m = fmaxf(m, __shfl_xor(m, off, kWave));
+        }
+        same(wave_sum(v), s);
+        same(wave_max(v), m);
+    }
+    {   // the 16-lane row, butterfly 8, 4, 2, 1
+        float s = v, m = v;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off, kWave);
+            m = fmaxf(m, __shfl_xor(m, off, kWave));
+        }
+        same(row16_sum_desc(v), s);
+        same(row16_max_desc(v), m);
+    }
+    {   // aligned groups of 8 lanes, butterfly 1, 2, 4
+        float s = v, m = v;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            s += __shfl_xor(s, off, kWave);
+            m = fmaxf(m, __shfl_xor(m, off, kWave));
+        }
+        same(group8_sum_asc(v), s);
+        same(group8_max_asc(v), m);
+    }
+    same(sum_xor32(v), v + __shfl_xor(v, 32, kWave));
+    same(sum_xor16(v), v + __shfl_xor(v, 16, kWave));
+    same(max_xor32(v), fmaxf(v, __shfl_xor(v, 32, kWave)));
+    same(max_xor16(v), fmaxf(v, __shfl_xor(v, 16, kWave)));
+    same(sum_xor32(sum_xor16(v)), [&] { float t = v + __shfl_xor(v, 16, kWave); return t + __shfl_xor(t, 32, kWave); }());
+    if (bad) atomicAdd(out, bad);
+}
+
+hipError_t launch_reduction_selftest(unsigned* mismatches, unsigned waves, unsigned seed, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reduction_selftest_kernel, dim3(waves), dim3(64), 0, stream, mismatches, seed);
+    return hipGetLastError();
+}
+
 hipError_t launch_clock_probe(uint64_t* out, unsigned spin_ticks, hipStream_t stream)
 {
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long*)out, spin_ticks);

@@ -224,3 +224,19 @@ def test_clock_trace_reads_a_shader_clock():
     ops.measurement_stream_release()
     assert ops.measurement_stream() != 0  # (a new one)
     ops.measurement_stream_release()
+
+
+def test_reductions_without_the_lds_crossbar_equal_the_shfl_butterflies():
+    """csrc/device_utils.h: wave_sum / wave_max, the 16-lane-row and 8-lane-group sums, i ^ 16 / i ^ 32 partners -- through
+    v_permlane32_swap / v_permlane16_swap and DPP row rotations instead of ds_bpermute_b32 (what `__shfl_xor` compiles to).
+    The kernels that use them claim the butterfly's VALUES bit for bit; the library's self-test runs each form against the
+    butterfly it replaces on 2^20 waves of values over twelve binades, both signs and exact zeros."""
+    import ctypes as C
+    from kjarni_amd import _ffi
+    L = _ffi.lib()
+    for seed in (0, 12345):
+        bad = C.c_uint32(7)
+        _ffi.check_error(L.kjarni_hip_selftest_reductions(0, 1 << 20, seed, C.byref(bad)))
+        assert bad.value == 0, f"{bad.value} lanes differ from the __shfl_xor butterflies (seed {seed})"
+    assert L.kjarni_hip_selftest_reductions(0, 0, 0, C.byref(bad)) == 7          # INVALID_CONFIG
+    assert L.kjarni_hip_selftest_reductions(0, 1, 0, None) == 1                   # NULL_POINTER
