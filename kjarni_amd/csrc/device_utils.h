@@ -95,6 +95,24 @@ __device__ __forceinline__ float group8_max_asc(float v)
 __device__ __forceinline__ float wave_sum(float v) { return row16_sum_desc(sum_xor16(sum_xor32(v))); }
 __device__ __forceinline__ float wave_max(float v) { return row16_max_desc(max_xor16(max_xor32(v))); }
 
+// ---- kernel arguments in ONE batch of scalar loads -----------------------------------------------------------------------------
+// The compiler loads a kernel argument where it is first used; a latency-bound kernel with early exits and optional pointers
+// (`if (n >= n_out) return;`, `bias ? bias[n] : 0`) then starts with a chain of scalar-load round trips -- argument, wait,
+// branch, next argument, wait ... -- before its first vector load is issued.  kj_args_now(...) names the arguments in an empty asm
+// statement with scalar-register constraints at the top of the kernel: all of them are loaded there, together, behind one wait
+// (with -amdgpu-kernarg-preload-count=16 in the Makefile the first 16 dwords come in SGPRs with the wave).  In the decode steps'
+// one-row GEMV the arguments are there 210-230 cycles after the wave's entry; worth ~1 % of a token (docs/history/r06.md 2b).
+template <typename T>
+__device__ __forceinline__ void kj_arg_now(const T& a)
+{
+    asm volatile("" ::"s"(a));
+}
+template <typename... T>
+__device__ __forceinline__ void kj_args_now(const T&... a)
+{
+    (kj_arg_now(a), ...);
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (a private L2 each).  The unit workgroup `wg` of a launch of `total`
 // workgroups should take so that every XCD owns ONE contiguous run of units (bijective for any total): the projections' tile
 // order does this, and a row-wise kernel that follows it finds the rows its XCD's L2 already holds.

@@ -680,9 +680,9 @@ namespace kjarni { namespace tune { std::atomic<int> g_gemm{0}, g_attention{0}, 
 KJARNI_EXPORT void kjarni_hip_set_gemm_variant(int32_t variant) { kjarni::tune::g_gemm = variant; }
 KJARNI_EXPORT void kjarni_hip_set_attention_variant(int32_t variant) { kjarni::tune::g_attention = variant; }
 KJARNI_EXPORT void kjarni_hip_set_cosine_variant(int32_t variant) { kjarni::tune::g_cosine = variant; }
-KJARNI_EXPORT int32_t kjarni_hip_attention_stamps(uint64_t* out8, int32_t reset)
+KJARNI_EXPORT int32_t kjarni_hip_attention_stamps(uint64_t* out16, int32_t reset)
 {
-    return out8 && kjarni::attention_stamps(reinterpret_cast<unsigned long long*>(out8), reset) == hipSuccess ? 0 : 5;
+    return out16 && kjarni::attention_stamps(reinterpret_cast<unsigned long long*>(out16), reset) == hipSuccess ? 0 : 5;
 }
 #endif
 

@@ -80,10 +80,7 @@ LlmConfig LlmConfig::from_json(const std::string& text)
 
 float* LlmModel::dalloc(size_t floats)
 {
-    float* d = nullptr;
-    hip_check(hipMalloc((void**)&d, std::max<size_t>(floats, 4) * sizeof(float)), "hipMalloc");
-    allocs_.push_back(d);
-    return d;
+    return static_cast<float*>(arena_.alloc(std::max<size_t>(floats, 4) * sizeof(float)));   // (device_arena.h: blocks, not one hipMalloc per tensor)
 }
 
 float* LlmModel::upload_f32(const std::vector<float>& host)
@@ -113,7 +110,7 @@ LlmModel::~LlmModel()
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (graph_) (void)hipGraphExecDestroy(graph_);
     if (stream_) (void)hipStreamDestroy(stream_);
-    for (void* p : allocs_) (void)hipFree(p);
+    arena_.release();
 }
 
 std::unique_ptr<LlmModel> LlmModel::load(const std::string& dir, int device, int weights, int max_context)

@@ -6,6 +6,7 @@
 //   model forward           crates/kjarni-models/src/models/llama/cpu_decoder.rs:142-219
 //   generation loop         crates/kjarni-transformers/src/decoder/generator.rs:228-381 (DecodingStrategy::Greedy)
 #pragma once
+#include "device_arena.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -102,7 +103,7 @@ private:
     int device_ = 0;
     bool bf16_ = false;
     size_t weight_bytes_ = 0;
-    std::vector<void*> allocs_;
+    DeviceArena arena_;   // every device buffer of the model
     std::vector<Layer> layers_;
     void *embed_ = nullptr, *lm_head_ = nullptr;
     float *final_norm_ = nullptr, *cos_ = nullptr, *sin_ = nullptr;

@@ -179,10 +179,7 @@ float* WhisperModel::upload(const std::vector<float>& host)
 
 float* WhisperModel::dalloc(size_t floats)
 {
-    float* d = nullptr;
-    hip_check(hipMalloc((void**)&d, std::max<size_t>(floats, 4) * sizeof(float)), "hipMalloc");
-    allocs_.push_back(d);
-    return d;
+    return static_cast<float*>(arena_.alloc(std::max<size_t>(floats, 4) * sizeof(float)));   // (device_arena.h: blocks, not one hipMalloc per tensor)
 }
 
 WhisperModel::~WhisperModel()
@@ -192,7 +189,7 @@ WhisperModel::~WhisperModel()
     for (hipGraphExec_t g : graphs_)
         if (g) (void)hipGraphExecDestroy(g);
     if (stream_) (void)hipStreamDestroy(stream_);
-    for (void* p : allocs_) (void)hipFree(p);
+    arena_.release();
 }
 
 std::unique_ptr<WhisperModel> WhisperModel::load(const std::string& dir, int device)

@@ -7,6 +7,7 @@
 //   decoder                        cpu/encoder_decoder/cpu_decoder.rs:399-516
 //   greedy loop, prompt, filtering crates/kjarni-models/src/models/whisper/transcriber.rs:122-460
 #pragma once
+#include "device_arena.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -121,7 +122,7 @@ private:
     ByteLevelVocab vocab_;
     int device_ = 0;
     uint32_t eos_ = 50257;
-    std::vector<void*> allocs_;
+    DeviceArena arena_;   // every device buffer of the model
     size_t weight_bytes_ = 0;
 
     // front end

@@ -62,7 +62,7 @@ struct GemvArgs {
 bool gemv_rows_takes_row_extras(const GemvArgs& args);
 hipError_t launch_gemv_rows(const GemvArgs& args, hipStream_t stream);
 #ifdef KJARNI_TUNING
-hipError_t attention_stamps(unsigned long long* out8, int reset);  // measurements: decode attention's cycles per phase
+hipError_t attention_stamps(unsigned long long* out16, int reset);  // measurements: decode attention's cycles per phase
 void set_gemv_rows_variant(int variant);  // 0 = rows staged in LDS when there are several, 1 = always the per-wave kernel
 #endif
 

@@ -170,6 +170,12 @@ __global__ __launch_bounds__(256) void decoder_embed_kernel(const uint32_t* __re
     }
 }
 
+#ifdef KJARNI_TUNING
+// Measurements (tuning build): shader cycles the decode attention's register path spends per phase, summed over workgroups --
+// [0] entry -> scores (the loads' round trips + the dots), [1] -> block max, [2] -> exp, weighted V, block sum, [3] -> slab
+// stored, [4] workgroups counted; [5] / [6] / [7]: the one-row GEMV's entry -> dot reduced, -> stored, waves sampled.  kjarni_hip_attention_stamps reads / resets them.
+__device__ unsigned long long g_att_stamp[16];   // ([8] .. [12]: the one-row LN GEMV's entry -> row arrived, -> arguments arrived, -> weight requests issued, waves, -> every request issued)
+#endif
 constexpr int GEMV_MAX_ROWS = 8;
 
 // Y[r, n] = epi(LN?(X[r, :]) . W[n, :] + bias[n]) (+ R[r, n]) for a handful of rows r: one wave per output
@@ -274,21 +280,58 @@ struct GemvEmbed {
     float scale;
 };
 
-template <int EPI, bool LN, int KCH, bool EMBED = false>
-__global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, const float* R, int n_out,
-                                                            int seg, float* Y0, float* __restrict__ Y1,
-                                                            float* __restrict__ Y2, int64_t ldy12, int row_off,
-                                                            const int* __restrict__ row_off_ptr, float* __restrict__ x_raw_out,
-                                                            float* __restrict__ x_norm_out, GemvEmbed emb)
+// COLS output columns per wave, WAVES waves per workgroup: a wave's requests for the row, gamma and beta are the same whatever
+// its column, and on a compute unit they queue behind one another in the one address pipe -- with one column per wave a wave
+// of the 1536-column projection needed ~2 300 cycles just to ISSUE its eight loads (stamps: docs/history/r06.md); with COLS
+// columns a wave issues 6 + 2 COLS instead of 8 COLS.  Each column's dot product keeps its own lane order and reduction.
+template <int EPI, bool LN, int KCH, bool EMBED = false, int COLS = 1, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void gemv_row_fast_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps,
+                                                                   const float* __restrict__ W, const float* __restrict__ bias,
+                                                                   const float* R, int n_out, int seg, float* Y0,
+                                                                   float* __restrict__ Y1, float* __restrict__ Y2, int64_t ldy12,
+                                                                   int row_off, const int* __restrict__ row_off_ptr,
+                                                                   float* __restrict__ x_raw_out, float* __restrict__ x_norm_out,
+                                                                   GemvEmbed emb)
 {
     constexpr int K = 256 * KCH;
+#ifdef KJARNI_TUNING
+    const unsigned long long gst0 = __builtin_amdgcn_s_memtime();
+#endif
+    // (every argument in one batch of scalar loads: device_utils.h)
+    kj_args_now(X, gamma, beta, eps, W, bias, R, n_out, seg, Y0, Y1, Y2, ldy12, row_off, row_off_ptr, x_raw_out, x_norm_out);
+    if (EMBED) kj_args_now(emb.ids, emb.word, emb.pos_table, emb.vocab, emb.max_pos, emb.pos, emb.pos_ptr, emb.scale);
+#ifdef KJARNI_TUNING
+    unsigned long long gsta;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gsta) : "s"(x_norm_out), "s"(ldy12) : "memory");   // (arguments arrived)
+#endif
     const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (n >= n_out) return;
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + n * (int64_t)K);
-    f32x4 x[KCH], w[KCH], g[KCH], bt[KCH];
+    const int wave = WAVES > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int64_t n0 = ((int64_t)blockIdx.x * WAVES + wave) * COLS;
+    if (n0 >= n_out) return;
+    f32x4 x[KCH], w[COLS][KCH], g[KCH], bt[KCH];
+#if defined(KJARNI_TUNING) && defined(KJARNI_GEMV_PROBE)
+    // (timing probe, results garbage: the arrays every wave shares read from a place of the wave's own instead)
+    gamma = W + ((n0 * 7 + 3) % n_out) * (int64_t)K;
+    beta = W + ((n0 * 13 + 5) % n_out) * (int64_t)K;
+    if (KJARNI_GEMV_PROBE >= 2) X = W + ((n0 * 11 + 1) % n_out) * (int64_t)K;
+#endif
+    // Order of issue = order of need, and nothing that waits stands before a request: the row offset (a device counter) is a
+    // scalar load waited for only at the store; the weight rows -- the one stream that comes from HBM -- go first.
+    int r0s = row_off;
+    if (seg > 0 && row_off_ptr) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(r0s) : "s"(row_off_ptr));
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        const int64_t nc = COLS > 1 && n0 + c >= n_out ? n_out - 1 : n0 + c;   // (a ragged last wave re-reads the last row)
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(W + nc * (int64_t)K);
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) w[c][j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    }
+#ifdef KJARNI_TUNING
+    asm volatile("" ::: "memory");
+    const unsigned long long gstw = __builtin_amdgcn_s_memtime();   // (weight requests issued)
+    asm volatile("" ::: "memory");
+#endif
     if (EMBED) {
         const uint32_t id = emb.ids[0];
         const int p = emb.pos_ptr ? *emb.pos_ptr : emb.pos;
@@ -307,7 +350,7 @@ __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restr
             }
             x[j] = v;
         }
-        if (n == 0 && x_raw_out) {
+        if (n0 == 0 && x_raw_out) {
 #pragma unroll
             for (int j = 0; j < KCH; ++j) *reinterpret_cast<f32x4*>(x_raw_out + (lane + 64 * j) * 4) = x[j];
         }
@@ -322,16 +365,26 @@ __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restr
             bt[j] = *reinterpret_cast<const f32x4*>(beta + (lane + 64 * j) * 4);
         }
     }
-    const float b = bias ? bias[n] : 0.0f;
-    const float res = EPI == EPI_BIAS_RESIDUAL ? R[n] : 0.0f;
-    const int which = seg > 0 ? (int)(n / seg) : 0;
-    const int64_t r0 = which == 0 ? 0 : (row_off_ptr ? *row_off_ptr : row_off);
-#pragma unroll
-    for (int j = 0; j < KCH; ++j) w[j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    // (bias and residual of the wave's columns: lane c holds column n0 + c's)
+    const int64_t nl = n0 + lane < n_out ? n0 + lane : n_out - 1;
+    float b = 0.0f, res = 0.0f;
+    if (lane < COLS) {
+        if (bias) b = bias[nl];
+        if (EPI == EPI_BIAS_RESIDUAL) res = R[nl];
+    }
+#ifdef KJARNI_TUNING
+    unsigned long long gstx = 0;
+    asm volatile("" ::: "memory");
+    const unsigned long long gsti = __builtin_amdgcn_s_memtime();   // (every request issued)
+#endif
     if (LN) {
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < KCH; ++j) s += (x[j][0] + x[j][1]) + (x[j][2] + x[j][3]);
+#ifdef KJARNI_TUNING
+        asm volatile("" : "+v"(s));
+        gstx = __builtin_amdgcn_s_memtime();   // (the input row has arrived)
+#endif
         const float mu = wave_sum(s) / (float)K;
         float v = 0.0f;
 #pragma unroll
@@ -343,22 +396,49 @@ __global__ __launch_bounds__(256) void gemv_row_fast_kernel(const float* __restr
         for (int j = 0; j < KCH; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[j][c] = (x[j][c] - mu) * rstd * g[j][c] + bt[j][c];
-        if (n == 0 && x_norm_out) {
+        if (n0 == 0 && x_norm_out) {
 #pragma unroll
             for (int j = 0; j < KCH; ++j) *reinterpret_cast<f32x4*>(x_norm_out + (lane + 64 * j) * 4) = x[j];
         }
     }
-    float acc = 0.0f;
+    float out = 0.0f;
 #pragma unroll
-    for (int j = 0; j < KCH; ++j)
+    for (int cc = 0; cc < COLS; ++cc) {
+        float acc = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc = fmaf(x[j][c], w[j][c], acc);
-    float v = wave_sum(acc) + b;
+        for (int j = 0; j < KCH; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = fmaf(x[j][c], w[cc][j][c], acc);
+        const float d = wave_sum(acc);
+        out = lane == cc ? d : out;
+    }
+    float v = out + b;
+#ifdef KJARNI_TUNING
+    asm volatile("" : "+v"(v));
+    const unsigned long long gst1 = __builtin_amdgcn_s_memtime();
+#endif
     if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
     if (EPI == EPI_BIAS_RESIDUAL) v += res;
-    const int64_t col = seg > 0 ? n - (int64_t)which * seg : n;
+    const int64_t n = n0 + lane;
+    const int which = seg > 0 ? (int)(n >= seg) + (int)(n >= 2 * (int64_t)seg) : 0;   // (n / seg: three segments at most)
+    const int64_t col = n - (int64_t)which * seg;
     float* Y = which == 0 ? Y0 : (which == 1 ? Y1 : Y2);
-    if (lane == 0) Y[(which == 0 ? 0 : r0 * ldy12) + col] = v;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0s));
+    if (lane < COLS && n < n_out) Y[(which == 0 ? 0 : (int64_t)r0s * ldy12) + col] = v;
+#ifdef KJARNI_TUNING
+    if (lane == 0 && n_out <= 4096 && (blockIdx.x & 31) == 0 && wave == 0) {   // (a sample of the waves; not the vocabulary head)
+        atomicAdd(&g_att_stamp[5], gst1 - gst0);
+        atomicAdd(&g_att_stamp[6], __builtin_amdgcn_s_memtime() - gst1);
+        atomicAdd(&g_att_stamp[7], 1ull);
+        if (LN) {
+            atomicAdd(&g_att_stamp[8], gstx - gst0);    // (entry -> the row arrived)
+            atomicAdd(&g_att_stamp[9], gsta - gst0);    // (entry -> arguments arrived)
+            atomicAdd(&g_att_stamp[10], gstw - gst0);   // (entry -> weight requests issued)
+            atomicAdd(&g_att_stamp[11], 1ull);
+            atomicAdd(&g_att_stamp[12], gsti - gst0);   // (entry -> every request issued)
+        }
+    }
+#endif
 }
 
 // The same projection for 2..8 rows (several tokens of one sequence, or the lanes of a lock-step decode): the rows are
@@ -660,12 +740,6 @@ __global__ __launch_bounds__(256) void gemv_rows_head_kernel(const float* __rest
 // causal >= 0 (or the pointer): query row s sees keys <= base + s (apply_causal_mask, utils/masks.rs:103-113: masked scores
 // are OVERWRITTEN with -1e9, which exp() then turns into exactly 0 next to any real score).
 // Slab layout per (row, head, split): [max, sum, 0, 0, acc[head_dim]] (16-byte aligned pieces).
-#ifdef KJARNI_TUNING
-// Measurements (tuning build): shader cycles the decode attention's register path spends per phase, summed over workgroups --
-// [0] entry -> scores (the loads' round trips + the dots), [1] -> block max, [2] -> exp, weighted V, block sum, [3] -> slab
-// stored, [4] workgroups counted.  kjarni_hip_attention_stamps reads / resets them.
-__device__ unsigned long long g_att_stamp[8];
-#endif
 constexpr int ATT_MAX_CHUNK = 512;
 constexpr int ATT_FAST = 8;  // keys per lane group that the short-range path holds in registers (128 keys per split at d = 64)
 
@@ -984,11 +1058,11 @@ __global__ void pick_finalize_kernel(unsigned long long* __restrict__ best, int 
 }  // namespace
 
 #ifdef KJARNI_TUNING
-hipError_t attention_stamps(unsigned long long* out8, int reset)
+hipError_t attention_stamps(unsigned long long* out16, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_att_stamp), 8 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_att_stamp), 16 * sizeof(unsigned long long));
     if (e != hipSuccess || !reset) return e;
-    static const unsigned long long zeros[8] = {};
+    static const unsigned long long zeros[16] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamp), zeros, sizeof(zeros));
 }
 #endif
@@ -1131,19 +1205,42 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
         (!ln || ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0)) {
         const GemvEmbed emb{a.embed_ids, a.embed_word, a.embed_pos_table, a.embed_vocab, a.embed_max_pos, a.embed_pos, a.embed_pos_ptr,
                             a.embed_scale};
+        int cols = 1, waves = 4;   // (columns per wave, waves per workgroup)
+#ifdef KJARNI_TUNING
+        if (const char* e = getenv("KJARNI_HIP_GEMV_COLS")) cols = atoi(e);
+        if (const char* e = getenv("KJARNI_HIP_GEMV_WAVES")) waves = atoi(e);
+        if ((cols != 1 && cols != 2 && cols != 4) || (waves != 1 && waves != 4)) return hipErrorInvalidValue;
+#endif
+        const dim3 fgrid((unsigned)((a.n_out + (int64_t)cols * waves - 1) / ((int64_t)cols * waves))), fblock(64 * waves);
+#define KJ_FAST4(EPI, LN, KCH, EMB, COLS, WAVES)                                                                                   \
+    hipLaunchKernelGGL((gemv_row_fast_kernel<EPI, LN, KCH, EMB, COLS, WAVES>), fgrid, fblock, 0, stream, a.X, a.gamma, a.beta, a.eps, \
+                       a.W, a.bias, a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr, a.x_raw_out,         \
+                       a.x_norm_out, emb)
+#ifdef KJARNI_TUNING
+#define KJ_FAST3(EPI, LN, KCH, EMB)                                                                                                \
+    do {                                                                                                                           \
+        if (waves == 4) {                                                                                                          \
+            if (cols == 1) KJ_FAST4(EPI, LN, KCH, EMB, 1, 4);                                                                      \
+            else if (cols == 2) KJ_FAST4(EPI, LN, KCH, EMB, 2, 4);                                                                 \
+            else KJ_FAST4(EPI, LN, KCH, EMB, 4, 4);                                                                                \
+        } else {                                                                                                                   \
+            if (cols == 1) KJ_FAST4(EPI, LN, KCH, EMB, 1, 1);                                                                      \
+            else if (cols == 2) KJ_FAST4(EPI, LN, KCH, EMB, 2, 1);                                                                 \
+            else KJ_FAST4(EPI, LN, KCH, EMB, 4, 1);                                                                                \
+        }                                                                                                                          \
+    } while (0)
+#else
+#define KJ_FAST3(EPI, LN, KCH, EMB) KJ_FAST4(EPI, LN, KCH, EMB, 1, 4)
+#endif
         if (a.embed_ids) {  // the first projection of a one-token step builds its input row itself (LN + Q | K | V, 512-float rows)
             if (!(ln && a.epi == EPI_BIAS && kch == 2)) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((gemv_row_fast_kernel<EPI_BIAS, true, 2, true>), grid, dim3(256), 0, stream, a.X, a.gamma, a.beta, a.eps, a.W,
-                               a.bias, a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr, a.x_raw_out, a.x_norm_out, emb);
+            KJ_FAST3(EPI_BIAS, true, 2, true);
             return hipGetLastError();
         }
-#define KJ_FAST2(EPI, LN, KCH)                                                                                                    \
-    hipLaunchKernelGGL((gemv_row_fast_kernel<EPI, LN, KCH>), grid, dim3(256), 0, stream, a.X, a.gamma, a.beta, a.eps, a.W, a.bias, \
-                       a.R, a.n_out, a.seg, a.Y0, a.Y1, a.Y2, a.ldy12, a.row_off, a.row_off_ptr, a.x_raw_out, a.x_norm_out, emb)
 #define KJ_FAST(EPI, LN)                                                                                                          \
     do {                                                                                                                          \
-        if (kch == 2) KJ_FAST2(EPI, LN, 2);                                                                                       \
-        else KJ_FAST2(EPI, LN, 8);                                                                                                \
+        if (kch == 2) KJ_FAST3(EPI, LN, 2, false);                                                                                \
+        else KJ_FAST3(EPI, LN, 8, false);                                                                                         \
     } while (0)
         switch (a.epi) {
         case EPI_BIAS:
@@ -1161,7 +1258,8 @@ hipError_t launch_gemv_rows(const GemvArgs& a, hipStream_t stream)
         default: return hipErrorInvalidValue;
         }
 #undef KJ_FAST
-#undef KJ_FAST2
+#undef KJ_FAST3
+#undef KJ_FAST4
         return hipGetLastError();
     }
     switch (a.epi) {

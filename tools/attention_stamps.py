@@ -1,4 +1,4 @@
-"""Shader cycles per phase of the decode attention's register path (tuning build only), over a Whisper or LLM decode.
+"""Shader cycles per phase of the decode attention's register path and of the one-row GEMV (tuning build only), over a Whisper or LLM decode.
 usage: KJARNI_FFI_LIB=.../libkjarni_ffi_tuning.so python tools/attention_stamps.py whisper|llm"""
 import ctypes as C, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ from kjarni_amd import _ffi
 from tests import synth
 
 L = _ffi.lib()
-buf = (C.c_uint64 * 8)()
+buf = (C.c_uint64 * 16)()
 which = sys.argv[1]
 with tempfile.TemporaryDirectory() as tmp:
     if which == "whisper":
@@ -28,4 +28,9 @@ with tempfile.TemporaryDirectory() as tmp:
     L.kjarni_hip_attention_stamps(buf, 0)
 n = max(1, buf[4])
 names = ["entry -> scores (loads + dots)", "-> block max", "-> exp, weighted V, block sum", "-> slab stored"]
-print(f"{which}: {buf[4]} workgroups; cycles per workgroup: " + "; ".join(f"{nm} {buf[i] / n:.0f}" for i, nm in enumerate(names)) + f"; total {sum(buf[i] for i in range(4)) / n:.0f}")
+print(f"{which}: decode attention, {buf[4]} workgroups; cycles per workgroup: " + "; ".join(f"{nm} {buf[i] / n:.0f}" for i, nm in enumerate(names)) + f"; total {sum(buf[i] for i in range(4)) / n:.0f}")
+if buf[11]:
+    m = buf[11]
+    print(f"{which}: one-row LN GEMV ({m} waves sampled), cycles from the wave's entry: arguments arrived {buf[9] / m:.0f}; weight requests issued {buf[10] / m:.0f}; every request issued {buf[12] / m:.0f}; the input row arrived {buf[8] / m:.0f}")
+if buf[7]:
+    print(f"{which}: one-row GEMV ({buf[7]} waves sampled): entry -> dot reduced {buf[5] / buf[7]:.0f} cycles, -> stored {buf[6] / buf[7]:.0f}")

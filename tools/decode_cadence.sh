@@ -7,7 +7,7 @@ which=${1:-whisper}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_c
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_c -- python tools/decode_probe.py $which > gpurun_out/prof_c.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_c -- python tools/decode_probe.py $which ${2:-2} > gpurun_out/prof_c.log 2>&1
 f=$(find gpurun_out/prof_c -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -22,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         }                                                                                     \
     } while (0)
 
-constexpr int K = 512, N = 512, KCH = K / 256;
+constexpr int K = 512, N = 512, KCH = K / 256;   // the homogeneous chains; the mixed chain below has its own shapes
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -129,8 +130,49 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_stage(const float* __restrict
     }
 }
 
+// A stage of the MIXED chain: y[0 .. n_out) = W x (+ LayerNorm first) over k = 256 KC floats, one column per wave, 4 waves per workgroup
+template <int KC, bool LN>
+__global__ __launch_bounds__(256) void mixed_stage(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                   float* __restrict__ y, int n_out)
+{
+    constexpr int KK = 256 * KC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= n_out) return;
+    f32x4 xv[KC], w[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) xv[j] = *reinterpret_cast<const f32x4*>(x + (lane + 64 * j) * 4);
+    const float b = bias[n & 511];
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + (size_t)n * KK);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) w[j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    if (LN) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+        const float mu = wave_sum_fast(s) / (float)KK;
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = fmaf(xv[j][c] - mu, xv[j][c] - mu, v);
+        const float rstd = 1.0f / sqrtf(wave_sum_fast(v) / (float)KK + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xv[j][c] = (xv[j][c] - mu) * rstd;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(xv[j][e], w[j][e], acc);
+    const float v = wave_sum_fast(acc) * 0.02f + b;
+    if (lane == 0) y[n] = v;
+}
+
 struct Bufs {
-    float *x[2], *W, *bias;
+    float *x[2], *W, *bias, *Wbig;   // Wbig: 768 MB -- a stage's weights 16 MB apart, 48 stages: nothing of it survives in the L2s / MALL
 };
 
 template <typename F>
@@ -165,6 +207,72 @@ static double time_chain(const char* name, F enqueue_stage, int stages)
     return us;
 }
 
+// A LayerNorm + GEMV stage (512 -> n_out) with PAD one-cycle, four-byte no-ops executed before its loads (WHERE = 0) or between
+// its loads and its arithmetic (WHERE = 1): what does a KB of code cost a stage that starts with a cold instruction cache?
+// ID makes distinct copies of the same code at different addresses.
+template <int ID, int PAD, int WHERE>
+__global__ __launch_bounds__(256) void padded_stage(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                    float* __restrict__ y, int n_out)
+{
+    constexpr int KC = 2, KK = 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= n_out) return;
+    if (PAD > 0 && WHERE == 0) asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(PAD));
+    f32x4 xv[KC], w[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) xv[j] = *reinterpret_cast<const f32x4*>(x + (lane + 64 * j) * 4);
+    const float b = bias[n & 511];
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(W + (size_t)n * KK);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) w[j] = __builtin_nontemporal_load(w4 + lane + 64 * j);
+    if (PAD > 0 && WHERE == 1) asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(PAD));
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    const float mu = wave_sum_fast(s) / (float)KK;
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v = fmaf(xv[j][c] - mu, xv[j][c] - mu, v);
+    const float rstd = 1.0f / sqrtf(wave_sum_fast(v) / (float)KK + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[j][c] = (xv[j][c] - mu) * rstd;
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(xv[j][e], w[j][e], acc);
+    const float r = wave_sum_fast(acc) * 0.02f + b + (float)ID * 0.0f;
+    if (lane == 0) y[n] = r;
+}
+
+template <int PAD, int WHERE>
+static void run_padded(const Bufs& b, int stages, bool rotate)
+{
+    char name[128];
+    snprintf(name, sizeof name, "LN 512 -> 1536, %4d no-ops %s, %s", PAD, WHERE ? "after the loads " : "before the loads",
+             rotate ? "8 copies of the code in turn" : "the same kernel every stage");
+    time_chain(name, [&](int i, hipStream_t s) {
+        const float* W = b.W + (size_t)(i % 20) * N * K;
+#define PS(ID) hipLaunchKernelGGL((padded_stage<ID, PAD, WHERE>), dim3(384), dim3(256), 0, s, b.x[i & 1], W, b.bias, b.x[(i + 1) & 1], 1536)
+        switch (rotate ? i & 7 : 0) {
+        case 0: PS(0); break;
+        case 1: PS(1); break;
+        case 2: PS(2); break;
+        case 3: PS(3); break;
+        case 4: PS(4); break;
+        case 5: PS(5); break;
+        case 6: PS(6); break;
+        default: PS(7); break;
+        }
+#undef PS
+    }, stages);
+}
+
 template <int WAVES, int COLS, int XP, int WP, bool LN, bool FAST = false>
 static void run_gemv(const char* name, const Bufs& b, int stages)
 {
@@ -175,13 +283,17 @@ static void run_gemv(const char* name, const Bufs& b, int stages)
     }, stages);
 }
 
-int main()
+int main(int argc, char** argv)
 {
     Bufs b;
-    CHECK(hipMalloc(&b.x[0], N * 4));
-    CHECK(hipMalloc(&b.x[1], N * 4));
+    CHECK(hipMalloc(&b.x[0], 2048 * 4));
+    CHECK(hipMalloc(&b.x[1], 2048 * 4));
+    CHECK(hipMemset(b.x[0], 0, 2048 * 4));
+    CHECK(hipMemset(b.x[1], 0, 2048 * 4));
     CHECK(hipMalloc(&b.W, (size_t)24 * N * K * 4));
     CHECK(hipMalloc(&b.bias, N * 4));
+    CHECK(hipMalloc(&b.Wbig, (size_t)768 << 20));
+    CHECK(hipMemset(b.Wbig, 0, (size_t)768 << 20));
     std::vector<float> h((size_t)24 * N * K);
     unsigned s = 12345;
     for (auto& v : h) {
@@ -201,10 +313,87 @@ int main()
         CHECK(hipMemcpy(&host, mm, 4, hipMemcpyDeviceToHost));
         printf("wave_sum_fast vs wave_sum on %zu waves of random data: %u mismatching lanes\n", h.size() / 64, host);
     }
+    if (argc > 1 && !strcmp(argv[1], "pad")) {   // the cost of code to a stage (instruction cache cold at every launch?)
+        for (int rep = 0; rep < 2; ++rep) {
+            run_padded<0, 0>(b, stages, false);
+            run_padded<0, 0>(b, stages, true);
+            run_padded<64, 0>(b, stages, false);
+            run_padded<256, 0>(b, stages, false);
+            run_padded<256, 0>(b, stages, true);
+            run_padded<256, 1>(b, stages, false);
+            run_padded<1024, 0>(b, stages, false);
+            run_padded<1024, 0>(b, stages, true);
+            run_padded<1024, 1>(b, stages, false);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         time_chain("empty kernels, 128 x 256 threads", [&](int i, hipStream_t st) { hipLaunchKernelGGL(empty_kernel, dim3(128), dim3(256), 0, st, b.x[i & 1], b.x[(i + 1) & 1]); }, stages);
         time_chain("empty kernels, 1 x 64 threads", [&](int i, hipStream_t st) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st, b.x[i & 1], b.x[(i + 1) & 1]); }, stages);
         time_chain("carry the row only (2 x 256 threads: load, add, store)", [&](int i, hipStream_t st) { hipLaunchKernelGGL(carry_kernel, dim3(2), dim3(256), 0, st, b.x[i & 1], b.x[(i + 1) & 1]); }, stages);
+        // the Whisper decoder layer's GEMV shapes in their order (no attention): LN + QKV 512 -> 1536, out 512 -> 512, LN + Q 512 -> 512,
+        // out 512 -> 512, LN + FC1 512 -> 2048, FC2 2048 -> 512; weights of a stage at a different place every time (6 layers' worth)
+        time_chain("MIXED chain: Whisper layer GEMV shapes (6 stages x 8 = 48)", [&](int i, hipStream_t st) {
+            const float* Wp = b.W + (size_t)((i * 5) % 20) * N * K;   // (up to 4 MB per stage inside the 24 MB block)
+            const float* xin = b.x[i & 1];
+            float* yout = b.x[(i + 1) & 1];
+            switch (i % 6) {
+            case 0: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(384), dim3(256), 0, st, xin, Wp, b.bias, yout, 1536); break;
+            case 1: hipLaunchKernelGGL((mixed_stage<2, false>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            case 2: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            case 3: hipLaunchKernelGGL((mixed_stage<2, false>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            case 4: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(512), dim3(256), 0, st, xin, Wp, b.bias, yout, 2048); break;
+            default: hipLaunchKernelGGL((mixed_stage<8, false>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            }
+        }, stages);
+        time_chain("MIXED chain, weights 16 MB apart in a 768 MB pool (cold every replay)", [&](int i, hipStream_t st) {
+            const float* Wp = b.Wbig + (size_t)i * (4u << 20);   // (floats: 16 MB apart)
+            const float* xin = b.x[i & 1];
+            float* yout = b.x[(i + 1) & 1];
+            switch (i % 6) {
+            case 0: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(384), dim3(256), 0, st, xin, Wp, b.bias, yout, 1536); break;
+            case 1: hipLaunchKernelGGL((mixed_stage<2, false>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            case 2: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            case 3: hipLaunchKernelGGL((mixed_stage<2, false>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            case 4: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(512), dim3(256), 0, st, xin, Wp, b.bias, yout, 2048); break;
+            default: hipLaunchKernelGGL((mixed_stage<8, false>), dim3(128), dim3(256), 0, st, xin, Wp, b.bias, yout, 512); break;
+            }
+        }, stages);
+        {   // the same mixed chain with every stage's weights AND its bias in hipMalloc allocations of their own (as a loader that
+            // uploads tensor by tensor leaves them), against one pool: page-table reach
+            static std::vector<float*> Ws, Bs;
+            if (Ws.empty()) {
+                const size_t sizes[6] = {(size_t)1536 * 512, (size_t)512 * 512, (size_t)512 * 512, (size_t)512 * 512, (size_t)2048 * 512, (size_t)512 * 2048};
+                for (int i = 0; i < stages; ++i) {
+                    float *w, *bb;
+                    CHECK(hipMalloc(&w, sizes[i % 6] * 4));
+                    CHECK(hipMemset(w, 0, sizes[i % 6] * 4));
+                    CHECK(hipMalloc(&bb, 2048 * 4));
+                    CHECK(hipMemset(bb, 0, 2048 * 4));
+                    Ws.push_back(w);
+                    Bs.push_back(bb);
+                }
+            }
+            time_chain("MIXED chain, every stage's weights and bias in their OWN hipMalloc", [&](int i, hipStream_t st) {
+                const float* Wp = Ws[i];
+                const float* xin = b.x[i & 1];
+                float* yout = b.x[(i + 1) & 1];
+                switch (i % 6) {
+                case 0: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(384), dim3(256), 0, st, xin, Wp, Bs[i], yout, 1536); break;
+                case 1: hipLaunchKernelGGL((mixed_stage<2, false>), dim3(128), dim3(256), 0, st, xin, Wp, Bs[i], yout, 512); break;
+                case 2: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(128), dim3(256), 0, st, xin, Wp, Bs[i], yout, 512); break;
+                case 3: hipLaunchKernelGGL((mixed_stage<2, false>), dim3(128), dim3(256), 0, st, xin, Wp, Bs[i], yout, 512); break;
+                case 4: hipLaunchKernelGGL((mixed_stage<2, true>), dim3(512), dim3(256), 0, st, xin, Wp, Bs[i], yout, 2048); break;
+                default: hipLaunchKernelGGL((mixed_stage<8, false>), dim3(128), dim3(256), 0, st, xin, Wp, Bs[i], yout, 512); break;
+                }
+            }, stages);
+        }
+        time_chain("same shape every stage: LN 512 -> 1536 (384 WG)", [&](int i, hipStream_t st) {
+            hipLaunchKernelGGL((mixed_stage<2, true>), dim3(384), dim3(256), 0, st, b.x[i & 1], b.W + (size_t)((i * 5) % 20) * N * K, b.bias, b.x[(i + 1) & 1], 1536); }, stages);
+        time_chain("same shape every stage: LN 512 -> 2048 (512 WG)", [&](int i, hipStream_t st) {
+            hipLaunchKernelGGL((mixed_stage<2, true>), dim3(512), dim3(256), 0, st, b.x[i & 1], b.W + (size_t)((i * 5) % 20) * N * K, b.bias, b.x[(i + 1) & 1], 2048); }, stages);
+        time_chain("same shape every stage: 2048 -> 512 (128 WG, 4 MB)", [&](int i, hipStream_t st) {
+            hipLaunchKernelGGL((mixed_stage<8, false>), dim3(128), dim3(256), 0, st, b.x[i & 1], b.W + (size_t)((i * 5) % 20) * N * K, b.bias, b.x[(i + 1) & 1], 512); }, stages);
         run_gemv<4, 1, 0, 1, true>("gemv LN, 128 WG x 4 waves x 1 col, plain row, nt weights (production)", b, stages);
         run_gemv<4, 1, 0, 1, true, true>("gemv LN, 128 WG x 4 waves x 1 col, DPP / permlane reductions", b, stages);
         run_gemv<4, 1, 0, 1, false>("gemv    , 128 WG x 4 waves x 1 col, plain row, nt weights", b, stages);
