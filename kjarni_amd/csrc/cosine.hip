@@ -235,6 +235,10 @@ constexpr int TK_TILE = 2048;               // candidates examined between two b
 constexpr int TK_PEND = 2 * TK_TILE;        // pending buffer (keys that beat the block's threshold)
 constexpr int TK_MAX_TILES_PER_BLOCK = 64;  // a block folds up to 131072 candidates into its best KPAD
 
+// The many-query searches' counters (word 0: overflow; word kCountStride (1 + q): entries in query q's candidate list) sit a
+// 128-byte line apart: thousands of atomics on 64 adjacent words were one line's worth of serial work (profiles/r06z).
+constexpr int kCountStride = 32;
+
 // Larger float -> larger uint32 (total order, -0 < +0); NaN sorts lowest.
 __device__ __forceinline__ uint32_t orderable(float f)
 {
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(const uint64_t* __
     __shared__ int pend_count;
     if (cand_count[0] != 0u) return;
     const int tid = threadIdx.x, qi = blockIdx.x;
-    const int64_t n = cand_count[1 + qi] < cap ? cand_count[1 + qi] : cap;
+    const int64_t n = cand_count[kCountStride * (1 + qi)] < cap ? cand_count[kCountStride * (1 + qi)] : cap;
     topk_block_reduce<KPAD>(nullptr, cand_key + (size_t)qi * cap, n, 0, (int)((n + TK_TILE - 1) / TK_TILE), ~0ull, pend, best, &pend_count);
     for (int i = tid; i < k_take; i += 256) {
         const uint64_t key = i < KPAD ? best[i] : 0ull;
@@ -794,7 +798,7 @@ struct ScanFuse {
     const int64_t* thr_idx;   // [nq, thr_k]: -1 where the sample had fewer documents (bound = -inf)
     int thr_k;
     uint64_t* cand_key;       // [nq, cap]: a list per query (index within the whole call)
-    unsigned* cand_count;     // [0]: overflow word, [1 + q]: candidates appended to query q's list
+    unsigned* cand_count;     // [0]: overflow word, [kCountStride (1 + q)]: candidates appended to query q's list
     unsigned cap;             // entries per query
     int q_base;               // this launch's first query
 };
@@ -807,6 +811,21 @@ struct ScanFuse {
 // maxima it is as tight as the k-th best of all sampled scores (P(max of 64 >= T) ~ 64 P(score >= T)) -- at a 64th of the
 // bytes and without the two-level selection over the sample (200 us of a 0.84 ms search of 10^6 documents).
 constexpr int SCAN_SCORES = 0, SCAN_FUSED = 1, SCAN_SAMPLE_MAX = 2;
+
+// dot / den as one v_rcp_f32 + a Newton step on the quotient (r = 1 / den to 1 ulp, v = dot r, v += (dot - den v) r): the IEEE
+// division sequence without its range scaling, which den = ||q|| ||doc|| never needs; 6 vector instructions per score instead
+// of 15.  ONE definition for the scan's epilogues and the filtered search's rescoring pass: the same bits from both.
+template <int MODE>
+__device__ __forceinline__ float mq_cosine(float dot, float qn, float dn)
+{
+    const float den = MODE == 0 ? fmaxf(qn * dn, 1e-9f) : qn * dn;   // vector.rs:131-148 | segment.rs:355-371
+    const float rc = __builtin_amdgcn_rcpf(den);
+    float v = dot * rc;
+    v = fmaf(fmaf(-den, v, dot), rc, v);
+    if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
+    return v;
+}
+
 template <int MODE, int KIND>
 __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* __restrict__ queries, int nq,
                                                                   const float* __restrict__ corpus, int64_t n_docs, int dim,
@@ -1036,14 +1055,7 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
             const int64_t d_base = (int64_t)c_tile * MQ_D + wid * 64 + l31;          // where the score goes (compact in a sample pass)
             const int64_t a_base = (int64_t)c_tile * tile_stride * MQ_D + wid * 64 + l31;  // the document's index
             const bool whole = nq == MQ_Q && ((int64_t)c_tile * tile_stride + 1) * MQ_D <= n_docs;  // no row or column of the tile is cut
-            auto cosine_of = [&](float dot, float qn, float dn) {
-                const float den = MODE == 0 ? fmaxf(qn * dn, 1e-9f) : qn * dn;   // vector.rs:131-148 | segment.rs:355-371
-                const float rc = __builtin_amdgcn_rcpf(den);
-                float v = dot * rc;
-                v = fmaf(fmaf(-den, v, dot), rc, v);
-                if (MODE == 1) v = dn < 1e-9f ? 0.0f : v;
-                return v;
-            };
+            auto cosine_of = [&](float dot, float qn, float dn) { return mq_cosine<MODE>(dot, qn, dn); };
             if (diag_no_epilogue) {
                 float keep = 0.0f;
 #pragma unroll
@@ -1136,7 +1148,7 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
                             const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
                             const int leader = (half << 5) + (mh ? __ffs((int)mh) - 1 : 0);
                             unsigned base = 0;
-                            if (mh != 0u && lane == leader) base = atomicAdd(fuse.cand_count + 1 + fuse.q_base + q, (unsigned)__popc(mh));
+                            if (mh != 0u && lane == leader) base = atomicAdd(fuse.cand_count + kCountStride * (1 + fuse.q_base + q), (unsigned)__popc(mh));
                             base = (unsigned)__shfl((int)base, leader, kWave);
                             if (hit) {
                                 const unsigned at = base + (unsigned)__popc(mh & ((1u << l31) - 1u));
@@ -1159,10 +1171,11 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
 // "no bound" (index -1) when fewer than k of them are finite.  One block per query, n <= 4 096: the maxima stay in registers as
 // 32-bit orderable keys and the k-th largest is found bit by bit from the top -- the largest x with at least k keys >= x --
 // 32 counting rounds (sixteen ballots + four LDS words each) instead of a sort.
+// `minus` is taken off the result (the bf16 sample's error bound; 0 for the f32 sample).
 // Also zeroes the search's candidate counters ([0] overflow word, [1 + q] list lengths): the launch in front of the fused scan.
 __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ maxima, int n, int64_t stride, int k,
                                                            float* __restrict__ thr_score, int64_t* __restrict__ thr_idx,
-                                                           unsigned* __restrict__ counters)
+                                                           unsigned* __restrict__ counters, float minus)
 {
     __shared__ int wave_count[2][4];
     const int tid = threadIdx.x, q = blockIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1186,9 +1199,352 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
     }
     if (tid == 0) {
         thr_idx[q] = found == 0u ? -1 : 0;
-        thr_score[q] = found == 0u ? -INFINITY : from_orderable(found);
-        counters[1 + q] = 0u;
+        thr_score[q] = found == 0u ? -INFINITY : from_orderable(found) - minus;
+        counters[kCountStride * (1 + q)] = 0u;
         if (q == 0) counters[0] = 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Many queries over a large corpus: a bf16 FILTER pass in front of the exact arithmetic.
+//
+// With a per-query lower bound t of the k-th best score the search only has to find the documents whose cosine reaches t.  The
+// f32 matrix cores make that pass MFMA-bound (32 flop per corpus byte); the bf16 matrix cores run at sixteen times their rate, so
+// the same pass on bf16-rounded operands is bound by the corpus stream alone -- and its scores are off by a KNOWN amount:
+// rounding both operands to 8 significant bits (round to nearest even, u = 2^-8) moves a product by at most (2u + u^2) |q_i d_i|,
+// the dot product by at most (2u + u^2) ||q|| ||d|| (Cauchy-Schwarz), f32 accumulation of the bf16 x bf16 products (exact in f32)
+// by another ~dim 2^-24.  So with eta = 0.0081 (2^-7 + 2^-16 + slack for the accumulation, the reciprocal and the square root;
+// norms in f32 from the unrounded rows):   | dot_bf16 / (||q|| ||d||) - cosine | <= eta.
+//  * KIND 1, the sample: the maximum of dot_bf16 / (||q|| ||d||) over each sampled tile of 16 documents; the k-th largest of a
+//    query's maxima, minus eta, is a score at least k documents reach exactly: the bound t (sample_bound_kernel).
+//  * KIND 0, the filter: every (query, document) with  dot_bf16 / ||d|| >= (t - eta) ||q||  -- a few hundred per query -- goes to
+//    the list of the WAVE that found it (no atomics: the position is the wave's own count + the lane's rank among the passes);
+//    cosine_rescore_kernel then computes the EXACT cosine of those pairs with the f32 MFMA sequence, norm arithmetic and division
+//    of cosine_scan_mfma_kernel (bit-identical scores), and the pairs not below t go to the per-query candidate lists that
+//    topk_candidates_kernel folds -- the lists the fused f32 scan would have produced.  What the filter cannot judge by the rule
+//    -- a document or query with a norm below 1e-4 or not finite, a NaN anywhere -- passes and is decided exactly.
+//
+// No LDS staging of the corpus, no barrier in the loop.  v_mfma_f32_16x16x32_bf16 takes B as lane (n = lane % 16, g = lane / 16)
+// -> 8 values of document n; with the K-step's 32 floats dealt as {4 g .. 4 g + 3} U {16 + 4 g .. 16 + 4 g + 3} the four lanes of
+// a document read 64 contiguous bytes per 16-byte load instruction, and the A operand (the 64 queries, rounded once, 4 KB per
+// K-step in the same dealing) comes from LDS by ds_read_b128.  A wave owns a tile of 16 documents: all its 2 NK row requests go
+// out first (the whole tile in registers), then NK x (convert, squares, 4 MFMAs); three waves per SIMD overlap one
+// another's waits.  An accumulator row of 16 lanes is ONE query x the tile's 16 documents.
+constexpr float kFilterEta = 0.0081f;
+constexpr int FILTER_LIST = 0, FILTER_SAMPLE_MAX = 1;
+constexpr size_t kFilterListBytes = (size_t)16 << 20;   // the filter pass's (query, document) lists, all waves together
+constexpr size_t kFilterMaxWaves = 4096;                // >= 4 x its largest grid (768 workgroups)
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t cu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bf16_pair(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, cbf16x2));  // v_cvt_pk_bf16_f32, round to nearest even
+}
+__device__ __forceinline__ cbf16x8 bf16_eight(const f32x4 x0, const f32x4 x1)
+{
+    const cu32x4 u = {bf16_pair(x0[0], x0[1]), bf16_pair(x0[2], x0[3]), bf16_pair(x1[0], x1[1]), bf16_pair(x1[2], x1[3])};
+    return __builtin_bit_cast(cbf16x8, u);
+}
+
+struct FilterOut {
+    uint64_t* wave_list;    // FILTER_LIST: [waves, cap_w] entries (query of the whole call << 32 | document)
+    unsigned* wave_count;   // [waves]: entries of each wave's list (written by every wave, also 0)
+    unsigned cap_w;
+    unsigned* overflow;     // raised when a list is full: the two-call form behind the search answers
+    int q_base;             // this launch's first query
+    float* maxima;          // FILTER_SAMPLE_MAX: [nq, max_stride]: per (query, sampled tile) the largest dot_bf16 / (||q|| ||d||)
+    int64_t max_stride;
+    int64_t units;          // FILTER_SAMPLE_MAX: sample units; unit u = unit_tiles consecutive tiles of 16 documents from tile
+    int tile_stride;        //   u * tile_stride on
+    int unit_tiles;
+};
+
+template <int NK, int KIND>   // dim = 32 NK
+__global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) void cosine_filter_bf16_kernel(const float* __restrict__ queries, int nq,
+                                                                                  const float* __restrict__ corpus, int64_t n_docs,
+                                                                                  const float* __restrict__ qn2,
+                                                                                  const float* __restrict__ thr_score,
+                                                                                  const int64_t* __restrict__ thr_idx, int thr_k,
+                                                                                  FilterOut out)
+{
+    constexpr int dim = 32 * NK;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
+    cu32x4* sQf = reinterpret_cast<cu32x4*>(fsm);                 // [NK][4 query blocks][64 lanes]: A fragments, ready to use
+    float* sTq = reinterpret_cast<float*>(fsm + NK * 4096);        // [64]: the bound in the dot / ||doc|| domain (sample: 1 / ||q||)
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, g = lane >> 4;
+    for (int f = tid; f < NK * 256; f += 256) {
+        const int s = f >> 8, b = (f >> 6) & 3, l = f & 63;
+        const int q = 16 * b + (l & 15);
+        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+        if (q < nq) {
+            const float* p = queries + (int64_t)q * dim + 32 * s + 4 * (l >> 4);
+            x0 = *reinterpret_cast<const f32x4*>(p);
+            x1 = *reinterpret_cast<const f32x4*>(p + 16);
+        }
+        sQf[f] = __builtin_bit_cast(cu32x4, bf16_eight(x0, x1));
+    }
+    if (tid < 64) {
+        float tq;
+        if (KIND == FILTER_SAMPLE_MAX) {
+            // 1 / ||q||; a query the rule does not cover (norm below 1e-4, not finite) or a row past nq: NaN -- its maxima come
+            // out as "no bound" and every document of it goes through the exact pass
+            const float qn = tid < nq ? sqrtf(qn2[tid]) : 0.0f;
+            tq = (qn >= 1e-4f && qn < INFINITY) ? 1.0f / qn : __builtin_nanf("");
+        } else {
+            // rows past nq: +inf (nothing passes).  No bound, a query too small for the rule, not finite: -inf (everything passes
+            // to the exact pass; the lists overflow and the two-call form answers, as for the f32 scan).
+            tq = INFINITY;
+            if (tid < nq) {
+                float t = -INFINITY;
+                if (thr_idx[(int64_t)tid * thr_k + thr_k - 1] >= 0) t = thr_score[(int64_t)tid * thr_k + thr_k - 1];
+                const float qn = sqrtf(qn2[tid]);
+                const float b = (t - kFilterEta) * qn;
+                tq = (t == -INFINITY || !(qn >= 1e-4f && qn < INFINITY) || b != b) ? -INFINITY : b - 1e-5f * fabsf(b) - 1e-30f;
+            }
+        }
+        sTq[tid] = tq;
+    }
+    __syncthreads();
+    // this lane's 16 queries: block b, accumulator register r -> query 16 b + 4 g + r; their bounds as 16 consecutive floats per
+    // lane group (read back per tile with four 16-byte LDS loads: 16 registers the tile's rows need more)
+    float* sTl = sTq + 64;   // [4 groups][16]
+    if (tid < 64) sTl[16 * (tid >> 4) + (tid & 15)] = sTq[16 * ((tid & 15) >> 2) + 4 * (tid >> 4) + (tid & 3)];
+    __syncthreads();
+    auto bounds = [&](float (&tq)[16]) {
+        asm volatile("" ::: "memory");   // (read them here, every tile: hoisted out of the tile loop they are 16 live registers)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sTl + 16 * g + 4 * b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tq[4 * b + r] = v[r];
+        }
+    };
+
+    const int64_t all_tiles = (n_docs + 15) >> 4;
+    const int64_t waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wid;
+    const uint32_t voff = (uint32_t)((n16 * dim + 4 * g) * 4);
+    // one tile of 16 documents: the approximate dot products of this lane's document with its 16 queries, 1 / ||doc||
+    auto tile_dots = [&](int64_t tile, f32x4 (&acc)[4], float& idn, bool& odd_doc, int64_t& ad) {
+        const int64_t d0 = tile << 4;
+        const int64_t rows = n_docs - d0 < 16 ? n_docs - d0 : 16;   // documents past n_docs: zeros
+        const __amdgpu_buffer_rsrc_t rD =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(corpus + d0 * dim), 0, (int)(rows * dim * 4), 0x00020000);
+        f32x4 x0[NK], x1[NK];
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            // (plain loads: the two requests of a K-step take the two halves of the same 128-byte lines, the second finds them in
+            // the L1 -- with the non-temporal bit it does not: 5.7 instead of 6.4 TB/s for this pattern alone,
+            // tools/lab/stream_pattern_lab.hip)
+            x0[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voff + 128 * s, 0, 0));
+            x1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voff + 128 * s + 64, 0, 0));
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x2 sq = {0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            const cbf16x8 bf = bf16_eight(x0[s], x1[s]);
+            sq = __builtin_elementwise_fma(f32x2{x0[s][0], x0[s][1]}, f32x2{x0[s][0], x0[s][1]}, sq);
+            sq = __builtin_elementwise_fma(f32x2{x0[s][2], x0[s][3]}, f32x2{x0[s][2], x0[s][3]}, sq);
+            sq = __builtin_elementwise_fma(f32x2{x1[s][0], x1[s][1]}, f32x2{x1[s][0], x1[s][1]}, sq);
+            sq = __builtin_elementwise_fma(f32x2{x1[s][2], x1[s][3]}, f32x2{x1[s][2], x1[s][3]}, sq);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const cbf16x8 af = __builtin_bit_cast(cbf16x8, sQf[(s * 4 + b) * 64 + lane]);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[b], 0, 0, 0);
+            }
+        }
+        // ||doc||^2: the four lanes of a document (g = 0 .. 3) hold a quarter each
+        const float dn = sqrtf(sum_xor32(sum_xor16(sq[0] + sq[1])));
+        odd_doc = !(dn >= 1e-4f && dn < INFINITY);   // too small for the rule, or not finite: the exact pass decides
+        idn = __builtin_amdgcn_rcpf(dn);
+        ad = d0 + n16;
+    };
+    if constexpr (KIND == FILTER_SAMPLE_MAX) {
+        // unit `it` = the unit_tiles consecutive tiles from tile it * tile_stride on
+        for (int64_t it = wave; it < out.units; it += waves) {
+            float run[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) run[e] = -INFINITY;
+#pragma unroll 1
+            for (int u = 0; u < out.unit_tiles; ++u) {
+                const int64_t tile = it * out.tile_stride + u;
+                if (tile >= all_tiles) break;
+                f32x4 acc[4];
+                float idn;
+                bool odd_doc;
+                int64_t ad;
+                tile_dots(tile, acc, idn, odd_doc, ad);
+                // documents the rule does not cover, lanes past n_docs and NaN dot products give no bound (fmaxf drops a NaN)
+                const bool ok = ad < n_docs && !odd_doc;
+                float tq[16];
+                bounds(tq);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) run[e] = fmaxf(run[e], ok ? acc[e >> 2][e & 3] * idn * tq[e] : -INFINITY);
+            }
+            // per query (a row of 16 lanes) the largest approximate cosine of the unit
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float m = row16_max_desc(run[e]);
+                const int q = 16 * (e >> 2) + 4 * g + (e & 3);
+                if (n16 == 0 && q < nq) out.maxima[(int64_t)q * out.max_stride + it] = m;
+            }
+        }
+        return;
+    }
+    unsigned count = 0;   // entries in this wave's list (wave-uniform)
+    for (int64_t it = wave; it < all_tiles; it += waves) {
+        f32x4 acc[4];
+        float idn;
+        bool odd_doc;
+        int64_t ad;
+        tile_dots(it, acc, idn, odd_doc, ad);
+        // bit e of `mask`: this lane's document passes for its query e (a NaN margin passes; a document the rule does not cover
+        // passes for every real query).  Nearly every tile ends at the ballot; in one that does not, the lanes that have passes
+        // -- one, as a rule -- take turns to write their entries at the wave's count.
+        float tq[16];
+        bounds(tq);
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            mask |= (odd_doc || !(fmaf(acc[e >> 2][e & 3], idn, -tq[e]) < 0.0f)) && tq[e] < INFINITY ? 1u << e : 0u;
+        if (ad >= n_docs) mask = 0u;
+        uint64_t lanes = __ballot(mask != 0u);
+        if (lanes == 0ull) continue;
+        const unsigned mine = (unsigned)__popc(mask);
+#pragma nounroll
+        while (lanes != 0ull) {
+            const int leader = __ffsll((long long)lanes) - 1;
+            const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)mine, leader);
+            if (lane == leader) {
+                unsigned at = count;
+#pragma nounroll
+                for (uint32_t mm = mask; mm != 0u; mm &= mm - 1u, ++at) {
+                    int e = __ffs((int)mm) - 1;
+                    asm volatile("" : "+v"(e));   // (opaque: nothing of this path is prepared outside the tile loop)
+                    const int q = out.q_base + 16 * (e >> 2) + 4 * g + (e & 3);
+                    if (at < out.cap_w) out.wave_list[(size_t)wave * out.cap_w + at] = ((uint64_t)(uint32_t)q << 32) | (uint64_t)(uint32_t)ad;
+                    else *out.overflow = 1u;   // the two-call form behind this search takes over
+                }
+            }
+            count += c;
+            lanes &= lanes - 1ull;
+        }
+    }
+    if (lane == 0) out.wave_count[wave] = count < out.cap_w ? count : out.cap_w;
+}
+
+// The exact pass of the filtered search: the filter waves' lists taken as ONE sequence (an exclusive prefix of their lengths in
+// LDS, a binary search per pair), 32 (query, document) pairs per wave and step -- full groups whatever the lists' lengths.  The dot
+// products are taken with the f32 MFMA sequence of cosine_scan_mfma_kernel -- v_mfma_f32_32x32x2_f32 over k pairs (16 ks + 8 kk + c,
+// + 4), c = 0 .. 3, kk = 0, 1, ks ascending -- with pair m's query as row m of A and pair n's document as column n of B: the
+// DIAGONAL of the 32 x 32 block holds the pairs' dot products (an output element depends on its own row and column only), and
+// ||doc||^2 comes from that kernel's partial sums: per 16-byte column c4 of a K-step an (even, odd) pair of fma chains over the
+// K-steps, v_c4 = even + odd, then (v0 + v1) + (v2 + v3).  Same bits as the scan's scores; the pairs not below the query's bound go
+// to its candidate list for topk_candidates_kernel.
+template <int MODE, int NK>   // dim = 32 NK
+__global__ __launch_bounds__(256) void cosine_rescore_kernel(const float* __restrict__ queries, const float* __restrict__ corpus,
+                                                             const float* __restrict__ qn2, const float* __restrict__ thr_score,
+                                                             const int64_t* __restrict__ thr_idx, int thr_k,
+                                                             const uint64_t* __restrict__ wave_list,
+                                                             const unsigned* __restrict__ wave_count, int n_lists, unsigned cap_w,
+                                                             unsigned* __restrict__ counters, unsigned cap, uint64_t* __restrict__ cand_key)
+{
+    constexpr int dim = 32 * NK;
+    __shared__ unsigned pre[kFilterMaxWaves + 1];   // exclusive prefix of the lists' lengths: pair p of the search is entry
+    __shared__ unsigned wave_total[4];              //   p - pre[w] of list w, pre[w] <= p < pre[w + 1]
+    if (counters[0] != 0u) return;   // a list overflowed: the two-call form answers
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    {
+        // 16 consecutive lists per thread (n_lists <= 4 096), a shuffle scan over the wave, the four wave totals through LDS
+        unsigned c[16], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int w = 16 * tid + j;
+            c[j] = w < n_lists ? (wave_count[w] < cap_w ? wave_count[w] : cap_w) : 0u;
+            sum += c[j];
+        }
+        unsigned incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, off, kWave);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wave_total[wid] = incl;
+        __syncthreads();
+        unsigned base = incl - sum;
+        for (int w = 0; w < wid; ++w) base += wave_total[w];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            pre[16 * tid + j] = base;
+            base += c[j];
+        }
+        if (tid == 255) pre[4096] = base;
+        __syncthreads();
+    }
+    const unsigned total = pre[4096];
+    const int l31 = lane & 31, half = lane >> 5;
+    // the diagonal element of column l31 sits in the lane half (l31 >> 2) & 1, accumulator register (l31 & 3) + 4 (l31 >> 3)
+    const bool holds_diag = half == ((l31 >> 2) & 1);
+    const int diag_reg = (l31 & 3) + 4 * (l31 >> 3);
+    for (unsigned g0 = ((unsigned)blockIdx.x * 4u + (unsigned)wid) * 32u; g0 < total; g0 += gridDim.x * 128u) {
+        const bool valid = g0 + (unsigned)l31 < total;
+        const unsigned pi = valid ? g0 + (unsigned)l31 : g0;   // (past the end: the group's first pair again)
+        int lo = 0, hi = 4096;   // pre[lo] <= pi < pre[hi]
+#pragma unroll 1
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= pi) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t pr = wave_list[(size_t)lo * cap_w + (pi - pre[lo])];
+        const int q = (int)(pr >> 32);
+        const uint32_t d = (uint32_t)pr;
+        const float* qp = queries + (int64_t)q * dim + 4 * half;
+        const float* dp = corpus + (int64_t)d * dim + 4 * half;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        float ev[2] = {0.f, 0.f}, od[2] = {0.f, 0.f};
+        // (the rows are cold and scattered: a batch of K-steps is requested together -- step by step every K-step would be a
+        // dependent round trip of its own)
+        constexpr int CH = (dim / 16) % 12 == 0 ? 12 : 8;   // K-steps per batch of requests (384: two batches of 24 + 24 requests)
+        static_assert((dim / 16) % CH == 0, "dim is a multiple of 128");
+#pragma unroll 1
+        for (int k0 = 0; k0 < dim / 16; k0 += CH) {
+            f32x4 a[2 * CH], b[2 * CH];
+#pragma unroll
+            for (int j = 0; j < 2 * CH; ++j) {
+                a[j] = *reinterpret_cast<const f32x4*>(qp + 16 * k0 + 8 * j);
+                b[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dp + 16 * k0 + 8 * j));
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * CH; ++j) {   // j = 2 (ks - k0) + kk
+                const int kk = j & 1;
+                ev[kk] = fmaf(b[j][0], b[j][0], ev[kk]);
+                od[kk] = fmaf(b[j][1], b[j][1], od[kk]);
+                ev[kk] = fmaf(b[j][2], b[j][2], ev[kk]);
+                od[kk] = fmaf(b[j][3], b[j][3], od[kk]);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][cc], b[j][cc], acc, 0, 0, 0);
+            }
+        }
+        const float v01 = sum_xor32(ev[0] + od[0]), v23 = sum_xor32(ev[1] + od[1]);   // columns (0, 1) and (2, 3) of the K-step
+        const float dn = sqrtf(v01 + v23);
+        float dot = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dot = r == diag_reg ? acc[r] : dot;
+        const float v = mq_cosine<MODE>(dot, sqrtf(qn2[q]), dn);
+        float t = -INFINITY;
+        if (thr_idx[(int64_t)q * thr_k + thr_k - 1] >= 0) t = thr_score[(int64_t)q * thr_k + thr_k - 1];
+        if (valid && holds_diag && !(v < t)) {   // (not below the bound: ties and NaN scores go to the selection)
+            const unsigned at = atomicAdd(counters + kCountStride * (1 + q), 1u);
+            if (at < cap) cand_key[(size_t)q * cap + at] = make_key(v, d);
+            else counters[0] = 1u;
+        }
     }
 }
 
@@ -1245,6 +1601,116 @@ hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t 
     }
     const hipError_t fe = qn2_given ? hipSuccess : hipFreeAsync(qn2, stream);
     return e != hipSuccess ? e : fe;
+}
+
+// The bf16 passes of a many-query search: blocks of 64 queries, 3 workgroups per CU (dim <= 384; 2 at 512).
+//   sample (maxima != null): per (query, unit) maxima [nq, units]
+//   filter: per-wave lists, then the exact pass over them (rescore), query block by query block
+struct FilterPlan {
+    int nk;
+    size_t lds;
+    unsigned grid;       // workgroups of the filter / rescoring launches (the lists are per wave: 4 grid of them)
+    unsigned cap_w;      // entries per wave list
+    int64_t units;       // the sample's units, their first tiles tile_stride apart, unit_tiles tiles of 16 documents each
+    int tile_stride, unit_tiles;
+};
+FilterPlan filter_plan(int64_t n_docs, int dim, size_t list_bytes)
+{
+    FilterPlan p{};
+    p.nk = dim / 32;
+    p.lds = (size_t)p.nk * 4096 + 512;
+    const int64_t tiles = (n_docs + 15) / 16;
+    p.grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, 256 * (p.nk <= 12 ? 3 : 2));
+#ifdef KJARNI_TUNING
+    if (const char* e = getenv("KJARNI_HIP_FILTER_GRID")) p.grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, std::min(1024, atoi(e)));
+#endif
+    p.cap_w = (unsigned)(list_bytes / 8 / ((size_t)p.grid * 4));
+    // ~1 / 40 of the corpus and at least 4 096 tiles (fewer only when the corpus has fewer); at most 4 096 units (sample_bound_kernel)
+    p.unit_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, (tiles + 4096 * 40 - 1) / (4096 * 40)));
+    p.units = std::min<int64_t>(4096, std::max<int64_t>(1, tiles / p.unit_tiles));
+    p.tile_stride = (int)std::max<int64_t>(p.unit_tiles, tiles / p.units);
+    return p;
+}
+
+template <int KIND>
+hipError_t filter_launch(const FilterPlan& p, const float* queries, int m, const float* corpus, int64_t n_docs, const float* qn2,
+                         const float* thr_score, const int64_t* thr_idx, int thr_k, const FilterOut& out, hipStream_t stream)
+{
+    // (the sample: two workgroups per CU fit, one round of them)
+    const unsigned grid = KIND == FILTER_SAMPLE_MAX ? (unsigned)std::min<int64_t>((p.units + 3) / 4, 512) : p.grid;
+#define KJ_FILTER(NK_)                                                                                                           \
+    do {                                                                                                                         \
+        auto kern = cosine_filter_bf16_kernel<NK_, KIND>;                                                                        \
+        if (p.lds > 48 * 1024) {                                                                                                 \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                      (int)p.lds);                                                               \
+            if (ea != hipSuccess) return ea;                                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds, stream, queries, m, corpus, n_docs, qn2, thr_score, thr_idx, thr_k, out); \
+    } while (0)
+    switch (p.nk) {
+    case 4: KJ_FILTER(4); break;
+    case 8: KJ_FILTER(8); break;
+    case 12: KJ_FILTER(12); break;
+    case 16: KJ_FILTER(16); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef KJ_FILTER
+    return hipGetLastError();
+}
+
+hipError_t filter_sample(const FilterPlan& p, const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, const float* qn2,
+                         float* maxima, hipStream_t stream)
+{
+    for (int q0 = 0; q0 < nq; q0 += MQ_Q) {
+        FilterOut out{};
+        out.maxima = maxima + (int64_t)q0 * p.units;
+        out.max_stride = p.units;
+        out.units = p.units;
+        out.tile_stride = p.tile_stride;
+        out.unit_tiles = p.unit_tiles;
+        const hipError_t e = filter_launch<FILTER_SAMPLE_MAX>(p, queries + (int64_t)q0 * dim, std::min(MQ_Q, nq - q0), corpus, n_docs, qn2 + q0,
+                                                              nullptr, nullptr, 1, out, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t filter_and_rescore(const FilterPlan& p, const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
+                              const float* qn2, const float* thr_score, const int64_t* thr_idx, int thr_k, uint64_t* wave_list,
+                              unsigned* wave_count, unsigned* counters, unsigned cap_q, uint64_t* cand_key, hipStream_t stream)
+{
+    for (int q0 = 0; q0 < nq; q0 += MQ_Q) {
+        FilterOut out{};
+        out.wave_list = wave_list;
+        out.wave_count = wave_count;
+        out.cap_w = p.cap_w;
+        out.overflow = counters;
+        out.q_base = q0;
+        hipError_t e = filter_launch<FILTER_LIST>(p, queries + (int64_t)q0 * dim, std::min(MQ_Q, nq - q0), corpus, n_docs, qn2 + q0,
+                                                  thr_score + (int64_t)q0 * thr_k, thr_idx + (int64_t)q0 * thr_k, thr_k, out, stream);
+        if (e != hipSuccess) return e;
+        // (queries, bounds and lists of the WHOLE call: the list entries carry the call's query index)
+#define KJ_RESCORE(MODE_, NK_)                                                                                                   \
+    hipLaunchKernelGGL((cosine_rescore_kernel<MODE_, NK_>), dim3(256), dim3(256), 0, stream, queries, corpus, qn2, thr_score, thr_idx, \
+                       thr_k, wave_list, wave_count, (int)p.grid * 4, p.cap_w, counters, cap_q, cand_key)
+#define KJ_RESCORE_M(NK_)                                                                                                        \
+    do {                                                                                                                         \
+        if (mode == 0) KJ_RESCORE(0, NK_);                                                                                       \
+        else KJ_RESCORE(1, NK_);                                                                                                 \
+    } while (0)
+        switch (p.nk) {
+        case 4: KJ_RESCORE_M(4); break;
+        case 8: KJ_RESCORE_M(8); break;
+        case 12: KJ_RESCORE_M(12); break;
+        default: KJ_RESCORE_M(16); break;
+        }
+#undef KJ_RESCORE_M
+#undef KJ_RESCORE
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace
@@ -1424,8 +1890,9 @@ size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k)
     size_t two = pad256((size_t)nq * (size_t)n_docs * sizeof(float)) + pad256(cosine_topk_workspace_bytes(nq, n_docs, k));
     // the fused many-query scan (nq >= 20 only): candidate list, counters, the sample's best k per query
     if (nq >= 20)
-        two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4) +
-               pad256((size_t)(nq + 8) * 4);   // (+ the queries' squared norms, shared by the passes of one search)
+        two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * kCountStride * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4) +
+               pad256((size_t)(nq + 8) * 4) +   // (+ the queries' squared norms, shared by the passes of one search)
+               pad256(kFilterListBytes) + pad256(kFilterMaxWaves * 4);   // (+ the bf16 filter pass's per-wave lists and their lengths)
     return fused > two ? fused : two;
 }
 
@@ -1475,13 +1942,21 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         uint64_t* cand_key = reinterpret_cast<uint64_t*>(p);
         p += pad256(kManyCandCap * 8);
         unsigned* counters = reinterpret_cast<unsigned*>(p);  // [0] overflow, [1 + q] list lengths
-        const size_t counter_bytes = pad256((size_t)(nq + 1) * 4);
+        const size_t counter_bytes = pad256((size_t)(nq + 1) * kCountStride * 4);
         p += counter_bytes;
         int64_t* thr_idx = reinterpret_cast<int64_t*>(p);
         p += pad256((size_t)nq * k * 8);
         float* thr_score = reinterpret_cast<float*>(p);
         p += pad256((size_t)nq * k * 4);
         float* qn2 = reinterpret_cast<float*>(p);   // the queries' squared norms: ONE launch for the sample, the scan and the fallback
+        p += pad256((size_t)(nq + 8) * 4);
+        uint64_t* wave_list = reinterpret_cast<uint64_t*>(p);   // the bf16 filter pass's per-wave (query, document) lists
+        p += pad256(kFilterListBytes);
+        unsigned* wave_count = reinterpret_cast<unsigned*>(p);
+        // Four widths have the bf16 filter pass + exact rescoring (HBM-bound); the others the f32 matrix-core scan with the
+        // selection inside (MFMA-bound).
+        const bool filtered = (dim == 128 || dim == 256 || dim == 384 || dim == 512) && !tune::scan_f32_select();
+        const FilterPlan fp = filtered ? filter_plan(n_docs, dim, kFilterListBytes) : FilterPlan{};
         const unsigned cap_q = (unsigned)(kManyCandCap / (size_t)nq);
         hipError_t e = query_sqnorms(queries, nq, dim, qn2, stream);
         if (e != hipSuccess) return e;
@@ -1496,12 +1971,21 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         const int64_t last_rows = std::min<int64_t>(MQ_D, n_docs - (ns - 1) * ts * (int64_t)MQ_D);
         const int64_t n_sample = (ns - 1) * MQ_D + last_rows;
         int thr_k = k;
-        if (k <= kSampleMaxK && ns * 4 <= 4096 && ns * 4 >= 8 * (int64_t)k) {
+        if (filtered && k <= kSampleMaxK && fp.units >= 8 * (int64_t)k) {
+            // the bf16 sample: per (query, unit of 16 unit_tiles documents) maxima; bound = their k-th largest - eta
+            e = filter_sample(fp, queries, nq, corpus, n_docs, dim, qn2, scores, stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)fp.units, fp.units, k, thr_score,
+                               thr_idx, counters, kFilterEta);   // (and zeroes the candidate counters)
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            thr_k = 1;
+        } else if (k <= kSampleMaxK && ns * 4 <= 4096 && ns * 4 >= 8 * (int64_t)k) {
             // a small k: the bound is the k-th largest of the sampled tiles' per-wave maxima (SCAN_SAMPLE_MAX) -- no sample scores
             e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, ns * 4, nullptr, nullptr, true, qn2);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)(ns * 4), ns * 4, k, thr_score, thr_idx,
-                               counters);   // (and zeroes the candidate counters)
+                               counters, 0.0f);   // (and zeroes the candidate counters)
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             thr_k = 1;
@@ -1513,9 +1997,16 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
             e = cosine_topk_impl(scores, nq, n_sample, k, topk_ws, thr_idx, thr_score, stream, nullptr);
             if (e != hipSuccess) return e;
         }
-        ScanFuse f{thr_score, thr_idx, thr_k, cand_key, counters, cap_q, 0};
-        e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, nullptr, stream, 1, -1, &f, nullptr, false, qn2);
-        if (e != hipSuccess) return e;
+        if (filtered) {
+            // the bf16 filter pass over the corpus (HBM-bound), then the exact cosines of what it lets through
+            e = filter_and_rescore(fp, queries, nq, corpus, n_docs, dim, mode, qn2, thr_score, thr_idx, thr_k, wave_list, wave_count, counters,
+                                   cap_q, cand_key, stream);
+            if (e != hipSuccess) return e;
+        } else {
+            ScanFuse f{thr_score, thr_idx, thr_k, cand_key, counters, cap_q, 0};
+            e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, nullptr, stream, 1, -1, &f, nullptr, false, qn2);
+            if (e != hipSuccess) return e;
+        }
         const int kpad = kpad_for(k);
 #define KJ_CAND(KP_)                                                                                                          \
     hipLaunchKernelGGL(topk_candidates_kernel<KP_>, dim3((unsigned)nq), dim3(256), 0, stream, cand_key, counters, cap_q, k, out_idx, \

@@ -45,6 +45,7 @@
 //    2  one query: scores + selection as separate launches instead of the fused pass
 //    3  many queries (diagnostic, results meaningless): every tile of the matrix-core scan reads the corpus' first 256 rows -- the kernel without its HBM stream
 //    4  the same without the epilogue; 5 the same without the norm arithmetic of the K-loop; 6 / 7: the real corpus stream without the epilogue / the norms
+//    8  many queries, large corpus: the f32 matrix-core scan selects (round 5's route) instead of the bf16 filter pass + exact rescoring
 #pragma once
 
 #ifdef KJARNI_TUNING
@@ -100,6 +101,7 @@ inline bool no_split_attention() { return attention() == 22 || attention() == 21
 
 inline bool scan_streaming_only() { return cosine() == 1; }
 inline bool scan_two_launches() { return cosine() == 2; }
+inline bool scan_f32_select() { return cosine() == 8; }
 inline int scan_diag() { return cosine() >= 3 && cosine() <= 7 ? cosine() - 2 : 0; }  // 1 same tile, 2 + no epilogue, 3 + no norms, 4 / 5: the real stream without epilogue / norms
 
 }  // namespace tune

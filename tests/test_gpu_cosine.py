@@ -321,14 +321,16 @@ def test_fused_many_query_search_against_the_oracle_at_its_own_size():
 
 
 @pytest.mark.parametrize("k", [12, 200])
-@pytest.mark.parametrize("case", ["random", "ascending", "overflow", "nonfinite"])
+@pytest.mark.parametrize("case", ["random", "ascending", "overflow", "nonfinite", "random_f32", "overflow_f32", "nonfinite_f32"])
 def test_many_queries_one_call_selects_inside_the_scan(case, k):
-    """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries selects inside the matrix-core scan: a strided
-    sample of the corpus gives every query a lower bound of its k-th best score, the full scan appends only scores at or above
-    it to a candidate list, a per-query selection finishes -- no [queries, documents] score array.  Same indices and score bits
-    as kjarni_hip_cosine_scores + kjarni_hip_cosine_topk: on random rows; on rows whose scores ascend with the index (the sample
-    under-estimates every bound); and when the candidate list overflows (identical queries, every sampled tile anti-correlated,
-    every other row correlated: 28 M candidates against a 4 M list), where the queued two-call form takes over.
+    """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries never writes a [queries, documents] score array: a
+    strided sample of the corpus gives every query a lower bound of its k-th best score, one pass over the corpus keeps only what
+    can reach it, a per-query selection finishes.  At widths 128 / 256 / 384 / 512 the pass is the bf16 FILTER (scores off by at most
+    eta, bound relaxed by it) and the survivors' exact cosines come from a rescoring pass with the f32 scan's arithmetic; at other
+    widths ("_f32" cases: 768) the f32 matrix-core scan itself selects.  Same indices and score bits as kjarni_hip_cosine_scores +
+    kjarni_hip_cosine_topk: on random rows; on rows whose scores ascend with the index (the sample under-estimates every bound);
+    and when the lists overflow (identical queries, every sampled row anti-correlated, every other row correlated), where the
+    queued two-call form takes over.
     k = 12: the bound comes from the sampled tiles' per-wave maxima (k <= 128); k = 200: from the sample's own top-k.
     "nonfinite": one query holds a NaN, another an infinity -- their scores are NaN, which the cheap bound test must not drop:
     those queries come back as the two-call form returns them (k rows, NaN scores), the other 68 unchanged."""
@@ -336,7 +338,9 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
     from kjarni_amd import _ffi
     L = _ffi.lib()
     dev = torch.device("cuda", 0)
-    n, dim, nq = 450_123, 384, 70
+    n, nq = 450_123, 70
+    dim = 768 if case.endswith("_f32") else 384   # (384: the bf16 filter pass + exact rescoring; 768: the f32 scan selects)
+    case = case.removesuffix("_f32")
     g = torch.Generator(device=dev).manual_seed(11)
     corpus = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
     q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
@@ -344,11 +348,19 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
         corpus += torch.linspace(0.0, 2.0, n, device=dev)[:, None] * q[3][None, :]
     if case == "overflow":
         q[:] = q[0]
-        tiles = (n + 255) // 256
-        sample_tiles = 512 if tiles >= 8192 else 256
-        ts = max(1, (tiles + sample_tiles - 1) // sample_tiles)   # (the sample stride of launch_cosine_search, cosine.hip)
-        row_tile = torch.arange(n, device=dev) // 256
-        sampled = (row_tile % ts) == 0
+        if dim == 384:   # (the sample units of filter_plan, cosine.hip: tiles of 16 documents)
+            tiles = (n + 15) // 16
+            unit_tiles = min(16, max(1, (tiles + 4096 * 40 - 1) // (4096 * 40)))
+            units = min(4096, max(1, tiles // unit_tiles))
+            ts = max(unit_tiles, tiles // units)
+            row_tile = torch.arange(n, device=dev) // 16
+            sampled = ((row_tile % ts) < unit_tiles) & ((row_tile // ts) < units)
+        else:            # (the sample stride of launch_cosine_search's f32 sample pass: tiles of 256 documents)
+            tiles = (n + 255) // 256
+            sample_tiles = 512 if tiles >= 8192 else 256
+            ts = max(1, (tiles + sample_tiles - 1) // sample_tiles)
+            row_tile = torch.arange(n, device=dev) // 256
+            sampled = (row_tile % ts) == 0
         corpus[sampled] = -q[0] + 0.01 * corpus[sampled]
         corpus[~sampled] = q[0] + 0.05 * corpus[~sampled]
     if case == "nonfinite":
@@ -387,3 +399,56 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
             assert bool(torch.equal(sc1.view(torch.int32), sc2.view(torch.int32))), (case, mode)
             assert bool((sc1[:, :-1] >= sc1[:, 1:]).all())
         del ws1
+
+
+def _bf16_rne(x):
+    """x rounded to bf16 (round to nearest even), as float32 -- what v_cvt_pk_bf16_f32 does to the filter pass's operands."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_filter_pass_keeps_documents_at_its_rounding_worst_case():
+    """The bf16 filter pass of the many-query search (widths 128 .. 512, >= 400 000 documents) may be off by eta = 0.0081 in the
+    cosine, and its bound is relaxed by exactly that.  Here the ten best documents of every query are the WORST case of the
+    rounding: every component of the query and of those documents has magnitude 1 + 2^-8 - 2^-12 (x a power of two), a hair below
+    the midpoint of two bf16 numbers, so all of them round DOWN by 2^-8 relative and the approximate cosine is 0.0073 below the
+    exact one -- while 400 ordinary rows per query sit at cosine 0.940, a hair below the tenth-best (0.9427), and give the sample
+    a tight bound.  An un-relaxed filter drops the tenth-best (approximate 0.9354 < 0.940); the search must return the planted
+    rows in order, scores within 1e-4 of the oracle.  (vector.rs:150-166, segment.rs:307-337)"""
+    import kjarni_amd
+    n, dim, nq, k = 420_000, 384, 24, 10
+    rng = np.random.default_rng(2024)
+    corpus = _unit_rows(n, dim, seed=77)
+    m_dn = np.float32(1.0 + 2.0 ** -8 - 2.0 ** -12)
+    assert float(_bf16_rne(np.array([m_dn]))[0]) == 1.0
+    signs = rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=(nq, dim))
+    queries = (signs * m_dn * np.float32(2.0)).astype(np.float32)
+    rows = rng.choice(n, nq * (k + 400), replace=False).reshape(nq, k + 400)
+    for j in range(nq):
+        qh = queries[j].astype(np.float64) / np.linalg.norm(queries[j].astype(np.float64))
+        for r in range(k):                                   # planted: 2 + r sign flips -> cosine 1 - 2 (2 + r) / 384
+            d = signs[j] * m_dn * np.float32(0.5)
+            flip = rng.choice(dim, 2 + r, replace=False)
+            d[flip] = -d[flip]
+            corpus[rows[j, r]] = d
+        for i in rows[j, k:]:                                # ordinary rows at cosine 0.940 +- 0.0004
+            c = 0.940 + rng.uniform(-4e-4, 4e-4)
+            u = rng.standard_normal(dim)
+            u -= (u @ qh) * qh
+            corpus[i] = (c * qh + np.sqrt(1.0 - c * c) * u / np.linalg.norm(u)).astype(np.float32)
+    # the worst case is really there: the filter's arithmetic, emulated, is 0.006 .. eta below the exact cosine on the planted rows
+    qb, db = _bf16_rne(queries[0]).astype(np.float64), _bf16_rne(corpus[rows[0, :k]]).astype(np.float64)
+    q64, d64 = queries[0].astype(np.float64), corpus[rows[0, :k]].astype(np.float64)
+    den = np.linalg.norm(q64) * np.linalg.norm(d64, axis=1)
+    err = (d64 @ q64) / den - (db @ qb) / den
+    assert 0.006 < err.min() and err.max() < 0.0081, err
+    for mode in (0, 1):
+        idx, sc = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
+        worst = 0.0
+        for j in range(nq):
+            ridx, rsc = O.search(queries[j], corpus, k, mode=mode)
+            assert list(ridx) == list(rows[j, :k]), "the planted rows are the oracle's top-k, in order"
+            assert list(idx[j]) == list(ridx), (mode, j, idx[j], ridx)
+            worst = max(worst, float(np.abs(sc[j] - rsc).max()))
+        assert report(f"cosine/filter_worst_case_rounding_420000x384_mode{mode}", worst, 1e-4) < 1e-4
