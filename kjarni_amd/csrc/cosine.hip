@@ -1326,13 +1326,13 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
     const int64_t all_tiles = (n_docs + 15) >> 4;
     const int64_t waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wid;
     const uint32_t voff = (uint32_t)((n16 * dim + 4 * g) * 4);
-    // one tile of 16 documents: the approximate dot products of this lane's document with its 16 queries, 1 / ||doc||
-    auto tile_dots = [&](int64_t tile, f32x4 (&acc)[4], float& idn, bool& odd_doc, int64_t& ad) {
+    // one tile of 16 documents: its rows requested (a tile past the corpus: a descriptor without extent -- zeros, no traffic) ...
+    auto request = [&](int64_t tile, f32x4 (&x0)[NK], f32x4 (&x1)[NK]) {
         const int64_t d0 = tile << 4;
-        const int64_t rows = n_docs - d0 < 16 ? n_docs - d0 : 16;   // documents past n_docs: zeros
+        int64_t rows = n_docs - d0 < 16 ? n_docs - d0 : 16;   // documents past n_docs: zeros
+        rows = rows > 0 ? rows : 0;
         const __amdgpu_buffer_rsrc_t rD =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(corpus + d0 * dim), 0, (int)(rows * dim * 4), 0x00020000);
-        f32x4 x0[NK], x1[NK];
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(corpus + (rows > 0 ? d0 : 0) * dim), 0, (int)(rows * dim * 4), 0x00020000);
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             // (plain loads: the two requests of a K-step take the two halves of the same 128-byte lines, the second finds them in
@@ -1341,6 +1341,9 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
             x0[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voff + 128 * s, 0, 0));
             x1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voff + 128 * s + 64, 0, 0));
         }
+    };
+    // ... and the approximate dot products of this lane's document with its 16 queries, 1 / ||doc||
+    auto dots = [&](const f32x4 (&x0)[NK], const f32x4 (&x1)[NK], f32x4 (&acc)[4], float& idn, bool& odd_doc) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x2 sq = {0.f, 0.f};
@@ -1361,7 +1364,6 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
         const float dn = sqrtf(sum_xor32(sum_xor16(sq[0] + sq[1])));
         odd_doc = !(dn >= 1e-4f && dn < INFINITY);   // too small for the rule, or not finite: the exact pass decides
         idn = __builtin_amdgcn_rcpf(dn);
-        ad = d0 + n16;
     };
     if constexpr (KIND == FILTER_SAMPLE_MAX) {
         // unit `it` = the unit_tiles consecutive tiles from tile it * tile_stride on
@@ -1373,11 +1375,12 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
             for (int u = 0; u < out.unit_tiles; ++u) {
                 const int64_t tile = it * out.tile_stride + u;
                 if (tile >= all_tiles) break;
-                f32x4 acc[4];
+                f32x4 x0[NK], x1[NK], acc[4];
                 float idn;
                 bool odd_doc;
-                int64_t ad;
-                tile_dots(tile, acc, idn, odd_doc, ad);
+                request(tile, x0, x1);
+                dots(x0, x1, acc, idn, odd_doc);
+                const int64_t ad = (tile << 4) + n16;
                 // documents the rule does not cover, lanes past n_docs and NaN dot products give no bound (fmaxf drops a NaN)
                 const bool ok = ad < n_docs && !odd_doc;
                 float tq[16];
@@ -1396,12 +1399,15 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
         return;
     }
     unsigned count = 0;   // entries in this wave's list (wave-uniform)
+    f32x4 x0[NK], x1[NK];
+    request(wave, x0, x1);
     for (int64_t it = wave; it < all_tiles; it += waves) {
         f32x4 acc[4];
         float idn;
         bool odd_doc;
-        int64_t ad;
-        tile_dots(it, acc, idn, odd_doc, ad);
+        dots(x0, x1, acc, idn, odd_doc);
+        request(it + waves, x0, x1);   // (the next tile's rows are on their way while this one's scores are looked at)
+        const int64_t ad = (it << 4) + n16;
         // bit e of `mask`: this lane's document passes for its query e (a NaN margin passes; a document the rule does not cover
         // passes for every real query).  Nearly every tile ends at the ballot; in one that does not, the lanes that have passes
         // -- one, as a rule -- take turns to write their entries at the wave's count.

@@ -321,7 +321,8 @@ def test_fused_many_query_search_against_the_oracle_at_its_own_size():
 
 
 @pytest.mark.parametrize("k", [12, 200])
-@pytest.mark.parametrize("case", ["random", "ascending", "overflow", "nonfinite", "random_f32", "overflow_f32", "nonfinite_f32"])
+@pytest.mark.parametrize("case", ["random", "ascending", "overflow", "nonfinite", "random_f32", "overflow_f32", "nonfinite_f32",
+                                  "random_dim128", "random_dim256", "random_dim512"])
 def test_many_queries_one_call_selects_inside_the_scan(case, k):
     """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries never writes a [queries, documents] score array: a
     strided sample of the corpus gives every query a lower bound of its k-th best score, one pass over the corpus keeps only what
@@ -341,6 +342,8 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
     n, nq = 450_123, 70
     dim = 768 if case.endswith("_f32") else 384   # (384: the bf16 filter pass + exact rescoring; 768: the f32 scan selects)
     case = case.removesuffix("_f32")
+    if case.startswith("random_dim"):             # (the filter pass's other widths: 4, 8, 16 K-steps of 32)
+        dim, case = int(case[len("random_dim"):]), "random"
     g = torch.Generator(device=dev).manual_seed(11)
     corpus = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
     q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
