@@ -1261,21 +1261,25 @@ struct FilterOut {
     int unit_tiles;
 };
 
-template <int NK, int KIND>   // dim = 32 NK
-__global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) void cosine_filter_bf16_kernel(const float* __restrict__ queries, int nq,
+// PARTS > 1 (widths above 512: the tile's rows no longer fit the registers): the tile goes through in PARTS pieces of NK / PARTS
+// K-steps -- a piece is requested when the piece before it has been consumed --, and the 96 / 128 KB of query fragments leave
+// room for ONE workgroup per CU, which therefore has WAVES = 12 (8 at 1 024) waves.
+template <int NK, int KIND, int PARTS = 1, int WAVES = 4>   // dim = 32 NK
+__global__ __launch_bounds__(64 * WAVES, WAVES > 4 ? WAVES / 4 : ((NK / PARTS <= 12 && KIND == FILTER_LIST) ? 3 : 2)) void cosine_filter_bf16_kernel(const float* __restrict__ queries, int nq,
                                                                                   const float* __restrict__ corpus, int64_t n_docs,
                                                                                   const float* __restrict__ qn2,
                                                                                   const float* __restrict__ thr_score,
                                                                                   const int64_t* __restrict__ thr_idx, int thr_k,
                                                                                   FilterOut out)
 {
-    constexpr int dim = 32 * NK;
+    constexpr int dim = 32 * NK, NP = NK / PARTS;
+    static_assert(NK % PARTS == 0, "whole K-steps per piece");
     extern __shared__ __attribute__((aligned(16))) uint8_t fsm[];
     cu32x4* sQf = reinterpret_cast<cu32x4*>(fsm);                 // [NK][4 query blocks][64 lanes]: A fragments, ready to use
     float* sTq = reinterpret_cast<float*>(fsm + NK * 4096);        // [64]: the bound in the dot / ||doc|| domain (sample: 1 / ||q||)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, g = lane >> 4;
-    for (int f = tid; f < NK * 256; f += 256) {
+    for (int f = tid; f < NK * 256; f += 64 * WAVES) {
         const int s = f >> 8, b = (f >> 6) & 3, l = f & 63;
         const int q = 16 * b + (l & 15);
         f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
@@ -1324,31 +1328,31 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
     };
 
     const int64_t all_tiles = (n_docs + 15) >> 4;
-    const int64_t waves = (int64_t)gridDim.x * 4, wave = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t waves = (int64_t)gridDim.x * WAVES, wave = (int64_t)blockIdx.x * WAVES + wid;
     const uint32_t voff = (uint32_t)((n16 * dim + 4 * g) * 4);
-    // one tile of 16 documents: its rows requested (a tile past the corpus: a descriptor without extent -- zeros, no traffic) ...
-    auto request = [&](int64_t tile, f32x4 (&x0)[NK], f32x4 (&x1)[NK]) {
+    // one piece (NP K-steps) of a tile of 16 documents: its rows requested (a tile past the corpus: a descriptor without extent
+    // -- zeros, no traffic) ...
+    auto request = [&](int64_t tile, int part, f32x4 (&x0)[NP], f32x4 (&x1)[NP]) {
         const int64_t d0 = tile << 4;
         int64_t rows = n_docs - d0 < 16 ? n_docs - d0 : 16;   // documents past n_docs: zeros
         rows = rows > 0 ? rows : 0;
         const __amdgpu_buffer_rsrc_t rD =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(corpus + (rows > 0 ? d0 : 0) * dim), 0, (int)(rows * dim * 4), 0x00020000);
+        const uint32_t vo = voff + (uint32_t)(128 * NP * part);
 #pragma unroll
-        for (int s = 0; s < NK; ++s) {
+        for (int s = 0; s < NP; ++s) {
             // (plain loads: the two requests of a K-step take the two halves of the same 128-byte lines, the second finds them in
             // the L1 -- with the non-temporal bit it does not: 5.7 instead of 6.4 TB/s for this pattern alone,
             // tools/lab/stream_pattern_lab.hip)
-            x0[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voff + 128 * s, 0, 0));
-            x1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, voff + 128 * s + 64, 0, 0));
+            x0[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, vo + 128 * s, 0, 0));
+            x1[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rD, vo + 128 * s + 64, 0, 0));
         }
     };
-    // ... and the approximate dot products of this lane's document with its 16 queries, 1 / ||doc||
-    auto dots = [&](const f32x4 (&x0)[NK], const f32x4 (&x1)[NK], f32x4 (&acc)[4], float& idn, bool& odd_doc) {
+    // ... and its share of the approximate dot products of this lane's document with its 16 queries, and of ||doc||^2
+    auto dots = [&](int part, const f32x4 (&x0)[NP], const f32x4 (&x1)[NP], f32x4 (&acc)[4], f32x2& sq) {
+        const cu32x4* frag = sQf + (size_t)part * NP * 256 + lane;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x2 sq = {0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NK; ++s) {
+        for (int s = 0; s < NP; ++s) {
             const cbf16x8 bf = bf16_eight(x0[s], x1[s]);
             sq = __builtin_elementwise_fma(f32x2{x0[s][0], x0[s][1]}, f32x2{x0[s][0], x0[s][1]}, sq);
             sq = __builtin_elementwise_fma(f32x2{x0[s][2], x0[s][3]}, f32x2{x0[s][2], x0[s][3]}, sq);
@@ -1356,9 +1360,29 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
             sq = __builtin_elementwise_fma(f32x2{x1[s][2], x1[s][3]}, f32x2{x1[s][2], x1[s][3]}, sq);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const cbf16x8 af = __builtin_bit_cast(cbf16x8, sQf[(s * 4 + b) * 64 + lane]);
+                const cbf16x8 af = __builtin_bit_cast(cbf16x8, frag[(s * 4 + b) * 64]);
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[b], 0, 0, 0);
             }
+        }
+        // (the squares are one dependent chain that the scheduler would finish long after the MFMAs, holding the piece's raw rows
+        // -- past the request that refills their registers: spills; the chain ends HERE)
+        if (PARTS > 1) asm volatile("" : "+v"(sq));
+    };
+    // A whole tile: its pieces in turn through ONE set of registers -- a piece is requested as soon as the piece before it has
+    // been consumed, the LAST request is the first piece of `next` (the wave's next tile: on its way while this tile's scores
+    // are looked at).  x0 / x1 hold the tile's first piece on entry and `next`'s on return.
+    auto tile_dots = [&](int64_t tile, int64_t next, f32x4 (&x0)[NP], f32x4 (&x1)[NP], f32x4 (&acc)[4], float& idn, bool& odd_doc) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x2 sq = {0.f, 0.f};
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) {
+            dots(part, x0, x1, acc, sq);
+            // (a fence for the instruction scheduler: it would start the next piece's requests early, into registers of their own)
+            if (PARTS > 1) __builtin_amdgcn_sched_barrier(0);
+            if (part + 1 < PARTS) request(tile, part + 1, x0, x1);
+            else request(next, 0, x0, x1);
+            if (PARTS > 1) __builtin_amdgcn_sched_barrier(0);
         }
         // ||doc||^2: the four lanes of a document (g = 0 .. 3) hold a quarter each
         const float dn = sqrtf(sum_xor32(sum_xor16(sq[0] + sq[1])));
@@ -1367,19 +1391,20 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
     };
     if constexpr (KIND == FILTER_SAMPLE_MAX) {
         // unit `it` = the unit_tiles consecutive tiles from tile it * tile_stride on
+        f32x4 x0[NP], x1[NP];
+        request(wave < out.units ? wave * out.tile_stride : all_tiles, 0, x0, x1);
         for (int64_t it = wave; it < out.units; it += waves) {
             float run[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) run[e] = -INFINITY;
 #pragma unroll 1
             for (int u = 0; u < out.unit_tiles; ++u) {
-                const int64_t tile = it * out.tile_stride + u;
-                if (tile >= all_tiles) break;
-                f32x4 x0[NK], x1[NK], acc[4];
+                const int64_t tile = it * out.tile_stride + u;   // (past the corpus: zeros, which give no bound)
+                const int64_t next = u + 1 < out.unit_tiles ? tile + 1 : (it + waves < out.units ? (it + waves) * out.tile_stride : all_tiles);
+                f32x4 acc[4];
                 float idn;
                 bool odd_doc;
-                request(tile, x0, x1);
-                dots(x0, x1, acc, idn, odd_doc);
+                tile_dots(tile, next, x0, x1, acc, idn, odd_doc);
                 const int64_t ad = (tile << 4) + n16;
                 // documents the rule does not cover, lanes past n_docs and NaN dot products give no bound (fmaxf drops a NaN)
                 const bool ok = ad < n_docs && !odd_doc;
@@ -1399,14 +1424,13 @@ __global__ __launch_bounds__(256, (NK <= 12 && KIND == FILTER_LIST) ? 3 : 2) voi
         return;
     }
     unsigned count = 0;   // entries in this wave's list (wave-uniform)
-    f32x4 x0[NK], x1[NK];
-    request(wave, x0, x1);
+    f32x4 x0[NP], x1[NP];
+    request(wave, 0, x0, x1);
     for (int64_t it = wave; it < all_tiles; it += waves) {
         f32x4 acc[4];
         float idn;
         bool odd_doc;
-        dots(x0, x1, acc, idn, odd_doc);
-        request(it + waves, x0, x1);   // (the next tile's rows are on their way while this one's scores are looked at)
+        tile_dots(it, it + waves, x0, x1, acc, idn, odd_doc);
         const int64_t ad = (it << 4) + n16;
         // bit e of `mask`: this lane's document passes for its query e (a NaN margin passes; a document the rule does not cover
         // passes for every real query).  Nearly every tile ends at the ballot; in one that does not, the lanes that have passes
@@ -1614,23 +1638,27 @@ hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t 
 //   filter: per-wave lists, then the exact pass over them (rescore), query block by query block
 struct FilterPlan {
     int nk;
+    int waves;           // per workgroup: 4; widths above 512 (one workgroup per CU: the query fragments take 96 / 128 KB) 12 / 8
     size_t lds;
-    unsigned grid;       // workgroups of the filter / rescoring launches (the lists are per wave: 4 grid of them)
+    unsigned grid;       // workgroups of the filter launch (the lists are per wave: waves x grid of them)
     unsigned cap_w;      // entries per wave list
     int64_t units;       // the sample's units, their first tiles tile_stride apart, unit_tiles tiles of 16 documents each
     int tile_stride, unit_tiles;
 };
+inline bool filter_width(int dim) { return dim == 128 || dim == 256 || dim == 384 || dim == 512 || dim == 768 || dim == 1024; }
 FilterPlan filter_plan(int64_t n_docs, int dim, size_t list_bytes)
 {
     FilterPlan p{};
     p.nk = dim / 32;
+    p.waves = p.nk <= 16 ? 4 : (p.nk == 24 ? 12 : 8);
     p.lds = (size_t)p.nk * 4096 + 512;
     const int64_t tiles = (n_docs + 15) / 16;
-    p.grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, 256 * (p.nk <= 12 ? 3 : 2));
+    const int per_cu = p.nk <= 12 ? 3 : (p.nk <= 16 ? 2 : 1);   // workgroups a CU holds
+    p.grid = (unsigned)std::min<int64_t>((tiles + p.waves - 1) / p.waves, 256 * per_cu);
 #ifdef KJARNI_TUNING
-    if (const char* e = getenv("KJARNI_HIP_FILTER_GRID")) p.grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, std::min(1024, atoi(e)));
+    if (const char* e = getenv("KJARNI_HIP_FILTER_GRID")) p.grid = (unsigned)std::min<int64_t>((tiles + p.waves - 1) / p.waves, std::min(4096 / p.waves, atoi(e)));
 #endif
-    p.cap_w = (unsigned)(list_bytes / 8 / ((size_t)p.grid * 4));
+    p.cap_w = (unsigned)(list_bytes / 8 / ((size_t)p.grid * p.waves));
     // ~1 / 40 of the corpus and at least 4 096 tiles (fewer only when the corpus has fewer); at most 4 096 units (sample_bound_kernel)
     p.unit_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, (tiles + 4096 * 40 - 1) / (4096 * 40)));
     p.units = std::min<int64_t>(4096, std::max<int64_t>(1, tiles / p.unit_tiles));
@@ -1642,23 +1670,33 @@ template <int KIND>
 hipError_t filter_launch(const FilterPlan& p, const float* queries, int m, const float* corpus, int64_t n_docs, const float* qn2,
                          const float* thr_score, const int64_t* thr_idx, int thr_k, const FilterOut& out, hipStream_t stream)
 {
-    // (the sample: two workgroups per CU fit, one round of them)
-    const unsigned grid = KIND == FILTER_SAMPLE_MAX ? (unsigned)std::min<int64_t>((p.units + 3) / 4, 512) : p.grid;
-#define KJ_FILTER(NK_)                                                                                                           \
+    // (the sample: one round of the workgroups a CU holds at its register budget -- two of four waves, one of 12 / 8)
+    const unsigned grid = KIND == FILTER_SAMPLE_MAX ? (unsigned)std::min<int64_t>((p.units + p.waves - 1) / p.waves, p.waves == 4 ? 512 : 256)
+                                                    : p.grid;
+#define KJ_FILTER(NK_, PARTS_, WAVES_)                                                                                           \
     do {                                                                                                                         \
-        auto kern = cosine_filter_bf16_kernel<NK_, KIND>;                                                                        \
+        auto kern = cosine_filter_bf16_kernel<NK_, KIND, PARTS_, WAVES_>;                                                        \
         if (p.lds > 48 * 1024) {                                                                                                 \
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                       (int)p.lds);                                                               \
             if (ea != hipSuccess) return ea;                                                                                     \
         }                                                                                                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p.lds, stream, queries, m, corpus, n_docs, qn2, thr_score, thr_idx, thr_k, out); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES_), p.lds, stream, queries, m, corpus, n_docs, qn2, thr_score, thr_idx, thr_k, \
+                           out);                                                                                                 \
     } while (0)
     switch (p.nk) {
-    case 4: KJ_FILTER(4); break;
-    case 8: KJ_FILTER(8); break;
-    case 12: KJ_FILTER(12); break;
-    case 16: KJ_FILTER(16); break;
+    case 4: KJ_FILTER(4, 1, 4); break;
+    case 8: KJ_FILTER(8, 1, 4); break;
+    case 12: KJ_FILTER(12, 1, 4); break;
+    case 16: KJ_FILTER(16, 1, 4); break;
+    case 24:   // (768: two pieces of 12 K-steps for the filter; the sample, whose epilogue holds 16 running maxima more, four of 6)
+        if (KIND == FILTER_SAMPLE_MAX) KJ_FILTER(24, 4, 12);
+        else KJ_FILTER(24, 2, 12);
+        break;
+    case 32:
+        if (KIND == FILTER_SAMPLE_MAX) KJ_FILTER(32, 4, 8);
+        else KJ_FILTER(32, 2, 8);
+        break;
     default: return hipErrorInvalidValue;
     }
 #undef KJ_FILTER
@@ -1699,7 +1737,7 @@ hipError_t filter_and_rescore(const FilterPlan& p, const float* queries, int nq,
         // (queries, bounds and lists of the WHOLE call: the list entries carry the call's query index)
 #define KJ_RESCORE(MODE_, NK_)                                                                                                   \
     hipLaunchKernelGGL((cosine_rescore_kernel<MODE_, NK_>), dim3(256), dim3(256), 0, stream, queries, corpus, qn2, thr_score, thr_idx, \
-                       thr_k, wave_list, wave_count, (int)p.grid * 4, p.cap_w, counters, cap_q, cand_key)
+                       thr_k, wave_list, wave_count, (int)p.grid * p.waves, p.cap_w, counters, cap_q, cand_key)
 #define KJ_RESCORE_M(NK_)                                                                                                        \
     do {                                                                                                                         \
         if (mode == 0) KJ_RESCORE(0, NK_);                                                                                       \
@@ -1709,7 +1747,9 @@ hipError_t filter_and_rescore(const FilterPlan& p, const float* queries, int nq,
         case 4: KJ_RESCORE_M(4); break;
         case 8: KJ_RESCORE_M(8); break;
         case 12: KJ_RESCORE_M(12); break;
-        default: KJ_RESCORE_M(16); break;
+        case 16: KJ_RESCORE_M(16); break;
+        case 24: KJ_RESCORE_M(24); break;
+        default: KJ_RESCORE_M(32); break;
         }
 #undef KJ_RESCORE_M
 #undef KJ_RESCORE
@@ -1959,9 +1999,9 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
         uint64_t* wave_list = reinterpret_cast<uint64_t*>(p);   // the bf16 filter pass's per-wave (query, document) lists
         p += pad256(kFilterListBytes);
         unsigned* wave_count = reinterpret_cast<unsigned*>(p);
-        // Four widths have the bf16 filter pass + exact rescoring (HBM-bound); the others the f32 matrix-core scan with the
-        // selection inside (MFMA-bound).
-        const bool filtered = (dim == 128 || dim == 256 || dim == 384 || dim == 512) && !tune::scan_f32_select();
+        // Six widths (filter_width) have the bf16 filter pass + exact rescoring (HBM-bound); the others the f32 matrix-core scan
+        // with the selection inside (MFMA-bound).
+        const bool filtered = filter_width(dim) && !tune::scan_f32_select();
         const FilterPlan fp = filtered ? filter_plan(n_docs, dim, kFilterListBytes) : FilterPlan{};
         const unsigned cap_q = (unsigned)(kManyCandCap / (size_t)nq);
         hipError_t e = query_sqnorms(queries, nq, dim, qn2, stream);

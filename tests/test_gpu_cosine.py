@@ -322,13 +322,13 @@ def test_fused_many_query_search_against_the_oracle_at_its_own_size():
 
 @pytest.mark.parametrize("k", [12, 200])
 @pytest.mark.parametrize("case", ["random", "ascending", "overflow", "nonfinite", "random_f32", "overflow_f32", "nonfinite_f32",
-                                  "random_dim128", "random_dim256", "random_dim512"])
+                                  "random_dim128", "random_dim256", "random_dim512", "random_dim768", "random_dim1024"])
 def test_many_queries_one_call_selects_inside_the_scan(case, k):
     """From 400 000 documents on, kjarni_hip_cosine_search with >= 20 queries never writes a [queries, documents] score array: a
     strided sample of the corpus gives every query a lower bound of its k-th best score, one pass over the corpus keeps only what
     can reach it, a per-query selection finishes.  At widths 128 / 256 / 384 / 512 the pass is the bf16 FILTER (scores off by at most
-    eta, bound relaxed by it) and the survivors' exact cosines come from a rescoring pass with the f32 scan's arithmetic; at other
-    widths ("_f32" cases: 768) the f32 matrix-core scan itself selects.  Same indices and score bits as kjarni_hip_cosine_scores +
+    eta, bound relaxed by it) and the survivors' exact cosines come from a rescoring pass with the f32 scan's arithmetic (768 and
+    1 024 the same with the tile in pieces); at other widths ("_f32" cases: 640) the f32 matrix-core scan itself selects.  Same indices and score bits as kjarni_hip_cosine_scores +
     kjarni_hip_cosine_topk: on random rows; on rows whose scores ascend with the index (the sample under-estimates every bound);
     and when the lists overflow (identical queries, every sampled row anti-correlated, every other row correlated), where the
     queued two-call form takes over.
@@ -340,9 +340,9 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
     L = _ffi.lib()
     dev = torch.device("cuda", 0)
     n, nq = 450_123, 70
-    dim = 768 if case.endswith("_f32") else 384   # (384: the bf16 filter pass + exact rescoring; 768: the f32 scan selects)
+    dim = 640 if case.endswith("_f32") else 384   # (384: the bf16 filter pass + exact rescoring; 640: the f32 scan selects)
     case = case.removesuffix("_f32")
-    if case.startswith("random_dim"):             # (the filter pass's other widths: 4, 8, 16 K-steps of 32)
+    if case.startswith("random_dim"):             # (the filter pass's other widths: 4, 8, 16 K-steps of 32; 24 and 32 in pieces)
         dim, case = int(case[len("random_dim"):]), "random"
     g = torch.Generator(device=dev).manual_seed(11)
     corpus = torch.randn((n, dim), generator=g, device=dev, dtype=torch.float32)
@@ -351,7 +351,7 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
         corpus += torch.linspace(0.0, 2.0, n, device=dev)[:, None] * q[3][None, :]
     if case == "overflow":
         q[:] = q[0]
-        if dim == 384:   # (the sample units of filter_plan, cosine.hip: tiles of 16 documents)
+        if dim != 640:   # (the sample units of filter_plan, cosine.hip: tiles of 16 documents)
             tiles = (n + 15) // 16
             unit_tiles = min(16, max(1, (tiles + 4096 * 40 - 1) // (4096 * 40)))
             units = min(4096, max(1, tiles // unit_tiles))

@@ -13,7 +13,7 @@ nq = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0   # (tuning build: kjarni_hip_set_cosine_variant)
-dim = 384
+dim = int(os.environ.get("DIM", "384"))
 L = _ffi.lib()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(2)
