@@ -1661,7 +1661,7 @@ FilterPlan filter_plan(int64_t n_docs, int dim, size_t list_bytes)
     p.cap_w = (unsigned)(list_bytes / 8 / ((size_t)p.grid * p.waves));
     // ~1 / 40 of the corpus and at least 4 096 tiles (fewer only when the corpus has fewer); at most 4 096 units (sample_bound_kernel)
     p.unit_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, (tiles + 4096 * 40 - 1) / (4096 * 40)));
-    p.units = std::min<int64_t>(4096, std::max<int64_t>(1, tiles / p.unit_tiles));
+    p.units = std::min<int64_t>(4096, std::max<int64_t>(1, tiles / p.unit_tiles / 8));   // (and at most 1 / 8 of a small corpus)
     p.tile_stride = (int)std::max<int64_t>(p.unit_tiles, tiles / p.units);
     return p;
 }
@@ -1925,6 +1925,14 @@ void final_lists(int kpad, const uint64_t* keys, int lists, int k, int64_t* out_
 namespace {
 constexpr size_t kManyCandCap = (size_t)4 << 20;       // candidate keys of the fused many-query scan over all its queries (32 MB)
 constexpr int64_t kManyFusedMinDocs = 400000;           // below: the two-call form (its selection is a small share there)
+constexpr int64_t kFilterMinDocs = 20000;               // the widths with the bf16 filter pass: 64 queries x 10^5 documents 0.30 -> 0.11 ms (profiles/r06zb)
+inline int64_t many_min_docs(int dim)
+{
+#ifdef KJARNI_TUNING
+    if (const char* e = getenv("KJARNI_HIP_FILTER_MIN_DOCS")) return filter_width(dim) ? atoll(e) : kManyFusedMinDocs;
+#endif
+    return filter_width(dim) && !tune::scan_f32_select() ? kFilterMinDocs : kManyFusedMinDocs;
+}
 constexpr int kSampleMaxK = 128;                        // up to this k the sample pass hands over per-wave maxima, not scores
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 }  // namespace
@@ -1979,7 +1987,7 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
     const size_t s_bytes = pad256((size_t)nq * (size_t)n_docs * sizeof(float));
     uint8_t* topk_ws = static_cast<uint8_t*>(workspace) + s_bytes;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) && ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
-    if (nq >= 20 && nq <= 1024 && n_docs >= kManyFusedMinDocs && k <= 1024 && aligned16 && dim % MQ_BK == 0 && dim >= 2 * MQ_BK &&
+    if (nq >= 20 && nq <= 1024 && n_docs >= many_min_docs(dim) && k <= 1024 && aligned16 && dim % MQ_BK == 0 && dim >= 2 * MQ_BK &&
         (int64_t)MQ_D * dim * 4 < ((int64_t)1 << 31) && (mode == 0 || mode == 1) && !tune::scan_streaming_only() &&
         !tune::scan_two_launches()) {
         // Many queries, selection inside the scan (ScanFuse): sample pass -> per-query bounds -> fused scan -> per-query selection
