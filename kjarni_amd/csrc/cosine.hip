@@ -1925,7 +1925,17 @@ void final_lists(int kpad, const uint64_t* keys, int lists, int k, int64_t* out_
 namespace {
 constexpr size_t kManyCandCap = (size_t)4 << 20;       // candidate keys of the fused many-query scan over all its queries (32 MB)
 constexpr int64_t kManyFusedMinDocs = 400000;           // below: the two-call form (its selection is a small share there)
+constexpr int kFilterMinQueries = 2;                    // queries from which the widths with the filter pass take it: a streaming pass
+                                                        // serves 4 queries, the filter pass 64 at 1.3 x the cost of ONE (profiles/r06zc)
 constexpr int64_t kFilterMinDocs = 20000;               // the widths with the bf16 filter pass: 64 queries x 10^5 documents 0.30 -> 0.11 ms (profiles/r06zb)
+// (a streaming pass serves 4 queries; the filter pass 64 at 1.3 x the cost of one)
+inline int many_min_queries(int dim)
+{
+#ifdef KJARNI_TUNING
+    if (const char* e = getenv("KJARNI_HIP_FILTER_MIN_QUERIES")) return filter_width(dim) ? atoi(e) : 20;
+#endif
+    return filter_width(dim) && !tune::scan_f32_select() ? kFilterMinQueries : 20;
+}
 inline int64_t many_min_docs(int dim)
 {
 #ifdef KJARNI_TUNING
@@ -1942,8 +1952,8 @@ size_t cosine_search_workspace_bytes(int nq, int64_t n_docs, int dim, int k)
     (void)dim;
     const size_t fused = (size_t)(2048 * 256 + 2 * 2048) * sizeof(uint64_t);
     size_t two = pad256((size_t)nq * (size_t)n_docs * sizeof(float)) + pad256(cosine_topk_workspace_bytes(nq, n_docs, k));
-    // the fused many-query scan (nq >= 20 only): candidate list, counters, the sample's best k per query
-    if (nq >= 20)
+    // the many-query searches (from kFilterMinQueries queries on): candidate list, counters, the sample's best k per query
+    if (nq >= kFilterMinQueries)
         two += pad256(kManyCandCap * 8) + pad256((size_t)(nq + 1) * kCountStride * 4) + pad256((size_t)nq * k * 8) + pad256((size_t)nq * k * 4) +
                pad256((size_t)(nq + 8) * 4) +   // (+ the queries' squared norms, shared by the passes of one search)
                pad256(kFilterListBytes) + pad256(kFilterMaxWaves * 4);   // (+ the bf16 filter pass's per-wave lists and their lengths)
@@ -1987,7 +1997,7 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
     const size_t s_bytes = pad256((size_t)nq * (size_t)n_docs * sizeof(float));
     uint8_t* topk_ws = static_cast<uint8_t*>(workspace) + s_bytes;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0) && ((reinterpret_cast<uintptr_t>(queries) & 15) == 0);
-    if (nq >= 20 && nq <= 1024 && n_docs >= many_min_docs(dim) && k <= 1024 && aligned16 && dim % MQ_BK == 0 && dim >= 2 * MQ_BK &&
+    if (nq >= many_min_queries(dim) && nq <= 1024 && n_docs >= many_min_docs(dim) && k <= 1024 && aligned16 && dim % MQ_BK == 0 && dim >= 2 * MQ_BK &&
         (int64_t)MQ_D * dim * 4 < ((int64_t)1 << 31) && (mode == 0 || mode == 1) && !tune::scan_streaming_only() &&
         !tune::scan_two_launches()) {
         // Many queries, selection inside the scan (ScanFuse): sample pass -> per-query bounds -> fused scan -> per-query selection

@@ -178,11 +178,15 @@ def test_full_size_properties():
                                            # the fused matrix-core scan at its edges: 20 queries (its first size), exactly 64, 65
                                            # (two passes), document counts around the 256-document tile, the narrowest / widest rows
                                            (257, 384, 20, 0), (255, 16, 64, 1), (1000, 1024, 65, 0), (513, 32, 130, 1),
-                                           (12, 384, 64, 0), (70_000, 384, 64, 0)])
+                                           (12, 384, 64, 0), (70_000, 384, 64, 0),
+                                           # 2 .. 19 queries over >= 20 000 documents: the bf16 filter route (widths 128 .. 1 024)
+                                           (30_000, 384, 3, 0), (30_000, 384, 5, 1), (45_000, 256, 19, 0), (21_000, 768, 7, 1)])
 def test_many_queries_gemm_route_matches_streaming_and_oracle(n, dim, nq, mode):
     """From 20 queries on, blocks of 64 go through the fused matrix-core scan (corpus read once per block, document norms
-    and cosines in the same launch); row widths it does not take (dim % 16 != 0) fall back to the streaming passes.
-    Both must agree with the oracle, zero rows and zero queries included."""
+    and cosines in the same launch); row widths it does not take (dim % 16 != 0) fall back to the streaming passes; from 20 000
+    documents on, at the widths that have it, 2 and more queries take the bf16 filter pass + exact rescoring.  All routes must
+    agree with the oracle and with one another (scores to 2e-6: the streaming passes sum in another order), zero rows and zero
+    queries included."""
     import kjarni_amd
     k = 12
     # (inputs drawn from successive seeds until every query's top-(k + 1) oracle scores are more than GAP apart: the indices
@@ -194,7 +198,7 @@ def test_many_queries_gemm_route_matches_streaming_and_oracle(n, dim, nq, mode):
     else:
         raise AssertionError("no well-separated inputs found")
     idx, sc = kjarni_amd.cosine_search(queries, corpus, k, mode=mode)
-    # the same queries in groups of 16: below 20 queries a call takes the streaming passes
+    # the same queries in groups of 16: below 20 queries a call takes the streaming passes (below 20 000 documents)
     parts = [kjarni_amd.cosine_search(queries[j0:j0 + 16], corpus, k, mode=mode) for j0 in range(0, nq, 16)]
     idx1, sc1 = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
     assert idx.shape == idx1.shape == (nq, k)
