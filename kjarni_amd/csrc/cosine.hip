@@ -1578,6 +1578,42 @@ __global__ __launch_bounds__(256) void cosine_rescore_kernel(const float* __rest
     }
 }
 
+// The same bound by ONE WAVE per query (four queries per workgroup) -- no barrier between the 32 counting rounds, which are what
+// sample_bound_kernel's 14 us consist of: the wave holds all n <= 64 KPL maxima (KPL keys per lane), a round is KPL compare-and-
+// counts per lane and one wave sum.  Used for the filtered search's sample when n <= 1 024 (KPL = 16; with 64 keys per lane the
+// block kernel wins: 37 against 14 us).
+template <int KPL>
+__global__ __launch_bounds__(256) void sample_bound_wave_kernel(const float* __restrict__ maxima, int n, int64_t stride, int k, int nq,
+                                                                float* __restrict__ thr_score, int64_t* __restrict__ thr_idx,
+                                                                unsigned* __restrict__ counters, float minus)
+{
+    const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (q >= nq) return;
+    uint32_t key[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int at = lane + 64 * i;
+        const float v = at < n ? maxima[(int64_t)q * stride + at] : -INFINITY;
+        key[i] = (v > -INFINITY) ? orderable(v) : 0u;   // (-inf, NaN and padding: 0; a finite score's key is never 0)
+    }
+    uint32_t found = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = found | (1u << bit);
+        // (every lane counts its own keys on the vector ALU, one DPP sum per round: a ballot + scalar count per key is a chain
+        // of vector-to-scalar hand-offs -- 58 us for 64 keys per lane; counts up to 4 096 are exact in f32)
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // (four short chains instead of one of KPL dependent adds)
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) c[i & 3] += key[i] >= cand ? 1.0f : 0.0f;
+        if (wave_sum((c[0] + c[1]) + (c[2] + c[3])) >= (float)k) found = cand;
+    }
+    if (lane == 0) {
+        thr_idx[q] = found == 0u ? -1 : 0;
+        thr_score[q] = found == 0u ? -INFINITY : from_orderable(found) - minus;
+        counters[kCountStride * (1 + q)] = 0u;
+        if (q == 0) counters[0] = 0u;
+    }
+}
+
 // One streaming pass over the corpus per group of SCAN_NQ queries.
 hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
                        float* scores, int64_t score_stride, hipStream_t stream);
@@ -2039,8 +2075,13 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
             // the bf16 sample: per (query, unit of 16 unit_tiles documents) maxima; bound = their k-th largest - eta
             e = filter_sample(fp, queries, nq, corpus, n_docs, dim, qn2, scores, stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)fp.units, fp.units, k, thr_score,
-                               thr_idx, counters, kFilterEta);   // (and zeroes the candidate counters)
+            // (and zeroes the candidate counters)
+            if (fp.units <= 1024)   // (a small sample: a wave per query without barriers; above, the block per query is faster)
+                hipLaunchKernelGGL(sample_bound_wave_kernel<16>, dim3((unsigned)(nq + 3) / 4), dim3(256), 0, stream, scores, (int)fp.units, fp.units,
+                                   k, nq, thr_score, thr_idx, counters, kFilterEta);
+            else
+                hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)fp.units, fp.units, k, thr_score,
+                                   thr_idx, counters, kFilterEta);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             thr_k = 1;
