@@ -1,3 +1,6 @@
+"""What the many-query search's passes leave behind (read out of the call's workspace after one search of 64 queries): overflow
+word, final candidates per query, the bounds against the 10th best score, the filter waves' list lengths.
+usage: python tools/filter_counts.py <n_docs>   (the workspace layout is launch_cosine_search's, cosine.hip)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
