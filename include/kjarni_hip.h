@@ -364,9 +364,15 @@ KjarniErrorCode kjarni_hip_cosine_topk(int32_t device, const float* scores_dev, 
 
 /* Scan + selection in one call on device pointers, enqueued on `stream`: per-query top-k with no caller-visible score
  * array.  One query over dim 128 / 256 / 384 / 512 / 768 / 1024 with k <= 256 runs ONE fused pass (every wave keeps its
- * best keys in registers; the scores never exist in memory) and one small merge launch; anything else runs the two calls
- * above inside the workspace.  Same order and the same scores, bit for bit, as kjarni_hip_cosine_scores +
- * kjarni_hip_cosine_topk.  workspace_dev: kjarni_hip_cosine_search_workspace_bytes(n_queries, n_docs, dim, k) bytes. */
+ * best keys in registers; the scores never exist in memory) and one small merge launch.  2 .. 1 024 queries over >= 20 000
+ * documents of those widths, k <= 1 024: a sample bounds every query's k-th best score, ONE bf16 pass over the corpus per
+ * 64 queries keeps the documents that can reach it (the pass's rounding error is bounded and the bound relaxed by it), and
+ * the survivors' cosines are taken exactly, with the f32 matrix-core scan's arithmetic; other widths (multiples of 16) from
+ * 20 queries and 400 000 documents on: the f32 matrix-core scan itself selects.  Anything else runs the two calls above
+ * inside the workspace.  Same order and the same scores as kjarni_hip_cosine_scores + kjarni_hip_cosine_topk, bit for bit --
+ * except that with 2 .. 19 queries kjarni_hip_cosine_scores streams the corpus and sums in another order than the
+ * matrix-core scan whose arithmetic the search then uses (scores within 2e-6).
+ * workspace_dev: kjarni_hip_cosine_search_workspace_bytes(n_queries, n_docs, dim, k) bytes. */
 size_t kjarni_hip_cosine_search_workspace_bytes(int32_t n_queries, int64_t n_docs, int32_t dim, int32_t k);
 KjarniErrorCode kjarni_hip_cosine_search(int32_t device, const float* queries_dev, int32_t n_queries,
                                          const float* corpus_dev, int64_t n_docs, int32_t dim,
