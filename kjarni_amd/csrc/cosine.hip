@@ -1624,9 +1624,32 @@ hipError_t scan_passes(const float* queries, int nq, const float* corpus, int64_
 //   run_flag:        the launches run only if *run_flag != 0
 //   sample_max:      (with tile_stride) per-(query, tile, wave) maxima [nq, n_tiles * 4] into `scores` instead of the scores
 //   qn2_given:       the queries' squared norms [nq] (query_sqnorms below), computed once by a caller that makes several passes
+// One wave per query, 16-byte pieces dealt lane by lane, an fma chain per lane, one wave sum (the arithmetic of the streaming
+// kernels' own query norm): a query's norm -- and with it its scores -- does not depend on how many queries share its call (as a
+// pass of the streaming scan over the query rows, rows of a last incomplete group were summed in another order).
+__global__ __launch_bounds__(256) void query_sqnorm_kernel(const float* __restrict__ queries, int nq, int dim, float* __restrict__ qn2)
+{
+    const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float* row = queries + (int64_t)q * dim;
+    float s = 0.0f;
+    if ((dim & 3) == 0 && (reinterpret_cast<uintptr_t>(queries) & 15) == 0) {
+        for (int c4 = lane; c4 < (dim >> 2); c4 += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s = fmaf(v[c], v[c], s);
+        }
+    } else {
+        for (int c = lane; c < dim; c += 64) s = fmaf(row[c], row[c], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) qn2[q] = s;
+}
+
 hipError_t query_sqnorms(const float* queries, int nq, int dim, float* qn2, hipStream_t stream)
 {
-    return scan_passes(queries, 1, queries, nq, dim, 2, qn2, nq, stream);  // (mode 2: squared norms of the rows; query operand unused)
+    hipLaunchKernelGGL(query_sqnorm_kernel, dim3((unsigned)(nq + 3) / 4), dim3(256), 0, stream, queries, nq, dim, qn2);
+    return hipGetLastError();
 }
 
 hipError_t scan_mfma(const float* queries, int nq, const float* corpus, int64_t n_docs, int dim, int mode,
