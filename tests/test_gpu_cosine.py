@@ -459,3 +459,16 @@ def test_filter_pass_keeps_documents_at_its_rounding_worst_case():
             assert list(idx[j]) == list(ridx), (mode, j, idx[j], ridx)
             worst = max(worst, float(np.abs(sc[j] - rsc).max()))
         assert report(f"cosine/filter_worst_case_rounding_420000x384_mode{mode}", worst, 1e-4) < 1e-4
+
+
+def test_many_query_search_fuzz_against_scores_plus_topk():
+    """tools/search_fuzz.py, 24 random cases (corpus size, width -- with and without the bf16 filter pass --, 2 .. 130 queries, k, both
+    zero-norm conventions, exact ties, zero rows, a zero query, ascending scores): kjarni_hip_cosine_search and
+    kjarni_hip_cosine_scores + kjarni_hip_cosine_topk agree in every index and every score bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "search_fuzz.py"), "24", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "24 / 24 cases agree bit for bit" in r.stdout
