@@ -1215,7 +1215,8 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
 // the dot product by at most (2u + u^2) ||q|| ||d|| (Cauchy-Schwarz), f32 accumulation of the bf16 x bf16 products (exact in f32)
 // by another ~dim 2^-24.  So with eta = 0.0081 (2^-7 + 2^-16 + slack for the accumulation, the reciprocal and the square root;
 // norms in f32 from the unrounded rows):   | dot_bf16 / (||q|| ||d||) - cosine | <= eta.
-//  * KIND 1, the sample: the maximum of dot_bf16 / (||q|| ||d||) over each sampled tile of 16 documents; the k-th largest of a
+//  * KIND 1, the sample: the maximum of dot_bf16 / (||q|| ||d||) over each sampled unit (1 .. 16 tiles of 16 documents, about a
+//    fortieth of a large corpus, an eighth at most of a small one: filter_plan); the k-th largest of a
 //    query's maxima, minus eta, is a score at least k documents reach exactly: the bound t (sample_bound_kernel).
 //  * KIND 0, the filter: every (query, document) with  dot_bf16 / ||d|| >= (t - eta) ||q||  -- a few hundred per query -- goes to
 //    the list of the WAVE that found it (no atomics: the position is the wave's own count + the lane's rank among the passes);
@@ -1228,8 +1229,8 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
 // -> 8 values of document n; with the K-step's 32 floats dealt as {4 g .. 4 g + 3} U {16 + 4 g .. 16 + 4 g + 3} the four lanes of
 // a document read 64 contiguous bytes per 16-byte load instruction, and the A operand (the 64 queries, rounded once, 4 KB per
 // K-step in the same dealing) comes from LDS by ds_read_b128.  A wave owns a tile of 16 documents: all its 2 NK row requests go
-// out first (the whole tile in registers), then NK x (convert, squares, 4 MFMAs); three waves per SIMD overlap one
-// another's waits.  An accumulator row of 16 lanes is ONE query x the tile's 16 documents.
+// out first (the whole tile in registers; the NEXT tile's as soon as this one's have been consumed, before its scores are looked
+// at), then NK x (convert, squares, 4 MFMAs); three waves per SIMD overlap one another's waits.  An accumulator row of 16 lanes is ONE query x the tile's 16 documents.
 constexpr float kFilterEta = 0.0081f;
 constexpr int FILTER_LIST = 0, FILTER_SAMPLE_MAX = 1;
 constexpr size_t kFilterListBytes = (size_t)16 << 20;   // the filter pass's (query, document) lists, all waves together
