@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void decoder_embed_kernel(const uint32_t* __re
 // Measurements (tuning build): shader cycles the decode attention's register path spends per phase, summed over workgroups --
 // [0] entry -> scores (the loads' round trips + the dots), [1] -> block max, [2] -> exp, weighted V, block sum, [3] -> slab
 // stored, [4] workgroups counted; [5] / [6] / [7]: the one-row GEMV's entry -> dot reduced, -> stored, waves sampled.  kjarni_hip_attention_stamps reads / resets them.
-__device__ unsigned long long g_att_stamp[16];   // ([8] .. [12]: the one-row LN GEMV's entry -> row arrived, -> arguments arrived, -> weight requests issued, waves, -> every request issued)
+__device__ unsigned long long g_att_stamp[16];   // ([15]: stamps on; [8] .. [12]: the one-row LN GEMV's entry -> row arrived, -> arguments arrived, -> weight requests issued, waves, -> every request issued)
 #endif
 constexpr int GEMV_MAX_ROWS = 8;
 
@@ -426,9 +426,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemv_row_fast_kernel(const float* 
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0s));
     if (lane < COLS && n < n_out) Y[(which == 0 ? 0 : (int64_t)r0s * ldy12) + col] = v;
 #ifdef KJARNI_TUNING
-    if (lane == 0 && n_out <= 4096 && (blockIdx.x & 31) == 0 && wave == 0) {   // (a sample of the waves; not the vocabulary head)
+    const unsigned long long gst2 = __builtin_amdgcn_s_memtime();   // (before the flag is read: its round trip is not the store's)
+    if (lane == 0 && n_out <= 4096 && (blockIdx.x & 31) == 0 && wave == 0 && g_att_stamp[15] != 0ull) {   // (a sample of the waves; not the vocabulary head; only while the stamps are being taken)
         atomicAdd(&g_att_stamp[5], gst1 - gst0);
-        atomicAdd(&g_att_stamp[6], __builtin_amdgcn_s_memtime() - gst1);
+        atomicAdd(&g_att_stamp[6], gst2 - gst1);
         atomicAdd(&g_att_stamp[7], 1ull);
         if (LN) {
             atomicAdd(&g_att_stamp[8], gstx - gst0);    // (entry -> the row arrived)
@@ -880,8 +881,8 @@ __global__ __launch_bounds__(256) void decode_attention_partial_kernel(const flo
     if (tid < lpk) *reinterpret_cast<f32x4*>(out + 4 + tid * 4) = (accs[tid] + accs[lpk + tid]) + (accs[2 * lpk + tid] + accs[3 * lpk + tid]);
     if (tid == 0) *reinterpret_cast<f32x4*>(out) = f32x4{(t1 > t0) ? mx : -INFINITY, (t1 > t0) ? sum : 0.0f, 0.0f, 0.0f};
 #ifdef KJARNI_TUNING
-    if (tid == 0 && fast_path) {
-        const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st4 = __builtin_amdgcn_s_memtime();   // (before the flag is read)
+    if (tid == 0 && fast_path && g_att_stamp[15] != 0ull) {   // (only while the stamps are being taken: the atomics cost a token 0.07 ms)
         atomicAdd(&g_att_stamp[0], st1 - st0);
         atomicAdd(&g_att_stamp[1], st2 - st1);
         atomicAdd(&g_att_stamp[2], st3 - st2);
@@ -1060,10 +1061,14 @@ __global__ void pick_finalize_kernel(unsigned long long* __restrict__ best, int 
 #ifdef KJARNI_TUNING
 hipError_t attention_stamps(unsigned long long* out16, int reset)
 {
+    // reset != 0: counters to zero and the stamps ON ([15] = 1); reset == 0: read them and switch the stamps OFF again
     hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_att_stamp), 16 * sizeof(unsigned long long));
-    if (e != hipSuccess || !reset) return e;
-    static const unsigned long long zeros[16] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamp), zeros, sizeof(zeros));
+    if (e != hipSuccess) return e;
+    unsigned long long next[16] = {};
+    if (reset) next[15] = 1ull;
+    else
+        for (int i = 0; i < 15; ++i) next[i] = out16[i];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamp), next, sizeof(next));
 }
 #endif
 

@@ -1,5 +1,7 @@
 """Shader cycles per phase of the decode attention's register path and of the one-row GEMV (tuning build only), over a Whisper or LLM decode.
-usage: KJARNI_FFI_LIB=.../libkjarni_ffi_tuning.so python tools/attention_stamps.py whisper|llm"""
+usage: KJARNI_FFI_LIB=.../libkjarni_ffi_tuning.so python tools/attention_stamps.py whisper|llm
+(kjarni_hip_attention_stamps(buf, 1) zeroes the counters and switches the stamps on, (buf, 0) reads them and switches them off:
+while they are off the tuning build decodes at the shipped build's speed)"""
 import ctypes as C, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
