@@ -282,9 +282,9 @@ class GpuSensors:
 
 def scan_leg(torch, np, dev, n_docs, check_rows=50000, dim=384, k=10):
     """R14, the other half of the hot path (kjarni-search/src/vector.rs:131-166, kjarni-rag/src/segment.rs:307-371): cosine
-    search = scan + top-k in ONE call (kjarni_hip_cosine_search) of 1 query and of 64 queries over a unit-norm Gaussian
+    search = scan + top-k in ONE call (kjarni_hip_cosine_search) of 1 query, of 8 and of 64 queries over a unit-norm Gaussian
     corpus [n_docs, 384] resident in HBM.  One query streams the corpus once: HBM-bound, dim x 4 algorithmic bytes per
-    document.  64 queries: a bf16 filter pass over the same bytes (HBM-bound) + the exact f32 cosines of the few hundred
+    document.  8 / 64 queries: a bf16 filter pass over the same bytes (HBM-bound) + the exact f32 cosines of the few hundred
     documents per query it lets through.  Each entry carries its own roofline; the output of the TIMED call itself is held to the CPU oracle
     after the clock has stopped (every returned score to 1e-6, the reference's order, and no missed document over a random
     subset of `check_rows` corpus rows)."""
@@ -297,7 +297,7 @@ def scan_leg(torch, np, dev, n_docs, check_rows=50000, dim=384, k=10):
     corpus /= torch.linalg.vector_norm(corpus, dim=1, keepdim=True)
     out = {"corpus": f"[{n_docs}, {dim}] unit-norm Gaussian rows resident in HBM, k = {k}, Segment semantics",
            "unit": "ms per search call (scan + top-k in one call, device pointers)"}
-    for nq in (1, 64):
+    for nq in (1, 8, 64):
         q = torch.randn((nq, dim), generator=g, device=dev, dtype=torch.float32)
         idx = torch.empty((nq, k), dtype=torch.int64, device=dev)
         sc = torch.empty((nq, k), dtype=torch.float32, device=dev)
