@@ -340,6 +340,14 @@ def scan_leg(torch, np, dev, n_docs, check_rows=50000, dim=384, k=10):
         qh = q.cpu().numpy()
         sub = np.sort(np.random.default_rng(5 + nq).choice(n_docs, min(check_rows, n_docs), replace=False))
         host_sub = corpus[torch.from_numpy(sub).to(dev)].cpu().numpy()
+        # the CPU side of this row: the oracle's restatement of the reference's search (vector.rs:150-166: one thread, a scalar dot
+        # + norm per document, then a sort) over the same subset, one query; a reported baseline, not the target
+        cpu_t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.search(qh[0], host_sub, k, mode=1)
+            cpu_t.append(time.perf_counter() - t0)
+        cpu_dqs = len(sub) / sorted(cpu_t)[1]
         same, worst, checked = True, 0.0, 0
         for j in range(nq if nq == 1 else 8):   # every 8th query of the 64
             jj = j * (nq // 8) if nq > 1 else 0
@@ -359,6 +367,10 @@ def scan_leg(torch, np, dev, n_docs, check_rows=50000, dim=384, k=10):
         assert same, f"scan leg: the timed call's top-{k} of {nq} quer{'y' if nq == 1 else 'ies'} is not the oracle's"
         assert worst < 1e-6, f"scan leg: scores differ from the oracle by {worst}"
         out[f"queries_{nq}"] = {"ms_per_call": round(ms, 4), "doc_queries_per_s": round(nq * n_docs / ms * 1e3, 0), "roofline": roof,
+                               "cpu_baseline": {"value": round(cpu_dqs, 0), "unit": "doc-queries/s", "cores": 1, "kind": "port",
+                                                "sample": f"oracle ko_search (the reference's one-thread scan + sort), 1 query over {len(sub)} of the "
+                                                          "corpus rows, median of 3"},
+                               "speedup_vs_cpu_baseline": round(nq * n_docs / ms * 1e3 / cpu_dqs, 1),
                                "timed_output_equals_oracle": same, "max_abs_score_err_vs_oracle": worst,
                                "queries_checked": checked, "subset_rows_checked_for_misses": int(len(sub))}
         del ws, idx, sc, q
