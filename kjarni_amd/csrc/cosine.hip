@@ -1173,15 +1173,16 @@ __global__ __launch_bounds__(256, 2) void cosine_scan_mfma_kernel(const float* _
 // 32 counting rounds (sixteen ballots + four LDS words each) instead of a sort.
 // `minus` is taken off the result (the bf16 sample's error bound; 0 for the f32 sample).
 // Also zeroes the search's candidate counters ([0] overflow word, [1 + q] list lengths): the launch in front of the fused scan.
+template <int KPT = 16>   // keys per thread: n <= 256 KPT
 __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restrict__ maxima, int n, int64_t stride, int k,
                                                            float* __restrict__ thr_score, int64_t* __restrict__ thr_idx,
                                                            unsigned* __restrict__ counters, float minus)
 {
     __shared__ int wave_count[2][4];
     const int tid = threadIdx.x, q = blockIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t key[16];
+    uint32_t key[KPT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < KPT; ++i) {
         const int at = tid + 256 * i;
         const float v = at < n ? maxima[(int64_t)q * stride + at] : -INFINITY;
         key[i] = (v > -INFINITY) ? orderable(v) : 0u;   // (-inf, NaN and padding: 0; a finite score's key is never 0)
@@ -1191,7 +1192,7 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
         const uint32_t cand = found | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c += __popcll(__ballot(key[i] >= cand));   // (the wave's count: wave-uniform)
+        for (int i = 0; i < KPT; ++i) c += __popcll(__ballot(key[i] >= cand));   // (the wave's count: wave-uniform)
         if (lane == 0) wave_count[bit & 1][wid] = c;
         __syncthreads();   // (two alternating slots: one barrier per round)
         const int total = wave_count[bit & 1][0] + wave_count[bit & 1][1] + wave_count[bit & 1][2] + wave_count[bit & 1][3];
@@ -1721,6 +1722,8 @@ FilterPlan filter_plan(int64_t n_docs, int dim, size_t list_bytes)
     p.cap_w = (unsigned)(list_bytes / 8 / ((size_t)p.grid * p.waves));
     // ~1 / 40 of the corpus and at least 4 096 tiles (fewer only when the corpus has fewer); at most 4 096 units (sample_bound_kernel)
     p.unit_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, (tiles + 4096 * 40 - 1) / (4096 * 40)));
+    // (4 096 units is also where the search is fastest: 2 048 / 1 024 / 512 units cost 10^6 documents 0.399 / 0.459 / 0.576 ms against
+    // 0.360 -- more candidates --, 6 144 / 8 192 0.379 / 0.390 against 0.366 -- a longer sample; docs/history/r06.md 4b)
     p.units = std::min<int64_t>(4096, std::max<int64_t>(1, tiles / p.unit_tiles / 8));   // (and at most 1 / 8 of a small corpus)
     p.tile_stride = (int)std::max<int64_t>(p.unit_tiles, tiles / p.units);
     return p;
@@ -2104,7 +2107,7 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
                 hipLaunchKernelGGL(sample_bound_wave_kernel<16>, dim3((unsigned)(nq + 3) / 4), dim3(256), 0, stream, scores, (int)fp.units, fp.units,
                                    k, nq, thr_score, thr_idx, counters, kFilterEta);
             else
-                hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)fp.units, fp.units, k, thr_score,
+                hipLaunchKernelGGL(sample_bound_kernel<16>, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)fp.units, fp.units, k, thr_score,
                                    thr_idx, counters, kFilterEta);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
@@ -2113,7 +2116,7 @@ hipError_t launch_cosine_search(const float* queries, int nq, const float* corpu
             // a small k: the bound is the k-th largest of the sampled tiles' per-wave maxima (SCAN_SAMPLE_MAX) -- no sample scores
             e = scan_mfma(queries, nq, corpus, n_docs, dim, mode, scores, stream, ts, ns * 4, nullptr, nullptr, true, qn2);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(sample_bound_kernel, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)(ns * 4), ns * 4, k, thr_score, thr_idx,
+            hipLaunchKernelGGL(sample_bound_kernel<16>, dim3((unsigned)nq), dim3(256), 0, stream, scores, (int)(ns * 4), ns * 4, k, thr_score, thr_idx,
                                counters, 0.0f);   // (and zeroes the candidate counters)
             e = hipGetLastError();
             if (e != hipSuccess) return e;
