@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256) void sample_bound_kernel(const float* __restri
 // by another ~dim 2^-24.  So with eta = 0.0081 (2^-7 + 2^-16 + slack for the accumulation, the reciprocal and the square root;
 // norms in f32 from the unrounded rows):   | dot_bf16 / (||q|| ||d||) - cosine | <= eta.
 //  * KIND 1, the sample: the maximum of dot_bf16 / (||q|| ||d||) over each sampled unit (1 .. 16 tiles of 16 documents, about a
-//    fortieth of a large corpus, an eighth at most of a small one: filter_plan); the k-th largest of a
+//    twentieth of a large corpus, an eighth at most of a small one: filter_plan); the k-th largest of a
 //    query's maxima, minus eta, is a score at least k documents reach exactly: the bound t (sample_bound_kernel).
 //  * KIND 0, the filter: every (query, document) with  dot_bf16 / ||d|| >= (t - eta) ||q||  -- a few hundred per query -- goes to
 //    the list of the WAVE that found it (no atomics: the position is the wave's own count + the lane's rank among the passes);
@@ -1720,8 +1720,9 @@ FilterPlan filter_plan(int64_t n_docs, int dim, size_t list_bytes)
     if (const char* e = getenv("KJARNI_HIP_FILTER_GRID")) p.grid = (unsigned)std::min<int64_t>((tiles + p.waves - 1) / p.waves, std::min(4096 / p.waves, atoi(e)));
 #endif
     p.cap_w = (unsigned)(list_bytes / 8 / ((size_t)p.grid * p.waves));
-    // ~1 / 40 of the corpus and at least 4 096 tiles (fewer only when the corpus has fewer); at most 4 096 units (sample_bound_kernel)
-    p.unit_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, (tiles + 4096 * 40 - 1) / (4096 * 40)));
+    // ~1 / 20 of a large corpus (10^7 documents: 8 tiles per unit 2.68 ms, 4: 2.73, 16: 2.75) and at least 4 096 tiles (fewer only
+    // when the corpus has fewer); at most 4 096 units (sample_bound_kernel)
+    p.unit_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, (tiles + 4096 * 20 - 1) / (4096 * 20)));
     // (4 096 units is also where the search is fastest: 2 048 / 1 024 / 512 units cost 10^6 documents 0.399 / 0.459 / 0.576 ms against
     // 0.360 -- more candidates --, 6 144 / 8 192 0.379 / 0.390 against 0.366 -- a longer sample; docs/history/r06.md 4b)
     p.units = std::min<int64_t>(4096, std::max<int64_t>(1, tiles / p.unit_tiles / 8));   // (and at most 1 / 8 of a small corpus)

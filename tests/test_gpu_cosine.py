@@ -357,7 +357,7 @@ def test_many_queries_one_call_selects_inside_the_scan(case, k):
         q[:] = q[0]
         if dim != 640:   # (the sample units of filter_plan, cosine.hip: tiles of 16 documents)
             tiles = (n + 15) // 16
-            unit_tiles = min(16, max(1, (tiles + 4096 * 40 - 1) // (4096 * 40)))
+            unit_tiles = min(16, max(1, (tiles + 4096 * 20 - 1) // (4096 * 20)))
             units = min(4096, max(1, tiles // unit_tiles // 8))
             ts = max(unit_tiles, tiles // units)
             row_tile = torch.arange(n, device=dev) // 16
